@@ -1,0 +1,430 @@
+"""CPU oracle for the adversarial-autoencoder training step.  TEST INFRASTRUCTURE.
+
+This file is the checker, not the product: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  The shipped path
+(aae-recommender_amd/aaerec/aae.py -> libaaerec_hip.so) never does.
+
+It restates, in plain NumPy float32 with explicit hand-derived backward passes
+(no autograd), what one `AdversarialAutoEncoder.partial_fit` of the reference
+computes (reference aaerec/aae.py:745-766):
+
+    ae_step   aae.py:676-711   Encoder(train) -> conditions -> Decoder -> BCE -> Adam(enc), Adam(dec)
+    disc_step aae.py:713-732   Encoder(eval) ; D(z_real), D(z_fake) -> Adam(disc)
+    gen_step  aae.py:734-743   Encoder(train) -> D -> Adam#2(enc)
+    Encoder   aae.py:104-146   L1-normalise, 3 Linear, dropout BEFORE activation
+    Decoder   aae.py:149-178   3 Linear + sigmoid
+    Discriminator aae.py:181-213
+    predict   aae.py:840-870   eval-mode enc -> conditions -> dec
+
+The arithmetic delegated by the reference to PyTorch (torch is unpinned in the
+reference's setup.py:3-14; the fixtures were produced with torch 2.10.0) is
+restated from PyTorch's published semantics:
+  F.normalize(x, p=1, dim=1, eps=1e-12)      x / max(sum|x|, eps)
+  nn.Dropout(p)                              x * (keep / (1-p))
+  nn.AlphaDropout(p)                         x * (keep*a) + ((keep-1)*alpha*a + alpha*a*p)
+  F.binary_cross_entropy(mean)               -(t*max(log x,-100) + (1-t)*max(log1p(-x),-100));
+                                             grad (x-t)/max((1-x)*x, 1e-12)/numel
+  optim.Adam (single-tensor, defaults)       m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
+                                             p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+  optim.SGD (momentum 0)                     p += -lr * g
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
+against tests/golden/*.npz, which tools/gen_golden.py produced by running the
+real reference (imported from /root/reference) in the build container: losses,
+every parameter and all four Adam states after each of 3-5 steps, across
+dropout / SELU / priors / SGD / conditions / ragged batches.
+"""
+import numpy as np
+
+f32 = np.float32
+TINY = f32(1e-12)          # aae.py:28
+SELU_ALPHA = 1.6732632423543772848170429916717
+SELU_SCALE = 1.0507009873554804934193349852946
+ADROP_ALPHA = 1.7580993408473766     # = SELU_ALPHA * SELU_SCALE, as torch's alpha_dropout
+
+
+# ---------------------------------------------------------------------------
+# activations  (getattr(nn, activation)(), aae.py:110)
+# ---------------------------------------------------------------------------
+def act_fwd(name, x):
+    if name == "ReLU":
+        return np.maximum(x, f32(0))
+    if name == "SELU":
+        neg = f32(SELU_SCALE * SELU_ALPHA) * np.expm1(np.minimum(x, f32(0)))
+        return np.where(x > 0, f32(SELU_SCALE) * x, neg).astype(f32)
+    if name == "Tanh":
+        return np.tanh(x)
+    if name == "Sigmoid":
+        return sigmoid(x)
+    if name == "ELU":
+        return np.where(x > 0, x, np.expm1(np.minimum(x, f32(0)))).astype(f32)
+    if name == "LeakyReLU":
+        return np.where(x > 0, x, f32(0.01) * x).astype(f32)
+    raise ValueError("activation not covered by the oracle: " + name)
+
+
+def act_bwd(name, x, y, g):
+    """dL/dx given pre-activation x, output y, upstream g."""
+    if name == "ReLU":
+        return np.where(x > 0, g, f32(0)).astype(f32)
+    if name == "SELU":
+        d = np.where(x > 0, f32(SELU_SCALE), y + f32(SELU_SCALE * SELU_ALPHA))
+        return (g * d).astype(f32)
+    if name == "Tanh":
+        return (g * (f32(1) - y * y)).astype(f32)
+    if name == "Sigmoid":
+        return (g * y * (f32(1) - y)).astype(f32)
+    if name == "ELU":
+        return (g * np.where(x > 0, f32(1), y + f32(1))).astype(f32)
+    if name == "LeakyReLU":
+        return np.where(x > 0, g, f32(0.01) * g).astype(f32)
+    raise ValueError(name)
+
+
+def sigmoid(x):
+    x = x.astype(f32)
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = f32(1) / (f32(1) + np.exp(-x[pos]))
+    e = np.exp(x[~pos])
+    out[~pos] = e / (f32(1) + e)
+    return out
+
+
+def softmax_rows(x):
+    m = x.max(axis=1, keepdims=True)
+    e = np.exp(x - m)
+    return (e / e.sum(axis=1, keepdims=True)).astype(f32)
+
+
+# ---------------------------------------------------------------------------
+# dropout (applied to the PRE-activation, aae.py:135-137)
+# ---------------------------------------------------------------------------
+class Drop:
+    """Holds one keep-mask; fwd/bwd for Dropout or AlphaDropout."""
+
+    def __init__(self, p, keep, alpha_mode):
+        self.p, self.alpha_mode = float(p), alpha_mode
+        self.keep = None if (keep is None or self.p == 0.0) else keep.astype(f32)
+        if self.keep is not None:
+            if alpha_mode:
+                a = 1.0 / np.sqrt((ADROP_ALPHA ** 2 * self.p + 1) * (1 - self.p))
+                self.mul = self.keep * f32(a)
+                self.add = ((self.keep - f32(1)) * f32(ADROP_ALPHA * a) + f32(ADROP_ALPHA * a * self.p)).astype(f32)
+            else:
+                self.mul = self.keep / f32(1 - self.p)
+                self.add = None
+
+    def fwd(self, x):
+        if self.keep is None:
+            return x
+        y = x * self.mul
+        return y if self.add is None else (y + self.add).astype(f32)
+
+    def bwd(self, g):
+        return g if self.keep is None else (g * self.mul).astype(f32)
+
+
+# ---------------------------------------------------------------------------
+# optimisers
+# ---------------------------------------------------------------------------
+class Adam:
+    """torch.optim.Adam defaults (betas .9/.999, eps 1e-8), one state per tensor name."""
+
+    def __init__(self, lr):
+        self.lr, self.m, self.v, self.t = float(lr), {}, {}, {}
+
+    def step(self, params, grads):
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for k, g in grads.items():
+            p = params[k]
+            if k not in self.m:
+                self.m[k], self.v[k], self.t[k] = np.zeros_like(p), np.zeros_like(p), 0
+            self.t[k] += 1
+            t = self.t[k]
+            m, v = self.m[k], self.v[k]
+            m += f32(1 - b1) * (g - m)                     # lerp_
+            v *= f32(b2)
+            v += (f32(1 - b2) * g) * g                     # addcmul_
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            denom = np.sqrt(v) / f32(bc2 ** 0.5) + f32(eps)
+            p += (f32(-(self.lr / bc1)) * m) / denom       # addcdiv_
+
+
+class SGD:
+    def __init__(self, lr):
+        self.lr, self.m, self.v, self.t = float(lr), {}, {}, {}
+
+    def step(self, params, grads):
+        for k, g in grads.items():
+            params[k] += f32(-self.lr) * g
+
+
+# ---------------------------------------------------------------------------
+# condition stand-ins for the fixtures (condition.py:90-99, 300-342, 397-508)
+# ---------------------------------------------------------------------------
+class ConcatConst:
+    """ConcatenationBasedConditioning with a constant encoded input [B, inc]."""
+
+    def __init__(self, inc):
+        self.inc = inc
+
+    def fwd(self, z, inp, train=True):
+        self._c = z.shape[1]
+        return np.concatenate([z, np.asarray(inp, dtype=f32)], axis=1)
+
+    def bwd(self, dz):
+        return dz[:, :self._c]
+
+    def step(self):
+        pass
+
+
+class BiasConst:
+    """ConditionalBiasing with a constant encoded input (condition.py:319-329)."""
+    inc = 0
+
+    def fwd(self, z, inp, train=True):
+        return (z + np.asarray(inp, dtype=f32)).astype(f32)
+
+    def bwd(self, dz):
+        return dz
+
+    def step(self):
+        pass
+
+
+class CategoricalSum:
+    """CategoricalCondition(reduce='sum', sparse=False): embedding rows summed per
+    doc, padding row 0 frozen at zero, own dense Adam (condition.py:441-505)."""
+
+    def __init__(self, weight, lr):
+        self.params = {"w": weight.astype(f32).copy()}
+        self.opt = Adam(lr)
+        self.inc = weight.shape[1]
+
+    def fwd(self, z, idx, train=True):
+        self._idx = np.asarray(idx)
+        self._c = z.shape[1]
+        e = self.params["w"][self._idx].sum(axis=1).astype(f32)
+        return np.concatenate([z, e], axis=1)
+
+    def bwd(self, dz):
+        de = dz[:, self._c:]
+        g = np.zeros_like(self.params["w"])
+        for b in range(self._idx.shape[0]):
+            for j in self._idx[b]:
+                if j != 0:
+                    g[j] += de[b]
+        self._g = g
+        return dz[:, :self._c]
+
+    def step(self):
+        self.opt.step(self.params, {"w": self._g})
+
+
+# ---------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------
+def _lin(x, W, b):
+    return (x @ W.T + b).astype(f32)
+
+
+class OracleAAE:
+    """State = torch-layout parameters ([out,in]) + four optimiser states."""
+
+    def __init__(self, params, gen_lr=1e-3, reg_lr=1e-3, prior="gauss", prior_scale=None,
+                 optimizer="adam", normalize_inputs=True, activation="ReLU",
+                 dropout=(0.2, 0.2), conditions=None):
+        # params: dict "enc.lin1.weight" -> ndarray (copied)
+        self.p = {k: np.array(v, dtype=f32) for k, v in params.items()}
+        self.N = self.p["enc.lin1.weight"].shape[1]
+        self.c = self.p["enc.lin3.weight"].shape[0]
+        self.prior, self.prior_scale = prior, prior_scale
+        self.final = {"gauss": None, "categorical": "softmax", "bernoulli": "sigmoid"}[prior]
+        self.normalize, self.act, self.dropout = normalize_inputs, activation, tuple(dropout)
+        mk = Adam if optimizer == "adam" else SGD
+        self.opt_enc, self.opt_dec = mk(gen_lr), mk(gen_lr)
+        self.opt_gen, self.opt_disc = mk(reg_lr), mk(reg_lr)
+        self.conditions = conditions or []
+        self.alpha_mode = activation == "SELU"
+
+    # -- pieces ------------------------------------------------------------
+    def _row_scale(self, indptr, values):
+        B = len(indptr) - 1
+        s = np.ones(B, dtype=f32)
+        if self.normalize:
+            for b in range(B):
+                l1 = np.abs(values[indptr[b]:indptr[b + 1]]).sum(dtype=f32)
+                s[b] = f32(1) / max(l1, TINY)
+        return s
+
+    def _first_layer(self, indptr, indices, values, s):
+        """a1[b] = b1 + sum_i (v_i * s_b) * W1[:, i]   (K2+K3 of SURVEY 2.1)."""
+        W, b1 = self.p["enc.lin1.weight"], self.p["enc.lin1.bias"]
+        B = len(indptr) - 1
+        a1 = np.empty((B, W.shape[0]), dtype=f32)
+        for b in range(B):
+            lo, hi = indptr[b], indptr[b + 1]
+            xn = (values[lo:hi] * s[b]).astype(f32) if self.normalize else values[lo:hi]
+            a1[b] = W[:, indices[lo:hi]] @ xn + b1
+        return a1
+
+    def _mlp_fwd(self, net, x0, masks, first_pre=None):
+        """3-layer stack; returns (output_pre_final, cache). masks: (keep1, keep2) or None."""
+        P = self.p
+        k1, k2 = masks if masks is not None else (None, None)
+        d1, d2 = Drop(self.dropout[0], k1, self.alpha_mode), Drop(self.dropout[1], k2, self.alpha_mode)
+        a1 = first_pre if first_pre is not None else _lin(x0, P[net + ".lin1.weight"], P[net + ".lin1.bias"])
+        u1 = d1.fwd(a1)
+        h1 = act_fwd(self.act, u1)
+        a2 = _lin(h1, P[net + ".lin2.weight"], P[net + ".lin2.bias"])
+        u2 = d2.fwd(a2)
+        h2 = act_fwd(self.act, u2)
+        a3 = _lin(h2, P[net + ".lin3.weight"], P[net + ".lin3.bias"])
+        return a3, dict(x0=x0, d1=d1, d2=d2, u1=u1, h1=h1, u2=u2, h2=h2)
+
+    def _mlp_bwd(self, net, g3, cache, need_dx=True):
+        """Given dL/da3 -> grads of lin3/lin2/lin1 (lin1 weight grad returned as da1), dL/dx0."""
+        P = self.p
+        G = {net + ".lin3.weight": (g3.T @ cache["h2"]).astype(f32), net + ".lin3.bias": g3.sum(0).astype(f32)}
+        gh2 = (g3 @ P[net + ".lin3.weight"]).astype(f32)
+        ga2 = cache["d2"].bwd(act_bwd(self.act, cache["u2"], cache["h2"], gh2))
+        G[net + ".lin2.weight"] = (ga2.T @ cache["h1"]).astype(f32)
+        G[net + ".lin2.bias"] = ga2.sum(0).astype(f32)
+        gh1 = (ga2 @ P[net + ".lin2.weight"]).astype(f32)
+        ga1 = cache["d1"].bwd(act_bwd(self.act, cache["u1"], cache["h1"], gh1))
+        G[net + ".lin1.bias"] = ga1.sum(0).astype(f32)
+        gx = (ga1 @ P[net + ".lin1.weight"]).astype(f32) if need_dx else None
+        return G, ga1, gx
+
+    def _enc_final_fwd(self, a3):
+        if self.final is None:
+            return a3
+        return softmax_rows(a3) if self.final == "softmax" else sigmoid(a3)
+
+    def _enc_final_bwd(self, z, gz):
+        if self.final is None:
+            return gz
+        if self.final == "sigmoid":
+            return (gz * z * (f32(1) - z)).astype(f32)
+        dot = (gz * z).sum(axis=1, keepdims=True)
+        return (z * (gz - dot)).astype(f32)
+
+    def _enc_w1_grad(self, indptr, indices, values, s, ga1):
+        """dW1[:, i] += (v_i * s_b) * ga1[b]  (K9): dense [h, N] result."""
+        g = np.zeros_like(self.p["enc.lin1.weight"])
+        for b in range(len(indptr) - 1):
+            lo, hi = indptr[b], indptr[b + 1]
+            xn = (values[lo:hi] * s[b]).astype(f32) if self.normalize else values[lo:hi]
+            np.add.at(g.T, indices[lo:hi], np.outer(xn, ga1[b]).astype(f32))
+        return g
+
+    def encode(self, indptr, indices, values, masks=None):
+        s = self._row_scale(indptr, values)
+        a1 = self._first_layer(indptr, indices, values, s)
+        a3, cache = self._mlp_fwd("enc", None, masks, first_pre=a1)
+        cache["a1"], cache["s"] = a1, s
+        return self._enc_final_fwd(a3), cache
+
+    def _disc(self, z, masks):
+        a3, cache = self._mlp_fwd("disc", z, masks)
+        return sigmoid(a3), cache
+
+    # -- the three sub-steps ----------------------------------------------
+    def ae_step(self, indptr, indices, values, masks, cond_inputs=None):
+        """masks = [enc.drop1, enc.drop2, dec.drop1, dec.drop2] keep-masks or None."""
+        mk = masks if masks is not None else [None] * 4
+        B, N = len(indptr) - 1, self.N
+        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
+        zc = z
+        for cond, inp in zip(self.conditions, cond_inputs or []):
+            zc = cond.fwd(zc, inp)
+        logits, dc = self._mlp_fwd("dec", zc, (mk[2], mk[3]))
+        xhat = sigmoid(logits)
+        T = np.zeros((B, N), dtype=f32)
+        for b in range(B):
+            T[b, indices[indptr[b]:indptr[b + 1]]] = values[indptr[b]:indptr[b + 1]]
+        x = xhat + TINY
+        t = T + TINY
+        with np.errstate(divide="ignore"):
+            lx = np.maximum(np.log(x), f32(-100))
+            l1x = np.maximum(np.log1p(-x), f32(-100))
+        loss = float((-(t * lx + (f32(1) - t) * l1x)).mean(dtype=np.float64))
+        gx = (x - t) / np.maximum((f32(1) - x) * x, f32(1e-12)) / f32(B * N)
+        glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
+        Gd, gda1, gzc = self._mlp_bwd("dec", glog, dc)
+        Gd["dec.lin1.weight"] = (gda1.T @ zc).astype(f32)
+        gz = gzc
+        for cond in reversed(self.conditions):
+            gz = cond.bwd(gz)
+        ga3 = self._enc_final_bwd(z, gz)
+        Ge, ga1, _ = self._mlp_bwd("enc", ga3, ec, need_dx=False)
+        Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, ec["s"], ga1)
+        self.opt_enc.step(self.p, Ge)
+        self.opt_dec.step(self.p, Gd)
+        for cond in self.conditions:
+            cond.step()
+        self.last = dict(enc_a1=ec["a1"], z=z, xhat=xhat)
+        return loss
+
+    def disc_step(self, indptr, indices, values, z_real, masks):
+        """enc in eval mode; masks = [disc.drop1, disc.drop2 (real)], [.. (fake)]."""
+        mk = masks if masks is not None else [None] * 4
+        B = len(indptr) - 1
+        zr = np.asarray(z_real, dtype=f32)
+        if self.prior_scale is not None:
+            zr = (zr * f32(self.prior_scale)).astype(f32)
+        zf, _ = self.encode(indptr, indices, values, None)
+        dr, cr = self._disc(zr, (mk[0], mk[1]))
+        df, cf = self._disc(zf, (mk[2], mk[3]))
+        loss = float(-(np.log(dr + TINY) + np.log(f32(1) - df + TINY)).mean(dtype=np.float64))
+        g_dr = (f32(-1.0 / B) / (dr + TINY)).astype(f32)
+        g_df = (f32(1.0 / B) / (f32(1) - df + TINY)).astype(f32)
+        G = {}
+        for d, g, cache in ((dr, g_dr, cr), (df, g_df, cf)):
+            ga3 = (g * d * (f32(1) - d)).astype(f32)
+            Gi, ga1, _ = self._mlp_bwd("disc", ga3, cache, need_dx=False)
+            Gi["disc.lin1.weight"] = (ga1.T @ cache["x0"]).astype(f32)
+            for k, v in Gi.items():
+                G[k] = v if k not in G else (G[k] + v).astype(f32)
+        self.opt_disc.step(self.p, G)
+        self.last["z_disc"] = zf
+        return loss
+
+    def gen_step(self, indptr, indices, values, masks):
+        """masks = [enc.drop1, enc.drop2, disc.drop1, disc.drop2]."""
+        mk = masks if masks is not None else [None] * 4
+        B = len(indptr) - 1
+        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
+        d, cd = self._disc(z, (mk[2], mk[3]))
+        loss = float(-np.log(d + TINY).mean(dtype=np.float64))
+        g_d = (f32(-1.0 / B) / (d + TINY)).astype(f32)
+        ga3d = (g_d * d * (f32(1) - d)).astype(f32)
+        _, _, gz = self._mlp_bwd("disc", ga3d, cd, need_dx=True)
+        ga3 = self._enc_final_bwd(z, gz)
+        Ge, ga1, _ = self._mlp_bwd("enc", ga3, ec, need_dx=False)
+        Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, ec["s"], ga1)
+        self.opt_gen.step(self.p, Ge)
+        self.last["z_gen"] = z
+        return loss
+
+    def partial_fit(self, indptr, indices, values, z_real, masks=None, cond_inputs=None):
+        """masks: the 12 keep-masks in the reference's call order (SURVEY 7 'RNG parity'):
+        enc.d1 enc.d2 dec.d1 dec.d2 | disc.d1 disc.d2 (real) disc.d1 disc.d2 (fake) |
+        enc.d1 enc.d2 disc.d1 disc.d2.  None = dropout off."""
+        if values.size and (values.max() > 1 or values.min() < 0):
+            raise RuntimeError("all elements of target should be between 0 and 1")
+        mk = masks if masks is not None else [None] * 12
+        r = self.ae_step(indptr, indices, values, mk[0:4], cond_inputs)
+        d = self.disc_step(indptr, indices, values, z_real, mk[4:8])
+        g = self.gen_step(indptr, indices, values, mk[8:12])
+        return r, d, g
+
+    def predict(self, indptr, indices, values, cond_inputs=None):
+        z, _ = self.encode(indptr, indices, values, None)
+        for cond, inp in zip(self.conditions, cond_inputs or []):
+            z = cond.fwd(z, inp, train=False)
+        logits, _ = self._mlp_fwd("dec", z, None)
+        return sigmoid(logits)
+

@@ -1,0 +1,79 @@
+"""Helpers shared by the oracle tests and the GPU parity tests: load a fixture
+written by tools/gen_golden.py and replay it on any implementation."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+STEP_CASES = [
+    "step_nodrop_gauss", "step_masks", "step_masks_uneven", "step_cond_concat",
+    "step_cond_categorical", "step_cond_concat_bias", "step_selu", "step_categorical_prior",
+    "step_bernoulli_prior", "step_prior_scale", "step_sgd", "step_nonorm", "step_ragged",
+    "step_tanh", "step_lrs", "step_wide",
+]
+
+NET_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
+
+
+class Fixture:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.cfg = json.loads(str(self.z["config_json"]))
+        self.steps = self.cfg["steps"]
+
+    def init_params(self):
+        return {k[len("init."):]: self.z[k] for k in self.z.files
+                if k.startswith("init.") and not k.startswith("init.cond")}
+
+    def model_kwargs(self):
+        c = self.cfg
+        kw = dict(gen_lr=c.get("gen_lr", 1e-3), reg_lr=c.get("reg_lr", 1e-3),
+                  prior=c.get("prior", "gauss"), prior_scale=c.get("prior_scale"),
+                  optimizer=c.get("optimizer", "adam"),
+                  normalize_inputs=c.get("normalize_inputs", True),
+                  activation=c.get("activation", "ReLU"),
+                  dropout=tuple(c.get("dropout", (0.0, 0.0))))
+        return kw
+
+    def batch(self, s, prefix=None):
+        p = prefix or f"step{s}"
+        return self.z[p + ".indptr"], self.z[p + ".indices"], self.z[p + ".values"]
+
+    def masks(self, s):
+        out, j = [], 0
+        while f"step{s}.mask{j}" in self.z.files:
+            out.append(self.z[f"step{s}.mask{j}"])
+            j += 1
+        return out or None
+
+    def cond_inputs(self, s, prefix=None):
+        p = prefix or f"step{s}"
+        out, j = [], 0
+        while f"{p}.cond{j}" in self.z.files:
+            out.append(self.z[f"{p}.cond{j}"])
+            j += 1
+        return out or None
+
+    def has_state(self, s):
+        return f"step{s}.enc.lin1.weight" in self.z.files
+
+    def expected_params(self, s):
+        out = {}
+        for net in ("enc", "dec", "disc"):
+            for k in NET_KEYS:
+                out[f"{net}.{k}"] = self.z[f"step{s}.{net}.{k}"]
+        return out
+
+    def expected_adam(self, s):
+        """{(optimiser, 'net.key'): (m, v, t)}"""
+        out = {}
+        for tag, net in (("A_enc", "enc"), ("A_dec", "dec"), ("A_gen", "enc"), ("A_disc", "disc")):
+            for i, k in enumerate(NET_KEYS):
+                key = f"step{s}.{tag}.{i}.m"
+                if key in self.z.files:
+                    out[(tag, f"{net}.{k}")] = (self.z[key], self.z[f"step{s}.{tag}.{i}.v"],
+                                                float(self.z[f"step{s}.{tag}.{i}.t"]))
+        return out

@@ -1,0 +1,78 @@
+"""Pins the CPU oracle (oracle/aae_oracle.py) to the golden vectors produced by the
+real reference (tools/gen_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+
+from golden_util import STEP_CASES, Fixture
+from oracle import aae_oracle as O
+
+TOL_LOSS = 2e-6     # relative, fp32 summation order only
+# absolute on parameters (values are O(0.1); Adam steps are O(lr)=1e-3).  Adam's first steps
+# compute lr*g/(|g|+1e-8): where |g| is itself ~1e-8 an fp32 summation-order difference in g
+# moves the update by a few 1e-6, so the bound is a small multiple of lr*1e-3, not 1 ulp.
+TOL_PARAM = 5e-6
+
+
+def build_oracle(fx):
+    conds = []
+    cond = fx.cfg["cond"]
+    if cond in ("concat30", "concat30+bias"):
+        conds.append(O.ConcatConst(30))
+    if cond == "concat30+bias":
+        conds.append(O.BiasConst())
+    if cond == "categorical":
+        conds.append(O.CategoricalSum(fx.z["init.cond.embedding"], lr=1e-2))
+    return O.OracleAAE(fx.init_params(), conditions=conds, **fx.model_kwargs())
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_oracle_reproduces_reference_steps(name):
+    fx = Fixture(name)
+    m = build_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        losses = m.partial_fit(ip, idx, val, fx.z[f"step{s}.z_real"], fx.masks(s), fx.cond_inputs(s))
+        want = fx.z[f"step{s}.losses"]
+        np.testing.assert_allclose(losses, want, rtol=TOL_LOSS, atol=1e-7, err_msg=f"{name} step {s} losses")
+        if s == 0 and "step0.act.enc_a1_ae" in fx.z.files:
+            np.testing.assert_allclose(m.last["enc_a1"], fx.z["step0.act.enc_a1_ae"], atol=1e-6)
+            np.testing.assert_allclose(m.last["z"], fx.z["step0.act.enc_z_ae"], atol=1e-6)
+            np.testing.assert_allclose(m.last["xhat"], fx.z["step0.act.dec_xhat"], atol=1e-6)
+            np.testing.assert_allclose(m.last["z_disc"], fx.z["step0.act.enc_z_disc"], atol=1e-6)
+            np.testing.assert_allclose(m.last["z_gen"], fx.z["step0.act.enc_z_gen"], atol=1e-6)
+        if not fx.has_state(s):
+            continue
+        for k, w in fx.expected_params(s).items():
+            np.testing.assert_allclose(m.p[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} step {s} {k}")
+        opts = {"A_enc": m.opt_enc, "A_dec": m.opt_dec, "A_gen": m.opt_gen, "A_disc": m.opt_disc}
+        for (tag, k), (em, ev, et) in fx.expected_adam(s).items():
+            o = opts[tag]
+            assert o.t[k] == et
+            np.testing.assert_allclose(o.m[k], em, atol=1e-9, rtol=2e-5, err_msg=f"{name} {tag} m {k}")
+            np.testing.assert_allclose(o.v[k], ev, atol=1e-13, rtol=5e-5, err_msg=f"{name} {tag} v {k}")
+        if fx.cfg["cond"] == "categorical":
+            np.testing.assert_allclose(m.conditions[0].params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
+
+
+@pytest.mark.parametrize("name", ["step_nodrop_gauss", "step_cond_concat", "step_cond_concat_bias",
+                                  "step_selu", "step_categorical_prior", "step_ragged"])
+def test_oracle_predict(name):
+    fx = Fixture(name)
+    m = build_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        m.partial_fit(ip, idx, val, fx.z[f"step{s}.z_real"], fx.masks(s), fx.cond_inputs(s))
+    ip, idx, val = fx.batch(0, prefix="predict")
+    got = m.predict(ip, idx, val, fx.cond_inputs(0, prefix="predict"))
+    np.testing.assert_allclose(got, fx.z["predict.out"], atol=1e-6)
+
+
+def test_oracle_rejects_counts_above_one():
+    """Reference behaviour (torch BCE): duplicate items give value 2.0 -> RuntimeError."""
+    fx = Fixture("step_nodrop_gauss")
+    m = build_oracle(fx)
+    ip, idx, val = fx.batch(0)
+    val = val.copy()
+    val[0] = 2.0
+    with pytest.raises(RuntimeError):
+        m.partial_fit(ip, idx, val, fx.z["step0.z_real"])

@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures for the AAE hot path from the *real* reference.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the
+reference package unmodified (with the three import shims listed in SURVEY.md
+section 8c), drives `AdversarialAutoEncoder.partial_fit` (aaerec/aae.py:745-766)
+step by step with recorded randomness, and dumps inputs + expected outputs as
+small .npz files under tests/golden/.  Only data is written: no reference
+source travels.
+
+    python tools/gen_golden.py            # regenerate every fixture
+
+Randomness capture:
+  * `prior_sampler` is wrapped so every z_real drawn in disc_step
+    (aae.py:716) is recorded.
+  * every nn.Dropout / nn.AlphaDropout of enc/dec/disc is replaced (after
+    construction, before the first step) by a recording module that draws the
+    same Bernoulli noise torch draws and stores the keep-mask in call order.
+    The generator asserts once that the recording modules reproduce torch's
+    own dropout bit for bit under the same seed.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    """stand-in modules, then import."""
+    for name in ("gensim", "gensim.models", "gensim.models.keyedvectors",
+                 "docutils", "docutils.nodes"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["gensim.models.keyedvectors"].KeyedVectors = type("KeyedVectors", (), {})
+    sys.modules["gensim.models"].keyedvectors = sys.modules["gensim.models.keyedvectors"]
+    sys.modules["gensim"].models = sys.modules["gensim.models"]
+    sys.modules["docutils.nodes"].inline = object
+    if not hasattr(np, "product"):
+        np.product = np.prod
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import aaerec.aae as ref_aae          # noqa
+    import aaerec.condition as ref_cond   # noqa
+    return ref_aae, ref_cond
+
+
+# ----------------------------------------------------------------------------
+# recording dropouts
+# ----------------------------------------------------------------------------
+class RecDropout(nn.Module):
+    """x * bernoulli(1-p) / (1-p); records the keep mask (uint8)."""
+
+    def __init__(self, p, log, tag):
+        super().__init__()
+        self.p, self.log, self.tag = float(p), log, tag
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        noise = torch.empty_like(x).bernoulli_(1 - self.p)
+        self.log.append((self.tag, noise.numpy().astype(np.uint8).copy()))
+        return x * noise.div(1 - self.p)
+
+
+class RecAlphaDropout(nn.Module):
+    """torch's alpha_dropout (aten/src/ATen/native/Dropout.cpp, feature=False,
+    alpha=True): a = 1/sqrt((alpha^2 p + 1)(1-p)); b = (noise-1)*alpha*a + alpha*a*p;
+    out = x * (noise*a) + b."""
+    ALPHA = 1.7580993408473766
+
+    def __init__(self, p, log, tag):
+        super().__init__()
+        self.p, self.log, self.tag = float(p), log, tag
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        p = self.p
+        noise = torch.empty_like(x).bernoulli_(1 - p)
+        self.log.append((self.tag, noise.numpy().astype(np.uint8).copy()))
+        a = 1.0 / np.sqrt((self.ALPHA ** 2 * p + 1) * (1 - p))
+        b = noise.add(-1).mul_(self.ALPHA * a).add_(self.ALPHA * a * p)
+        return x * noise.mul(a) + b
+
+
+def _selfcheck_recording_dropouts():
+    x = torch.randn(7, 13)
+    for cls, ref in ((RecDropout, nn.Dropout), (RecAlphaDropout, nn.AlphaDropout)):
+        log = []
+        torch.manual_seed(123)
+        got = cls(0.3, log, "t").train()(x)
+        torch.manual_seed(123)
+        want = ref(0.3).train()(x)
+        assert torch.equal(got, want), cls.__name__
+
+
+# ----------------------------------------------------------------------------
+# synthetic batches
+# ----------------------------------------------------------------------------
+def make_batch(rng, B, N, min_len=1, max_len=8, dup_row=None, empty_row=None):
+    rows = []
+    for b in range(B):
+        n = int(rng.integers(min_len, max_len + 1))
+        rows.append(list(rng.choice(N, size=n, replace=False)))
+    if dup_row is not None:          # duplicate item -> value 2.0 after tocsr(); NOTE: the
+        # reference then fails in F.binary_cross_entropy ("all elements of target should be
+        # between 0 and 1", torch>=1.x) - our partial_fit mirrors that error, no fixture.
+        rows[dup_row] = rows[dup_row] + [rows[dup_row][0]]
+    if empty_row is not None and empty_row < B:
+        rows[empty_row] = []
+    ind0 = [b for b, r in enumerate(rows) for _ in r]
+    ind1 = [i for r in rows for i in r]
+    X = sp.coo_matrix((np.ones(len(ind0)), (ind0, ind1)), shape=(B, N)).tocsr()
+    X.sum_duplicates()
+    X.sort_indices()
+    return X
+
+
+def state_np(module):
+    return {k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def optim_np(opt, params):
+    """Adam: exp_avg / exp_avg_sq / step per parameter, in `params` order.
+    SGD: nothing (momentum=0)."""
+    out = {}
+    for i, p in enumerate(params):
+        st = opt.state.get(p, {})
+        if "exp_avg" in st:
+            out[f"{i}.m"] = st["exp_avg"].numpy().copy()
+            out[f"{i}.v"] = st["exp_avg_sq"].numpy().copy()
+            out[f"{i}.t"] = np.asarray(float(st["step"]))
+    return out
+
+
+ENC_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
+
+
+def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
+             cond=None, batch_kw=None, last_B=None, capture_acts=True, states='all', **model_kw):
+    """Drive `steps` partial_fit calls on the reference; return a flat dict of arrays."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(1000 + seed)
+    model_kw.setdefault("dropout", (0.0, 0.0))
+    conditions = None
+    cond_inc = 0
+    cond_batches = None
+    if cond == "concat30":
+        class ConstConcat(ref_cond.ConcatenationBasedConditioning):
+            def size_increment(self):
+                return 30
+
+            def encode(self, inputs):
+                return torch.as_tensor(inputs, dtype=torch.float32)
+        conditions = ref_cond.ConditionList([("title", ConstConcat())])
+        cond_inc = 30
+    elif cond == "categorical":
+        cc = ref_cond.CategoricalCondition(8, sparse=False, use_cuda=False, reduce="sum", lr=1e-2)
+        conditions = ref_cond.ConditionList([("authors", cc)])
+        cond_inc = 8
+    elif cond == "concat30+bias":
+        class ConstConcat(ref_cond.ConcatenationBasedConditioning):
+            def size_increment(self):
+                return 30
+
+            def encode(self, inputs):
+                return torch.as_tensor(inputs, dtype=torch.float32)
+
+        class ConstBias(ref_cond.ConditionalBiasing):
+            def encode(self, inputs):
+                return torch.as_tensor(inputs, dtype=torch.float32)
+        conditions = ref_cond.ConditionList([("title", ConstConcat()), ("b", ConstBias())])
+        cond_inc = 30
+
+    m = ref_aae.AdversarialAutoEncoder(n_hidden=h, n_code=c, batch_size=B, n_epochs=1,
+                                       conditions=conditions, verbose=True, **model_kw)
+    # build nets + optimisers exactly as fit() does (aae.py:782-804)
+    m.enc = ref_aae.Encoder(N, h, c, final_activation=m.encoder_activation,
+                            normalize_inputs=m.normalize_inputs, activation=m.activation,
+                            dropout=m.dropout)
+    m.dec = ref_aae.Decoder(c + cond_inc, h, N, activation=m.activation, dropout=m.dropout)
+    m.disc = ref_aae.Discriminator(c, h, dropout=m.dropout, activation=m.activation)
+    og = ref_aae.TORCH_OPTIMIZERS[m.optimizer]
+    m.enc_optim = og(m.enc.parameters(), lr=m.gen_lr)
+    m.dec_optim = og(m.dec.parameters(), lr=m.gen_lr)
+    m.gen_optim = og(m.enc.parameters(), lr=m.reg_lr)
+    m.disc_optim = og(m.disc.parameters(), lr=m.reg_lr)
+
+    # recording dropouts
+    masks_log = []
+    selu = (m.activation == "SELU")
+    for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", m.disc)):
+        for li, attr in enumerate(("drop1", "drop2")):
+            cls = RecAlphaDropout if selu else RecDropout
+            setattr(net, attr, cls(m.dropout[li], masks_log, f"{net_name}.{attr}"))
+
+    # recording prior
+    z_log = []
+    orig_sampler = m.prior_sampler
+
+    def rec_sampler(size):
+        z = orig_sampler(size)
+        z_log.append(z.numpy().copy())
+        return z
+    m.prior_sampler = rec_sampler
+
+    # loss capture
+    loss_log = []
+    ref_aae.log_losses = lambda *l: loss_log.append(l)
+    ref_aae.USE_WANDB = False
+
+    out = {}
+    cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond=cond or "", cond_inc=cond_inc,
+               n_hidden=h, n_code=c, **{k: (list(v) if isinstance(v, tuple) else v)
+                                        for k, v in model_kw.items()})
+    for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", m.disc)):
+        for k, v in state_np(net).items():
+            out[f"init.{net_name}.{k}"] = v
+
+    if cond == "categorical":
+        # fit the vocabulary on all raw inputs first (AAERecommender.train -> fit_transform)
+        raw_all = [[f"a{int(x)}" for x in rng.integers(0, 12, size=int(rng.integers(1, 4)))]
+                   for _ in range(B * steps)]
+        cdata = conditions.fit_transform([raw_all])[0]
+        out["init.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+
+    acts = {}
+    if capture_acts:
+        def hook(tag):
+            def fn(mod, inp, outp):
+                acts.setdefault(tag, []).append(outp.detach().numpy().copy())
+            return fn
+        m.enc.lin1.register_forward_hook(hook("enc_a1"))
+        m.enc.register_forward_hook(hook("enc_z"))
+        m.dec.register_forward_hook(hook("dec_xhat"))
+
+    for s in range(steps):
+        Bs = last_B if (last_B is not None and s == steps - 1) else B
+        X = make_batch(rng, Bs, N, **(batch_kw or {}))
+        out[f"step{s}.indptr"] = X.indptr.astype(np.int64)
+        out[f"step{s}.indices"] = X.indices.astype(np.int32)
+        out[f"step{s}.values"] = X.data.astype(np.float32)
+        cbatch = None
+        if cond in ("concat30",):
+            cv = (rng.standard_normal((Bs, 30)) * 0.5).astype(np.float32)
+            out[f"step{s}.cond0"] = cv
+            cbatch = [cv]
+        elif cond == "concat30+bias":
+            cv = (rng.standard_normal((Bs, 30)) * 0.5).astype(np.float32)
+            bv = (rng.standard_normal((Bs, c + 30)) * 0.1).astype(np.float32)
+            out[f"step{s}.cond0"] = cv
+            out[f"step{s}.cond1"] = bv
+            cbatch = [cv, bv]
+        elif cond == "categorical":
+            lists = cdata[s * B: s * B + Bs]
+            L = max(len(l) for l in lists)
+            out[f"step{s}.cond0"] = np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
+            cbatch = [lists]
+        n_masks0, n_z0 = len(masks_log), len(z_log)
+        m.partial_fit(X.toarray(), condition_data=cbatch, step=s)
+        out[f"step{s}.losses"] = np.asarray(loss_log[-1], dtype=np.float64)
+        out[f"step{s}.z_real"] = z_log[n_z0]
+        for j, (tag, mk) in enumerate(masks_log[n_masks0:]):
+            out[f"step{s}.mask{j}"] = mk
+            cfg.setdefault("mask_order", []).append(tag) if s == 0 else None
+        if states == 'last' and s != steps - 1:
+            continue
+        for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", m.disc)):
+            for k, v in state_np(net).items():
+                out[f"step{s}.{net_name}.{k}"] = v
+        ep, dp, xp = list(m.enc.parameters()), list(m.dec.parameters()), list(m.disc.parameters())
+        for tag, opt, ps in (("A_enc", m.enc_optim, ep), ("A_dec", m.dec_optim, dp),
+                             ("A_gen", m.gen_optim, ep), ("A_disc", m.disc_optim, xp)):
+            for k, v in optim_np(opt, ps).items():
+                out[f"step{s}.{tag}.{k}"] = v
+        if cond == "categorical":
+            out[f"step{s}.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+        if capture_acts and s == 0:
+            # forward order inside partial_fit: ae (train), disc (eval), gen (train)
+            out["step0.act.enc_a1_ae"] = acts["enc_a1"][0]
+            out["step0.act.enc_z_ae"] = acts["enc_z"][0]
+            out["step0.act.dec_xhat"] = acts["dec_xhat"][0]
+            out["step0.act.enc_z_disc"] = acts["enc_z"][1]
+            out["step0.act.enc_z_gen"] = acts["enc_z"][2]
+
+    # predict with the trained model on the last batch (eval mode; aae.py:840-870)
+    Xp = make_batch(rng, B, N, **(batch_kw or {}))
+    out["predict.indptr"] = Xp.indptr.astype(np.int64)
+    out["predict.indices"] = Xp.indices.astype(np.int32)
+    out["predict.values"] = Xp.data.astype(np.float32)
+    pc = None
+    if cond == "concat30":
+        pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+        out["predict.cond0"] = pcv
+        pc = [pcv]
+    elif cond == "concat30+bias":
+        pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+        pbv = (rng.standard_normal((B, c + 30)) * 0.1).astype(np.float32)
+        out["predict.cond0"], out["predict.cond1"] = pcv, pbv
+        pc = [pcv, pbv]
+    elif cond == "categorical":
+        lists = cdata[:B]
+        L = max(len(l) for l in lists)
+        out["predict.cond0"] = np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
+        pc = [lists]
+    m.batch_size = 7   # exercises the ragged last predict batch
+    out["predict.out"] = m.predict(Xp, condition_data=pc).astype(np.float32)
+    out["config_json"] = np.asarray(json.dumps(cfg))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB, "
+          f"losses step0={out['step0.losses']}")
+    return out
+
+
+def gen_metric_known_answers():
+    """Known answers for the metric side, produced by calling the reference's own
+    evaluation functions on literal inputs (evaluation.py:94-115,183-199)."""
+    import aaerec.evaluation as ev
+    rng = np.random.default_rng(7)
+    y_true = (rng.random((40, 60)) < 0.08).astype(np.float64)
+    y_pred = rng.random((40, 60))
+    x_test = (rng.random((40, 60)) < 0.05).astype(np.float64)
+    out = {"y_true": y_true, "y_pred": y_pred, "x_test": x_test}
+    out["removed"] = ev.remove_non_missing(y_pred, sp.csr_matrix(x_test), copy=True)
+    for key in ("mrr", "mrr@5", "mrr@10", "map", "map@10", "P@1", "P@5", "P@10"):
+        if key in ev.METRICS:
+            mean, std = ev.METRICS[key](y_true, out["removed"])
+            out["metric." + key] = np.asarray([mean, std])
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics:", {k: v for k, v in out.items() if k.startswith("metric.")})
+
+
+def gen_e2e_c1(ref_aae):
+    """Config C1 end to end on the reference: prototype-set generator,
+    Evaluation-free (direct train/predict on CSR) so the same spec runs on our side.
+    Stores the spec + the reference's MRR@10 (mean over docs)."""
+    import aaerec.evaluation as ev
+    rng = np.random.RandomState(42)
+    N, n_proto, n_docs = 1000, 100, 2000
+    protos = [rng.choice(N, size=10, replace=False) for _ in range(n_proto)]
+    docs = []
+    for _ in range(n_docs):
+        p = protos[rng.randint(n_proto)]
+        k = rng.randint(6, 10)
+        docs.append(sorted(rng.choice(p, size=k, replace=False).tolist()))
+    n_test = 200
+    train, test = docs[:-n_test], docs[-n_test:]
+    # hide one item of every test doc
+    test_in, test_out = [], []
+    for d in test:
+        j = rng.randint(len(d))
+        test_out.append([d[j]])
+        test_in.append(d[:j] + d[j + 1:])
+
+    def csr(rows):
+        i0 = [b for b, r in enumerate(rows) for _ in r]
+        i1 = [i for r in rows for i in r]
+        return sp.coo_matrix((np.ones(len(i0)), (i0, i1)), shape=(len(rows), N)).tocsr()
+
+    Xtr, Xin, Yout = csr(train), csr(test_in), csr(test_out)
+    mrrs = []
+    for seed in range(3):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        m = ref_aae.AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=100, batch_size=100,
+                                           gen_lr=0.01, reg_lr=0.001, verbose=False)
+        m.fit(Xtr)
+        pred = m.predict(Xin)
+        pred = ev.remove_non_missing(pred, Xin, copy=True)
+        mean, std = ev.METRICS["mrr@10"](Yout.toarray(), pred)
+        mrrs.append(mean)
+        print("e2e_c1 seed", seed, "MRR@10", mean)
+    out = dict(train_indptr=Xtr.indptr, train_indices=Xtr.indices,
+               in_indptr=Xin.indptr, in_indices=Xin.indices,
+               out_indptr=Yout.indptr, out_indices=Yout.indices,
+               N=np.asarray(N), ref_mrr10=np.asarray(mrrs))
+    np.savez_compressed(os.path.join(OUT, "e2e_c1.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_aae, ref_cond = import_reference()
+    _selfcheck_recording_dropouts()
+    which = set(sys.argv[1:])
+
+    def want(n):
+        return not which or n in which
+
+    if want("steps"):
+        run_case(ref_aae, ref_cond, "step_nodrop_gauss", seed=0)
+        run_case(ref_aae, ref_cond, "step_masks", seed=1, dropout=(0.2, 0.2))
+        run_case(ref_aae, ref_cond, "step_masks_uneven", seed=2, dropout=(0.1, 0.3), B=13)
+        run_case(ref_aae, ref_cond, "step_cond_concat", seed=3, cond="concat30", dropout=(0.2, 0.2))
+        run_case(ref_aae, ref_cond, "step_cond_categorical", seed=4, cond="categorical")
+        run_case(ref_aae, ref_cond, "step_cond_concat_bias", seed=12, cond="concat30+bias")
+        run_case(ref_aae, ref_cond, "step_selu", seed=5, activation="SELU", dropout=(0.2, 0.2))
+        run_case(ref_aae, ref_cond, "step_categorical_prior", seed=6, prior="categorical")
+        run_case(ref_aae, ref_cond, "step_bernoulli_prior", seed=7, prior="bernoulli")
+        run_case(ref_aae, ref_cond, "step_prior_scale", seed=8, prior_scale=2.0)
+        run_case(ref_aae, ref_cond, "step_sgd", seed=9, optimizer="sgd", gen_lr=0.05, reg_lr=0.02)
+        run_case(ref_aae, ref_cond, "step_nonorm", seed=10, normalize_inputs=False)
+        run_case(ref_aae, ref_cond, "step_ragged", seed=11, dropout=(0.2, 0.2),
+                 batch_kw=dict(empty_row=5, max_len=12), last_B=5)
+        run_case(ref_aae, ref_cond, "step_tanh", seed=13, activation="Tanh", dropout=(0.2, 0.2))
+        run_case(ref_aae, ref_cond, "step_lrs", seed=14, gen_lr=0.01, reg_lr=0.0005, steps=5,
+                 dropout=(0.2, 0.2))
+        # one wider case so multi-tile kernel paths are pinned too
+        run_case(ref_aae, ref_cond, "step_wide", seed=15, N=1100, h=72, c=24, B=40, steps=2,
+                 dropout=(0.2, 0.2), batch_kw=dict(max_len=20), capture_acts=False, states='last')
+    if want("metrics"):
+        gen_metric_known_answers()
+    if want("e2e"):
+        gen_e2e_c1(ref_aae)
+
+
+if __name__ == "__main__":
+    main()
