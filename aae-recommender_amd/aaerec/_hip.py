@@ -1,0 +1,400 @@
+"""ctypes binding of libaaerec_hip.so (C ABI: include/aaerec_hip.h).
+
+PyTorch is used for plumbing only: it owns the HBM arena (one uint8 tensor), gives the
+current HIP stream and lets parameter / gradient views be handed to torch.distributed
+(RCCL).  All arithmetic of the AAE step runs in the hand-written gfx950 kernels.
+
+There is NO CPU fallback: importing this module without the built library, or creating a
+model without a GPU, raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # must be imported before the library so both share one HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaaerec_hip.so")
+
+ABI_VERSION = 1
+ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5}
+FINALS = {"linear": 0, "softmax": 1, "sigmoid": 2}
+OPTIMIZERS = {"adam": 0, "sgd": 1}
+PRIORS = {"gauss": 0, "categorical": 1, "bernoulli": 2}
+RNG_INJECT, RNG_DEVICE = 0, 1
+GRAD_FUSED, GRAD_EXPORT = 0, 1
+
+# tensor ids (aaerec_hip.h)
+T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3 = range(10)
+T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, T_GRAD = 16, 32, 48, 64, 80
+T_ACT_Z, T_ACT_LOSSES, T_ACT_A1 = 96, 97, 98
+O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
+
+
+class AaeConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("n_items", C.c_int32), ("n_hidden", C.c_int32),
+                ("n_code", C.c_int32), ("cond_inc", C.c_int32), ("max_batch", C.c_int32),
+                ("max_nnz", C.c_int32), ("activation", C.c_int32), ("enc_final", C.c_int32),
+                ("optimizer", C.c_int32), ("normalize_inputs", C.c_int32), ("rng_mode", C.c_int32),
+                ("prior", C.c_int32), ("grad_mode", C.c_int32), ("dropout1", C.c_float),
+                ("dropout2", C.c_float), ("gen_lr", C.c_float), ("reg_lr", C.c_float),
+                ("prior_scale", C.c_float), ("has_prior_scale", C.c_int32), ("seed", C.c_uint64),
+                ("reserved", C.c_int32 * 8)]
+
+
+class AaeBatch(C.Structure):
+    _fields_ = [("indptr_dev", C.c_void_p), ("indices_dev", C.c_void_p), ("values_dev", C.c_void_p),
+                ("rows_dev", C.c_void_p), ("row_start", C.c_int32), ("n_rows", C.c_int32),
+                ("nnz_bound", C.c_int32)]
+
+
+class AaeRngInject(C.Structure):
+    _fields_ = [("masks_dev", C.c_void_p * 12), ("z_real_dev", C.c_void_p)]
+
+
+class AaeTensor(C.Structure):
+    _fields_ = [("byte_offset", C.c_size_t), ("rows", C.c_int64), ("cols", C.c_int64), ("ld", C.c_int64)]
+
+
+_PROTOS = {
+    "aae_abi_version": (C.c_int, []),
+    "aae_last_error": (C.c_char_p, []),
+    "aae_arena_bytes": (C.c_int, [C.POINTER(AaeConfig), C.POINTER(C.c_size_t)]),
+    "aae_create": (C.c_int, [C.POINTER(AaeConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "aae_destroy": (C.c_int, [C.c_void_p]),
+    "aae_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AaeTensor)]),
+    "aae_set_lr": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "aae_load_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aae_store_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aae_load_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "aae_store_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "aae_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_ae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
+    "aae_ae_decode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
+    "aae_ae_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_disc_gen": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_disc_step": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_gen_step": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_read_losses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.c_void_p]),
+    "aae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
+    "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
+}
+
+_lib = None
+
+
+class AaeHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the library and bind every symbol of the header.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the AAE step.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.aae_abi_version() != ABI_VERSION:
+        raise ImportError("libaaerec_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise AaeHipError(f"libaaerec_hip error {rc}: {load_library().aae_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class DeviceCSR:
+    """A CSR matrix resident in HBM (int64 indptr, int32 indices, float32 values)."""
+
+    def __init__(self, X, device):
+        X = X.tocsr()
+        X.sum_duplicates()
+        self.shape = X.shape
+        self.nnz_per_row_max = int(np.diff(X.indptr).max()) if X.shape[0] else 0
+        self.indptr = torch.as_tensor(X.indptr.astype(np.int64), device=device)
+        self.indices = torch.as_tensor(X.indices.astype(np.int32), device=device)
+        self.values = torch.as_tensor(X.data.astype(np.float32), device=device)
+
+    @classmethod
+    def from_arrays(cls, indptr, indices, values, n_cols, device):
+        self = cls.__new__(cls)
+        self.shape = (len(indptr) - 1, n_cols)
+        self.nnz_per_row_max = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
+        self.indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64), device=device)
+        self.indices = torch.as_tensor(np.asarray(indices, dtype=np.int32), device=device)
+        self.values = torch.as_tensor(np.asarray(values, dtype=np.float32), device=device)
+        return self
+
+
+# state_dict key <-> (net, layer)
+_NETS = {"enc": 0, "dec": 1, "disc": 2}
+_PARAM_ID = {("enc", 1): T_ENC_W1T, ("enc", 2): T_ENC_W2, ("enc", 3): T_ENC_W3,
+             ("dec", 1): T_DEC_V1, ("dec", 2): T_DEC_V2, ("dec", 3): T_DEC_V3,
+             ("disc", 1): T_DISC_D1, ("disc", 2): T_DISC_D2, ("disc", 3): T_DISC_D3}
+
+
+class HipAAE:
+    """One model replica on one GPU: owns the arena and the C handle."""
+
+    def __init__(self, n_items, n_hidden, n_code, cond_inc=0, max_batch=100, max_nnz=None,
+                 activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
+                 normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
+                 rng_mode="device", seed=0, grad_mode="fused", device=None):
+        lib = load_library()
+        if not torch.cuda.is_available():
+            raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
+        if activation not in ACTIVATIONS:
+            raise ValueError(f"activation {activation!r} has no gfx950 kernel (supported: {sorted(ACTIVATIONS)})")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.lib = lib
+        cfg = AaeConfig()
+        cfg.abi_version = ABI_VERSION
+        cfg.n_items, cfg.n_hidden, cfg.n_code, cfg.cond_inc = n_items, n_hidden, n_code, cond_inc
+        cfg.max_batch = max_batch
+        cfg.max_nnz = int(max_nnz if max_nnz is not None else min(2 ** 31 - 1, max_batch * n_items))
+        cfg.activation = ACTIVATIONS[activation]
+        cfg.enc_final = FINALS[{"gauss": "linear", "categorical": "softmax", "bernoulli": "sigmoid"}[prior]]
+        cfg.optimizer = OPTIMIZERS[optimizer]
+        cfg.normalize_inputs = int(bool(normalize_inputs))
+        cfg.rng_mode = RNG_DEVICE if rng_mode == "device" else RNG_INJECT
+        cfg.prior = PRIORS[prior]
+        cfg.grad_mode = GRAD_EXPORT if grad_mode == "export" else GRAD_FUSED
+        cfg.dropout1, cfg.dropout2 = float(dropout[0]), float(dropout[1])
+        cfg.gen_lr, cfg.reg_lr = float(gen_lr), float(reg_lr)
+        cfg.has_prior_scale = int(prior_scale is not None)
+        cfg.prior_scale = float(prior_scale) if prior_scale is not None else 1.0
+        cfg.seed = int(seed) & (2 ** 64 - 1)
+        self.cfg = cfg
+        self.N, self.h, self.c, self.cond_inc = n_items, n_hidden, n_code, cond_inc
+        self.max_batch = max_batch
+        nbytes = C.c_size_t()
+        _check(lib.aae_arena_bytes(C.byref(cfg), C.byref(nbytes)))
+        with torch.cuda.device(self.device):
+            self.arena = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            assert self.arena.data_ptr() % 256 == 0
+            h = C.c_void_p()
+            _check(lib.aae_create(C.byref(cfg), C.c_void_p(self.arena.data_ptr()), nbytes.value, self._stream(),
+                                  C.byref(h)))
+        self.handle = h
+        _check(lib.aae_set_lr(self.handle, float(gen_lr), float(reg_lr)))
+        self._keep = []   # device buffers of the running step
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.aae_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- views into the arena ---------------------------------------------------------
+    def tensor(self, tid, padded=False):
+        """float32 view [rows, cols] (strided by ld) of a tensor of the model."""
+        info = AaeTensor()
+        _check(self.lib.aae_tensor_info(self.handle, tid, C.byref(info)))
+        flat = self.arena[info.byte_offset: info.byte_offset + info.rows * info.ld * 4].view(torch.float32)
+        full = flat.view(info.rows, info.ld)
+        return full if padded else full[:, :info.cols]
+
+    # ---- state_dict in the reference layout ------------------------------------------
+    def load_params(self, params):
+        """params: {'enc.lin1.weight': ndarray [out,in], 'enc.lin1.bias': ...} (any subset of layers,
+        weight and bias together)."""
+        for (net, layer), tid in _PARAM_ID.items():
+            wk, bk = f"{net}.lin{layer}.weight", f"{net}.lin{layer}.bias"
+            if wk not in params:
+                continue
+            w = torch.as_tensor(np.asarray(params[wk], dtype=np.float32), device=self.device)
+            b = torch.as_tensor(np.asarray(params[bk], dtype=np.float32), device=self.device)
+            self._put(tid, w, b)
+        torch.cuda.synchronize(self.device)
+
+    def _put(self, tid, w, b, tid_b1=T_ENC_B1):
+        if self._is_w1t(tid):
+            self.tensor(tid).copy_(w.t())
+            self.tensor(tid_b1)[0].copy_(b)
+        else:
+            t = self.tensor(tid)
+            t[:, :-1].copy_(w)
+            t[:, -1].copy_(b)
+
+    @staticmethod
+    def _is_w1t(tid):
+        return tid in (T_ENC_W1T, T_ADAM_ENC, T_ADAM_ENC + 1, T_ADAM_GEN, T_ADAM_GEN + 1)
+
+    def _get(self, tid, tid_b1):
+        if self._is_w1t(tid):
+            return self.tensor(tid).t().contiguous().cpu().numpy(), self.tensor(tid_b1)[0].cpu().numpy().copy()
+        t = self.tensor(tid)
+        return t[:, :-1].contiguous().cpu().numpy(), t[:, -1].contiguous().cpu().numpy()
+
+    def state_dict(self):
+        out = {}
+        for (net, layer), tid in _PARAM_ID.items():
+            w, b = self._get(tid, T_ENC_B1)
+            out[f"{net}.lin{layer}.weight"], out[f"{net}.lin{layer}.bias"] = w, b
+        return out
+
+    def adam_state(self, which):
+        """{'lin1.weight': (m, v), ...} of optimiser `which` in 'enc','dec','gen','disc', + step."""
+        base, net, lo = {"enc": (T_ADAM_ENC, "enc", 0), "gen": (T_ADAM_GEN, "enc", 0),
+                         "dec": (T_ADAM_DEC, "dec", 0), "disc": (T_ADAM_DISC, "disc", 0)}[which]
+        out = {}
+        if net == "enc":
+            slots = {1: 0, 2: 2, 3: 3}
+            b1m, b1v = base + 2, base + 3
+        else:
+            slots = {1: 0, 2: 1, 3: 2}
+        for layer, slot in slots.items():
+            tm, tv = base + 2 * slot, base + 2 * slot + 1
+            if net == "enc" and layer == 1:
+                mw, mb = self._get(tm, b1m)
+                vw, vb = self._get(tv, b1v)
+            else:
+                mw, mb = self._get(tm, None)
+                vw, vb = self._get(tv, None)
+            out[f"lin{layer}.weight"] = (mw, vw)
+            out[f"lin{layer}.bias"] = (mb, vb)
+        step = C.c_int64()
+        oid = {"enc": O_ENC, "dec": O_DEC, "gen": O_GEN, "disc": O_DISC}[which]
+        _check(self.lib.aae_store_adam(self.handle, oid, 2, None, None, None, None, C.byref(step)))
+        out["step"] = step.value
+        return out
+
+    # ---- batches / randomness ----------------------------------------------------------
+    def _batch(self, csr, row_start, n_rows, rows=None):
+        b = AaeBatch()
+        b.indptr_dev, b.indices_dev, b.values_dev = csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr()
+        b.rows_dev = rows.data_ptr() if rows is not None else None
+        b.row_start, b.n_rows = int(row_start), int(n_rows)
+        b.nnz_bound = int(min(self.cfg.max_nnz, n_rows * max(1, csr.nnz_per_row_max)))
+        return b
+
+    def _inject(self, masks, z_real):
+        if masks is None and z_real is None:
+            return None
+        inj = AaeRngInject()
+        keep = []
+        for i in range(12):
+            mk = None if masks is None or i >= len(masks) or masks[i] is None else masks[i]
+            if mk is not None:
+                t = torch.as_tensor(np.ascontiguousarray(mk, dtype=np.uint8), device=self.device) \
+                    if not torch.is_tensor(mk) else mk.to(self.device, torch.uint8).contiguous()
+                keep.append(t)
+                inj.masks_dev[i] = t.data_ptr()
+            else:
+                inj.masks_dev[i] = None
+        if z_real is not None:
+            z = torch.as_tensor(np.ascontiguousarray(z_real, dtype=np.float32), device=self.device) \
+                if not torch.is_tensor(z_real) else z_real.to(self.device, torch.float32).contiguous()
+            keep.append(z)
+            inj.z_real_dev = z.data_ptr()
+        self._keep = keep
+        return inj
+
+    # ---- the step --------------------------------------------------------------------
+    def step(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
+        """One partial_fit without generic conditions (cond: device tensor [n_rows, cond_inc])."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        inj = self._inject(masks, z_real)
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous()
+            self._keep.append(cond)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_step(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
+                                     self._stream()))
+
+    def ae_encode(self, csr, row_start, n_rows, rows=None, masks=None, z_real=None):
+        b = self._batch(csr, row_start, n_rows, rows)
+        inj = self._inject(masks, z_real)
+        z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_ae_encode(self.handle, C.byref(b), C.byref(inj) if inj else None, _ptr(z),
+                                          self._stream()))
+        return z
+
+    def ae_decode_backward(self, zc):
+        zc = zc.detach().to(self.device, torch.float32).contiguous()
+        assert zc.shape[1] == self.c + self.cond_inc, "conditions.size_increment() mismatch"
+        dzc = torch.empty_like(zc)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_ae_decode_backward(self.handle, _ptr(zc), zc.shape[1], None, _ptr(dzc), self._stream()))
+        return dzc
+
+    def ae_encoder_backward(self, dz):
+        dz = dz.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(dz)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_ae_encoder_backward(self.handle, _ptr(dz), dz.shape[1], self._stream()))
+
+    def disc_gen(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_disc_gen(self.handle, None, self._stream()))
+
+    def disc_step(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_disc_step(self.handle, None, self._stream()))
+
+    def gen_step(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_gen_step(self.handle, None, self._stream()))
+
+    def apply_updates(self, which):
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_apply_updates(self.handle, which, self._stream()))
+
+    def set_grad_scale(self, scale):
+        _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))
+
+    def losses(self):
+        out = (C.c_float * 3)()
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_read_losses(self.handle, C.byref(out), self._stream()))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    # ---- predict ------------------------------------------------------------------------
+    def _out_buffer(self, n_rows):
+        ld = (self.N + 3) & ~3
+        return torch.empty(n_rows, ld, dtype=torch.float32, device=self.device)
+
+    def predict(self, csr, row_start, n_rows, cond=None):
+        b = self._batch(csr, row_start, n_rows)
+        out = self._out_buffer(n_rows)
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(out), out.shape[1], self._stream()))
+        return out[:, :self.N]
+
+    def encode(self, csr, row_start, n_rows):
+        b = self._batch(csr, row_start, n_rows)
+        z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_encode(self.handle, C.byref(b), _ptr(z), self._stream()))
+        return z
+
+    def decode(self, zc):
+        zc = zc.detach().to(self.device, torch.float32).contiguous()
+        out = self._out_buffer(zc.shape[0])
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_decode(self.handle, _ptr(zc), zc.shape[1], zc.shape[0], _ptr(out), out.shape[1],
+                                       self._stream()))
+        return out[:, :self.N]

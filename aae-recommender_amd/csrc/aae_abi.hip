@@ -1,0 +1,841 @@
+// libaaerec_hip.so - C ABI (include/aaerec_hip.h) and step orchestration.
+//
+// One `aae_model` = the three nets + four optimisers that AdversarialAutoEncoder.fit builds
+// (reference aaerec/aae.py:782-804), laid out in one caller-owned HBM arena:
+//
+//   parameters      item-major for the two vocabulary-sized layers (ENC_W1T [N][h], DEC_V3
+//                   [N][h+1]) so that a gathered / streamed row is one contiguous 800-byte line;
+//                   every other Linear "augmented" [out][in+1] (bias = last column) so that the
+//                   forward GEMM adds the bias and the weight-gradient GEMM yields the bias
+//                   gradient for free (activations carry a constant-1 column).
+//   optimiser state exp_avg / exp_avg_sq with the layout of their parameter, two independent
+//                   states for the encoder (enc_optim, gen_optim; aae.py:800,803).
+//   activations     fp32 [rows][ld], ld = round4(width+1).
+//
+// The step is a fixed sequence of kernel launches on one stream (no host sync, no allocation),
+// so a caller may capture it into a hipGraph.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/aaerec_hip.h"
+#include "gemm_f32.h"
+#include "kernels.h"
+
+using namespace aae;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(AAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define LAUNCHCHK(what)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) return fail(AAE_EHIP, std::string(what) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != AAE_OK) return rc_; } while (0)
+
+namespace {
+
+inline int r4(int x) { return (x + 3) & ~3; }
+
+struct Ten {
+    float* p = nullptr; size_t off = 0; int64_t rows = 0, cols = 0, ld = 0;
+    size_t floats() const { return (size_t)rows * ld; }
+};
+
+enum { P_W1T = 0, P_B1, P_W2, P_W3, P_V1, P_V2, P_V3, P_D1, P_D2, P_D3, NP };
+enum { O_ENC = 0, O_DEC = 1, O_GEN = 2, O_DISC = 3 };
+
+}  // namespace
+
+struct aae_model {
+    aae_config cfg;
+    char* base; size_t bytes;
+    int N, h, c, cp, R, R2;
+    int ldh, ldw1, ldc, ldz, ldn;
+    bool alpha_mode;
+    float grad_scale;
+    // parameters, two Adam-state sets (index 0: the owning optimiser, 1: gen_optim for enc),
+    // gradients (all in export mode, gW1T always)
+    Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
+    // activations
+    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gzc, ga3, zin, xh1, xh2, dout, zsave;
+    int max_slabs;
+    float* bce_partials; int bce_partials_cap;
+    float* fix_partials;
+    float* losses;
+    OptScalars* sc;          // [4]
+    long long* step_ctr;
+    // state of the running step
+    BatchView bv; bool have_batch; int rows; int phase;
+    aae_rng_inject inj;      // randomness of the running step (inject mode)
+};
+
+namespace {
+
+struct Arena {
+    char* base; size_t off = 0; bool dry;
+    float* take(size_t nfloats, size_t* off_out) {
+        off = (off + 255) & ~(size_t)255;
+        size_t o = off; off += nfloats * sizeof(float);
+        if (off_out) *off_out = o;
+        return dry ? nullptr : reinterpret_cast<float*>(base + o);
+    }
+    Ten mat(int64_t rows, int64_t cols, int64_t ld) {
+        Ten t; t.rows = rows; t.cols = cols; t.ld = ld;
+        t.p = take((size_t)rows * ld, &t.off);
+        return t;
+    }
+};
+
+int validate(const aae_config* c) {
+    if (!c) return fail(AAE_EINVAL, "cfg is NULL");
+    if (c->abi_version != AAE_ABI_VERSION) return fail(AAE_EINVAL, "abi_version mismatch");
+    if (c->n_items < 1 || c->n_hidden < 1 || c->n_code < 1 || c->cond_inc < 0)
+        return fail(AAE_EINVAL, "n_items/n_hidden/n_code must be positive");
+    if (c->n_hidden > 4096) return fail(AAE_EINVAL, "n_hidden > 4096 not supported");
+    if (c->max_batch < 1 || c->max_nnz < 1) return fail(AAE_EINVAL, "max_batch/max_nnz must be positive");
+    if (c->max_batch > 16384) return fail(AAE_EINVAL, "max_batch > 16384 not supported");
+    if (c->activation < 0 || c->activation > AAE_ACT_LEAKYRELU) return fail(AAE_EINVAL, "unknown activation");
+    if (c->enc_final < 0 || c->enc_final > AAE_FINAL_SIGMOID) return fail(AAE_EINVAL, "unknown enc_final");
+    if (c->optimizer != AAE_OPT_ADAM && c->optimizer != AAE_OPT_SGD) return fail(AAE_EINVAL, "unknown optimizer");
+    if (c->rng_mode != AAE_RNG_INJECT && c->rng_mode != AAE_RNG_DEVICE) return fail(AAE_EINVAL, "unknown rng_mode");
+    if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
+    if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
+        return fail(AAE_EINVAL, "dropout must be in [0,1)");
+    for (int i = 0; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    return AAE_OK;
+}
+
+// lays the model out; with dry=true only measures
+size_t layout(aae_model* m, char* base, bool dry) {
+    const aae_config& c = m->cfg;
+    m->N = c.n_items; m->h = c.n_hidden; m->c = c.n_code; m->cp = c.n_code + c.cond_inc;
+    m->R = c.max_batch; m->R2 = 2 * c.max_batch;
+    m->ldh = r4(m->h + 1); m->ldw1 = r4(m->h); m->ldc = r4(m->cp + 1); m->ldz = r4(m->c + 1); m->ldn = r4(m->N);
+    Arena a{base, 0, dry};
+    const int N = m->N, h = m->h, cc = m->c, cp = m->cp;
+    m->P[P_W1T] = a.mat(N, h, m->ldw1);
+    m->P[P_B1] = a.mat(1, h, m->ldw1);
+    m->P[P_W2] = a.mat(h, h + 1, m->ldh);
+    m->P[P_W3] = a.mat(cc, h + 1, m->ldh);
+    m->P[P_V1] = a.mat(h, cp + 1, m->ldc);
+    m->P[P_V2] = a.mat(h, h + 1, m->ldh);
+    m->P[P_V3] = a.mat(N, h + 1, m->ldh);
+    m->P[P_D1] = a.mat(h, cc + 1, m->ldz);
+    m->P[P_D2] = a.mat(h, h + 1, m->ldh);
+    m->P[P_D3] = a.mat(1, h + 1, m->ldh);
+    for (int i = 0; i < NP; ++i) {
+        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+    }
+    for (int i = P_W1T; i <= P_W3; ++i) {
+        m->M[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+        m->V[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+    }
+    m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
+    if (c.grad_mode == AAE_GRAD_EXPORT)
+        for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+    const int R = m->R, R2 = m->R2;
+    m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
+    m->zc = a.mat(R, cp + 1, m->ldc);
+    m->dh1 = a.mat(R, h + 1, m->ldh); m->dh2 = a.mat(R, h + 1, m->ldh);
+    m->G = a.mat(R, N, m->ldn);
+    // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
+    {
+        int tiles = ((R + 63) / 64) * ((h + 63) / 64);
+        m->max_slabs = std::max(1, std::min(128, 512 / tiles));
+        m->slabs = a.mat((int64_t)m->max_slabs * R, h, m->ldh);
+    }
+    m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
+    m->gzc = a.mat(R, cp + 1, m->ldc);
+    m->ga3 = a.mat(R2, cc + 1, m->ldz);
+    m->zin = a.mat(R2, cc + 1, m->ldz);
+    m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
+    m->dout = a.mat(R2, 1, 4);
+    m->zsave = a.mat(R, cc, m->ldz);
+    m->bce_partials_cap = ((N + 63) / 64) * ((R + 63) / 64);
+    m->bce_partials = a.take(m->bce_partials_cap, nullptr);
+    m->fix_partials = a.take(R, nullptr);
+    m->losses = a.take(4, nullptr);
+    m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
+    m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
+    return (a.off + 255) & ~(size_t)255;
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+DropSpec make_drop(const aae_model* m, int layer, bool train, const uint8_t* ma, const uint8_t* mb, int split,
+                   int width, uint32_t stream_id) {
+    DropSpec d; memset(&d, 0, sizeof(d));
+    float p = layer == 0 ? m->cfg.dropout1 : m->cfg.dropout2;
+    d.enabled = (train && p > 0.f) ? 1 : 0;
+    if (!d.enabled) return d;
+    d.mask_a = ma; d.mask_b = mb; d.split_row = split; d.width = width;
+    d.device_rng = m->cfg.rng_mode == AAE_RNG_DEVICE;
+    d.keep_threshold = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
+    d.stream_id = stream_id;
+    if (m->alpha_mode) {
+        const double alpha = 1.7580993408473766;
+        double a = 1.0 / sqrt((alpha * alpha * p + 1.0) * (1.0 - p));
+        d.mul_keep = (float)a;
+        d.add_keep = (float)(alpha * a * p);
+        d.add_drop = (float)(-alpha * a) + (float)(alpha * a * p);
+    } else {
+        d.mul_keep = 1.0f / (1.0f - p);
+        d.add_keep = 0.f; d.add_drop = 0.f;
+    }
+    if (!d.device_rng && !ma && !mb) d.enabled = 0;   // inject mode without masks: identity
+    return d;
+}
+
+inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 2048); }
+
+// ------------------------------------------------------------------------------------------
+// GEMM wrappers (see gemm_f32.h for operand forms)
+// ------------------------------------------------------------------------------------------
+// Y[rows][out] = epi( X[rows][in+1] * Wa[out][in+1]^T )
+template <class Epi>
+int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s) {
+    GemmShape g{X, Wa.p, rows, (int)Wa.rows, (int)Wa.cols, ldx, (int)Wa.ld, r4((int)Wa.cols) + 16};
+    g.k_per_split = ((int)Wa.cols + 15) / 16 * 16;
+    (void)launch_gemm<0, 1>(g, epi, 1, s);
+    LAUNCHCHK("linear_fwd");
+    return AAE_OK;
+}
+// dX[rows][n_in] = epi( Gd[rows][out] * Wa[out][0:n_in] )
+template <class Epi>
+int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s) {
+    GemmShape g{Gd, Wa.p, rows, n_in, (int)Wa.rows, ldg, (int)Wa.ld, 0};
+    g.k_per_split = ((int)Wa.rows + 15) / 16 * 16;
+    (void)launch_gemm<0, 0>(g, epi, 1, s);
+    LAUNCHCHK("linear_dx");
+    return AAE_OK;
+}
+// dWa[out][in+1] = Gd[rows][out]^T * X[rows][in+1]  -> optimiser update (or gradient export)
+int linear_dw(aae_model* m, const float* Gd, int ldg, int rows, const float* X, int ldx, int pid, int which,
+              hipStream_t s) {
+    const Ten& W = m->P[pid];
+    GemmShape g{Gd, X, (int)W.rows, (int)W.cols, rows, ldg, ldx, 0};
+    g.k_per_split = (rows + 15) / 16 * 16;
+    if (m->cfg.grad_mode == AAE_GRAD_EXPORT) {
+        EpiStore e; e.out = m->Gr[pid].p; e.ld = (int)W.ld;
+        (void)launch_gemm<1, 0>(g, e, 1, s);
+    } else {
+        const int set = (which == O_GEN) ? 1 : 0;
+        EpiAdam e; e.p = W.p; e.m = m->M[set][pid].p; e.v = m->V[set][pid].p; e.ld = (int)W.ld; e.sc = m->sc + which;
+        (void)launch_gemm<1, 0>(g, e, 1, s);
+    }
+    LAUNCHCHK("linear_dw");
+    return AAE_OK;
+}
+
+int set_batch(aae_model* m, const aae_batch* b) {
+    if (!b || !b->indptr_dev || !b->indices_dev || !b->values_dev) return fail(AAE_EINVAL, "batch pointers are NULL");
+    if (b->n_rows < 1 || b->n_rows > m->R) return fail(AAE_EINVAL, "batch n_rows outside [1, max_batch]");
+    if (b->nnz_bound > m->cfg.max_nnz) return fail(AAE_EINVAL, "batch nnz_bound > max_nnz");
+    m->bv.indptr = b->indptr_dev; m->bv.indices = b->indices_dev; m->bv.values = b->values_dev;
+    m->bv.rows = b->rows_dev; m->bv.row_start = b->row_start; m->bv.n_rows = b->n_rows;
+    m->rows = b->n_rows; m->have_batch = true;
+    return AAE_OK;
+}
+
+// Encoder forward (aae.py:129-146) into `z_dst` [rows][ldz_dst] (first n_code columns).
+// train=false: eval mode (no dropout).  reuse_a1: skip the gather, start from m->a1.
+int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t* mk2, uint32_t sid1, uint32_t sid2,
+                    bool reuse_a1, float* z_dst, int ldz_dst, hipStream_t s) {
+    const int B = m->rows, h = m->h;
+    DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
+    DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, B, h, sid2);
+    if (!reuse_a1) {
+        size_t shm = (size_t)4 * r4(h) * sizeof(float);
+        hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
+                           m->P[P_B1].p, h, m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation,
+                           d1, m->cfg.seed, m->step_ctr);
+        LAUNCHCHK("enc_gather");
+    } else {
+        hipLaunchKernelGGL(drop_act_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->a1.p, m->eh1.p, B, h,
+                           m->ldh, m->cfg.activation, d1, m->cfg.seed, m->step_ctr);
+        LAUNCHCHK("drop_act");
+    }
+    EpiDropAct e2; e2.out = m->eh2.p; e2.ld = m->ldh; e2.act = m->cfg.activation; e2.d = d2; e2.seed = m->cfg.seed;
+    e2.step_ctr = m->step_ctr;
+    TRY(linear_fwd(m->eh1.p, m->ldh, B, m->P[P_W2], e2, s));
+    EpiStore e3; e3.out = z_dst; e3.ld = ldz_dst;
+    TRY(linear_fwd(m->eh2.p, m->ldh, B, m->P[P_W3], e3, s));
+    if (m->cfg.enc_final != AAE_FINAL_LINEAR) {
+        hipLaunchKernelGGL(final_act_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, z_dst, B, m->c, ldz_dst,
+                           m->cfg.enc_final, (float*)nullptr, 0);
+        LAUNCHCHK("final_act_fwd");
+    }
+    return AAE_OK;
+}
+
+// Encoder backward from dL/dz (gz [rows][ldgz]) + optimiser `which` (O_ENC or O_GEN) on all
+// encoder parameters.  z [rows][ldzz] is the encoder output of the matching forward.
+int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, int ldzz, const uint8_t* mk1,
+                     const uint8_t* mk2, uint32_t sid1, uint32_t sid2, int which, hipStream_t s) {
+    const int B = m->rows, h = m->h, cc = m->c;
+    DropSpec d1 = make_drop(m, 0, true, mk1, nullptr, B, h, sid1);
+    DropSpec d2 = make_drop(m, 1, true, mk2, nullptr, B, h, sid2);
+    const float* ga3 = gz; int ldga3 = ldgz;
+    if (m->cfg.enc_final != AAE_FINAL_LINEAR) {
+        hipLaunchKernelGGL(final_act_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, z, ldzz, gz, ldgz, m->ga3.p,
+                           m->ldz, B, cc, m->cfg.enc_final);
+        LAUNCHCHK("final_act_bwd");
+        ga3 = m->ga3.p; ldga3 = m->ldz;
+    }
+    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + which);
+    // lin3: dX first (needs the old weights), then dW + update
+    EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->eh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
+    b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
+    TRY(linear_dx(ga3, ldga3, B, m->P[P_W3], h, b2, s));
+    TRY(linear_dw(m, ga3, ldga3, B, m->eh2.p, m->ldh, P_W3, which, s));
+    // lin2
+    EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->eh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
+    b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s));
+    TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->eh1.p, m->ldh, P_W2, which, s));
+    // lin1: sparse scatter into gW1T, bias column sum
+    const int set = (which == O_GEN) ? 1 : 0;
+    const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
+                       m->cfg.normalize_inputs, m->Gr[P_W1T].p, m->ldw1, 0);
+    LAUNCHCHK("enc_scatter");
+    hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 255) / 256), dim3(256), 0, s, m->gb1.p, B, h, m->ldh,
+                       m->P[P_B1].p, m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr,
+                       m->sc + which);
+    LAUNCHCHK("colsum_adam");
+    if (!exportg) {
+        size_t n4 = m->P[P_W1T].floats() / 4;
+        hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
+                           m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
+        LAUNCHCHK("adam_dense W1T");
+        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h, 0,
+                           m->Gr[P_W1T].p, m->ldw1, 1);
+        LAUNCHCHK("enc_scatter zero");
+    }
+    return AAE_OK;
+}
+
+// Discriminator forward on `rows` rows of m->zin (aae.py:195-213) -> m->dout (sigmoid)
+int disc_forward(aae_model* m, int rows, const uint8_t* m1a, const uint8_t* m1b, const uint8_t* m2a,
+                 const uint8_t* m2b, int split, uint32_t sid1, uint32_t sid2, hipStream_t s) {
+    const int h = m->h;
+    DropSpec d1 = make_drop(m, 0, true, m1a, m1b, split, h, sid1);
+    DropSpec d2 = make_drop(m, 1, true, m2a, m2b, split, h, sid2);
+    EpiDropAct e1; e1.out = m->xh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
+    e1.step_ctr = m->step_ctr;
+    TRY(linear_fwd(m->zin.p, m->ldz, rows, m->P[P_D1], e1, s));
+    EpiDropAct e2 = e1; e2.out = m->xh2.p; e2.d = d2;
+    TRY(linear_fwd(m->xh1.p, m->ldh, rows, m->P[P_D2], e2, s));
+    EpiSigmoid e3; e3.out = m->dout.p; e3.ld = 4;
+    TRY(linear_fwd(m->xh2.p, m->ldh, rows, m->P[P_D3], e3, s));
+    return AAE_OK;
+}
+
+int finalize_bce_loss(aae_model* m, int nblocks, hipStream_t s) {
+    const int B = m->rows;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, nblocks, m->fix_partials, B,
+                       1.0f / ((float)B * (float)m->N), m->losses, 0);
+    LAUNCHCHK("loss_finalize");
+    return AAE_OK;
+}
+
+int decoder_hidden_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t* mk2, int rows,
+                           hipStream_t s) {
+    DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, rows, m->h, 2);
+    DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, rows, m->h, 3);
+    EpiDropAct e1; e1.out = m->dh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
+    e1.step_ctr = m->step_ctr;
+    TRY(linear_fwd(m->zc.p, m->ldc, rows, m->P[P_V1], e1, s));
+    EpiDropAct e2 = e1; e2.out = m->dh2.p; e2.d = d2;
+    TRY(linear_fwd(m->dh1.p, m->ldh, rows, m->P[P_V2], e2, s));
+    return AAE_OK;
+}
+
+int stage_zc(aae_model* m, const float* src, int64_t ld, int rows, hipStream_t s) {
+    if (src != m->zc.p) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)rows * m->cp)), dim3(256), 0, s, src, (int)ld, m->zc.p,
+                           m->ldc, rows, m->cp, 1.0f);
+        LAUNCHCHK("copy zc");
+    }
+    return AAE_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int aae_abi_version(void) { return AAE_ABI_VERSION; }
+const char* aae_last_error(void) { return g_err.c_str(); }
+
+int aae_arena_bytes(const aae_config* cfg, size_t* bytes_out) {
+    TRY(validate(cfg));
+    if (!bytes_out) return fail(AAE_EINVAL, "bytes_out is NULL");
+    aae_model tmp; memset((void*)&tmp, 0, sizeof(tmp)); tmp.cfg = *cfg;
+    *bytes_out = layout(&tmp, nullptr, true);
+    return AAE_OK;
+}
+
+int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void* stream, aae_handle* out) {
+    TRY(validate(cfg));
+    if (!arena_dev || !out) return fail(AAE_EINVAL, "arena/out is NULL");
+    if (reinterpret_cast<uintptr_t>(arena_dev) & 255) return fail(AAE_EINVAL, "arena must be 256-byte aligned");
+    aae_model* m = new aae_model();
+    memset((void*)m, 0, sizeof(*m));
+    m->cfg = *cfg;
+    size_t need = layout(m, static_cast<char*>(arena_dev), false);
+    if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
+    m->base = static_cast<char*>(arena_dev); m->bytes = need;
+    m->alpha_mode = cfg->activation == AAE_ACT_SELU;
+    m->grad_scale = 1.f;
+    hipStream_t s = S(stream);
+    hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
+    if (e != hipSuccess) { delete m; return fail(AAE_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
+    // constant-1 columns of the activation buffers that feed augmented weights
+    struct { Ten* t; int col; } ones[] = {{&m->eh1, m->h}, {&m->eh2, m->h}, {&m->zc, m->cp}, {&m->dh1, m->h},
+                                           {&m->dh2, m->h}, {&m->zin, m->c}, {&m->xh1, m->h}, {&m->xh2, m->h}};
+    for (auto& o : ones)
+        hipLaunchKernelGGL(fill_col_kernel, dim3(((int)o.t->rows + 255) / 256), dim3(256), 0, s, o.t->p, (int)o.t->ld,
+                           (int)o.t->rows, o.col, 1.0f);
+    OptScalars hs[4]; memset(hs, 0, sizeof(hs));
+    for (int i = 0; i < 4; ++i) {
+        hs[i].t = 0; hs[i].is_sgd = cfg->optimizer == AAE_OPT_SGD;
+        hs[i].lr = (i == O_ENC || i == O_DEC) ? (double)cfg->gen_lr : (double)cfg->reg_lr;
+        hs[i].neg_step_size = 0.f; hs[i].bc2_sqrt = 1.f;
+    }
+    e = hipMemcpyAsync(m->sc, hs, sizeof(hs), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { delete m; return fail(AAE_EHIP, std::string("init: ") + hipGetErrorString(e)); }
+    *out = m;
+    return AAE_OK;
+}
+
+int aae_destroy(aae_handle h) { delete h; return AAE_OK; }
+
+int aae_set_grad_scale(aae_handle h, float scale) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    h->grad_scale = scale; return AAE_OK;
+}
+
+// learning rates are float32 in aae_config; callers that need the exact Python double can set it here
+int aae_set_lr(aae_handle h, double gen_lr, double reg_lr) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    OptScalars hs[4];
+    HIPCHK(hipMemcpy(hs, h->sc, sizeof(hs), hipMemcpyDeviceToHost));
+    hs[O_ENC].lr = gen_lr; hs[O_DEC].lr = gen_lr; hs[O_GEN].lr = reg_lr; hs[O_DISC].lr = reg_lr;
+    HIPCHK(hipMemcpy(h->sc, hs, sizeof(hs), hipMemcpyHostToDevice));
+    return AAE_OK;
+}
+
+int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
+    if (!h || !out) return fail(AAE_EINVAL, "handle/out is NULL");
+    const Ten* t = nullptr;
+    Ten tmp;
+    auto adam = [&](int base, int lo, int hi, int set) -> const Ten* {
+        int k = id - base, pid = lo + k / 2;
+        if (k < 0 || pid > hi) return nullptr;
+        return (k & 1) ? &h->V[set][pid] : &h->M[set][pid];
+    };
+    if (id >= 0 && id < AAE_T_N_PARAMS) t = &h->P[id];
+    else if (id >= AAE_T_ADAM_ENC && id < AAE_T_ADAM_ENC + 8) t = adam(AAE_T_ADAM_ENC, P_W1T, P_W3, 0);
+    else if (id >= AAE_T_ADAM_GEN && id < AAE_T_ADAM_GEN + 8) t = adam(AAE_T_ADAM_GEN, P_W1T, P_W3, 1);
+    else if (id >= AAE_T_ADAM_DEC && id < AAE_T_ADAM_DEC + 6) t = adam(AAE_T_ADAM_DEC, P_V1, P_V3, 0);
+    else if (id >= AAE_T_ADAM_DISC && id < AAE_T_ADAM_DISC + 6) t = adam(AAE_T_ADAM_DISC, P_D1, P_D3, 0);
+    else if (id >= AAE_T_GRAD && id < AAE_T_GRAD + NP) { t = &h->Gr[id - AAE_T_GRAD]; if (!t->rows) t = nullptr; }
+    else if (id == AAE_T_ACT_Z) t = &h->zsave;
+    else if (id == AAE_T_ACT_A1) t = &h->a1;
+    else if (id == AAE_T_ACT_LOSSES) {
+        tmp.rows = 1; tmp.cols = 4; tmp.ld = 4; tmp.off = (size_t)((char*)h->losses - h->base); t = &tmp;
+    }
+    if (!t) return fail(AAE_EINVAL, "unknown tensor id");
+    out->byte_offset = t->off; out->rows = t->rows; out->cols = t->cols; out->ld = t->ld;
+    return AAE_OK;
+}
+
+// ---- state_dict import / export ----------------------------------------------------------
+static int param_id(int net, int layer) {
+    if (layer < 1 || layer > 3 || net < 0 || net > 2) return -1;
+    static const int tab[3][3] = {{P_W1T, P_W2, P_W3}, {P_V1, P_V2, P_V3}, {P_D1, P_D2, P_D3}};
+    return tab[net][layer - 1];
+}
+
+// host [out][in] (+ bias[out]) <-> device tensor `t` (+ bias tensor tb for enc.lin1)
+static int put_linear(aae_handle h, int pid, const Ten& t, const Ten* tb, const float* w, const float* b) {
+    std::vector<float> buf(t.floats(), 0.f);
+    if (pid == P_W1T) {   // torch [h][N] -> item-major [N][h]
+        const int N = h->N, hh = h->h;
+        if (w) for (int o = 0; o < hh; ++o) for (int i = 0; i < N; ++i) buf[(size_t)i * t.ld + o] = w[(size_t)o * N + i];
+        if (w) HIPCHK(hipMemcpy(t.p, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+        if (b && tb) {
+            std::vector<float> bb(tb->floats(), 0.f);
+            memcpy(bb.data(), b, sizeof(float) * hh);
+            HIPCHK(hipMemcpy(tb->p, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
+        }
+        return AAE_OK;
+    }
+    const int out = (int)t.rows, in = (int)t.cols - 1;
+    HIPCHK(hipMemcpy(buf.data(), t.p, buf.size() * 4, hipMemcpyDeviceToHost));
+    for (int o = 0; o < out; ++o) {
+        if (w) memcpy(&buf[(size_t)o * t.ld], &w[(size_t)o * in], sizeof(float) * in);
+        if (b) buf[(size_t)o * t.ld + in] = b[o];
+    }
+    HIPCHK(hipMemcpy(t.p, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+    return AAE_OK;
+}
+
+static int get_linear(aae_handle h, int pid, const Ten& t, const Ten* tb, float* w, float* b) {
+    std::vector<float> buf(t.floats());
+    HIPCHK(hipMemcpy(buf.data(), t.p, buf.size() * 4, hipMemcpyDeviceToHost));
+    if (pid == P_W1T) {
+        const int N = h->N, hh = h->h;
+        if (w) for (int o = 0; o < hh; ++o) for (int i = 0; i < N; ++i) w[(size_t)o * N + i] = buf[(size_t)i * t.ld + o];
+        if (b && tb) {
+            std::vector<float> bb(tb->floats());
+            HIPCHK(hipMemcpy(bb.data(), tb->p, bb.size() * 4, hipMemcpyDeviceToHost));
+            memcpy(b, bb.data(), sizeof(float) * hh);
+        }
+        return AAE_OK;
+    }
+    const int out = (int)t.rows, in = (int)t.cols - 1;
+    for (int o = 0; o < out; ++o) {
+        if (w) memcpy(&w[(size_t)o * in], &buf[(size_t)o * t.ld], sizeof(float) * in);
+        if (b) b[o] = buf[(size_t)o * t.ld + in];
+    }
+    return AAE_OK;
+}
+
+int aae_load_linear(aae_handle h, int net, int layer, const float* w, const float* b) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    int pid = param_id(net, layer);
+    if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    HIPCHK(hipDeviceSynchronize());
+    return put_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
+}
+int aae_store_linear(aae_handle h, int net, int layer, float* w, float* b) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    int pid = param_id(net, layer);
+    if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    HIPCHK(hipDeviceSynchronize());
+    return get_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
+}
+
+static int adam_sel(int which, int layer, int* pid, int* set) {
+    if (layer < 1 || layer > 3) return -1;
+    switch (which) {
+        case O_ENC: *pid = param_id(0, layer); *set = 0; return 0;
+        case O_DEC: *pid = param_id(1, layer); *set = 0; return 0;
+        case O_GEN: *pid = param_id(0, layer); *set = 1; return 0;
+        case O_DISC: *pid = param_id(2, layer); *set = 0; return 0;
+    }
+    return -1;
+}
+int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const float* v_w, const float* m_b,
+                  const float* v_b, int64_t step) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    int pid, set;
+    if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    HIPCHK(hipDeviceSynchronize());
+    const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
+    const Ten* vb = pid == P_W1T ? &h->V[set][P_B1] : nullptr;
+    TRY(put_linear(h, pid, h->M[set][pid], mb, m_w, m_b));
+    TRY(put_linear(h, pid, h->V[set][pid], vb, v_w, v_b));
+    if (step >= 0) {
+        OptScalars hs;
+        HIPCHK(hipMemcpy(&hs, h->sc + which, sizeof(hs), hipMemcpyDeviceToHost));
+        hs.t = step;
+        HIPCHK(hipMemcpy(h->sc + which, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    }
+    return AAE_OK;
+}
+int aae_store_adam(aae_handle h, int which, int layer, float* m_w, float* v_w, float* m_b, float* v_b,
+                   int64_t* step) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    int pid, set;
+    if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    HIPCHK(hipDeviceSynchronize());
+    const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
+    const Ten* vb = pid == P_W1T ? &h->V[set][P_B1] : nullptr;
+    TRY(get_linear(h, pid, h->M[set][pid], mb, m_w, m_b));
+    TRY(get_linear(h, pid, h->V[set][pid], vb, v_w, v_b));
+    if (step) {
+        OptScalars hs;
+        HIPCHK(hipMemcpy(&hs, h->sc + which, sizeof(hs), hipMemcpyDeviceToHost));
+        *step = hs.t;
+    }
+    return AAE_OK;
+}
+
+// ---- the step ----------------------------------------------------------------------------
+// The aae_rng_inject handed to a phase stays in force for the later phases of the same step;
+// its device buffers must stay valid until the step's kernels have run.
+static void remember_inject(aae_model* m, const aae_rng_inject* inj, bool reset) {
+    if (inj) m->inj = *inj;
+    else if (reset) memset(&m->inj, 0, sizeof(m->inj));
+}
+
+int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* inj, float* z_out, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    TRY(set_batch(m, batch));
+    remember_inject(m, inj, true);
+    hipStream_t s = S(stream);
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, s, m->step_ctr);
+    TRY(encoder_forward(m, true, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, false, m->zc.p, m->ldc, s));
+    // keep a copy of z for the encoder backward (condition plugins replace zc)
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
+                       m->zsave.p, m->ldz, m->rows, m->c, 1.0f);
+    if (z_out)
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
+                           z_out, m->c, m->rows, m->c, 1.0f);
+    LAUNCHCHK("ae_encode copies");
+    m->phase = 1;
+    return AAE_OK;
+}
+
+int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, const aae_rng_inject* inj,
+                           float* dzc_out, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->phase != 1) return fail(AAE_ESTATE, "aae_ae_decode_backward without aae_ae_encode");
+    remember_inject(m, inj, false);
+    hipStream_t s = S(stream);
+    const int B = m->rows, N = m->N, h = m->h, cp = m->cp;
+    if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, B, s));
+    const uint8_t* mk2 = m->inj.masks_dev[2];
+    const uint8_t* mk3 = m->inj.masks_dev[3];
+    TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
+    // output layer + BCE: G = dL/dlogits [B][N]
+    const float gscale = m->grad_scale / ((float)B * (float)N);
+    {
+        EpiBce e; e.G = m->G.p; e.ldg = m->ldn; e.gscale = gscale; e.partials = m->bce_partials;
+        TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s));
+        hipLaunchKernelGGL(bce_fixup_kernel, dim3(B), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
+                           h + 1, m->G.p, m->ldn, gscale, m->fix_partials);
+        LAUNCHCHK("bce_fixup");
+        TRY(finalize_bce_loss(m, ((N + 63) / 64) * ((B + 63) / 64), s));
+    }
+    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + O_DEC);
+    // dA2 = G * V3 (K = N items, split-K slabs), then back through act2/drop2
+    DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
+    DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
+    {
+        int tiles = ((B + 63) / 64) * ((h + 63) / 64);
+        int splits = std::max(1, std::min(m->max_slabs, 512 / tiles));
+        int kps = ((N + splits - 1) / splits + 15) / 16 * 16;
+        splits = (N + kps - 1) / kps;
+        GemmShape g{m->G.p, m->P[P_V3].p, B, h, N, m->ldn, m->ldh, kps};
+        EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
+        (void)launch_gemm<0, 0>(g, e, splits, s);
+        LAUNCHCHK("dA2 gemm");
+        hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
+                           e.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2, m->cfg.seed,
+                           m->step_ctr);
+        LAUNCHCHK("slab_reduce");
+    }
+    // dV3 = G^T * dh2 -> dec_optim on V3 (the 24 B/param streaming kernel)
+    TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
+    // lin2
+    EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
+    b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_V2], h, b1, s));
+    TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->dh1.p, m->ldh, P_V2, O_DEC, s));
+    // lin1
+    EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
+    TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_V1], cp, ez, s));
+    TRY(linear_dw(m, m->gb1.p, m->ldh, B, m->zc.p, m->ldc, P_V1, O_DEC, s));
+    if (dzc_out) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cp)), dim3(256), 0, s, m->gzc.p, m->ldc, dzc_out, cp,
+                           B, cp, 1.0f);
+        LAUNCHCHK("copy dzc");
+    }
+    m->phase = 2;
+    return AAE_OK;
+}
+
+int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->phase != 2) return fail(AAE_ESTATE, "aae_ae_encoder_backward without aae_ae_decode_backward");
+    hipStream_t s = S(stream);
+    const float* gz = dz_dev ? dz_dev : m->gzc.p;
+    int ld = dz_dev ? (int)dz_ld : m->ldc;
+    TRY(encoder_backward(m, gz, ld, m->zsave.p, m->ldz, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, O_ENC, s));
+    m->phase = 3;
+    return AAE_OK;
+}
+
+// disc_step (aae.py:713-732)
+int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->phase != 3) return fail(AAE_ESTATE, "aae_disc_step before the ae phases of the step");
+    remember_inject(m, inj, false);
+    hipStream_t s = S(stream);
+    const int B = m->rows, h = m->h, cc = m->c;
+    const aae_rng_inject& I = m->inj;
+    const float pscale = m->cfg.has_prior_scale ? m->cfg.prior_scale : 1.0f;
+    // ---- disc_step: z_real rows [0,B), z_fake = Enc_eval(X) rows [B,2B)
+    if (m->cfg.rng_mode == AAE_RNG_DEVICE) {
+        hipLaunchKernelGGL(prior_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, B, cc,
+                           m->cfg.prior, pscale, m->cfg.seed, m->step_ctr);
+    } else {
+        if (!I.z_real_dev) return fail(AAE_EINVAL, "rng_mode=inject needs z_real_dev");
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, I.z_real_dev, cc, m->zin.p,
+                           m->ldz, B, cc, pscale);
+    }
+    LAUNCHCHK("prior");
+    TRY(encoder_forward(m, false, nullptr, nullptr, 0, 0, false, m->zin.p + (size_t)B * m->ldz, m->ldz, s));
+    TRY(disc_forward(m, 2 * B, I.masks_dev[4], I.masks_dev[6], I.masks_dev[5], I.masks_dev[7], B, 4, 5, s));
+    hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, s, m->dout.p, 4, B, 0, m->grad_scale, m->ga3.p, 4,
+                       m->losses, 1);
+    LAUNCHCHK("adv_loss disc");
+    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + O_DISC);
+    {
+        DropSpec d1 = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4);
+        DropSpec d2 = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5);
+        EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->xh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
+        b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
+        TRY(linear_dx(m->ga3.p, 4, 2 * B, m->P[P_D3], h, b2, s));
+        TRY(linear_dw(m, m->ga3.p, 4, 2 * B, m->xh2.p, m->ldh, P_D3, O_DISC, s));
+        EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
+        TRY(linear_dx(m->gb0.p, m->ldh, 2 * B, m->P[P_D2], h, b1, s));
+        TRY(linear_dw(m, m->gb0.p, m->ldh, 2 * B, m->xh1.p, m->ldh, P_D2, O_DISC, s));
+        TRY(linear_dw(m, m->gb1.p, m->ldh, 2 * B, m->zin.p, m->ldz, P_D1, O_DISC, s));
+    }
+    m->phase = 4;
+    return AAE_OK;
+}
+
+// gen_step (aae.py:734-743): Enc_train(X) - layer-1 pre-activations are unchanged since the
+// disc_step forward, so m->a1 is re-used - then D on rows [0,B)
+int aae_gen_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->phase != 4) return fail(AAE_ESTATE, "aae_gen_step before aae_disc_step");
+    remember_inject(m, inj, false);
+    hipStream_t s = S(stream);
+    const int B = m->rows, h = m->h, cc = m->c;
+    const aae_rng_inject& I = m->inj;
+    TRY(encoder_forward(m, true, I.masks_dev[8], I.masks_dev[9], 8, 9, true, m->zin.p, m->ldz, s));
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, m->zsave.p,
+                       m->ldz, B, cc, 1.0f);
+    TRY(disc_forward(m, B, I.masks_dev[10], nullptr, I.masks_dev[11], nullptr, B, 10, 11, s));
+    hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, s, m->dout.p, 4, B, 1, m->grad_scale, m->ga3.p, 4,
+                       m->losses, 2);
+    LAUNCHCHK("adv_loss gen");
+    {
+        DropSpec d1 = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10);
+        DropSpec d2 = make_drop(m, 1, true, I.masks_dev[11], nullptr, B, h, 11);
+        EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->xh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
+        b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
+        TRY(linear_dx(m->ga3.p, 4, B, m->P[P_D3], h, b2, s));
+        EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
+        TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_D2], h, b1, s));
+        EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
+        TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_D1], cc, ez, s));
+    }
+    TRY(encoder_backward(m, m->gzc.p, m->ldc, m->zsave.p, m->ldz, I.masks_dev[8], I.masks_dev[9], 8, 9, O_GEN, s));
+    m->phase = 0;
+    return AAE_OK;
+}
+
+int aae_disc_gen(aae_handle m, const aae_rng_inject* inj, void* stream) {
+    TRY(aae_disc_step(m, inj, stream));
+    return aae_gen_step(m, nullptr, stream);
+}
+
+int aae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inj, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    hipStream_t s = S(stream);
+    TRY(aae_ae_encode(m, batch, inj, nullptr, stream));
+    if (m->cfg.cond_inc > 0) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->cfg.cond_inc)), dim3(256), 0, s, cond_dev,
+                           m->cfg.cond_inc, m->zc.p + m->c, m->ldc, m->rows, m->cfg.cond_inc, 1.0f);
+        LAUNCHCHK("copy cond");
+    }
+    TRY(aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream));
+    TRY(aae_ae_encoder_backward(m, nullptr, 0, stream));
+    TRY(aae_disc_gen(m, nullptr, stream));
+    return AAE_OK;
+}
+
+int aae_read_losses(aae_handle m, float out[3], void* stream) {
+    if (!m || !out) return fail(AAE_EINVAL, "handle/out is NULL");
+    float tmp[4];
+    HIPCHK(hipMemcpyAsync(tmp, m->losses, sizeof(tmp), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    out[0] = tmp[0]; out[1] = tmp[1]; out[2] = tmp[2];
+    return AAE_OK;
+}
+
+// ---- predict (aae.py:840-870) -----------------------------------------------------------
+int aae_encode(aae_handle m, const aae_batch* batch, float* z_out, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    TRY(set_batch(m, batch));
+    hipStream_t s = S(stream);
+    TRY(encoder_forward(m, false, nullptr, nullptr, 0, 0, false, m->zc.p, m->ldc, s));
+    if (z_out) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
+                           z_out, m->c, m->rows, m->c, 1.0f);
+        LAUNCHCHK("copy z");
+    }
+    m->phase = 0;
+    return AAE_OK;
+}
+
+int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows, float* out_dev, int64_t out_ld,
+               void* stream) {
+    if (!m || !out_dev) return fail(AAE_EINVAL, "handle/out is NULL");
+    if (n_rows < 1 || n_rows > m->R) return fail(AAE_EINVAL, "n_rows outside [1, max_batch]");
+    if (out_ld < m->N || (out_ld & 3) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
+        return fail(AAE_EINVAL, "out_dev must be 16-byte aligned with out_ld >= n_items and out_ld % 4 == 0");
+    hipStream_t s = S(stream);
+    if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, n_rows, s));
+    TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
+    EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
+    TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s));
+    return AAE_OK;
+}
+
+int aae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev, float* out_dev, int64_t out_ld,
+                void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    TRY(aae_encode(m, batch, nullptr, stream));
+    if (m->cfg.cond_inc > 0) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->cfg.cond_inc)), dim3(256), 0, S(stream),
+                           cond_dev, m->cfg.cond_inc, m->zc.p + m->c, m->ldc, m->rows, m->cfg.cond_inc, 1.0f);
+        LAUNCHCHK("copy cond");
+    }
+    return aae_decode(m, nullptr, 0, m->rows, out_dev, out_ld, stream);
+}
+
+// ---- data parallel: optimiser step on all-reduced gradients ------------------------------
+int aae_apply_updates(aae_handle m, int which, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_apply_updates needs grad_mode=export");
+    if (which < 0 || which > 3) return fail(AAE_EINVAL, "bad optimiser id");
+    hipStream_t s = S(stream);
+    int lo = which == O_DEC ? P_V1 : which == O_DISC ? P_D1 : P_W1T;
+    int hi = which == O_DEC ? P_V3 : which == O_DISC ? P_D3 : P_W3;
+    const int set = which == O_GEN ? 1 : 0;
+    for (int pid = lo; pid <= hi; ++pid) {
+        size_t n4 = m->P[pid].floats() / 4;
+        hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[pid].p, m->M[set][pid].p,
+                           m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, pid == P_W1T ? 1 : 0);
+        LAUNCHCHK("adam_dense");
+    }
+    return AAE_OK;
+}
+
+}  // extern "C"

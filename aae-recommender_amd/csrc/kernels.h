@@ -1,0 +1,334 @@
+// The non-GEMM kernels of the AAE step (gfx950).  All are HBM/latency-bound row or element
+// kernels: coalesced float4 row segments, one wave (64 lanes) per gathered row, LDS partial sums.
+#pragma once
+#include "device_common.h"
+#include "gemm_f32.h"
+
+namespace aae {
+
+struct BatchView {
+    const int64_t* indptr; const int32_t* indices; const float* values;
+    const int32_t* rows; int row_start; int n_rows;
+    __device__ __forceinline__ int doc(int b) const { return rows ? rows[b] : row_start + b; }
+};
+
+// ---------------------------------------------------------------------------------------
+// K2+K3 (+K4): sparse multi-hot -> first encoder Linear.  reference: F.normalize(inp, 1) +
+// enc.lin1 (+ drop1, act1), aae.py:132-137.
+//   a1[b,:] = b1 + sum_{e in row b} (v_e * s_b) * W1T[idx_e, :],  s_b = 1/max(sum|v|, 1e-12)
+// One workgroup per document; its 4 waves take every 4th entry, each lane a float4 of the
+// 800-byte (h=200) weight row, partial sums meet in LDS.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const float* __restrict__ W1T, int ldw,
+                                                         const float* __restrict__ b1, int h, int normalize,
+                                                         float* __restrict__ a1, float* __restrict__ y, int ld,
+                                                         int act, DropSpec d, uint64_t seed, const long long* step_ctr) {
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [4][hp]
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hp = (h + 3) & ~3;
+    const int dc = bv.doc(b);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    float s = 1.f;
+    if (normalize) {
+        float l1 = 0.f;
+        for (int64_t e = lo + tid; e < hi; e += 256) l1 += fabsf(bv.values[e]);
+        l1 = wave_sum(l1);
+        if (lane == 0) red[wave] = l1;
+        __syncthreads();
+        l1 = (red[0] + red[1]) + (red[2] + red[3]);
+        s = 1.f / fmaxf(l1, 1e-12f);
+    }
+    for (int c0 = lane * 4; c0 < hp; c0 += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = lo + wave; e < hi; e += 4) {
+            const int idx = bv.indices[e];
+            float x = bv.values[e];
+            if (normalize) x *= s;
+            const float4 w = *reinterpret_cast<const float4*>(W1T + (size_t)idx * ldw + c0);
+            acc.x += x * w.x; acc.y += x * w.y; acc.z += x * w.z; acc.w += x * w.w;
+        }
+        *reinterpret_cast<float4*>(&part[wave * hp + c0]) = acc;
+    }
+    __syncthreads();
+    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
+    for (int c = tid; c < h; c += 256) {
+        float v = ((part[c] + part[hp + c]) + (part[2 * hp + c] + part[3 * hp + c])) + b1[c];
+        a1[(size_t)b * ld + c] = v;
+        if (y) {
+            if (d.enabled) v = drop_fwd(d, drop_keep(d, key, b, c), v);
+            y[(size_t)b * ld + c] = act_fwd(act, v);
+        }
+    }
+}
+
+// y = act(dropout(a))  elementwise over [rows][h]  (gen_step re-uses disc_step's a1)
+__global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__ y, int rows, int h, int ld,
+                                int act, DropSpec d, uint64_t seed, const long long* step_ctr) {
+    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * h; i += gridDim.x * blockDim.x) {
+        int r = i / h, c = i - r * h;
+        float v = a[(size_t)r * ld + c];
+        if (d.enabled) v = drop_fwd(d, drop_keep(d, key, r, c), v);
+        y[(size_t)r * ld + c] = act_fwd(act, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K9: backward of the sparse first layer.  gW1T[idx_e, :] += (v_e * s_b) * ga1[b, :].
+// One wave per entry, each atomic wave-instruction adds 256 contiguous bytes (the shape the
+// memory-side float atomics run at full rate for).  zero != 0: store zeros instead (resets the
+// touched rows after the optimiser consumed them).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
+                                                          int h, int normalize, float* __restrict__ gW1T, int ldw,
+                                                          int zero) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dc = bv.doc(b);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    float s = 1.f;
+    if (normalize && !zero) {
+        float l1 = 0.f;
+        for (int64_t e = lo + tid; e < hi; e += 256) l1 += fabsf(bv.values[e]);
+        l1 = wave_sum(l1);
+        if (lane == 0) red[wave] = l1;
+        __syncthreads();
+        l1 = (red[0] + red[1]) + (red[2] + red[3]);
+        s = 1.f / fmaxf(l1, 1e-12f);
+    }
+    for (int64_t e = lo + wave; e < hi; e += 4) {
+        const int idx = bv.indices[e];
+        float x = bv.values[e];
+        if (normalize) x *= s;
+        float* dst = gW1T + (size_t)idx * ldw;
+        for (int c = lane; c < h; c += 64) {
+            if (zero) dst[c] = 0.f;
+            else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
+        }
+    }
+}
+
+// dense torch.optim.Adam/SGD over a flat tensor with a materialised gradient (K10)
+__global__ void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                  float* __restrict__ g, size_t n4, const OptScalars* sc, int zero_g) {
+    const OptScalars s = *sc;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = make_float4(0, 0, 0, 0), vv = mm;
+        if (!s.is_sgd) { mm = reinterpret_cast<float4*>(m)[i]; vv = reinterpret_cast<float4*>(v)[i]; }
+        adam_update(pp.x, mm.x, vv.x, gg.x, s); adam_update(pp.y, mm.y, vv.y, gg.y, s);
+        adam_update(pp.z, mm.z, vv.z, gg.z, s); adam_update(pp.w, mm.w, vv.w, gg.w, s);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        if (!s.is_sgd) { reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv; }
+        if (zero_g) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// bias gradient of the first encoder layer: db1[c] = sum_b ga1[b][c], then its optimiser
+// update (or export).  One thread per column.
+__global__ void colsum_adam_kernel(const float* __restrict__ ga, int rows, int h, int ld, float* p, float* m,
+                                   float* v, float* gout, const OptScalars* sc) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= h) return;
+    float g = 0.f;
+    for (int r = 0; r < rows; ++r) g += ga[(size_t)r * ld + c];
+    if (gout) { gout[c] = g; return; }
+    const OptScalars s = *sc;
+    float pp = p[c], mm = s.is_sgd ? 0.f : m[c], vv = s.is_sgd ? 0.f : v[c];
+    adam_update(pp, mm, vv, g, s);
+    p[c] = pp;
+    if (!s.is_sgd) { m[c] = mm; v[c] = vv; }
+}
+
+// ---------------------------------------------------------------------------------------
+// BCE fix-up for the non-zero targets (the GEMM epilogue assumed target 0 everywhere):
+// one wave per CSR entry recomputes that logit as a 201-long dot product, rewrites dL/dlogit
+// and emits the loss difference.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fixup_kernel(BatchView bv, const float* __restrict__ hdec, int ldh,
+                                                        const float* __restrict__ V3a, int ldv, int kdim,
+                                                        float* __restrict__ G, int ldg, float gscale,
+                                                        float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dc = bv.doc(b);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    float dl = 0.f;
+    for (int64_t e = lo + wave; e < hi; e += 4) {
+        const int n = bv.indices[e];
+        float acc = 0.f;
+        for (int k = lane; k < kdim; k += 64) acc += hdec[(size_t)b * ldh + k] * V3a[(size_t)n * ldv + k];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float g0, l0, g1, l1;
+            bce_elem(acc, 0.f, gscale, g0, l0);
+            bce_elem(acc, bv.values[e], gscale, g1, l1);
+            G[(size_t)b * ldg + n] = g1;
+            dl += l1 - l0;
+        }
+    }
+    if (lane == 0) red[wave] = dl;
+    __syncthreads();
+    if (tid == 0) partials[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out = (sum_z slab[z]) * act'(y) * dropout_scale      (consumer of the split-K dA2 GEMM)
+__global__ void slab_reduce_actbwd_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                          int rows, int h, int ld, const float* __restrict__ y, int ldy,
+                                          float* __restrict__ out, int act, DropSpec d, uint64_t seed,
+                                          const long long* step_ctr) {
+    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * h; i += gridDim.x * blockDim.x) {
+        int r = i / h, c = i - r * h;
+        float acc = 0.f;
+        for (int z = 0; z < nslab; ++z) acc += slabs[(size_t)z * slab_stride + (size_t)r * ld + c];
+        acc *= act_grad_from_y(act, y[(size_t)r * ldy + c]);
+        if (d.enabled) acc *= drop_bwd_mul(d, drop_keep(d, key, r, c));
+        out[(size_t)r * ld + c] = acc;
+    }
+}
+
+// losses[slot] = scale * sum(partials[0..n))  in a fixed order (deterministic), one workgroup
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ pa, int na,
+                                                            const float* __restrict__ pb, int nb, float scale,
+                                                            float* losses, int slot) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < na; i += 256) acc += (double)pa[i];
+    for (int i = threadIdx.x; i < nb; i += 256) acc += (double)pb[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) losses[slot] = (float)(red[0] * (double)scale);
+}
+
+// ---------------------------------------------------------------------------------------
+// encoder output activation (PRIOR_ACTIVATIONS, aae.py:97-101): rows of width c, in place.
+// One wave per row.  fwd: z = softmax(a) | sigmoid(a) | a.   bwd: ga from gz and z.
+// ---------------------------------------------------------------------------------------
+__global__ void final_act_fwd_kernel(float* __restrict__ z, int rows, int c, int ld, int kind,
+                                     float* __restrict__ copy_out, int ld_copy) {
+    int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float* zr = z + (size_t)r * ld;
+    if (kind == 1) {
+        float mx = -INFINITY;
+        for (int j = lane; j < c; j += 64) mx = fmaxf(mx, zr[j]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int j = lane; j < c; j += 64) sum += expf(zr[j] - mx);
+        sum = wave_sum(sum);
+        for (int j = lane; j < c; j += 64) zr[j] = expf(zr[j] - mx) / sum;
+    } else if (kind == 2) {
+        for (int j = lane; j < c; j += 64) zr[j] = sigmoidf_(zr[j]);
+    }
+    if (copy_out)
+        for (int j = lane; j < c; j += 64) copy_out[(size_t)r * ld_copy + j] = zr[j];
+}
+
+__global__ void final_act_bwd_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gz, int ldg,
+                                     float* __restrict__ ga, int lda, int rows, int c, int kind) {
+    int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* zr = z + (size_t)r * ldz;
+    const float* gr = gz + (size_t)r * ldg;
+    float* o = ga + (size_t)r * lda;
+    if (kind == 1) {
+        float dot = 0.f;
+        for (int j = lane; j < c; j += 64) dot += gr[j] * zr[j];
+        dot = wave_sum(dot);
+        for (int j = lane; j < c; j += 64) o[j] = zr[j] * (gr[j] - dot);
+    } else if (kind == 2) {
+        for (int j = lane; j < c; j += 64) o[j] = gr[j] * zr[j] * (1.f - zr[j]);
+    } else {
+        for (int j = lane; j < c; j += 64) o[j] = gr[j];
+    }
+}
+
+// strided 2-D copy: dst[r][c] = src[r][c] * scale
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows,
+                              int cols, float scale) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+        int r = i / cols, c = i - r * cols;
+        dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c] * scale;
+    }
+}
+
+__global__ void fill_col_kernel(float* dst, int ld, int rows, int col, float v) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) dst[(size_t)r * ld + col] = v;
+}
+
+// z_real ~ prior (PRIOR_SAMPLERS, aae.py:78-94) from the counter generator, times prior_scale
+__global__ void prior_kernel(float* __restrict__ z, int ld, int rows, int c, int prior, float scale, uint64_t seed,
+                             const long long* step_ctr) {
+    const uint64_t key = rng_key(seed, (uint64_t)*step_ctr, 100);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * c; i += gridDim.x * blockDim.x) {
+        int r = i / c, j = i - r * c;
+        float v = 0.f;
+        if (prior == 0) {   // gauss: Box-Muller
+            uint32_t u1 = hash_u32(key, ((uint64_t)r << 32) | (uint32_t)(2 * j));
+            uint32_t u2 = hash_u32(key, ((uint64_t)r << 32) | (uint32_t)(2 * j + 1));
+            float f1 = ((float)u1 + 1.f) * 2.3283064365386963e-10f;   // (0,1]
+            float f2 = (float)u2 * 2.3283064365386963e-10f;
+            v = sqrtf(-2.f * logf(f1)) * cosf(6.283185307179586f * f2);
+        } else if (prior == 1) {   // categorical: one-hot of a uniform class per row
+            uint32_t u = hash_u32(key, ((uint64_t)r << 32) | 0xFFFFFFFFu);
+            v = ((int)(u % (uint32_t)c) == j) ? 1.f : 0.f;
+        }                     // bernoulli: the reference's randint(0,1) is always 0 (aae.py:86-88)
+        z[(size_t)r * ld + j] = v * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// adversarial losses on the discriminator outputs (aae.py:726-727, 738) and their gradients
+// w.r.t. the discriminator's last pre-activation.  Single workgroup, B <= a few thousand.
+//   mode 0 (disc_step): rows [0,B) real, [B,2B) fake
+//       D = -mean(log(dr+T) + log(1-df+T));  g_r = -1/B/(dr+T)*dr(1-dr);  g_f = +1/B/(1-df+T)*df(1-df)
+//   mode 1 (gen_step): rows [0,B) fake
+//       G = -mean(log(df+T));                g   = -1/B/(df+T)*df(1-df)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adv_loss_kernel(const float* __restrict__ dout, int ldo, int B, int mode,
+                                                       float gscale, float* __restrict__ ga, int lda,
+                                                       float* losses, int slot) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    const float invB = 1.f / (float)B;
+    const int rows = mode == 0 ? 2 * B : B;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        float dv = dout[(size_t)r * ldo];
+        float g, l;
+        if (mode == 0 && r >= B) { l = logf(1.f - dv + kTiny); g = invB / (1.f - dv + kTiny); }
+        else { l = logf(dv + kTiny); g = -invB / (dv + kTiny); }
+        ga[(size_t)r * lda] = g * dv * (1.f - dv) * gscale;
+        acc += (double)l;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) losses[slot] = (float)(-red[0] / (double)B);
+}
+
+// optimiser step counters -> scalars (see OptScalars), one thread
+__global__ void advance_opt_kernel(OptScalars* sc) {
+    OptScalars s = *sc;
+    s.t += 1;
+    if (s.is_sgd) { s.neg_step_size = (float)(-s.lr); s.bc2_sqrt = 1.f; }
+    else {
+        double bc1 = 1.0 - pow(0.9, (double)s.t), bc2 = 1.0 - pow(0.999, (double)s.t);
+        s.neg_step_size = (float)(-(s.lr / bc1));
+        s.bc2_sqrt = (float)sqrt(bc2);
+    }
+    *sc = s;
+}
+__global__ void advance_counter_kernel(long long* ctr) { *ctr += 1; }
+
+}  // namespace aae

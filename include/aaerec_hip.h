@@ -1,0 +1,213 @@
+/*
+ * aaerec_hip.h - C ABI of libaaerec_hip.so: the MI355X (gfx950) implementation of the
+ * adversarial-autoencoder training step of lgalke/aae-recommender.
+ *
+ * The reference has no FFI boundary of its own: the hot path sits behind duck-typed Python
+ * protocols.  Each entry point below names the reference interface it
+ * replaces (file:line, relative to the reference checkout).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AAE_E* code; aae_last_error() gives
+ *     text.  Nothing throws, nothing calls exit().
+ *   - all `*_dev` pointers are device pointers on the current HIP device; work is enqueued on
+ *     the `stream` argument (a hipStream_t passed as void*; NULL = default stream).  No entry
+ *     point synchronises the device except aae_read_losses / aae_load_* / aae_store_*.
+ *   - one handle per model replica and per rank; a handle is not thread-safe.
+ *   - the caller owns the arena (one device allocation of aae_arena_bytes() bytes, 256-byte
+ *     aligned); the library lays out parameters, optimiser state and activations inside it
+ *     (aae_tensor_info gives every view), so a host framework can alias them (e.g. as
+ *     torch tensors for RCCL collectives) without copies.
+ */
+#ifndef AAEREC_HIP_H
+#define AAEREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AAE_ABI_VERSION 1
+
+/* error codes */
+#define AAE_OK 0
+#define AAE_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define AAE_ENOMEM (-2)   /* arena too small */
+#define AAE_EHIP (-3)     /* a HIP runtime call failed */
+#define AAE_ESTATE (-4)   /* call sequence violated (e.g. decode before encode) */
+
+/* activation ids: getattr(nn, activation) in aaerec/aae.py:110 */
+enum { AAE_ACT_RELU = 0, AAE_ACT_SELU = 1, AAE_ACT_TANH = 2, AAE_ACT_SIGMOID = 3,
+       AAE_ACT_ELU = 4, AAE_ACT_LEAKYRELU = 5 };
+/* encoder output activation: PRIOR_ACTIVATIONS, aaerec/aae.py:97-101 */
+enum { AAE_FINAL_LINEAR = 0, AAE_FINAL_SOFTMAX = 1, AAE_FINAL_SIGMOID = 2 };
+/* TORCH_OPTIMIZERS, aaerec/aae.py:216-219 */
+enum { AAE_OPT_ADAM = 0, AAE_OPT_SGD = 1 };
+/* where dropout masks and z_real come from */
+enum { AAE_RNG_INJECT = 0,   /* caller supplies them (parity tests, reference-RNG mode) */
+       AAE_RNG_DEVICE = 1 }; /* counter-based generator inside the kernels */
+/* prior for AAE_RNG_DEVICE: PRIOR_SAMPLERS, aaerec/aae.py:90-94 */
+enum { AAE_PRIOR_GAUSS = 0, AAE_PRIOR_CATEGORICAL = 1, AAE_PRIOR_BERNOULLI = 2 };
+/* what happens to gradients */
+enum { AAE_GRAD_FUSED = 0,   /* optimiser update fused into the weight-gradient kernels */
+       AAE_GRAD_EXPORT = 1 };/* gradients are materialised (data-parallel: all-reduce, then
+                                aae_apply_updates) */
+
+/* AdversarialAutoEncoder.__init__ keyword arguments, aaerec/aae.py:588-606, plus sizes that
+ * the reference infers in fit() (aae.py:773-793) and build-only knobs. */
+typedef struct aae_config {
+    int32_t abi_version;      /* AAE_ABI_VERSION */
+    int32_t n_items;          /* X.shape[1] */
+    int32_t n_hidden;
+    int32_t n_code;
+    int32_t cond_inc;         /* conditions.size_increment(), 0 without conditions */
+    int32_t max_batch;        /* largest number of rows per step / per predict call */
+    int32_t max_nnz;          /* largest number of CSR entries in one batch */
+    int32_t activation;       /* AAE_ACT_* */
+    int32_t enc_final;        /* AAE_FINAL_* */
+    int32_t optimizer;        /* AAE_OPT_* */
+    int32_t normalize_inputs; /* F.normalize(inp, 1) at aae.py:132-133 */
+    int32_t rng_mode;         /* AAE_RNG_* */
+    int32_t prior;            /* AAE_PRIOR_* (device rng only) */
+    int32_t grad_mode;        /* AAE_GRAD_* */
+    float dropout1, dropout2; /* dropout=(.2,.2) */
+    float gen_lr, reg_lr;
+    float prior_scale;        /* used when has_prior_scale != 0 (aae.py:717-718) */
+    int32_t has_prior_scale;
+    uint64_t seed;            /* device rng */
+    int32_t reserved[8];      /* must be zero */
+} aae_config;
+
+typedef struct aae_model* aae_handle;
+
+/* A batch = `n_rows` rows picked out of a CSR matrix that is already resident in HBM
+ * (replaces X_shuf[start:end].toarray() + torch.FloatTensor(X).cuda(), aae.py:823,751-754).
+ * rows_dev == NULL means rows row_start .. row_start+n_rows-1.  Column indices must be unique
+ * within a row and values in [0,1] (the reference's BCE raises otherwise). */
+typedef struct aae_batch {
+    const int64_t* indptr_dev;
+    const int32_t* indices_dev;
+    const float* values_dev;
+    const int32_t* rows_dev;
+    int32_t row_start;
+    int32_t n_rows;
+    int32_t nnz_bound;        /* upper bound on the entries of these rows (<= cfg.max_nnz) */
+} aae_batch;
+
+/* Injected randomness for one partial_fit, in the reference's draw order:
+ * keep masks (uint8 0/1, dense row-major [rows][width]) for
+ *   0 enc.drop1 1 enc.drop2 2 dec.drop1 3 dec.drop2            (ae_step,  aae.py:687-691)
+ *   4 disc.drop1 5 disc.drop2 on z_real, 6,7 the same on z_fake (disc_step, aae.py:724)
+ *   8 enc.drop1 9 enc.drop2 10 disc.drop1 11 disc.drop2         (gen_step, aae.py:736-737)
+ * and z_real [rows][n_code] BEFORE prior_scale.  A NULL mask = keep everything. */
+typedef struct aae_rng_inject {
+    const uint8_t* masks_dev[12];
+    const float* z_real_dev;
+} aae_rng_inject;
+
+/* tensor ids for aae_tensor_info.  Linear layers are stored "augmented": row o holds
+ * weight[o, 0:in] followed by bias[o] at column `in`, rows padded to `ld` floats (zeros).
+ * The two vocabulary-sized layers are item-major: ENC_W1T row i = enc.lin1.weight[:, i]
+ * (bias separate, ENC_B1); DEC_V3 row i = dec.lin3.weight[i, :] ++ dec.lin3.bias[i]. */
+enum {
+    AAE_T_ENC_W1T = 0, AAE_T_ENC_B1, AAE_T_ENC_W2, AAE_T_ENC_W3,
+    AAE_T_DEC_V1, AAE_T_DEC_V2, AAE_T_DEC_V3,
+    AAE_T_DISC_D1, AAE_T_DISC_D2, AAE_T_DISC_D3,
+    AAE_T_N_PARAMS,
+    /* optimiser state: base + 2*param_id (+1 for exp_avg_sq) */
+    AAE_T_ADAM_ENC = 16,   /* enc_optim  (aae.py:800), params 0..3 */
+    AAE_T_ADAM_GEN = 32,   /* gen_optim  (aae.py:803), params 0..3 */
+    AAE_T_ADAM_DEC = 48,   /* dec_optim  (aae.py:801), params 4..6 -> slots 0..2 */
+    AAE_T_ADAM_DISC = 64,  /* disc_optim (aae.py:804), params 7..9 -> slots 0..2 */
+    /* gradients (AAE_GRAD_EXPORT only), same shapes as the parameters */
+    AAE_T_GRAD = 80,       /* + param_id */
+    /* activations useful to callers */
+    AAE_T_ACT_Z = 96,      /* encoder output of the last encode call [rows][n_code] */
+    AAE_T_ACT_LOSSES = 97, /* float[4]: R, D, G of the last step, spare */
+    AAE_T_ACT_A1 = 98      /* first-layer pre-activations of the last encode [rows][n_hidden] */
+};
+
+typedef struct aae_tensor {
+    size_t byte_offset;   /* from the arena base */
+    int64_t rows, cols;   /* logical shape (cols includes the bias column where augmented) */
+    int64_t ld;           /* row stride in floats */
+} aae_tensor;
+
+int aae_abi_version(void);
+const char* aae_last_error(void);
+
+/* construction: the nets + 4 optimisers of fit(), aae.py:782-804 */
+int aae_arena_bytes(const aae_config* cfg, size_t* bytes_out);
+int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void* stream,
+               aae_handle* out);
+int aae_destroy(aae_handle h);
+int aae_tensor_info(aae_handle h, int tensor_id, aae_tensor* out);
+/* gen_lr / reg_lr as the exact Python doubles (aae_config carries them as float32) */
+int aae_set_lr(aae_handle h, double gen_lr, double reg_lr);
+
+/* nn.Linear state in the reference's state_dict layout (weight [out,in] row-major, bias
+ * [out]), host pointers.  Synchronous. net: 0 enc 1 dec 2 disc; layer: 1..3. */
+int aae_load_linear(aae_handle h, int net, int layer, const float* weight_host,
+                    const float* bias_host);
+int aae_store_linear(aae_handle h, int net, int layer, float* weight_host, float* bias_host);
+/* optimiser state_dict (exp_avg / exp_avg_sq in [out,in] + [out] layout, step count).
+ * which: 0 enc_optim 1 dec_optim 2 gen_optim 3 disc_optim. */
+int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const float* v_w,
+                  const float* m_b, const float* v_b, int64_t step);
+int aae_store_adam(aae_handle h, int which, int layer, float* m_w, float* v_w, float* m_b,
+                   float* v_b, int64_t* step);
+
+/* AdversarialAutoEncoder.partial_fit, aae.py:745-766, without conditions or with a constant
+ * concatenated condition block cond_dev [rows][cond_inc] (PretrainedWordEmbeddingCondition,
+ * condition.py:345-369).  inject may be NULL when cfg.rng_mode == AAE_RNG_DEVICE. */
+int aae_step(aae_handle h, const aae_batch* batch, const float* cond_dev,
+             const aae_rng_inject* inject, void* stream);
+
+/* The same step cut at the condition boundary, for arbitrary ConditionList plugins whose
+ * encode_impose runs in the host framework (condition.py:90-99):
+ *   aae_ae_encode          Encoder forward in train mode            (aae.py:687)
+ *   [host: zc = conditions.encode_impose(z, cond)]                   (aae.py:688-690)
+ *   aae_ae_decode_backward Decoder forward, BCE, decoder backward + dec_optim.step;
+ *                          writes dL/dzc [rows][n_code+cond_inc]     (aae.py:692-707)
+ *   [host: backprop dzc through the conditions -> dz; conditions.step()]
+ *   aae_ae_encoder_backward encoder backward + enc_optim.step        (aae.py:703-706)
+ *   aae_disc_gen           disc_step + gen_step                      (aae.py:713-743)
+ * The aae_rng_inject handed to a phase stays in force for the later phases of the same step;
+ * its device buffers must stay valid until the step's kernels have run. */
+int aae_ae_encode(aae_handle h, const aae_batch* batch, const aae_rng_inject* inject,
+                  float* z_out_dev, void* stream);
+int aae_ae_decode_backward(aae_handle h, const float* zc_dev, int64_t zc_ld,
+                           const aae_rng_inject* inject, float* dzc_out_dev, void* stream);
+int aae_ae_encoder_backward(aae_handle h, const float* dz_dev, int64_t dz_ld, void* stream);
+int aae_disc_gen(aae_handle h, const aae_rng_inject* inject, void* stream);
+/* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
+ * between them) */
+int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);
+int aae_gen_step(aae_handle h, const aae_rng_inject* inject, void* stream);
+
+/* recon / disc / gen loss of the last step (the three .item() calls, aae.py:711,732,743).
+ * Synchronises `stream`. */
+int aae_read_losses(aae_handle h, float out_host[3], void* stream);
+
+/* AdversarialAutoEncoder.predict, aae.py:840-870: eval-mode encoder -> (constant concat
+ * condition) -> decoder -> sigmoid, out_dev [rows][out_ld] float32. */
+int aae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, float* out_dev,
+                int64_t out_ld, void* stream);
+/* split form for generic conditions */
+int aae_encode(aae_handle h, const aae_batch* batch, float* z_out_dev, void* stream);
+int aae_decode(aae_handle h, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
+               float* out_dev, int64_t out_ld, void* stream);
+
+/* data parallel (AAE_GRAD_EXPORT): after the caller has all-reduced the AAE_T_GRAD tensors of
+ * optimiser `which` (0 enc 1 dec 2 gen 3 disc), apply torch.optim.Adam/SGD.step to them. */
+int aae_apply_updates(aae_handle h, int which, void* stream);
+/* scale applied to this rank's loss gradients (local_rows / global_rows) so that the
+ * all-reduced sum equals the single-process mean over the global batch. */
+int aae_set_grad_scale(aae_handle h, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AAEREC_HIP_H */

@@ -1,0 +1,113 @@
+"""GPU parity, through the C ABI: replay every golden fixture (generated from the real
+reference by tools/gen_golden.py) on libaaerec_hip.so with the recorded randomness injected,
+and compare losses, parameters and Adam states after every step.
+
+Tolerances (fp32): losses 1e-5 relative; parameters 1e-5 absolute (Adam turns an fp32
+summation-order difference of a ~1e-8 gradient into a few 1e-6 of parameter, see
+tests/test_oracle_golden.py); reconstructions 1e-5 absolute (north star: 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import STEP_CASES, Fixture
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOSS, TOL_PARAM, TOL_RECON = 1e-5, 1e-5, 1e-5
+FUSED_CASES = [c for c in STEP_CASES if c not in ("step_cond_categorical", "step_cond_concat_bias")]
+
+
+def make_model(fx, **over):
+    from aaerec._hip import HipAAE
+    c = fx.cfg
+    kw = fx.model_kwargs()
+    kw.update(over)
+    inc = c["cond_inc"]
+    m = HipAAE(c["N"], c["h"], c["c"], cond_inc=inc, max_batch=c["B"], rng_mode="inject", **kw)
+    m.load_params(fx.init_params())
+    return m
+
+
+def csr_of(fx, m, s, prefix=None):
+    from aaerec._hip import DeviceCSR
+    ip, idx, val = fx.batch(s, prefix)
+    return DeviceCSR.from_arrays(ip, idx, val, fx.cfg["N"], m.device)
+
+
+def check_state(fx, m, s, name):
+    got = m.state_dict()
+    for k, w in fx.expected_params(s).items():
+        np.testing.assert_allclose(got[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} step {s} {k}")
+    exp = fx.expected_adam(s)
+    if not exp:
+        return
+    states = {"A_enc": m.adam_state("enc"), "A_dec": m.adam_state("dec"),
+              "A_gen": m.adam_state("gen"), "A_disc": m.adam_state("disc")}
+    for (tag, k), (em, ev, et) in exp.items():
+        st = states[tag]
+        gm, gv = st[k.split(".", 1)[1]]
+        assert st["step"] == et
+        np.testing.assert_allclose(gm, em, atol=2e-9, rtol=1e-4, err_msg=f"{name} {tag} m {k}")
+        np.testing.assert_allclose(gv, ev, atol=1e-12, rtol=2e-4, err_msg=f"{name} {tag} v {k}")
+
+
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_step_matches_reference(name):
+    fx = Fixture(name)
+    m = make_model(fx)
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = fx.cond_inputs(s)
+        cond_t = torch.as_tensor(cond[0], device=m.device) if cond else None
+        m.step(csr, 0, B, cond=cond_t, masks=fx.masks(s), z_real=fx.z[f"step{s}.z_real"])
+        got = m.losses()
+        np.testing.assert_allclose(got, fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6,
+                                   err_msg=f"{name} step {s} losses")
+        if fx.has_state(s):
+            check_state(fx, m, s, name)
+    # predict with the trained weights (ragged last predict batch is the host's job: one call here)
+    pcsr = csr_of(fx, m, 0, prefix="predict")
+    pc = fx.cond_inputs(0, prefix="predict")
+    pc_t = torch.as_tensor(pc[0], device=m.device) if pc else None
+    out = m.predict(pcsr, 0, pcsr.shape[0], cond=pc_t).cpu().numpy()
+    np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)
+
+
+def test_first_layer_and_code_match_reference():
+    fx = Fixture("step_nodrop_gauss")
+    m = make_model(fx)
+    csr = csr_of(fx, m, 0)
+    z = m.ae_encode(csr, 0, csr.shape[0]).cpu().numpy()
+    from aaerec import _hip
+    a1 = m.tensor(_hip.T_ACT_A1)[:csr.shape[0]].cpu().numpy()
+    np.testing.assert_allclose(a1, fx.z["step0.act.enc_a1_ae"], atol=1e-6)
+    np.testing.assert_allclose(z, fx.z["step0.act.enc_z_ae"], atol=1e-6)
+
+
+def test_split_phase_equals_fused_step():
+    """aae_ae_encode / decode_backward / encoder_backward / disc_gen with the concatenation done
+    by the caller must give the same result as aae_step."""
+    fx = Fixture("step_cond_concat")
+    m = make_model(fx)
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = torch.as_tensor(fx.cond_inputs(s)[0], device=m.device)
+        z = m.ae_encode(csr, 0, B, masks=fx.masks(s), z_real=fx.z[f"step{s}.z_real"])
+        dzc = m.ae_decode_backward(torch.cat([z, cond], 1))
+        m.ae_encoder_backward(dzc[:, :fx.cfg["c"]])
+        m.disc_gen()
+        np.testing.assert_allclose(m.losses(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
+        check_state(fx, m, s, "split")
+
+
+def test_abi_rejects_bad_calls():
+    from aaerec._hip import AaeHipError
+    fx = Fixture("step_nodrop_gauss")
+    m = make_model(fx)
+    with pytest.raises(AaeHipError):
+        m.disc_gen()                       # no ae phase before
+    csr = csr_of(fx, m, 0)
+    with pytest.raises(AaeHipError):
+        m.step(csr, 0, fx.cfg["B"] + 1)    # more rows than max_batch
