@@ -81,7 +81,10 @@ _PROTOS = {
     "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
+    "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM = range(5)
 
 _lib = None
 
@@ -213,6 +216,23 @@ class HipAAE:
         flat = self.arena[info.byte_offset: info.byte_offset + info.rows * info.ld * 4].view(torch.float32)
         full = flat.view(info.rows, info.ld)
         return full if padded else full[:, :info.cols]
+
+    def _span(self, tid_lo, tid_hi):
+        """One flat float32 view from the start of tensor tid_lo to the end of tid_hi (they are
+        adjacent in the arena; the 256-byte alignment gaps in between are never written)."""
+        a, b = AaeTensor(), AaeTensor()
+        _check(self.lib.aae_tensor_info(self.handle, tid_lo, C.byref(a)))
+        _check(self.lib.aae_tensor_info(self.handle, tid_hi, C.byref(b)))
+        end = b.byte_offset + b.rows * b.ld * 4
+        return self.arena[a.byte_offset:end].view(torch.float32)
+
+    def grad_buckets(self, which):
+        """Flat gradient views to all-reduce for optimiser `which` (export mode)."""
+        if which in (O_ENC, O_GEN):
+            return [self._span(T_GRAD + T_ENC_W1T, T_GRAD + T_ENC_W1T), self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
+        if which == O_DEC:
+            return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2), self._span(T_GRAD + T_DEC_V3, T_GRAD + T_DEC_V3)]
+        return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
 
     # ---- state_dict in the reference layout ------------------------------------------
     def load_params(self, params):
@@ -363,6 +383,15 @@ class HipAAE:
 
     def set_grad_scale(self, scale):
         _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))
+
+    def profile_enable(self, on=True):
+        _check(self.lib.aae_profile_enable(self.handle, int(on)))
+
+    def profile_read(self, kernel_id):
+        """(total_ms, launches) of the hipEvent pairs recorded around `kernel_id` since the last read."""
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.aae_profile_read(self.handle, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def losses(self):
         out = (C.c_float * 3)()

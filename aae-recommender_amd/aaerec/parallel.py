@@ -1,0 +1,54 @@
+"""Data-parallel AAE step: one process per GPU, gradients summed over RCCL (xGMI).
+
+New functionality defined by BASELINE.json (the reference is single-device, aae.py:794-797).
+Every rank holds a full replica (parameters + four optimiser states) and a shard of the global
+batch.  The loss is a mean over the GLOBAL batch, so each rank scales its loss gradients by
+local_rows / global_rows (aae_set_grad_scale) and the all-reduce is a plain SUM; after it every
+rank runs the identical optimiser update, so replicas stay bit-identical.
+
+Exchange points per step (the order the reference's single-process step imposes):
+    after decoder backward      dec grads  (V3 [N,h+1] dense, V1, V2)      -> dec_optim
+    after encoder backward      enc grads  (W1T [N,h] row-sparse, small)   -> enc_optim
+    after disc_step             disc grads (~50 k floats)                  -> disc_optim
+    after gen_step              enc grads again                            -> gen_optim
+
+`model` is anything with the export-mode phase interface of aaerec._hip.HipAAE
+(ae_encode / ae_decode_backward / ae_encoder_backward / disc_step / gen_step / apply_updates /
+set_grad_scale / grad_buckets), which is what lets the gloo CPU tests drive this file with an
+oracle-backed stand-in.
+"""
+O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
+
+
+class DataParallelAAE:
+    def __init__(self, model, dist, group=None):
+        self.model, self.dist, self.group = model, dist, group
+        self.world = dist.get_world_size(group)
+
+    def _allreduce(self, which):
+        for t in self.model.grad_buckets(which):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def step(self, csr, row_start, n_rows, global_rows=None, rows=None, cond_fn=None, masks=None, z_real=None):
+        """cond_fn(z) -> (zc, backward(dzc) -> dz) for condition plugins; None = no condition."""
+        m = self.model
+        if global_rows is None:
+            global_rows = n_rows * self.world
+        m.set_grad_scale(n_rows / float(global_rows))
+        z = m.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
+        if cond_fn is None:
+            dz = m.ae_decode_backward(z)
+        else:
+            zc, back = cond_fn(z)
+            dz = back(m.ae_decode_backward(zc))
+        self._allreduce(O_DEC)
+        m.apply_updates(O_DEC)
+        m.ae_encoder_backward(dz)
+        self._allreduce(O_ENC)
+        m.apply_updates(O_ENC)
+        m.disc_step()
+        self._allreduce(O_DISC)
+        m.apply_updates(O_DISC)
+        m.gen_step()
+        self._allreduce(O_GEN)
+        m.apply_updates(O_GEN)

@@ -80,6 +80,10 @@ struct aae_model {
     // state of the running step
     BatchView bv; bool have_batch; int rows; int phase;
     aae_rng_inject inj;      // randomness of the running step (inject mode)
+    // optional per-kernel timing (hipEvent pairs on the launch stream)
+    bool prof_on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* prof_ev;   // [AAE_K_N]
+    size_t prof_used[8];
 };
 
 namespace {
@@ -176,6 +180,26 @@ size_t layout(aae_model* m, char* base, bool dry) {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// scoped hipEvent pair around one kernel launch when profiling is enabled
+struct ProfScope {
+    aae_model* m; int k; hipStream_t s; bool on;
+    ProfScope(aae_model* m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_), on(m_->prof_on) {
+        if (!on) return;
+        auto& v = m->prof_ev[k];
+        if (m->prof_used[k] == v.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            v.emplace_back(a, b);
+        }
+        (void)hipEventRecord(v[m->prof_used[k]].first, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(m->prof_ev[k][m->prof_used[k]].second, s);
+        m->prof_used[k]++;
+    }
+};
+
 DropSpec make_drop(const aae_model* m, int layer, bool train, const uint8_t* ma, const uint8_t* mb, int split,
                    int width, uint32_t stream_id) {
     DropSpec d; memset(&d, 0, sizeof(d));
@@ -259,6 +283,7 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
     DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
     DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, B, h, sid2);
     if (!reuse_a1) {
+        ProfScope ps(m, AAE_K_ENC_GATHER, s);
         size_t shm = (size_t)4 * r4(h) * sizeof(float);
         hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
                            m->P[P_B1].p, h, m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation,
@@ -319,6 +344,7 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     LAUNCHCHK("colsum_adam");
     if (!exportg) {
         size_t n4 = m->P[P_W1T].floats() / 4;
+        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
                            m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
         LAUNCHCHK("adam_dense W1T");
@@ -424,7 +450,39 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     return AAE_OK;
 }
 
-int aae_destroy(aae_handle h) { delete h; return AAE_OK; }
+int aae_destroy(aae_handle h) {
+    if (!h) return AAE_OK;
+    if (h->prof_ev) {
+        for (int k = 0; k < AAE_K_N; ++k)
+            for (auto& pr : h->prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        delete[] h->prof_ev;
+    }
+    delete h;
+    return AAE_OK;
+}
+
+int aae_profile_enable(aae_handle h, int on) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    if (on && !h->prof_ev) h->prof_ev = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[AAE_K_N];
+    h->prof_on = on != 0;
+    return AAE_OK;
+}
+
+int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* launches) {
+    if (!h || !total_ms || !launches) return fail(AAE_EINVAL, "NULL argument");
+    if (kernel_id < 0 || kernel_id >= AAE_K_N) return fail(AAE_EINVAL, "bad kernel id");
+    *total_ms = 0.0; *launches = 0;
+    if (!h->prof_ev) return AAE_OK;
+    auto& v = h->prof_ev[kernel_id];
+    for (size_t i = 0; i < h->prof_used[kernel_id]; ++i) {
+        HIPCHK(hipEventSynchronize(v[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, v[i].first, v[i].second));
+        *total_ms += ms; *launches += 1;
+    }
+    h->prof_used[kernel_id] = 0;
+    return AAE_OK;
+}
 
 int aae_set_grad_scale(aae_handle h, float scale) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
@@ -620,7 +678,10 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     const float gscale = m->grad_scale / ((float)B * (float)N);
     {
         EpiBce e; e.G = m->G.p; e.ldg = m->ldn; e.gscale = gscale; e.partials = m->bce_partials;
-        TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s));
+        {
+            ProfScope ps(m, AAE_K_DEC_BCE_FWD, s);
+            TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s));
+        }
         hipLaunchKernelGGL(bce_fixup_kernel, dim3(B), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
                            h + 1, m->G.p, m->ldn, gscale, m->fix_partials);
         LAUNCHCHK("bce_fixup");
@@ -645,7 +706,10 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         LAUNCHCHK("slab_reduce");
     }
     // dV3 = G^T * dh2 -> dec_optim on V3 (the 24 B/param streaming kernel)
-    TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
+    {
+        ProfScope ps(m, AAE_K_DEC_DV3_ADAM, s);
+        TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
+    }
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AAE training docs/sec at |items|=100k, hidden=200 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--items N] [--hidden H]
+
+A "step" is one AdversarialAutoEncoder.partial_fit (ae_step + disc_step + gen_step with all
+four optimiser updates, reference aaerec/aae.py:745-766) over one batch of B synthetic docs per
+GPU, inputs (the CSR corpus) already resident in HBM.  For N > 1 launch with
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
+GPU, RCCL); every rank processes its own B docs per step (weak scaling) and the gradients are
+summed across ranks before the optimisers run.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel that takes the most time in the
+step, from hipEvent pairs recorded around its launches inside the timed region;
+`cpu_baseline` is the PyTorch-CPU dense port of the reference step (oracle/dense_torch_port.py)
+timed on this box's host cores over a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=100, help="docs per GPU per step (reference default 100, aae.py:599)")
+    ap.add_argument("--items", type=int, default=100000)
+    ap.add_argument("--hidden", type=int, default=200)
+    ap.add_argument("--code", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def kernel_models(N, h, B, nnz_per_batch):
+    """ALGORITHMIC bytes / flops per launch of the instrumented kernels."""
+    P3 = N * (h + 1)      # decoder output layer, augmented with its bias column
+    P1 = N * h            # encoder first layer
+    return {
+        "enc_gather":  dict(bytes=nnz_per_batch * h * 4, flops=2 * nnz_per_batch * h),
+        "dec_bce_fwd": dict(bytes=4 * P3 + 4 * B * N, flops=2 * B * P3),
+        "dec_da2":     dict(bytes=4 * P3 + 4 * B * N, flops=2 * B * N * h),
+        "dec_dv3_adam": dict(bytes=24 * P3 + 4 * B * N, flops=2 * B * P3),
+        "enc_w1_adam": dict(bytes=28 * P1, flops=0),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the AAE step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from aaerec._hip import HipAAE, DeviceCSR
+    from aaerec import _hip
+    from oracle.dense_torch_port import init_params, DenseTorchAAE
+    from tools.synth import throughput_corpus
+
+    N, h, c, B = a.items, a.hidden, a.code, a.batch
+    n_batches = 64
+    X = throughput_corpus(n_batches * B, N, seed=1234 + rank)
+    nnz_per_batch = X.nnz / n_batches
+    csr = DeviceCSR(X, dev)
+    params = init_params(N, h, c, seed=0)
+    model = HipAAE(N, h, c, max_batch=B, rng_mode="device", seed=1 + rank,
+                   grad_mode="export" if world > 1 else "fused", device=dev)
+    model.load_params(params)
+    if world > 1:
+        from aaerec.parallel import DataParallelAAE
+        runner = DataParallelAAE(model, dist)
+        step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
+    else:
+        step = lambda i: model.step(csr, (i % n_batches) * B, B)   # noqa: E731
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        step(i)
+    model.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    model.profile_enable(False)
+    losses = model.losses()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    docs_per_s = a.steps * B * world / dt
+
+    names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam"]
+    km = kernel_models(N, h, B, nnz_per_batch)
+    kstats = {}
+    for kid, name in enumerate(names):
+        ms, n = model.profile_read(kid)
+        if n:
+            avg_s = ms / n * 1e-3
+            kstats[name] = dict(launches_per_step=n / a.steps, avg_us=round(avg_s * 1e6, 2),
+                                step_share=round(ms * 1e-3 / dt, 4),
+                                GBps=round(km[name]["bytes"] / avg_s / 1e9, 1),
+                                TFLOPs=round(km[name]["flops"] / avg_s / 1e12, 2))
+    roofline = None
+    if kstats:
+        dom = max(kstats, key=lambda k: kstats[k]["step_share"])
+        ks = kstats[dom]
+        hbm_frac = ks["GBps"] / HBM_PEAK_GBS
+        mfma_frac = ks["TFLOPs"] / MFMA_F32_PEAK_TF
+        if hbm_frac >= mfma_frac:
+            roofline = dict(kernel=dom, bound="hbm", achieved=ks["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(hbm_frac, 4), traffic=None)
+        else:
+            roofline = dict(kernel=dom, bound="mfma", achieved=ks["TFLOPs"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                            frac=round(mfma_frac, 4), traffic=None)
+        roofline["avg_us"] = ks["avg_us"]
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ref = DenseTorchAAE(params)
+        Xc = X[:B * 8]
+        ref.partial_fit(Xc[0:B].toarray())               # warm-up
+        done, t0c = 0, time.perf_counter()
+        while True:
+            s0 = (done % 7 + 1) * B
+            ref.partial_fit(Xc[s0:s0 + B].toarray())     # toarray() is part of the reference's loop (aae.py:823)
+            done += 1
+            el = time.perf_counter() - t0c
+            if (el > a.cpu_seconds and done >= 3) or done >= 200:
+                break
+        cpu = dict(value=round(done * B / el, 1), unit="docs/s", cores=cores, kind="port",
+                   sample=f"{done} partial_fit steps of batch {B} (toarray + dense PyTorch-CPU step), "
+                          f"{el:.1f} s after 1 warm-up step")
+
+    if rank == 0:
+        out = {
+            "metric": "train docs/sec at |items|=100k h=200",
+            "value": round(docs_per_s, 1), "unit": "docs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3 PubMed-scale synthetic Bags: |items|={N}, hidden={h}, code={c}, fp32, "
+                                   f"batch={B} docs/GPU/step, full partial_fit (ae+disc+gen, 4 Adam)",
+                       "n_items": N, "n_hidden": h, "n_code": c, "batch_per_gpu": B, "global_batch": B * world,
+                       "nnz_per_batch": round(nnz_per_batch, 1), "rng": "device", "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
+            "losses_last_step": [round(x, 5) for x in losses],
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = round(docs_per_s / cpu["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,18 @@ int aae_apply_updates(aae_handle h, int which, void* stream);
  * all-reduced sum equals the single-process mean over the global batch. */
 int aae_set_grad_scale(aae_handle h, float scale);
 
+/* Live per-kernel timing for bench.py's roofline line: when enabled, a hipEvent pair is
+ * recorded on the launch stream around each launch of the kernels below; aae_profile_read
+ * waits for them, returns the summed duration and resets the counter. */
+enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer */
+       AAE_K_DEC_BCE_FWD,      /* decoder output GEMM + sigmoid/BCE epilogue */
+       AAE_K_DEC_DA2,          /* dL/dlogits * V3 (split-K) */
+       AAE_K_DEC_DV3_ADAM,     /* dV3 GEMM + fused Adam on V3 */
+       AAE_K_ENC_W1_ADAM,      /* dense Adam over the encoder's first layer */
+       AAE_K_N };
+int aae_profile_enable(aae_handle h, int on);
+int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,27 @@ def test_oracle_rejects_counts_above_one():
     val[0] = 2.0
     with pytest.raises(RuntimeError):
         m.partial_fit(ip, idx, val, fx.z["step0.z_real"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the PyTorch-CPU dense port (bench.py's cpu_baseline) is pinned to the same golden vectors
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["step_nodrop_gauss", "step_masks", "step_selu", "step_categorical_prior",
+                                  "step_prior_scale", "step_sgd", "step_nonorm", "step_ragged", "step_cond_concat"])
+def test_dense_port_reproduces_reference_steps(name):
+    import scipy.sparse as sp
+    from oracle.dense_torch_port import DenseTorchAAE
+    fx = Fixture(name)
+    m = DenseTorchAAE(fx.init_params(), **fx.model_kwargs())
+    N = fx.cfg["N"]
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, N)).toarray()
+        cond = fx.cond_inputs(s)
+        losses = m.partial_fit(X, z_real=fx.z[f"step{s}.z_real"], masks=fx.masks(s) or [None] * 12,
+                               cond=cond[0] if cond else None)
+        np.testing.assert_allclose(losses, fx.z[f"step{s}.losses"], rtol=2e-6, atol=1e-7)
+        if fx.has_state(s):
+            got = m.state_dict()
+            for k, w in fx.expected_params(s).items():
+                np.testing.assert_allclose(got[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} step {s} {k}")
