@@ -45,7 +45,7 @@ class AaeConfig(C.Structure):
 class AaeBatch(C.Structure):
     _fields_ = [("indptr_dev", C.c_void_p), ("indices_dev", C.c_void_p), ("values_dev", C.c_void_p),
                 ("rows_dev", C.c_void_p), ("row_start", C.c_int32), ("n_rows", C.c_int32),
-                ("nnz_bound", C.c_int32)]
+                ("nnz_bound", C.c_int32), ("max_row_nnz", C.c_int32)]
 
 
 class AaeRngInject(C.Structure):
@@ -306,6 +306,7 @@ class HipAAE:
         b.rows_dev = rows.data_ptr() if rows is not None else None
         b.row_start, b.n_rows = int(row_start), int(n_rows)
         b.nnz_bound = int(min(self.cfg.max_nnz, n_rows * max(1, csr.nnz_per_row_max)))
+        b.max_row_nnz = int(csr.nnz_per_row_max)
         return b
 
     def _inject(self, masks, z_real):

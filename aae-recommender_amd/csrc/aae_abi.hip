@@ -74,6 +74,8 @@ struct aae_model {
     int max_slabs;
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
+    float* rscale;           // [R] 1/L1 of the rows of the running batch
+    int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
     OptScalars* sc;          // [4]
     long long* step_ctr;
@@ -169,9 +171,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
-    m->bce_partials_cap = ((N + 63) / 64) * ((R + 63) / 64);
+    m->bce_partials_cap = ((N + 31) / 32) * ((R + 31) / 32);
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
-    m->fix_partials = a.take(R, nullptr);
+    m->fix_partials = a.take((size_t)R * 64, nullptr);
+    m->rscale = a.take(R, nullptr);
     m->losses = a.take(4, nullptr);
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
     m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
@@ -233,8 +236,9 @@ inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n +
 template <class Epi>
 int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s) {
     GemmShape g{X, Wa.p, rows, (int)Wa.rows, (int)Wa.cols, ldx, (int)Wa.ld, r4((int)Wa.cols) + 16};
-    g.k_per_split = ((int)Wa.cols + 15) / 16 * 16;
-    (void)launch_gemm<0, 1>(g, epi, 1, s);
+    g.k_per_split = ((int)Wa.cols + 63) / 64 * 64;
+    if (Wa.rows > 4096) (void)launch_gemm<0, 1, 16, 64>(g, epi, 1, s);   // vocabulary-wide: streaming regime
+    else (void)launch_gemm<0, 1, 64, 32>(g, epi, 1, s);
     LAUNCHCHK("linear_fwd");
     return AAE_OK;
 }
@@ -242,8 +246,8 @@ int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi,
 template <class Epi>
 int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s) {
     GemmShape g{Gd, Wa.p, rows, n_in, (int)Wa.rows, ldg, (int)Wa.ld, 0};
-    g.k_per_split = ((int)Wa.rows + 15) / 16 * 16;
-    (void)launch_gemm<0, 0>(g, epi, 1, s);
+    g.k_per_split = ((int)Wa.rows + 63) / 64 * 64;
+    (void)launch_gemm<0, 0, 64, 32>(g, epi, 1, s);
     LAUNCHCHK("linear_dx");
     return AAE_OK;
 }
@@ -252,14 +256,15 @@ int linear_dw(aae_model* m, const float* Gd, int ldg, int rows, const float* X, 
               hipStream_t s) {
     const Ten& W = m->P[pid];
     GemmShape g{Gd, X, (int)W.rows, (int)W.cols, rows, ldg, ldx, 0};
-    g.k_per_split = (rows + 15) / 16 * 16;
+    g.k_per_split = (rows + 63) / 64 * 64;
+    const bool big = W.rows > 4096;
     if (m->cfg.grad_mode == AAE_GRAD_EXPORT) {
         EpiStore e; e.out = m->Gr[pid].p; e.ld = (int)W.ld;
-        (void)launch_gemm<1, 0>(g, e, 1, s);
+        if (big) (void)launch_gemm<1, 0, 16, 64>(g, e, 1, s); else (void)launch_gemm<1, 0, 64, 32>(g, e, 1, s);
     } else {
         const int set = (which == O_GEN) ? 1 : 0;
         EpiAdam e; e.p = W.p; e.m = m->M[set][pid].p; e.v = m->V[set][pid].p; e.ld = (int)W.ld; e.sc = m->sc + which;
-        (void)launch_gemm<1, 0>(g, e, 1, s);
+        if (big) (void)launch_gemm<1, 0, 16, 64>(g, e, 1, s); else (void)launch_gemm<1, 0, 64, 32>(g, e, 1, s);
     }
     LAUNCHCHK("linear_dw");
     return AAE_OK;
@@ -272,6 +277,10 @@ int set_batch(aae_model* m, const aae_batch* b) {
     m->bv.indptr = b->indptr_dev; m->bv.indices = b->indices_dev; m->bv.values = b->values_dev;
     m->bv.rows = b->rows_dev; m->bv.row_start = b->row_start; m->bv.n_rows = b->n_rows;
     m->rows = b->n_rows; m->have_batch = true;
+    {   // 16 entries per workgroup pass; unknown row bound -> 64 strided chunks
+        int mr = b->max_row_nnz > 0 ? b->max_row_nnz : 1024;
+        m->chunks = std::max(1, std::min(64, (mr + 15) / 16));
+    }
     return AAE_OK;
 }
 
@@ -287,7 +296,7 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
         size_t shm = (size_t)4 * r4(h) * sizeof(float);
         hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
                            m->P[P_B1].p, h, m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation,
-                           d1, m->cfg.seed, m->step_ctr);
+                           d1, m->cfg.seed, m->step_ctr, m->rscale);
         LAUNCHCHK("enc_gather");
     } else {
         hipLaunchKernelGGL(drop_act_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->a1.p, m->eh1.p, B, h,
@@ -321,7 +330,6 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
         LAUNCHCHK("final_act_bwd");
         ga3 = m->ga3.p; ldga3 = m->ldz;
     }
-    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + which);
     // lin3: dX first (needs the old weights), then dW + update
     EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->eh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
     b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
@@ -335,10 +343,10 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     // lin1: sparse scatter into gW1T, bias column sum
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
-                       m->cfg.normalize_inputs, m->Gr[P_W1T].p, m->ldw1, 0);
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
+                       m->rscale, m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
-    hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 255) / 256), dim3(256), 0, s, m->gb1.p, B, h, m->ldh,
+    hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, m->gb1.p, B, h, m->ldh,
                        m->P[P_B1].p, m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr,
                        m->sc + which);
     LAUNCHCHK("colsum_adam");
@@ -348,8 +356,8 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
                            m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
         LAUNCHCHK("adam_dense W1T");
-        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h, 0,
-                           m->Gr[P_W1T].p, m->ldw1, 1);
+        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
+                           m->rscale, m->Gr[P_W1T].p, m->ldw1, 1);
         LAUNCHCHK("enc_scatter zero");
     }
     return AAE_OK;
@@ -373,7 +381,8 @@ int disc_forward(aae_model* m, int rows, const uint8_t* m1a, const uint8_t* m1b,
 
 int finalize_bce_loss(aae_model* m, int nblocks, hipStream_t s) {
     const int B = m->rows;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, nblocks, m->fix_partials, B,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, nblocks, m->fix_partials,
+                       B * m->chunks,
                        1.0f / ((float)B * (float)m->N), m->losses, 0);
     LAUNCHCHK("loss_finalize");
     return AAE_OK;
@@ -441,7 +450,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     for (int i = 0; i < 4; ++i) {
         hs[i].t = 0; hs[i].is_sgd = cfg->optimizer == AAE_OPT_SGD;
         hs[i].lr = (i == O_ENC || i == O_DEC) ? (double)cfg->gen_lr : (double)cfg->reg_lr;
-        hs[i].neg_step_size = 0.f; hs[i].bc2_sqrt = 1.f;
+        hs[i].neg_step_size = 0.f; hs[i].bc2_sqrt = 1.f; hs[i].inv_bc2_sqrt = 1.f;
     }
     e = hipMemcpyAsync(m->sc, hs, sizeof(hs), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -650,7 +659,7 @@ int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* in
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
-    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, s, m->step_ctr);
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr);
     TRY(encoder_forward(m, true, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, false, m->zc.p, m->ldc, s));
     // keep a copy of z for the encoder backward (condition plugins replace zc)
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
@@ -682,23 +691,26 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             ProfScope ps(m, AAE_K_DEC_BCE_FWD, s);
             TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s));
         }
-        hipLaunchKernelGGL(bce_fixup_kernel, dim3(B), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
+        hipLaunchKernelGGL(bce_fixup_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
                            h + 1, m->G.p, m->ldn, gscale, m->fix_partials);
         LAUNCHCHK("bce_fixup");
-        TRY(finalize_bce_loss(m, ((N + 63) / 64) * ((B + 63) / 64), s));
+        const int ts = m->P[P_V3].rows > 4096 ? 64 : 32;   // tile edge linear_fwd picks for this layer
+        TRY(finalize_bce_loss(m, ((N + ts - 1) / ts) * ((B + ts - 1) / ts), s));
     }
-    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + O_DEC);
     // dA2 = G * V3 (K = N items, split-K slabs), then back through act2/drop2
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
     {
         int tiles = ((B + 63) / 64) * ((h + 63) / 64);
         int splits = std::max(1, std::min(m->max_slabs, 512 / tiles));
-        int kps = ((N + splits - 1) / splits + 15) / 16 * 16;
+        int kps = ((N + splits - 1) / splits + 63) / 64 * 64;
         splits = (N + kps - 1) / kps;
         GemmShape g{m->G.p, m->P[P_V3].p, B, h, N, m->ldn, m->ldh, kps};
         EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
-        (void)launch_gemm<0, 0>(g, e, splits, s);
+        {
+            ProfScope ps(m, AAE_K_DEC_DA2, s);
+            (void)launch_gemm<0, 0, 64, 64>(g, e, splits, s);
+        }
         LAUNCHCHK("dA2 gemm");
         hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
                            e.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2, m->cfg.seed,
@@ -763,7 +775,6 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
     hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, s, m->dout.p, 4, B, 0, m->grad_scale, m->ga3.p, 4,
                        m->losses, 1);
     LAUNCHCHK("adv_loss disc");
-    hipLaunchKernelGGL(advance_opt_kernel, dim3(1), dim3(1), 0, s, m->sc + O_DISC);
     {
         DropSpec d1 = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4);
         DropSpec d2 = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5);

@@ -102,14 +102,18 @@ struct OptScalars {
     float bc2_sqrt;
     int is_sgd;
     double lr;
+    float inv_bc2_sqrt;   // 1 / bc2_sqrt
+    int pad_;
 };
 
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const OptScalars& s) {
     if (s.is_sgd) { p = p + s.neg_step_size * g; return; }
     m = m + 0.1f * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
     v = v * 0.999f + (0.001f * g) * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    float denom = sqrtf(v) / s.bc2_sqrt + 1e-8f;  // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
-    p = p + (s.neg_step_size * m) / denom;        // param.addcdiv_(exp_avg, denom, -step_size)
+    // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, -step_size) with the
+    // 1-ulp hardware sqrt / reciprocal (v_sqrt_f32, v_rcp_f32): |error| < 3e-7 of an O(lr) update
+    float denom = __builtin_amdgcn_sqrtf(v) * s.inv_bc2_sqrt + 1e-8f;
+    p = p + (s.neg_step_size * m) * __builtin_amdgcn_rcpf(denom);
 }
 
 __device__ __forceinline__ float wave_sum(float x) {

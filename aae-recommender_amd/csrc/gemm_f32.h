@@ -6,7 +6,7 @@
 //   AT = 0: A stored [M][K] (k contiguous)      AT = 1: A stored [K][M] (m contiguous)
 //   BT = 0: B stored [K][N] (n contiguous)      BT = 1: B stored [N][K] (k contiguous)
 //
-// Operands are staged global -> registers -> LDS in k-major images As[16][64+16], Bs[16][64+16]
+// Operands are staged global -> registers -> LDS in k-major images As[BK][64+16], Bs[BK][64+16]
 // (the +16 pad puts the two k-rows a ds_read_b32 half-wave touches on disjoint banks), the next
 // k-slab's global loads are issued before the current slab's MFMAs.  After the k loop the
 // accumulators go through LDS once more so that every epilogue reads and writes global memory
@@ -24,104 +24,110 @@ struct GemmShape {
     int k_per_split;   // multiple of 16; gridDim.z slices
 };
 
-constexpr int kTile = 64;
-constexpr int kBK = 16;
-constexpr int kLdT = kTile + 16;   // operand image row stride (floats)
-constexpr int kLdC = kTile + 4;    // accumulator image row stride (floats)
-
-template <int AT, int BT, class Epi>
+// TS = square tile edge per 256-thread workgroup (4 waves as 2x2, each wave (TS/2)^2):
+//   64 for the streaming GEMMs over the item vocabulary; 32 for the tiny layer GEMMs, where a
+//   64-tile grid is <= 16 workgroups and each wave's MFMA chain is the critical path (4x more
+//   workgroups, 4x shorter chains).
+// BK = k-depth of one staged slab: 16 for the streaming GEMMs (small LDS footprint, 8 workgroups
+//   per CU hide the load latency), 64 for the tiny ones (4x fewer load->barrier round trips).
+template <int AT, int BT, int BK, int TS, class Epi>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
-    __shared__ __attribute__((aligned(16))) float smem[kTile * kLdC];
+    constexpr int LDT = TS + 16;                    // operand image row stride (floats): the two k-rows a
+                                                    // ds_read_b32 half-wave touches land on disjoint banks
+    constexpr int LDC = TS + 4;                     // accumulator image row stride
+    constexpr int NV = TS * BK / 1024;              // float4 per thread and operand per slab
+    constexpr int MI = TS / 32;                     // 16x16 MFMA blocks per wave and dimension
+    constexpr int kSmem = (2 * BK * LDT > TS * LDC) ? 2 * BK * LDT : TS * LDC;
+    static_assert(NV >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
     float* As = smem;
-    float* Bs = smem + kBK * kLdT;
+    float* Bs = smem + BK * LDT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const int m0 = blockIdx.y * kTile, n0 = blockIdx.x * kTile;
+    const int wm = (wave >> 1) * (TS / 2), wn = (wave & 1) * (TS / 2);
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra, rb;
-    auto load_a = [&](int k0) {
-        ra = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (AT == 0) {
-            int m = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-            if (m < g.M && k < kend) {
-                ra = *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k);
-                if (k + 1 >= kend) ra.y = 0.f;
-                if (k + 2 >= kend) ra.z = 0.f;
-                if (k + 3 >= kend) ra.w = 0.f;
-            }
-        } else {
-            int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;
-            if (k < kend && m < g.M) {
-                ra = *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m);
-                if (m + 1 >= g.M) ra.y = 0.f;
-                if (m + 2 >= g.M) ra.z = 0.f;
-                if (m + 3 >= g.M) ra.w = 0.f;
+    float4 ra[NV], rb[NV];
+    // k-contiguous operand (tile rows = m or n): float4 index f -> row f / (BK/4), k = 4 * (f % (BK/4))
+    // m/n-contiguous operand:                    float4 index f -> k = f / (TS/4), 4 columns at 4 * (f % (TS/4))
+    auto load_kc = [&](const float* P, int ld, int r0, int rmax, int k0, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int f = tid + 256 * j;
+            int row = r0 + f / (BK / 4), k = k0 + (f % (BK / 4)) * 4;
+            if (row < rmax && k < kend) {
+                r[j] = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+                if (k + 1 >= kend) r[j].y = 0.f;
+                if (k + 2 >= kend) r[j].z = 0.f;
+                if (k + 3 >= kend) r[j].w = 0.f;
             }
         }
     };
-    auto load_b = [&](int k0) {
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (BT == 1) {
-            int n = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-            if (n < g.N && k < kend) {
-                rb = *reinterpret_cast<const float4*>(g.B + (size_t)n * g.ldb + k);
-                if (k + 1 >= kend) rb.y = 0.f;
-                if (k + 2 >= kend) rb.z = 0.f;
-                if (k + 3 >= kend) rb.w = 0.f;
-            }
-        } else {
-            int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4;
-            if (k < kend && n < g.N) {
-                rb = *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n);
-                if (n + 1 >= g.N) rb.y = 0.f;
-                if (n + 2 >= g.N) rb.z = 0.f;
-                if (n + 3 >= g.N) rb.w = 0.f;
+    auto load_mc = [&](const float* P, int ld, int c0, int cmax, int k0, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int f = tid + 256 * j;
+            int k = k0 + f / (TS / 4), cidx = c0 + (f % (TS / 4)) * 4;
+            if (k < kend && cidx < cmax) {
+                r[j] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + cidx);
+                if (cidx + 1 >= cmax) r[j].y = 0.f;
+                if (cidx + 2 >= cmax) r[j].z = 0.f;
+                if (cidx + 3 >= cmax) r[j].w = 0.f;
             }
         }
     };
-    auto store_tiles = [&]() {
-        if (AT == 0) {
-            int r = tid >> 2, kq = (tid & 3) * 4;
-            As[(kq + 0) * kLdT + r] = ra.x; As[(kq + 1) * kLdT + r] = ra.y;
-            As[(kq + 2) * kLdT + r] = ra.z; As[(kq + 3) * kLdT + r] = ra.w;
-        } else {
-            *reinterpret_cast<float4*>(&As[(tid >> 4) * kLdT + (tid & 15) * 4]) = ra;
+    auto store_kc = [&](float* T, const float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+            T[(kq + 0) * LDT + row] = r[j].x; T[(kq + 1) * LDT + row] = r[j].y;
+            T[(kq + 2) * LDT + row] = r[j].z; T[(kq + 3) * LDT + row] = r[j].w;
         }
-        if (BT == 1) {
-            int r = tid >> 2, kq = (tid & 3) * 4;
-            Bs[(kq + 0) * kLdT + r] = rb.x; Bs[(kq + 1) * kLdT + r] = rb.y;
-            Bs[(kq + 2) * kLdT + r] = rb.z; Bs[(kq + 3) * kLdT + r] = rb.w;
-        } else {
-            *reinterpret_cast<float4*>(&Bs[(tid >> 4) * kLdT + (tid & 15) * 4]) = rb;
+    };
+    auto store_mc = [&](float* T, const float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            *reinterpret_cast<float4*>(&T[(f / (TS / 4)) * LDT + (f % (TS / 4)) * 4]) = r[j];
         }
+    };
+    auto load_tiles = [&](int k0) {
+        if (AT == 0) load_kc(g.A, g.lda, m0, g.M, k0, ra); else load_mc(g.A, g.lda, m0, g.M, k0, ra);
+        if (BT == 1) load_kc(g.B, g.ldb, n0, g.N, k0, rb); else load_mc(g.B, g.ldb, n0, g.N, k0, rb);
     };
 
     if (kbeg < kend) {
-        load_a(kbeg); load_b(kbeg);
-        for (int k0 = kbeg; k0 < kend; k0 += kBK) {
-            store_tiles();
+        load_tiles(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            if (AT == 0) store_kc(As, ra); else store_mc(As, ra);
+            if (BT == 1) store_kc(Bs, rb); else store_mc(Bs, rb);
             __syncthreads();
-            if (k0 + kBK < kend) { load_a(k0 + kBK); load_b(k0 + kBK); }
+            if (k0 + BK < kend) load_tiles(k0 + BK);
             const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
-            for (int kk = 0; kk < kBK; kk += 4) {
-                float a0 = As[(kk + fk) * kLdT + wm + fr];
-                float a1 = As[(kk + fk) * kLdT + wm + 16 + fr];
-                float b0 = Bs[(kk + fk) * kLdT + wn + fr];
-                float b1 = Bs[(kk + fk) * kLdT + wn + 16 + fr];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int kk = 0; kk < BK; kk += 4) {
+                float a[MI], b[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    a[i] = As[(kk + fk) * LDT + wm + i * 16 + fr];
+                    b[i] = Bs[(kk + fk) * LDT + wn + i * 16 + fr];
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
         }
@@ -130,22 +136,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     // accumulators -> LDS image (C/D map of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg)
     float* Cs = smem;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cs[(wm + i * 16 + (lane >> 4) * 4 + r) * kLdC + wn + j * 16 + (lane & 15)] = acc[i][j][r];
+                Cs[(wm + i * 16 + (lane >> 4) * 4 + r) * LDC + wn + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
 
     typename Epi::State st;
     epi.begin(st);
+    constexpr int RPP = 1024 / TS;                  // tile rows covered per pass of 256 float4
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int row = p * 16 + (tid >> 4), col = (tid & 15) * 4;
+    for (int p = 0; p < TS / RPP; ++p) {
+        int row = p * RPP + tid / (TS / 4), col = (tid % (TS / 4)) * 4;
         int gm = m0 + row, gn = n0 + col;
         if (gm < g.M && gn < g.N) {
-            float4 v = *reinterpret_cast<const float4*>(&Cs[row * kLdC + col]);
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
             epi.apply(st, gm, gn, g.N, v, (int)blockIdx.z);
         }
     }
@@ -239,6 +246,21 @@ __device__ __forceinline__ void bce_elem(float logit, float t_raw, float gscale,
     g = (x - t) / fmaxf((1.f - x) * x, 1e-12f) * (s * (1.f - s)) * gscale;
 }
 
+// The same for target == 0 (every element the GEMM epilogue sees), simplified analytically:
+//   x - t = s and (1-x)x = s(1-s) up to 1e-12, so dL/dl = s * gscale;
+//   loss = -log1p(-x) = softplus(l) = max(l,0) + log1p(exp(-|l|))  (the t*log(x) term is <= 1e-10).
+// fp32 saturation of the reference is kept: for l > 17.33 sigmoid rounds to exactly 1.0f, the
+// reference's log1p(-1) = -inf is clamped to -100 and its s(1-s) factor zeroes the gradient.
+__device__ __forceinline__ void bce_elem_t0(float l, float gscale, float& g, float& loss) {
+    float e = __expf(-fabsf(l));
+    float r = __builtin_amdgcn_rcpf(1.f + e);
+    float s = l >= 0.f ? r : e * r;
+    float lp = e < 0.01f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+    g = s * gscale;
+    loss = fmaxf(l, 0.f) + lp;
+    if (l > 17.32868f) { g = 0.f; loss = 100.f; }
+}
+
 struct EpiBce {
     struct State { float loss; };
     float* G; int ldg; float gscale; float* partials;
@@ -248,7 +270,7 @@ struct EpiBce {
         float4 gv;
         for (int i = 0; i < 4; ++i) {
             float gg = 0.f, ll = 0.f;
-            if (gn + i < N) bce_elem((&v.x)[i], 0.f, gscale, gg, ll);
+            if (gn + i < N) bce_elem_t0((&v.x)[i], gscale, gg, ll);
             (&gv.x)[i] = gg; st.loss += ll;
         }
         if (gn + 3 < N) { *reinterpret_cast<float4*>(o) = gv; return; }
@@ -288,10 +310,10 @@ struct EpiAdam : EpiNoState {
     }
 };
 
-template <int AT, int BT, class Epi>
+template <int AT, int BT, int BK, int TS, class Epi>
 inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
-    dim3 grid((g.N + kTile - 1) / kTile, (g.M + kTile - 1) / kTile, splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, Epi>), grid, dim3(256), 0, s, g, epi);
+    dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS, splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, BK, TS, Epi>), grid, dim3(256), 0, s, g, epi);
     return hipGetLastError();
 }
 

@@ -22,7 +22,8 @@ struct BatchView {
 __global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const float* __restrict__ W1T, int ldw,
                                                          const float* __restrict__ b1, int h, int normalize,
                                                          float* __restrict__ a1, float* __restrict__ y, int ld,
-                                                         int act, DropSpec d, uint64_t seed, const long long* step_ctr) {
+                                                         int act, DropSpec d, uint64_t seed, const long long* step_ctr,
+                                                         float* __restrict__ rscale) {
     extern __shared__ __attribute__((aligned(16))) float part[];   // [4][hp]
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const flo
         l1 = (red[0] + red[1]) + (red[2] + red[3]);
         s = 1.f / fmaxf(l1, 1e-12f);
     }
+    if (tid == 0) rscale[b] = s;
     for (int c0 = lane * 4; c0 < hp; c0 += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int64_t e = lo + wave; e < hi; e += 4) {
@@ -76,35 +78,30 @@ __global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // K9: backward of the sparse first layer.  gW1T[idx_e, :] += (v_e * s_b) * ga1[b, :].
-// One wave per entry, each atomic wave-instruction adds 256 contiguous bytes (the shape the
-// memory-side float atomics run at full rate for).  zero != 0: store zeros instead (resets the
-// touched rows after the optimiser consumed them).
+// grid (docs, chunks): a workgroup takes 16-entry chunks of its document, one wave per entry;
+// each atomic wave-instruction adds 256 contiguous bytes (the shape the memory-side float
+// atomics run at full rate for).  zero != 0: store zeros instead (resets the touched rows after
+// the optimiser consumed them).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
-                                                          int h, int normalize, float* __restrict__ gW1T, int ldw,
-                                                          int zero) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                          int h, const float* __restrict__ rscale,
+                                                          float* __restrict__ gW1T, int ldw, int zero) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
-    float s = 1.f;
-    if (normalize && !zero) {
-        float l1 = 0.f;
-        for (int64_t e = lo + tid; e < hi; e += 256) l1 += fabsf(bv.values[e]);
-        l1 = wave_sum(l1);
-        if (lane == 0) red[wave] = l1;
-        __syncthreads();
-        l1 = (red[0] + red[1]) + (red[2] + red[3]);
-        s = 1.f / fmaxf(l1, 1e-12f);
-    }
-    for (int64_t e = lo + wave; e < hi; e += 4) {
-        const int idx = bv.indices[e];
-        float x = bv.values[e];
-        if (normalize) x *= s;
-        float* dst = gW1T + (size_t)idx * ldw;
-        for (int c = lane; c < h; c += 64) {
-            if (zero) dst[c] = 0.f;
-            else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
+    const float s = zero ? 0.f : rscale[b];
+    for (int64_t e0 = lo + 16 * (int64_t)blockIdx.y; e0 < hi; e0 += 16 * (int64_t)gridDim.y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t e = e0 + 4 * j + wave;
+            if (e >= hi) break;
+            const int idx = bv.indices[e];
+            const float x = bv.values[e] * s;
+            float* dst = gW1T + (size_t)idx * ldw;
+            for (int c = lane; c < h; c += 64) {
+                if (zero) dst[c] = 0.f;
+                else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
+            }
         }
     }
 }
@@ -127,13 +124,22 @@ __global__ void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, 
 }
 
 // bias gradient of the first encoder layer: db1[c] = sum_b ga1[b][c], then its optimiser
-// update (or export).  One thread per column.
-__global__ void colsum_adam_kernel(const float* __restrict__ ga, int rows, int h, int ld, float* p, float* m,
-                                   float* v, float* gout, const OptScalars* sc) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= h) return;
+// update (or export).  Block = 64 columns x 16 waves striding the rows, LDS tree over waves.
+__global__ __launch_bounds__(1024) void colsum_adam_kernel(const float* __restrict__ ga, int rows, int h, int ld,
+                                                           float* p, float* m, float* v, float* gout,
+                                                           const OptScalars* sc) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float g = 0.f;
-    for (int r = 0; r < rows; ++r) g += ga[(size_t)r * ld + c];
+    if (c < h)
+        for (int r = wave; r < rows; r += 16) g += ga[(size_t)r * ld + c];
+    red[wave][lane] = g;
+    __syncthreads();
+    if (wave != 0 || c >= h) return;
+    g = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) g += red[w][lane];
     if (gout) { gout[c] = g; return; }
     const OptScalars s = *sc;
     float pp = p[c], mm = s.is_sgd ? 0.f : m[c], vv = s.is_sgd ? 0.f : v[c];
@@ -144,8 +150,8 @@ __global__ void colsum_adam_kernel(const float* __restrict__ ga, int rows, int h
 
 // ---------------------------------------------------------------------------------------
 // BCE fix-up for the non-zero targets (the GEMM epilogue assumed target 0 everywhere):
-// one wave per CSR entry recomputes that logit as a 201-long dot product, rewrites dL/dlogit
-// and emits the loss difference.
+// one wave per CSR entry recomputes that logit as a (h+1)-long dot product, rewrites dL/dlogit
+// with the reference's exact formula and emits the loss difference.  grid (docs, chunks).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_fixup_kernel(BatchView bv, const float* __restrict__ hdec, int ldh,
                                                         const float* __restrict__ V3a, int ldv, int kdim,
@@ -156,22 +162,27 @@ __global__ __launch_bounds__(256) void bce_fixup_kernel(BatchView bv, const floa
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
     float dl = 0.f;
-    for (int64_t e = lo + wave; e < hi; e += 4) {
-        const int n = bv.indices[e];
-        float acc = 0.f;
-        for (int k = lane; k < kdim; k += 64) acc += hdec[(size_t)b * ldh + k] * V3a[(size_t)n * ldv + k];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float g0, l0, g1, l1;
-            bce_elem(acc, 0.f, gscale, g0, l0);
-            bce_elem(acc, bv.values[e], gscale, g1, l1);
-            G[(size_t)b * ldg + n] = g1;
-            dl += l1 - l0;
+    for (int64_t e0 = lo + 16 * (int64_t)blockIdx.y; e0 < hi; e0 += 16 * (int64_t)gridDim.y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t e = e0 + 4 * j + wave;
+            if (e >= hi) break;
+            const int n = bv.indices[e];
+            float acc = 0.f;
+            for (int k = lane; k < kdim; k += 64) acc += hdec[(size_t)b * ldh + k] * V3a[(size_t)n * ldv + k];
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                float g0, l0, g1, l1;
+                bce_elem_t0(acc, gscale, g0, l0);
+                bce_elem(acc, bv.values[e], gscale, g1, l1);
+                G[(size_t)b * ldg + n] = g1;
+                dl += l1 - l0;
+            }
         }
     }
     if (lane == 0) red[wave] = dl;
     __syncthreads();
-    if (tid == 0) partials[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) partials[b * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // out = (sum_z slab[z]) * act'(y) * dropout_scale      (consumer of the split-K dA2 GEMM)
@@ -317,18 +328,22 @@ __global__ __launch_bounds__(256) void adv_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0) losses[slot] = (float)(-red[0] / (double)B);
 }
 
-// optimiser step counters -> scalars (see OptScalars), one thread
-__global__ void advance_opt_kernel(OptScalars* sc) {
-    OptScalars s = *sc;
+// once per step, one launch: rng step counter += 1 and the four optimisers' step counts ->
+// scalars (see OptScalars).  Thread i = optimiser i.
+__global__ void advance_step_kernel(OptScalars* sc, long long* ctr) {
+    const int i = threadIdx.x;
+    if (i == 0) *ctr += 1;
+    if (i >= 4) return;
+    OptScalars s = sc[i];
     s.t += 1;
-    if (s.is_sgd) { s.neg_step_size = (float)(-s.lr); s.bc2_sqrt = 1.f; }
+    if (s.is_sgd) { s.neg_step_size = (float)(-s.lr); s.bc2_sqrt = 1.f; s.inv_bc2_sqrt = 1.f; }
     else {
         double bc1 = 1.0 - pow(0.9, (double)s.t), bc2 = 1.0 - pow(0.999, (double)s.t);
         s.neg_step_size = (float)(-(s.lr / bc1));
         s.bc2_sqrt = (float)sqrt(bc2);
+        s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
-    *sc = s;
+    sc[i] = s;
 }
-__global__ void advance_counter_kernel(long long* ctr) { *ctr += 1; }
 
 }  // namespace aae

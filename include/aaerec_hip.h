@@ -94,6 +94,7 @@ typedef struct aae_batch {
     int32_t row_start;
     int32_t n_rows;
     int32_t nnz_bound;        /* upper bound on the entries of these rows (<= cfg.max_nnz) */
+    int32_t max_row_nnz;      /* upper bound on the entries of any one of these rows; 0 = unknown */
 } aae_batch;
 
 /* Injected randomness for one partial_fit, in the reference's draw order:
