@@ -1,0 +1,392 @@
+"""Adversarially regularised autoencoder recommender on MI355X.
+
+Same classes, constructor keywords and method semantics as reference aaerec/aae.py
+(`AdversarialAutoEncoder` 589-870: fit / partial_fit / predict / train / eval / zero_grad;
+`AAERecommender` 873-977: train / predict), but the step itself - Encoder / Decoder /
+Discriminator forward and backward, BCE, the three losses and the four Adam optimisers - runs in
+libaaerec_hip.so (hand-written gfx950 kernels, C ABI include/aaerec_hip.h) instead of
+torch.nn modules.  This file is host-side orchestration only: shuffling, batching, condition
+plugins, logging.  It fails loudly without the built library or without a GPU.
+
+Build-only keyword arguments (all optional, defaults keep the reference behaviour):
+    device      torch device string, default the current HIP device
+    rng_mode    'device'    dropout masks and z_real from the counter generator in the kernels
+                'reference' draw them on the host from torch's global CPU generator in exactly
+                            the order the reference's modules do, so a run is comparable with
+                            the reference step by step (slower: masks are uploaded every step)
+    seed        seed of the device generator (default: drawn from torch's global generator)
+    data_parallel  torch.distributed process group (or True for the default group): shard every
+                batch over the ranks and all-reduce gradients over RCCL
+"""
+import numpy as np
+import scipy.sparse as sp
+import sklearn  # noqa: F401  (sklearn.utils.shuffle semantics are reproduced with np.random below)
+import torch
+
+from . import _hip
+from .base import Recommender
+from .condition import _check_conditions
+
+torch.manual_seed(42)            # reference aae.py:27
+TINY = 1e-12
+STATUS_FORMAT = "[ R: {:.4f} | D: {:.4f} | G: {:.4f} ]"
+
+
+def log_losses(*losses):
+    print("\r" + STATUS_FORMAT.format(*losses), end="", flush=True)
+
+
+def sample_categorical(size):
+    batch_size, n_classes = size
+    return torch.from_numpy(np.eye(n_classes)[np.random.randint(0, n_classes, batch_size)].astype("float32"))
+
+
+def sample_bernoulli(size):
+    return torch.from_numpy(np.random.randint(0, 1, size).astype("float32"))   # sic: always 0 (aae.py:86-88)
+
+
+PRIOR_SAMPLERS = {"categorical": sample_categorical, "bernoulli": sample_bernoulli, "gauss": torch.randn}
+PRIOR_ACTIVATIONS = {"categorical": "softmax", "bernoulli": "sigmoid", "gauss": "linear"}
+TORCH_OPTIMIZERS = ("sgd", "adam")
+
+
+class _NetView:
+    """What the reference exposes as model.enc / .dec / .disc: here a named view of the kernel
+    library's parameters with the nn.Module methods the drivers touch."""
+
+    def __init__(self, owner, name):
+        self._owner, self._name, self.training = owner, name, True
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        return None      # gradients never outlive the fused kernels
+
+    def state_dict(self):
+        sd = self._owner.hip.state_dict()
+        pre = self._name + "."
+        return {k[len(pre):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items() if k.startswith(pre)}
+
+    def load_state_dict(self, sd):
+        self._owner.hip.load_params({self._name + "." + k: np.asarray(v) for k, v in sd.items()})
+
+
+class _OptimView:
+    def __init__(self, owner, name):
+        self._owner, self._name = owner, name
+
+    def state_dict(self):
+        return self._owner.hip.adam_state(self._name)
+
+
+class AdversarialAutoEncoder:
+    """ Adversarial Autoencoder """
+
+    def __init__(self, n_hidden=100, n_code=50, gen_lr=0.001, reg_lr=0.001, prior="gauss", prior_scale=None,
+                 batch_size=100, n_epochs=500, optimizer="adam", normalize_inputs=True, activation="ReLU",
+                 dropout=(.2, .2), conditions=None, verbose=True,
+                 device=None, rng_mode="device", seed=None, data_parallel=None):
+        self.prior = prior.lower()
+        self.prior_scale = prior_scale
+        self.prior_sampler = PRIOR_SAMPLERS[self.prior]
+        self.encoder_activation = PRIOR_ACTIVATIONS[self.prior]
+        self.optimizer = optimizer.lower()
+        if self.optimizer not in TORCH_OPTIMIZERS:
+            raise KeyError(self.optimizer)
+        self.n_hidden, self.n_code = n_hidden, n_code
+        self.gen_lr, self.reg_lr = gen_lr, reg_lr
+        self.batch_size, self.n_epochs, self.verbose = batch_size, n_epochs, verbose
+        self.normalize_inputs, self.dropout, self.activation = normalize_inputs, dropout, activation
+        self.conditions = conditions
+        self.enc = self.dec = self.disc = None
+        self.enc_optim = self.dec_optim = self.gen_optim = self.disc_optim = None
+        if rng_mode not in ("device", "reference"):
+            raise ValueError("rng_mode must be 'device' or 'reference'")
+        self.device, self.rng_mode, self.seed, self.data_parallel = device, rng_mode, seed, data_parallel
+        self.hip = None
+        self._dp = None
+        self.last_losses = None
+
+    def __str__(self):
+        desc = "Adversarial Autoencoder"
+        desc += " ({}, {}, {}, {}, {})".format(self.n_hidden, self.n_hidden, self.n_code, self.n_hidden, self.n_hidden)
+        desc += " optimized by " + self.optimizer
+        desc += " with learning rates Gen, Reg = {}, {}".format(self.gen_lr, self.reg_lr)
+        desc += ", using a batch size of {}".format(self.batch_size)
+        desc += "\nMatching the {} distribution".format(self.prior)
+        desc += " by {} activation.".format(self.encoder_activation)
+        if self.conditions:
+            desc += "\nConditioned on " + ", ".join(self.conditions.keys())
+        return desc
+
+    # ---- nn.Module-like switches (the kernels take the mode per call) ----------------------
+    def eval(self):
+        for net in (self.enc, self.dec, self.disc):
+            if net is not None:
+                net.eval()
+        if self.conditions:
+            self.conditions.eval()
+
+    def train(self):
+        for net in (self.enc, self.dec, self.disc):
+            if net is not None:
+                net.train()
+        if self.conditions:
+            self.conditions.train()
+
+    def zero_grad(self):
+        return None
+
+    # ---- construction: the nets + 4 optimisers of the reference's fit() (aae.py:782-804) ----
+    def _build(self, n_items, code_inc):
+        dist_group = None
+        if self.data_parallel is not None and self.data_parallel is not False:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("data_parallel needs torch.distributed to be initialised")
+            dist_group = None if self.data_parallel is True else self.data_parallel
+        seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
+            if self.rng_mode == "device" else 0
+        self.hip = _hip.HipAAE(
+            n_items, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
+            activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
+            normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
+            rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
+            grad_mode="export" if self.data_parallel else "fused", device=self.device)
+        # nn.Linear default initialisation, drawn from torch's global CPU generator in the
+        # reference's construction order (Encoder, Decoder, Discriminator; lin1, lin2, lin3 each),
+        # so equal seeds give equal initial weights
+        params = {}
+        shapes = [("enc", (n_items, self.n_hidden, self.n_code)),
+                  ("dec", (self.n_code + code_inc, self.n_hidden, n_items)),
+                  ("disc", (self.n_code, self.n_hidden, 1))]
+        for net, (n_in, n_hid, n_out) in shapes:
+            for layer, (i, o) in enumerate(((n_in, n_hid), (n_hid, n_hid), (n_hid, n_out)), start=1):
+                lin = torch.nn.Linear(i, o)
+                params["{}.lin{}.weight".format(net, layer)] = lin.weight.detach().numpy()
+                params["{}.lin{}.bias".format(net, layer)] = lin.bias.detach().numpy()
+        self.hip.load_params(params)
+        self.enc, self.dec, self.disc = (_NetView(self, n) for n in ("enc", "dec", "disc"))
+        self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")
+        self.gen_optim, self.disc_optim = _OptimView(self, "gen"), _OptimView(self, "disc")
+        if self.data_parallel:
+            import torch.distributed as dist
+            from .parallel import DataParallelAAE
+            self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
+
+    # ---- randomness in the reference's draw order (rng_mode='reference') -------------------
+    def _host_randomness(self, B):
+        h, p1, p2 = self.n_hidden, self.dropout[0], self.dropout[1]
+
+        def mask(p):
+            return None if p == 0 else torch.empty(B, h).bernoulli_(1 - p).to(torch.uint8)
+        masks = [mask(p1), mask(p2), mask(p1), mask(p2)]                 # ae_step: enc, dec
+        z_real = self.prior_sampler((B, self.n_code))                    # disc_step (aae.py:716)
+        masks += [mask(p1), mask(p2), mask(p1), mask(p2)]                # D(z_real), D(z_fake)
+        masks += [mask(p1), mask(p2), mask(p1), mask(p2)]                # gen_step: enc, disc
+        return masks, z_real.to(torch.float32)
+
+    def _is_constant_concat(self):
+        return all(getattr(c, "constant_concat", False) for c in self.conditions.values())
+
+    def _run_step(self, csr, row_start, n_rows, rows, c_batch):
+        """One partial_fit on rows of a device-resident CSR."""
+        masks = z_real = None
+        if self.rng_mode == "reference":
+            masks, z_real = self._host_randomness(n_rows)
+        hip = self.hip
+        use_condition = c_batch is not None
+        if self._dp is not None:
+            cond_fn = self._cond_fn(c_batch) if use_condition else None
+            self._dp.step(csr, row_start, n_rows, global_rows=getattr(self._dp, "global_rows", None), rows=rows,
+                          cond_fn=cond_fn, masks=masks, z_real=z_real)
+        elif not use_condition:
+            hip.step(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
+        elif self._is_constant_concat():
+            blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
+            hip.step(csr, row_start, n_rows, rows=rows, cond=torch.cat([b.to(hip.device) for b in blocks], 1),
+                     masks=masks, z_real=z_real)
+        else:
+            z = hip.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
+            zc, back = self._cond_fn(c_batch)(z)
+            hip.ae_encoder_backward(back(hip.ae_decode_backward(zc)))
+            hip.disc_gen()
+
+    def _cond_fn(self, c_batch):
+        """z -> (zc, backward) through the condition plugins with torch autograd
+        (aae.py:688-690, 699-700, 708-709)."""
+        conditions = self.conditions
+
+        def fn(z):
+            z = z.detach().requires_grad_(True)
+            zc = conditions.encode_impose(z, c_batch)
+
+            def back(dzc):
+                conditions.zero_grad()
+                zc.backward(dzc.to(zc.device))
+                conditions.step()
+                return z.grad
+            return zc, back
+        return fn
+
+    # ---- public API ------------------------------------------------------------------------
+    def partial_fit(self, X, y=None, condition_data=None, step=None):
+        """ Performs reconstrction, discimination, generator training steps on one dense batch """
+        if y is not None:
+            raise NotImplementedError("(Semi-)supervised usage not supported")
+        use_condition = _check_conditions(self.conditions, condition_data)
+        Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
+        if self.hip is None:
+            self._build(Xs.shape[1], self.conditions.size_increment() if use_condition else 0)
+        _validate_targets(Xs)
+        if Xs.shape[0] > self.hip.max_batch:
+            raise ValueError("batch of {} rows exceeds batch_size={}".format(Xs.shape[0], self.hip.max_batch))
+        csr = _hip.DeviceCSR(Xs, self.hip.device)
+        self.train()
+        self._run_step(csr, 0, Xs.shape[0], None, condition_data if use_condition else None)
+        if self.verbose:
+            self.last_losses = self.hip.losses()
+            log_losses(*self.last_losses)
+        return self
+
+    def fit(self, X, y=None, condition_data=None):
+        if y is not None:
+            raise NotImplementedError("(Semi-)supervised usage not supported")
+        use_condition = _check_conditions(self.conditions, condition_data)
+        code_inc = self.conditions.size_increment() if use_condition else 0
+        print(("Using condition, code size:" if use_condition else "Not using condition, code size:"),
+              self.n_code + code_inc)
+        X = X.tocsr()
+        _validate_targets(X)
+        self._build(X.shape[1], code_inc)
+        csr = _hip.DeviceCSR(X, self.hip.device)       # the corpus stays resident in HBM
+        n_docs = X.shape[0]
+        self.train()
+        step = 0
+        for epoch in range(self.n_epochs):
+            if self.verbose:
+                print("Epoch", epoch + 1)
+            # sklearn.utils.shuffle(X, *condition_data) == one permutation from np.random's
+            # global state applied to every array (aae.py:813-817); only the permutation moves
+            perm = np.arange(n_docs)
+            np.random.shuffle(perm)
+            perm_dev = torch.as_tensor(perm.astype(np.int32), device=self.hip.device)
+            for start in range(0, n_docs, self.batch_size):
+                stop = min(start + self.batch_size, n_docs)
+                if self._dp is not None:
+                    # every rank walks the same permutation (same np.random state) and takes its
+                    # contiguous share of the global batch; a tail batch with fewer rows than
+                    # ranks is skipped on all ranks
+                    lo, hi = self._dp.shard(start, stop)
+                    if lo is None:
+                        continue
+                    self._dp.global_rows = stop - start
+                    start, stop = lo, hi
+                rows = perm_dev[start:stop]
+                c_batch = None
+                if use_condition:
+                    idx = perm[start:stop]
+                    c_batch = [_take(c, idx) for c in condition_data]
+                self._run_step(csr, 0, int(rows.numel()), rows, c_batch)
+                if self.verbose:
+                    self.last_losses = self.hip.losses()
+                    log_losses(*self.last_losses)
+                step += 1
+            if self.verbose:
+                print()
+        self.last_losses = self.hip.losses()
+        return self
+
+    def predict(self, X, condition_data=None):
+        self.eval()
+        use_condition = _check_conditions(self.conditions, condition_data)
+        if self.conditions:
+            self.conditions.eval()
+        Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
+        csr = _hip.DeviceCSR(Xs, self.hip.device)
+        fused = (not use_condition) or self._is_constant_concat()
+        pred = []
+        with torch.no_grad():
+            for start in range(0, Xs.shape[0], self.batch_size):
+                n = min(self.batch_size, Xs.shape[0] - start)
+                c_batch = [_take(c, slice(start, start + n)) for c in condition_data] if use_condition else None
+                if fused:
+                    cond = None
+                    if use_condition:
+                        cond = torch.cat([c.encode(x).to(self.hip.device)
+                                          for c, x in zip(self.conditions.values(), c_batch)], 1)
+                    out = self.hip.predict(csr, start, n, cond=cond)
+                else:
+                    z = self.hip.encode(csr, start, n)
+                    out = self.hip.decode(self.conditions.encode_impose(z, c_batch))
+                pred.append(out.cpu().numpy())
+        return np.vstack(pred)
+
+
+def _take(c, idx):
+    """Row selection on whatever a condition's transform produced (ndarray, sparse, list)."""
+    if isinstance(c, (list, tuple)):
+        if isinstance(idx, slice):
+            return list(c[idx])
+        return [c[i] for i in idx]
+    return c[idx]
+
+
+def _validate_targets(X):
+    """The reference's F.binary_cross_entropy rejects targets outside [0,1] (duplicate items in a
+    bag give 2.0 after tocsr()); keep that error behaviour."""
+    if X.nnz and (X.data.max() > 1 or X.data.min() < 0):
+        raise RuntimeError("all elements of target should be between 0 and 1")
+
+
+class AAERecommender(Recommender):
+    """
+    Adversarially Regularized Recommender
+    =====================================
+    Keyword arguments are forwarded to AdversarialAutoEncoder (n_hidden, n_code, n_epochs,
+    batch_size, gen_lr, reg_lr, prior, activation, dropout, normalize_inputs, verbose, ...).
+    """
+
+    def __init__(self, adversarial=True, conditions=None, **kwargs):
+        super().__init__()
+        self.verbose = kwargs.get("verbose", True)
+        self.conditions = conditions
+        self.model_params = kwargs
+        self.adversarial = adversarial
+        self.model = None
+
+    def __str__(self):
+        desc = "Adversarial Autoencoder" if self.adversarial else "Autoencoder"
+        if self.conditions:
+            desc += " conditioned on: " + ", ".join(self.conditions.keys())
+        desc += "\nModel Params: " + str(self.model_params)
+        return desc
+
+    def train(self, training_set):
+        print(self)
+        X = training_set.tocsr()
+        if self.conditions:
+            print("Fit transforming conditions:", self.conditions)
+            condition_data = self.conditions.fit_transform(training_set.get_attributes(self.conditions.keys()))
+        else:
+            print("Start of training, not using condition...", self.conditions)
+            condition_data = None
+        if not self.adversarial:
+            raise NotImplementedError("adversarial=False (the plain AutoEncoder, reference aae.py:221-458) is "
+                                      "outside the accelerated hot path of this build (SURVEY.md section 8f)")
+        self.model = AdversarialAutoEncoder(conditions=self.conditions, **self.model_params)
+        print(self.model)
+        print(self.conditions)
+        self.model.fit(X, condition_data=condition_data)
+
+    def predict(self, test_set):
+        X = test_set.tocsr()
+        condition_data = None
+        if self.conditions:
+            condition_data = self.conditions.transform(test_set.get_attributes(self.conditions.keys()))
+        return self.model.predict(X, condition_data=condition_data)

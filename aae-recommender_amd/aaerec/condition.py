@@ -1,0 +1,381 @@
+"""Condition (side-information) plugin API - mirrors reference aaerec/condition.py.
+
+A ConditionList is an ordered dict {attribute name: condition}.  On the hot path only
+`encode_impose / zero_grad / step / train / eval / size_increment` are used
+(reference aae.py:688-709, 773-780, 844-865): the encoder output z leaves the HIP kernels as a
+torch tensor, every condition encodes its batch input and imposes it (concatenate / add /
+multiply) with ordinary differentiable torch ops, the result goes back into the decoder
+kernels, and the gradient the kernels return for it is back-propagated through this small torch
+graph so trainable conditions (embedding tables with their own optimiser) keep learning.
+
+Conditions whose encoded input is a constant block that is concatenated
+(`PretrainedWordEmbeddingCondition`, anything with `constant_concat = True`) take the fully
+fused kernel path instead: their block is copied next to z on the device.
+"""
+import itertools as it
+from abc import ABC, abstractmethod
+from collections import Counter, OrderedDict
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+from torch import optim
+
+
+def _check_conditions(conditions, condition_data):
+    """True iff conditions are in use; asserts that spec and data match (reference 31-57)."""
+    if not conditions and not condition_data:
+        return False
+    assert isinstance(conditions, ConditionList), "`conditions` no instance of ConditionList"
+    assert condition_data and conditions, "Mismatch between condition spec and supplied condition data."
+    assert len(condition_data) == len(conditions), "Unexpected number of supplied condition data"
+    return True
+
+
+class ConditionList(OrderedDict):
+    def __init__(self, items):
+        super().__init__(items)
+        assert all(isinstance(v, ConditionBase) for v in self.values())
+
+    def fit(self, raw_inputs):
+        assert len(raw_inputs) == len(self)
+        for cond, inp in zip(self.values(), raw_inputs):
+            cond.fit(inp)
+        return self
+
+    def transform(self, raw_inputs):
+        assert len(raw_inputs) == len(self)
+        return [cond.transform(inp) for cond, inp in zip(self.values(), raw_inputs)]
+
+    def fit_transform(self, raw_inputs):
+        assert len(raw_inputs) == len(self)
+        return [cond.fit_transform(inp) for cond, inp in zip(self.values(), raw_inputs)]
+
+    def encode_impose(self, x, condition_inputs, dim=None):
+        assert len(condition_inputs) == len(self)
+        for cond, inp in zip(self.values(), condition_inputs):
+            x = cond.encode_impose(x, inp, dim)
+        return x
+
+    def encode(self, condition_inputs):
+        assert len(condition_inputs) == len(self)
+        return [cond.encode(inp) for cond, inp in zip(self.values(), condition_inputs)]
+
+    def zero_grad(self):
+        for cond in self.values():
+            cond.zero_grad()
+        return self
+
+    def step(self):
+        for cond in self.values():
+            cond.step()
+        return self
+
+    def size_increment(self):
+        return sum(cond.size_increment() for cond in self.values())
+
+    def train(self):
+        for cond in self.values():
+            if hasattr(cond, "train"):
+                cond.train()
+
+    def eval(self):
+        for cond in self.values():
+            if hasattr(cond, "eval"):
+                cond.eval()
+
+
+_PROTOCOL = ("encode", "impose", "encode_impose", "size_increment", "fit", "transform", "fit_transform",
+             "zero_grad", "step", "train", "eval")
+
+
+class ConditionBase(ABC):
+    """fit/transform once on the whole attribute column; encode + impose per batch; optional own
+    parameters updated through zero_grad/step."""
+
+    def fit(self, raw_inputs):
+        return self
+
+    def transform(self, raw_inputs):
+        return raw_inputs
+
+    def fit_transform(self, raw_inputs):
+        return self.fit(raw_inputs).transform(raw_inputs)
+
+    @abstractmethod
+    def size_increment(self):
+        """How many columns the condition appends to the code (0 for bias / scale)."""
+
+    def encode(self, inputs):
+        return inputs
+
+    @abstractmethod
+    def impose(self, inputs, encoded_condition, dim=None):
+        raise NotImplementedError
+
+    def encode_impose(self, inputs, condition_input, dim=None):
+        return self.impose(inputs, self.encode(condition_input), dim=None)
+
+    def zero_grad(self):
+        return self
+
+    def step(self):
+        return self
+
+    def train(self):
+        return self
+
+    def eval(self):
+        return self
+
+    @classmethod
+    def __subclasshook__(cls, C):
+        if cls is ConditionBase:
+            if all(any(name in B.__dict__ for B in C.__mro__) for name in _PROTOCOL):
+                return True
+        return NotImplemented
+
+
+def _to_device_like(encoded, ref):
+    if torch.is_tensor(encoded) and torch.is_tensor(ref) and encoded.device != ref.device:
+        return encoded.to(ref.device)
+    return encoded
+
+
+class ConcatenationBasedConditioning(ConditionBase):
+    dim = 1
+
+    @abstractmethod
+    def size_increment(self):
+        """Subclasses say how wide their block is."""
+
+    def impose(self, inputs, encoded_condition, dim=None):
+        return torch.cat([inputs, _to_device_like(encoded_condition, inputs)], dim=self.dim if dim is None else dim)
+
+
+class ConditionalBiasing(ConditionBase):
+    def impose(self, inputs, encoded_condition, dim=None):
+        return inputs + _to_device_like(encoded_condition, inputs)
+
+    def size_increment(self):
+        return 0
+
+
+class ConditionalScaling(ConditionBase):
+    def impose(self, inputs, encoded_condition, dim=None):
+        return inputs * _to_device_like(encoded_condition, inputs)
+
+    def size_increment(self):
+        return 0
+
+
+class CountCondition(ConditionBase):
+    """Binary bag-of-words of a text attribute, hstacked onto sparse inputs (reference 258-281)."""
+
+    def __init__(self, **cv_params):
+        from sklearn.feature_extraction.text import CountVectorizer
+        self.cv = CountVectorizer(binary=True, **cv_params)
+
+    def fit(self, raw_inputs):
+        self.cv.fit(raw_inputs)
+        return self
+
+    def transform(self, raw_inputs):
+        return self.cv.transform(raw_inputs)
+
+    def fit_transform(self, raw_inputs):
+        return self.cv.fit_transform(raw_inputs)
+
+    def impose(self, x, encoded_inputs, dim=None):
+        assert dim is None, "dim not supported for scipy.sparse based imposing"
+        return sp.hstack([x, encoded_inputs])
+
+    def size_increment(self):
+        return len(self.cv.vocabulary_)
+
+
+class PretrainedWordEmbeddingCondition(ConcatenationBasedConditioning):
+    """Fixed document vectors (TF-IDF weighted mean of pre-trained word vectors) concatenated to
+    the code (reference 345-369).  `vectors` is either a gensim-KeyedVectors-like object (needs
+    the optional aaerec.ub vectoriser) or any object with fit/transform/fit_transform and an
+    `embedding` array of shape [vocab, dim]."""
+    constant_concat = True
+
+    def __init__(self, vectors, dim=1, use_cuda=None, **tfidf_params):
+        if all(hasattr(vectors, a) for a in ("fit", "transform", "embedding")):
+            self.vect = vectors
+        else:
+            try:
+                from .ub import GensimEmbeddedVectorizer
+            except ImportError as exc:   # the TF-IDF x embedding preprocessing is outside the hot path
+                raise ImportError("PretrainedWordEmbeddingCondition with raw word vectors needs the optional "
+                                  "aaerec.ub vectoriser; pass a fitted vectoriser object instead") from exc
+            self.vect = GensimEmbeddedVectorizer(vectors, **tfidf_params)
+        self.dim = dim
+        use_cuda = torch.cuda.is_available() if use_cuda is None else use_cuda
+        self.device = torch.device("cuda") if use_cuda else torch.device("cpu")
+
+    def fit(self, raw_inputs):
+        self.vect.fit(raw_inputs)
+        return self
+
+    def transform(self, raw_inputs):
+        return self.vect.transform(raw_inputs)
+
+    def fit_transform(self, raw_inputs):
+        return self.vect.fit_transform(raw_inputs)
+
+    def encode(self, inputs):
+        return torch.as_tensor(inputs, dtype=torch.float32, device=self.device)
+
+    def size_increment(self):
+        return self.vect.embedding.shape[1]
+
+
+class EmbeddingBagCondition(ConcatenationBasedConditioning):
+    """Trainable nn.EmbeddingBag + its own Adam (reference 372-394)."""
+
+    def __init__(self, num_embeddings, embedding_dim, **kwargs):
+        self.embedding_bag = nn.EmbeddingBag(num_embeddings, embedding_dim, **kwargs)
+        self.optimizer = optim.Adam(self.embedding_bag.parameters())
+        self.embedding_dim = embedding_dim
+
+    def encode(self, inputs):
+        return self.embedding_bag(inputs)
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def step(self):
+        self.optimizer.step()
+
+    def size_increment(self):
+        return self.embedding_dim
+
+
+class CategoricalCondition(ConcatenationBasedConditioning):
+    """Trainable embedding of a categorical attribute; index 0 = padding / out of vocabulary
+    (reference 397-508)."""
+    padding_idx = 0
+
+    def __init__(self, embedding_dim, vocab_size=None, sparse=True, use_cuda=None, embedding_on_gpu=False,
+                 lr=1e-3, reduce=None, **embedding_params):
+        self.vocab_size, self.embedding_dim = vocab_size, embedding_dim
+        self.vocab = self.embedding = self.optimizer = None
+        self.lr, self.sparse = lr, sparse
+        self.use_cuda = torch.cuda.is_available() if use_cuda is None else use_cuda
+        self.embedding_on_gpu = embedding_on_gpu
+        assert "padding_idx" not in embedding_params, "Padding is fixed with token 0"
+        self.embedding_params = embedding_params
+        assert reduce is None or reduce in ("mean", "sum", "max"), "Reduce neither None nor in 'mean','sum','max'"
+        self.reduce = reduce
+
+    def fit(self, raw_inputs):
+        flat = raw_inputs if self.reduce is None else list(it.chain.from_iterable(raw_inputs))
+        if self.vocab_size is None:
+            cutoff = len(flat)
+        elif isinstance(self.vocab_size, float):
+            cutoff = int(self.vocab_size * len(flat))
+        else:
+            cutoff = int(self.vocab_size)
+        self.vocab = {value: i + 1 for i, (value, _) in enumerate(Counter(flat).most_common(cutoff))}
+        self.embedding = nn.Embedding(len(self.vocab) + 1, self.embedding_dim, padding_idx=self.padding_idx,
+                                      **self.embedding_params, sparse=self.sparse)
+        if self.use_cuda and self.embedding_on_gpu:
+            self.embedding = self.embedding.cuda()
+        opt = optim.SparseAdam if self.sparse else optim.Adam
+        self.optimizer = opt(self.embedding.parameters(), lr=self.lr)
+        return self
+
+    def transform(self, raw_inputs):
+        get = self.vocab.get
+        if self.reduce is None:
+            return [get(x, self.padding_idx) for x in raw_inputs]
+        return [[get(x, self.padding_idx) for x in row] for row in raw_inputs]
+
+    def _pad_batch(self, batch_inputs):
+        width = max(len(row) for row in batch_inputs)
+        return [list(row) + [self.padding_idx] * (width - len(row)) for row in batch_inputs]
+
+    def encode(self, inputs):
+        if self.reduce is not None:
+            inputs = self._pad_batch(inputs)
+        idx = torch.tensor(inputs, device=self.embedding.weight.device)
+        hid = self.embedding(idx)
+        if self.reduce is not None:
+            hid = getattr(hid, self.reduce)(1)
+            if self.reduce == "max":
+                hid = hid[0]
+        if self.use_cuda:
+            hid = hid.cuda()
+        return hid
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def step(self):
+        self.optimizer.step()
+
+    def size_increment(self):
+        return self.embedding_dim
+
+
+class Condition(ConditionBase):
+    """Generic condition assembled from a preprocessor, an encoder module and an optimiser
+    (reference 514-603)."""
+
+    def __init__(self, preprocessor=None, encoder=None, optimizer=None, mode="concat", size_increment=0, dim=1):
+        if encoder is not None:
+            assert callable(encoder)
+        assert mode in ("concat", "bias", "scale")
+        if mode == "concat":
+            assert size_increment > 0, "Specify size increment in concat mode"
+        else:
+            assert size_increment == 0, "Size increment should be zero in bias or scale modes"
+        if preprocessor is not None:
+            for meth in ("fit", "transform", "fit_transform"):
+                assert hasattr(preprocessor, meth), "Preprocessor has no {} method".format(meth)
+        if optimizer is not None:
+            assert hasattr(optimizer, "zero_grad") and hasattr(optimizer, "step")
+        self.preprocessor, self.encoder, self.optimizer = preprocessor, encoder, optimizer
+        self.mode_, self.dim, self._inc = mode, dim, size_increment
+
+    def fit(self, raw_inputs):
+        if self.preprocessor is not None:
+            self.preprocessor.fit(raw_inputs)
+        return self
+
+    def transform(self, raw_inputs):
+        return self.preprocessor.transform(raw_inputs) if self.preprocessor is not None else raw_inputs
+
+    def fit_transform(self, raw_inputs):
+        return self.preprocessor.fit_transform(raw_inputs) if self.preprocessor is not None else raw_inputs
+
+    def encode(self, inputs):
+        return self.encoder(inputs) if self.encoder is not None else inputs
+
+    def impose(self, inputs, encoded_condition, dim=None):
+        enc = _to_device_like(encoded_condition, inputs)
+        if self.mode_ == "concat":
+            return torch.cat([inputs, enc], dim=self.dim)
+        return inputs + enc if self.mode_ == "bias" else inputs * enc
+
+    def size_increment(self):
+        return self._inc
+
+    def zero_grad(self):
+        if self.optimizer is not None:
+            self.optimizer.zero_grad()
+
+    def step(self):
+        if self.optimizer is not None:
+            self.optimizer.step()
+
+    def train(self):
+        if self.encoder is not None and hasattr(self.encoder, "train"):
+            self.encoder.train()
+
+    def eval(self):
+        if self.encoder is not None and hasattr(self.encoder, "eval"):
+            self.encoder.eval()

@@ -24,6 +24,18 @@ class DataParallelAAE:
     def __init__(self, model, dist, group=None):
         self.model, self.dist, self.group = model, dist, group
         self.world = dist.get_world_size(group)
+        self.global_rows = None
+
+    def shard(self, start, stop):
+        """Contiguous share [lo, hi) of the global batch [start, stop) for this rank, or
+        (None, None) when the batch has fewer rows than ranks (skipped on every rank)."""
+        n = stop - start
+        if n < self.world:
+            return None, None
+        rank = self.dist.get_rank(self.group)
+        base, extra = divmod(n, self.world)
+        lo = start + rank * base + min(rank, extra)
+        return lo, lo + base + (1 if rank < extra else 0)
 
     def _allreduce(self, which):
         for t in self.model.grad_buckets(which):

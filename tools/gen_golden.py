@@ -379,7 +379,16 @@ def gen_e2e_c1(ref_aae):
         mean, std = ev.METRICS["mrr@10"](Yout.toarray(), pred)
         mrrs.append(mean)
         print("e2e_c1 seed", seed, "MRR@10", mean)
-    out = dict(train_indptr=Xtr.indptr, train_indices=Xtr.indices,
+    # short run: the reference's predictions after 3 epochs pin the whole fit() pipeline
+    # (initialisation order, shuffling, batching incl. the short last batch, dropout/prior draws)
+    torch.manual_seed(7)
+    np.random.seed(7)
+    m = ref_aae.AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100,
+                                       gen_lr=0.01, reg_lr=0.001, verbose=False)
+    m.fit(Xtr)
+    pred_short = m.predict(Xin[:40]).astype(np.float32)
+    out = dict(pred_short=pred_short, short_seed=np.asarray(7),
+               train_indptr=Xtr.indptr, train_indices=Xtr.indices,
                in_indptr=Xin.indptr, in_indices=Xin.indices,
                out_indptr=Yout.indptr, out_indices=Yout.indices,
                N=np.asarray(N), ref_mrr10=np.asarray(mrrs))
