@@ -64,6 +64,7 @@ _PROTOS = {
     "aae_destroy": (C.c_int, [C.c_void_p]),
     "aae_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AaeTensor)]),
     "aae_set_lr": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "aae_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_load_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aae_store_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aae_load_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
@@ -169,7 +170,8 @@ class HipAAE:
         cfg.abi_version = ABI_VERSION
         cfg.n_items, cfg.n_hidden, cfg.n_code, cfg.cond_inc = n_items, n_hidden, n_code, cond_inc
         cfg.max_batch = max_batch
-        cfg.max_nnz = int(max_nnz if max_nnz is not None else min(2 ** 31 - 1, max_batch * n_items))
+        # capacity of the per-batch scratch lists; the default allows 4096 entries per row
+        cfg.max_nnz = int(max_nnz if max_nnz is not None else min(2 ** 31 - 1, max_batch * min(n_items, 4096)))
         cfg.activation = ACTIVATIONS[activation]
         cfg.enc_final = FINALS[{"gauss": "linear", "categorical": "softmax", "bernoulli": "sigmoid"}[prior]]
         cfg.optimizer = OPTIMIZERS[optimizer]
@@ -235,9 +237,15 @@ class HipAAE:
         return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
 
     # ---- state_dict in the reference layout ------------------------------------------
+    def sync(self):
+        """Replay the deferred W1T updates so that arena views show eager-equivalent values."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_sync(self.handle, self._stream()))
+
     def load_params(self, params):
         """params: {'enc.lin1.weight': ndarray [out,in], 'enc.lin1.bias': ...} (any subset of layers,
         weight and bias together)."""
+        self.sync()
         for (net, layer), tid in _PARAM_ID.items():
             wk, bk = f"{net}.lin{layer}.weight", f"{net}.lin{layer}.bias"
             if wk not in params:
@@ -267,6 +275,7 @@ class HipAAE:
         return t[:, :-1].contiguous().cpu().numpy(), t[:, -1].contiguous().cpu().numpy()
 
     def state_dict(self):
+        self.sync()
         out = {}
         for (net, layer), tid in _PARAM_ID.items():
             w, b = self._get(tid, T_ENC_B1)
@@ -277,6 +286,7 @@ class HipAAE:
         """{'lin1.weight': (m, v), ...} of optimiser `which` in 'enc','dec','gen','disc', + step."""
         base, net, lo = {"enc": (T_ADAM_ENC, "enc", 0), "gen": (T_ADAM_GEN, "enc", 0),
                          "dec": (T_ADAM_DEC, "dec", 0), "disc": (T_ADAM_DISC, "disc", 0)}[which]
+        self.sync()
         out = {}
         if net == "enc":
             slots = {1: 0, 2: 2, 3: 3}
@@ -305,7 +315,10 @@ class HipAAE:
         b.indptr_dev, b.indices_dev, b.values_dev = csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr()
         b.rows_dev = rows.data_ptr() if rows is not None else None
         b.row_start, b.n_rows = int(row_start), int(n_rows)
-        b.nnz_bound = int(min(self.cfg.max_nnz, n_rows * max(1, csr.nnz_per_row_max)))
+        b.nnz_bound = int(n_rows * max(1, csr.nnz_per_row_max))
+        if b.nnz_bound > self.cfg.max_nnz:
+            raise ValueError(f"batch may hold {b.nnz_bound} entries but the model was created with max_nnz="
+                             f"{self.cfg.max_nnz}")
         b.max_row_nnz = int(csr.nnz_per_row_max)
         return b
 

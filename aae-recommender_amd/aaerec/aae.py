@@ -143,7 +143,7 @@ class AdversarialAutoEncoder:
         return None
 
     # ---- construction: the nets + 4 optimisers of the reference's fit() (aae.py:782-804) ----
-    def _build(self, n_items, code_inc):
+    def _build(self, n_items, code_inc, max_row_nnz=None):
         dist_group = None
         if self.data_parallel is not None and self.data_parallel is not False:
             import torch.distributed as dist
@@ -154,6 +154,7 @@ class AdversarialAutoEncoder:
             if self.rng_mode == "device" else 0
         self.hip = _hip.HipAAE(
             n_items, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
+            max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
             activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
@@ -263,7 +264,7 @@ class AdversarialAutoEncoder:
               self.n_code + code_inc)
         X = X.tocsr()
         _validate_targets(X)
-        self._build(X.shape[1], code_inc)
+        self._build(X.shape[1], code_inc, max_row_nnz=max(int(X.getnnz(1).max()) if X.shape[0] else 1, 4096))
         csr = _hip.DeviceCSR(X, self.hip.device)       # the corpus stays resident in HBM
         n_docs = X.shape[0]
         self.train()

@@ -75,6 +75,9 @@ struct aae_model {
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
     float* rscale;           // [R] 1/L1 of the rows of the running batch
+    // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
+    bool lazy;
+    int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
     int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
     OptScalars* sc;          // [4]
@@ -175,6 +178,12 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
     m->fix_partials = a.take((size_t)R * 64, nullptr);
     m->rscale = a.take(R, nullptr);
+    m->tsync = reinterpret_cast<int*>(a.take(N, nullptr));
+    m->mark = reinterpret_cast<int*>(a.take(N, nullptr));
+    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+    m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
+    m->stamp = m->ucount ? m->ucount + 1 : nullptr;
+    m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
     m->losses = a.take(4, nullptr);
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
     m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
@@ -284,6 +293,34 @@ int set_batch(aae_model* m, const aae_batch* b) {
     return AAE_OK;
 }
 
+// lazy Adam: list the distinct items of the running batch and bring their W1T rows up to date
+// (through step t-1 before a training gather, through step t for predict / export)
+int lazy_prepare(aae_model* m, int upto_off, bool bump, hipStream_t s) {
+    if (bump) hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, s, m->stamp, m->ucount);
+    int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
+    hipLaunchKernelGGL(uniq_items_kernel, dim3(m->rows, gy), dim3(256), 0, s, m->bv, m->mark, m->stamp, m->ulist,
+                       m->ucount);
+    LAUNCHCHK("uniq_items");
+    if (m->cfg.optimizer == AAE_OPT_ADAM) {
+        int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+        hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->N, m->tsync,
+                           m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,
+                           m->ldw1, m->h, m->tab, m->step_ctr, upto_off);
+        LAUNCHCHK("w1_catchup");
+    }
+    return AAE_OK;
+}
+
+// lazy Adam: every row of W1T (and its four moment tensors) through the current step
+int lazy_flush(aae_model* m, hipStream_t s) {
+    if (!m->lazy || m->cfg.optimizer != AAE_OPT_ADAM) return AAE_OK;
+    hipLaunchKernelGGL(w1_catchup_kernel, dim3(std::min(m->N, 8192)), dim3(256), 0, s, (const int*)nullptr,
+                       (const int*)nullptr, m->N, m->tsync, m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p,
+                       m->M[1][P_W1T].p, m->V[1][P_W1T].p, m->ldw1, m->h, m->tab, m->step_ctr, 0);
+    LAUNCHCHK("w1_catchup all");
+    return AAE_OK;
+}
+
 // Encoder forward (aae.py:129-146) into `z_dst` [rows][ldz_dst] (first n_code columns).
 // train=false: eval mode (no dropout).  reuse_a1: skip the gather, start from m->a1.
 int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t* mk2, uint32_t sid1, uint32_t sid2,
@@ -350,7 +387,14 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
                        m->P[P_B1].p, m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr,
                        m->sc + which);
     LAUNCHCHK("colsum_adam");
-    if (!exportg) {
+    if (m->lazy) {
+        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
+        int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
+                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
+                           m->tsync, m->step_ctr, which == O_GEN ? 1 : 0);
+        LAUNCHCHK("w1_sparse_adam");
+    } else if (!exportg) {
         size_t n4 = m->P[P_W1T].floats() / 4;
         ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
@@ -436,6 +480,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
+    m->lazy = cfg->grad_mode == AAE_GRAD_FUSED;
     m->grad_scale = 1.f;
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
@@ -533,6 +578,13 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
     return AAE_OK;
 }
 
+// brings every deferred update up to date so that the arena views of ENC_W1T and its optimiser
+// state hold the values an eager implementation would
+int aae_sync(aae_handle h, void* stream) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    return lazy_flush(h, S(stream));
+}
+
 // ---- state_dict import / export ----------------------------------------------------------
 static int param_id(int net, int layer) {
     if (layer < 1 || layer > 3 || net < 0 || net > 2) return -1;
@@ -589,6 +641,7 @@ int aae_load_linear(aae_handle h, int net, int layer, const float* w, const floa
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid = param_id(net, layer);
     if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     return put_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
 }
@@ -596,6 +649,7 @@ int aae_store_linear(aae_handle h, int net, int layer, float* w, float* b) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid = param_id(net, layer);
     if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     return get_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
 }
@@ -615,6 +669,7 @@ int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const fl
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid, set;
     if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
     const Ten* vb = pid == P_W1T ? &h->V[set][P_B1] : nullptr;
@@ -625,6 +680,13 @@ int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const fl
         HIPCHK(hipMemcpy(&hs, h->sc + which, sizeof(hs), hipMemcpyDeviceToHost));
         hs.t = step;
         HIPCHK(hipMemcpy(h->sc + which, &hs, sizeof(hs), hipMemcpyHostToDevice));
+        if (which == O_ENC || which == O_GEN) {
+            // enc_optim and gen_optim step together; the rng/lazy step counter follows them
+            long long t = step;
+            HIPCHK(hipMemcpy(h->step_ctr, &t, sizeof(t), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(fill_int_kernel, dim3(256), dim3(256), 0, 0, h->tsync, (size_t)h->N, (int)step);
+            HIPCHK(hipDeviceSynchronize());
+        }
     }
     return AAE_OK;
 }
@@ -633,6 +695,7 @@ int aae_store_adam(aae_handle h, int which, int layer, float* m_w, float* v_w, f
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid, set;
     if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
     const Ten* vb = pid == P_W1T ? &h->V[set][P_B1] : nullptr;
@@ -659,7 +722,9 @@ int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* in
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
-    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr);
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                       m->stamp, m->ucount);
+    if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
     TRY(encoder_forward(m, true, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, false, m->zc.p, m->ldc, s));
     // keep a copy of z for the encoder backward (condition plugins replace zc)
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
@@ -858,6 +923,7 @@ int aae_encode(aae_handle m, const aae_batch* batch, float* z_out, void* stream)
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     TRY(set_batch(m, batch));
     hipStream_t s = S(stream);
+    if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
     TRY(encoder_forward(m, false, nullptr, nullptr, 0, 0, false, m->zc.p, m->ldc, s));
     if (z_out) {
         hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,

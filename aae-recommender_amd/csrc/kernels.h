@@ -328,11 +328,127 @@ __global__ __launch_bounds__(256) void adv_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0) losses[slot] = (float)(-red[0] / (double)B);
 }
 
+// ---------------------------------------------------------------------------------------
+// Deferred ("lazy") Adam on the encoder's first layer W1T [N][h].
+//
+// torch.optim.Adam touches every row of enc.lin1.weight in every enc_optim.step() and
+// gen_optim.step() (aae.py:706,742) although only the rows of the items present in the batch
+// have a gradient: for all other rows g = 0 and the update
+//     m <- m + 0.1(0 - m);  v <- 0.999 v;  p <- p - step_size_t * m / (sqrt(v)/bc2_t + eps)
+// depends on nothing but the row's own (p, m, v) and the step number.  Rows are independent, so
+// those zero-gradient updates are postponed until a row is read again (gathered by a batch, or
+// exported): a row carries `tsync` = the last step whose two updates (enc_optim then gen_optim)
+// it has received, and w1_catchup replays steps tsync+1 .. upto with the SAME fp32 operations
+// in the SAME order the dense kernel would have used.  Since m shrinks by 0.9 per replayed step
+// while sqrt(v) shrinks by 0.9995, the parameter increments die out geometrically: after
+// kLazyReplay steps their sum is < 32 * lr * 0.9^kLazyReplay (~5e-11 for lr = 1e-3), far below
+// one ulp of any weight that matters, so the replay stops there and the rest of the gap only
+// decays m and v in closed form.  HBM traffic per step drops from 2 * 28 B * N * h to the
+// touched rows.
+// ---------------------------------------------------------------------------------------
+constexpr int kLazyReplay = 192;
+constexpr int kLazyTabCap = 65536;   // beyond it bc1 = bc2 = 1 exactly in fp32: the last row is the limit
+
+struct LazyTab { float nss_gen, nss_reg, ibc2, pad; };   // per step t: -lr_gen/bc1, -lr_reg/bc1, 1/sqrt(bc2)
+
+// distinct items of the batch -> ulist (order arbitrary), *ucount
+__global__ __launch_bounds__(256) void uniq_items_kernel(BatchView bv, int* __restrict__ mark,
+                                                         const int* __restrict__ stamp_p, int* __restrict__ ulist,
+                                                         int* __restrict__ ucount) {
+    const int b = blockIdx.x;
+    const int dc = bv.doc(b);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    const int stamp = *stamp_p;
+    for (int64_t e = lo + (int64_t)blockIdx.y * 256 + threadIdx.x; e < hi; e += (int64_t)gridDim.y * 256) {
+        const int idx = bv.indices[e];
+        if (atomicExch(&mark[idx], stamp) != stamp) ulist[atomicAdd(ucount, 1)] = idx;
+    }
+}
+
+__device__ __forceinline__ void lazy_replay(float& p, float& m1, float& v1, float& m3, float& v3, int t0, int upto,
+                                            const LazyTab* __restrict__ tab) {
+    const int n = upto - t0;
+    const int nl = n < kLazyReplay ? n : kLazyReplay;
+    for (int j = 1; j <= nl; ++j) {
+        const int tt = t0 + j;
+        const LazyTab T = tab[tt < kLazyTabCap ? tt : kLazyTabCap - 1];
+        m1 = m1 + 0.1f * (0.f - m1);
+        v1 = v1 * 0.999f;
+        p = p + (T.nss_gen * m1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v1) * T.ibc2 + 1e-8f);
+        m3 = m3 + 0.1f * (0.f - m3);
+        v3 = v3 * 0.999f;
+        p = p + (T.nss_reg * m3) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v3) * T.ibc2 + 1e-8f);
+    }
+    const int rest = n - nl;
+    if (rest > 0) {
+        const float dm = exp2f((float)rest * -0.15200309344504997f);    // 0.9^rest
+        const float dv = exp2f((float)rest * -0.0014434168696687186f);  // 0.999^rest
+        m1 *= dm; m3 *= dm; v1 *= dv; v3 *= dv;
+    }
+}
+
+// rows = ulist[0..*ucount) (or every row when ulist == NULL); one workgroup per row.
+// upto = *step_ctr + upto_off  (training gather: -1 = through the previous step; export/predict: 0)
+__global__ __launch_bounds__(256) void w1_catchup_kernel(const int* __restrict__ ulist, const int* __restrict__ ucount,
+                                                         int n_rows_all, int* __restrict__ tsync,
+                                                         float* __restrict__ W, float* __restrict__ M1,
+                                                         float* __restrict__ V1, float* __restrict__ M3,
+                                                         float* __restrict__ V3, int ld, int h,
+                                                         const LazyTab* __restrict__ tab, const long long* step_ctr,
+                                                         int upto_off) {
+    const int upto = (int)*step_ctr + upto_off;
+    const int cnt = ulist ? *ucount : n_rows_all;
+    for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const int row = ulist ? ulist[r] : r;
+        const int t0 = tsync[row];
+        if (t0 < upto) {
+            for (int c = threadIdx.x; c < h; c += 256) {
+                const size_t o = (size_t)row * ld + c;
+                float p = W[o], m1 = M1[o], v1 = V1[o], m3 = M3[o], v3 = V3[o];
+                lazy_replay(p, m1, v1, m3, v3, t0, upto, tab);
+                W[o] = p; M1[o] = m1; V1[o] = v1; M3[o] = m3; V3[o] = v3;
+            }
+        }
+        __syncthreads();                       // every thread has read tsync[row]
+        if (threadIdx.x == 0 && t0 < upto) tsync[row] = upto;
+    }
+}
+
+// optimiser step on the touched rows with the scattered gradient; clears the gradient rows.
+// mark_synced: this was gen_optim (the second update of the step) -> tsync[row] = current step
+__global__ __launch_bounds__(256) void w1_sparse_adam_kernel(const int* __restrict__ ulist,
+                                                             const int* __restrict__ ucount, float* __restrict__ W,
+                                                             float* __restrict__ M, float* __restrict__ V,
+                                                             float* __restrict__ G, int ld, int h, const OptScalars* sc,
+                                                             int* __restrict__ tsync, const long long* step_ctr,
+                                                             int mark_synced) {
+    const OptScalars s = *sc;
+    const int cnt = *ucount;
+    for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const int row = ulist[r];
+        for (int c = threadIdx.x; c < h; c += 256) {
+            const size_t o = (size_t)row * ld + c;
+            float p = W[o], m = s.is_sgd ? 0.f : M[o], v = s.is_sgd ? 0.f : V[o];
+            adam_update(p, m, v, G[o], s);
+            W[o] = p; G[o] = 0.f;
+            if (!s.is_sgd) { M[o] = m; V[o] = v; }
+        }
+        if (mark_synced && threadIdx.x == 0) tsync[row] = (int)*step_ctr;
+    }
+}
+
+__global__ void fill_int_kernel(int* p, size_t n, int v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// predict-time prologue of the unique-row pass: new stamp, empty list
+__global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucount = 0; }
+
 // once per step, one launch: rng step counter += 1 and the four optimisers' step counts ->
-// scalars (see OptScalars).  Thread i = optimiser i.
-__global__ void advance_step_kernel(OptScalars* sc, long long* ctr) {
+// scalars (see OptScalars) + this step's row of the lazy-Adam table.  Thread i = optimiser i.
+__global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount) {
     const int i = threadIdx.x;
-    if (i == 0) *ctr += 1;
+    if (i == 0) { *ctr += 1; *stamp += 1; *ucount = 0; }
     if (i >= 4) return;
     OptScalars s = sc[i];
     s.t += 1;
@@ -344,6 +460,10 @@ __global__ void advance_step_kernel(OptScalars* sc, long long* ctr) {
         s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
     sc[i] = s;
+    if (tab && s.t < kLazyTabCap) {        // optimiser 0 = enc_optim (gen_lr), 2 = gen_optim (reg_lr)
+        if (i == 0) { tab[s.t].nss_gen = s.neg_step_size; tab[s.t].ibc2 = s.inv_bc2_sqrt; }
+        if (i == 2) tab[s.t].nss_reg = s.neg_step_size;
+    }
 }
 
 }  // namespace aae

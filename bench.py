@@ -55,7 +55,8 @@ def kernel_models(N, h, B, nnz_per_batch):
         "dec_bce_fwd": dict(bytes=4 * P3 + 4 * B * N, flops=2 * B * P3),
         "dec_da2":     dict(bytes=4 * P3 + 4 * B * N, flops=2 * B * N * h),
         "dec_dv3_adam": dict(bytes=24 * P3 + 4 * B * N, flops=2 * B * P3),
-        "enc_w1_adam": dict(bytes=28 * P1, flops=0),
+        # deferred Adam: only the rows of the items in the batch move (read p,g,m,v; write p,m,v,g=0)
+        "enc_w1_adam": dict(bytes=32 * nnz_per_batch * h, flops=0),
     }
 
 

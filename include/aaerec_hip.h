@@ -145,6 +145,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                aae_handle* out);
 int aae_destroy(aae_handle h);
 int aae_tensor_info(aae_handle h, int tensor_id, aae_tensor* out);
+/* The Adam updates of ENC_W1T rows whose items are absent from a batch are deferred (they do not
+ * depend on the batch) and replayed when a row is next read.  aae_sync replays everything that
+ * is pending, after which the arena views of ENC_W1T / ADAM_ENC / ADAM_GEN hold the values an
+ * eager implementation would.  aae_load_* / aae_store_* call it themselves. */
+int aae_sync(aae_handle h, void* stream);
 /* gen_lr / reg_lr as the exact Python doubles (aae_config carries them as float32) */
 int aae_set_lr(aae_handle h, double gen_lr, double reg_lr);
 

@@ -111,3 +111,42 @@ def test_abi_rejects_bad_calls():
     csr = csr_of(fx, m, 0)
     with pytest.raises(AaeHipError):
         m.step(csr, 0, fx.cfg["B"] + 1)    # more rows than max_batch
+
+
+def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps():
+    """The lazy W1T optimiser (rows of absent items are updated when next read, replay truncated
+    after 192 steps) against the oracle's eager dense Adam: 260 steps over a 900-item vocabulary
+    where most items are seen only a few times, so gaps of 0..250 steps all occur."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    rng = np.random.default_rng(5)
+    N, h, c, B, steps = 900, 12, 6, 6, 260
+    params = init_params(N, h, c, seed=3)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.0, 0.0))
+    dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+    dev.load_params(params)
+    ora = O.OracleAAE(params, **kw)
+    # skewed popularity: items 0..19 in most batches, the tail rarely
+    p = 1.0 / np.arange(1, N + 1) ** 1.3
+    p /= p.sum()
+    for s in range(steps):
+        rows = [np.sort(rng.choice(N, size=int(rng.integers(1, 6)), replace=False, p=p)) for _ in range(B)]
+        ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        idx = np.concatenate(rows).astype(np.int32)
+        val = np.ones(len(idx), dtype=np.float32)
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        csr = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+        dev.step(csr, 0, B, z_real=zr)
+        want = ora.partial_fit(ip, idx, val, zr)
+        if s % 20 == 0 or s == steps - 1:
+            np.testing.assert_allclose(dev.losses(), want, rtol=2e-4, atol=1e-6, err_msg=f"step {s}")
+    got = dev.state_dict()
+    for k, w in ora.p.items():
+        np.testing.assert_allclose(got[k], w, atol=3e-5, rtol=0, err_msg=k)
+    st = dev.adam_state("enc")
+    np.testing.assert_allclose(st["lin1.weight"][0], ora.opt_enc.m["enc.lin1.weight"], atol=1e-8, rtol=1e-3)
+    np.testing.assert_allclose(st["lin1.weight"][1], ora.opt_enc.v["enc.lin1.weight"], atol=1e-12, rtol=1e-3)
+    st = dev.adam_state("gen")
+    np.testing.assert_allclose(st["lin1.weight"][1], ora.opt_gen.v["enc.lin1.weight"], atol=1e-12, rtol=1e-3)
+    assert st["step"] == steps

@@ -368,7 +368,7 @@ def gen_e2e_c1(ref_aae):
 
     Xtr, Xin, Yout = csr(train), csr(test_in), csr(test_out)
     mrrs = []
-    for seed in range(3):
+    for seed in range(8):
         torch.manual_seed(seed)
         np.random.seed(seed)
         m = ref_aae.AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=100, batch_size=100,
