@@ -85,7 +85,7 @@ _PROTOS = {
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
-K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM = range(5)
+K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED = range(6)
 
 _lib = None
 
@@ -158,7 +158,7 @@ class HipAAE:
     def __init__(self, n_items, n_hidden, n_code, cond_inc=0, max_batch=100, max_nnz=None,
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
-                 rng_mode="device", seed=0, grad_mode="fused", device=None):
+                 rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -184,6 +184,7 @@ class HipAAE:
         cfg.has_prior_scale = int(prior_scale is not None)
         cfg.prior_scale = float(prior_scale) if prior_scale is not None else 1.0
         cfg.seed = int(seed) & (2 ** 64 - 1)
+        cfg.reserved[0] = 1 if unfused_decoder else 0
         self.cfg = cfg
         self.N, self.h, self.c, self.cond_inc = n_items, n_hidden, n_code, cond_inc
         self.max_batch = max_batch

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -26,6 +27,7 @@
 #include "../../include/aaerec_hip.h"
 #include "gemm_f32.h"
 #include "kernels.h"
+#include "dec_fused.h"
 
 using namespace aae;
 
@@ -77,6 +79,9 @@ struct aae_model {
     float* rscale;           // [R] 1/L1 of the rows of the running batch
     // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
     bool lazy;
+    // fused decoder output layer (dec_fused.h): tile-bucketed batch entries, eligibility
+    int n_cu; bool fused_ok; int fused_nb; bool force_unfused;
+    int* tcount; int* tstart; int* teb; int* ten; float* tev;
     int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
     int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
@@ -123,7 +128,8 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 0; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 1; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[0] != 0 && c->reserved[0] != 1) return fail(AAE_EINVAL, "reserved[0] must be 0 or 1");
     return AAE_OK;
 }
 
@@ -165,7 +171,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
         m->max_slabs = std::max(1, std::min(128, 512 / tiles));
-        m->slabs = a.mat((int64_t)m->max_slabs * R, h, m->ldh);
+        // the fused decoder kernel writes one dA2 slab per workgroup (<= 304 CUs assumed for sizing)
+        int nslab = m->max_slabs;
+        if (R <= 16 * kMB && dec_fused_lds_bytes(R, h) <= 160 * 1024) nslab = std::max(nslab, 304 + 16);
+        m->slabs = a.mat((int64_t)nslab * R, h, m->ldh);
     }
     m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
     m->gzc = a.mat(R, cp + 1, m->ldc);
@@ -174,7 +183,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
-    m->bce_partials_cap = ((N + 31) / 32) * ((R + 31) / 32);
+    m->bce_partials_cap = std::max(512, ((N + 31) / 32) * ((R + 31) / 32));
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
     m->fix_partials = a.take((size_t)R * 64, nullptr);
     m->rscale = a.take(R, nullptr);
@@ -184,6 +193,14 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
     m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
+    {
+        const size_t nt = (size_t)(N + kTI - 1) / kTI + 1;
+        m->tcount = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->tstart = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->teb = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ten = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->tev = a.take((size_t)c.max_nnz, nullptr);
+    }
     m->losses = a.take(4, nullptr);
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
     m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
@@ -481,6 +498,25 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
     m->lazy = cfg->grad_mode == AAE_GRAD_FUSED;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            delete m; return fail(AAE_EHIP, "no HIP device");
+        }
+        m->n_cu = std::min(cus, 304);
+        const int nb = (m->h + 1 + 15) / 16;
+        m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
+        m->fused_ok = m->fused_nb != 0 && m->ldh <= 256 && (m->ldh % 4) == 0 && m->ldh <= kSD - 2;
+        m->force_unfused = cfg->reserved[0] == 1;   // debugging / A-B switch: reserved[0] = 1 keeps the 3-kernel path
+        if (m->fused_ok) {
+            const int maxlds = 160 * 1024;
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) m->fused_ok = false;
+        }
+    }
     m->grad_scale = 1.f;
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
@@ -748,8 +784,52 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     const uint8_t* mk2 = m->inj.masks_dev[2];
     const uint8_t* mk3 = m->inj.masks_dev[3];
     TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
-    // output layer + BCE: G = dL/dlogits [B][N]
     const float gscale = m->grad_scale / ((float)B * (float)N);
+    DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
+    DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
+    const size_t fused_lds = dec_fused_lds_bytes(B, h);
+    if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
+        // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
+        const int ntiles = (N + kTI - 1) / kTI;
+        const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
+        hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
+        hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
+        hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten,
+                           m->tev);
+        LAUNCHCHK("tile buckets");
+        DecFusedArgs fa;
+        fa.dh2 = m->dh2.p; fa.ldh = m->ldh;
+        fa.V3a = m->P[P_V3].p; fa.M = m->M[0][P_V3].p; fa.V = m->V[0][P_V3].p; fa.ldv = m->ldh;
+        fa.gradV3 = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_V3].p : nullptr;
+        fa.N = N; fa.B = B; fa.h = h; fa.gscale = gscale;
+        fa.te.start = m->tstart; fa.te.eb = m->teb; fa.te.en = m->ten; fa.te.ev = m->tev;
+        fa.slabs = m->slabs.p; fa.slab_stride = (size_t)m->R * m->ldh; fa.ld_slab = m->ldh;
+        fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
+        { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
+        const int grid = std::min(ntiles, m->n_cu);
+        {
+            ProfScope ps(m, AAE_K_DEC_FUSED, s);
+            switch (m->fused_nb) {
+                case 4: hipLaunchKernelGGL(dec_fused_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                case 7: hipLaunchKernelGGL(dec_fused_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                default: hipLaunchKernelGGL(dec_fused_kernel<13>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+            }
+        }
+        LAUNCHCHK("dec_fused");
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, grid, m->fix_partials, 0,
+                           1.0f / ((float)B * (float)N), m->losses, 0);
+        // 256+ slabs -> 16 partial slabs (stored behind the per-workgroup ones) -> sum + act'/dropout
+        float* part = m->slabs.p + (size_t)304 * fa.slab_stride;
+        const size_t n4 = (size_t)B * m->ldh / 4;
+        hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
+                           fa.slab_stride, n4, part, fa.slab_stride);
+        hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h, 64)), dim3(64), 0, s, part, 16,
+                           fa.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2, m->cfg.seed,
+                           m->step_ctr);
+        LAUNCHCHK("slab_reduce");
+    } else {
+    // ---- unfused path: output layer + BCE: G = dL/dlogits [B][N]
     {
         EpiBce e; e.G = m->G.p; e.ldg = m->ldn; e.gscale = gscale; e.partials = m->bce_partials;
         {
@@ -763,8 +843,6 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         TRY(finalize_bce_loss(m, ((N + ts - 1) / ts) * ((B + ts - 1) / ts), s));
     }
     // dA2 = G * V3 (K = N items, split-K slabs), then back through act2/drop2
-    DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
-    DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
     {
         int tiles = ((B + 63) / 64) * ((h + 63) / 64);
         int splits = std::max(1, std::min(m->max_slabs, 512 / tiles));
@@ -786,6 +864,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     {
         ProfScope ps(m, AAE_K_DEC_DV3_ADAM, s);
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
+    }
     }
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;

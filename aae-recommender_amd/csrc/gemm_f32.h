@@ -58,48 +58,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     float4 ra[NV], rb[NV];
     // k-contiguous operand (tile rows = m or n): float4 index f -> row f / (BK/4), k = 4 * (f % (BK/4))
     // m/n-contiguous operand:                    float4 index f -> k = f / (TS/4), 4 columns at 4 * (f % (TS/4))
+    // NOTE: every load is issued unconditionally from a clamped (always valid) address, and the
+    // out-of-range lanes are zeroed only when the registers are written to LDS one slab later - a
+    // load under a lane-dependent `if`, or any use right behind it, makes the wave wait for it
+    // (vmcnt(0)) and serialises the slab's memory round trips with its MFMAs.
     auto load_kc = [&](const float* P, int ld, int r0, int rmax, int k0, float4* r) {
+        const int kmax4 = ((kend + 3) & ~3) - 4;          // last float4 that starts inside the padded row
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int f = tid + 256 * j;
-            int row = r0 + f / (BK / 4), k = k0 + (f % (BK / 4)) * 4;
-            if (row < rmax && k < kend) {
-                r[j] = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
-                if (k + 1 >= kend) r[j].y = 0.f;
-                if (k + 2 >= kend) r[j].z = 0.f;
-                if (k + 3 >= kend) r[j].w = 0.f;
-            }
+            const int row = min(r0 + f / (BK / 4), rmax - 1), k = min(k0 + (f % (BK / 4)) * 4, kmax4);
+            r[j] = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
         }
     };
     auto load_mc = [&](const float* P, int ld, int c0, int cmax, int k0, float4* r) {
+        const int cmax4 = ((cmax + 3) & ~3) - 4;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int f = tid + 256 * j;
-            int k = k0 + f / (TS / 4), cidx = c0 + (f % (TS / 4)) * 4;
-            if (k < kend && cidx < cmax) {
-                r[j] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + cidx);
-                if (cidx + 1 >= cmax) r[j].y = 0.f;
-                if (cidx + 2 >= cmax) r[j].z = 0.f;
-                if (cidx + 3 >= cmax) r[j].w = 0.f;
-            }
+            const int k = min(k0 + f / (TS / 4), kend - 1), cidx = min(c0 + (f % (TS / 4)) * 4, cmax4);
+            r[j] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + cidx);
         }
     };
-    auto store_kc = [&](float* T, const float4* r) {
+    auto store_kc = [&](float* T, const float4* r, int r0, int rmax, int k0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int f = tid + 256 * j;
-            int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
-            T[(kq + 0) * LDT + row] = r[j].x; T[(kq + 1) * LDT + row] = r[j].y;
-            T[(kq + 2) * LDT + row] = r[j].z; T[(kq + 3) * LDT + row] = r[j].w;
+            const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+            const bool ok = r0 + row < rmax;
+            const int k = k0 + kq;
+            T[(kq + 0) * LDT + row] = (ok && k < kend) ? r[j].x : 0.f;
+            T[(kq + 1) * LDT + row] = (ok && k + 1 < kend) ? r[j].y : 0.f;
+            T[(kq + 2) * LDT + row] = (ok && k + 2 < kend) ? r[j].z : 0.f;
+            T[(kq + 3) * LDT + row] = (ok && k + 3 < kend) ? r[j].w : 0.f;
         }
     };
-    auto store_mc = [&](float* T, const float4* r) {
+    auto store_mc = [&](float* T, const float4* r, int c0, int cmax, int k0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int f = tid + 256 * j;
-            *reinterpret_cast<float4*>(&T[(f / (TS / 4)) * LDT + (f % (TS / 4)) * 4]) = r[j];
+            const int kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
+            const bool ok = k0 + kr < kend;
+            const int cidx = c0 + cq;
+            float4 v;
+            v.x = (ok && cidx < cmax) ? r[j].x : 0.f;
+            v.y = (ok && cidx + 1 < cmax) ? r[j].y : 0.f;
+            v.z = (ok && cidx + 2 < cmax) ? r[j].z : 0.f;
+            v.w = (ok && cidx + 3 < cmax) ? r[j].w : 0.f;
+            *reinterpret_cast<float4*>(&T[kr * LDT + cq]) = v;
         }
     };
     auto load_tiles = [&](int k0) {
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     if (kbeg < kend) {
         load_tiles(kbeg);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            if (AT == 0) store_kc(As, ra); else store_mc(As, ra);
-            if (BT == 1) store_kc(Bs, rb); else store_mc(Bs, rb);
+            if (AT == 0) store_kc(As, ra, m0, g.M, k0); else store_mc(As, ra, m0, g.M, k0);
+            if (BT == 1) store_kc(Bs, rb, n0, g.N, k0); else store_mc(Bs, rb, n0, g.N, k0);
             __syncthreads();
             if (k0 + BK < kend) load_tiles(k0 + BK);
             const int fr = lane & 15, fk = lane >> 4;
@@ -238,12 +244,17 @@ struct EpiActBwd {
 //   loss_e = -(t*max(log x,-100) + (1-t)*max(log1p(-x),-100)),  x = sigmoid(l) + TINY, t = TINY
 //   dL/dl  = (x - t) / max((1-x)*x, 1e-12) * s*(1-s) * gscale,  gscale = grad_scale/(B*N)
 __device__ __forceinline__ void bce_elem(float logit, float t_raw, float gscale, float& g, float& loss) {
-    float s = sigmoidf_(logit);
-    float x = s + kTiny, t = t_raw + kTiny;
-    float lx = fmaxf(__logf(x), -100.f);
-    float l1x = fmaxf(log1pf(-x), -100.f);
+    // sigmoid, log(x) and softplus from one exp; hardware rcp/log (1 ulp) instead of libm calls
+    const float e = __expf(-fabsf(logit));
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float s = logit >= 0.f ? r : e * r;
+    const float x = s + kTiny, t = t_raw + kTiny;
+    const float lx = fmaxf(__logf(x), -100.f);
+    const float lp = e < 0.01f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+    // max(log1p(-x), -100) = -softplus(logit) until sigmoid rounds to 1.0f (logit > 17.33), then -100
+    const float l1x = logit > 17.32868f ? -100.f : -(fmaxf(logit, 0.f) + lp);
     loss = -(t * lx + (1.f - t) * l1x);
-    g = (x - t) / fmaxf((1.f - x) * x, 1e-12f) * (s * (1.f - s)) * gscale;
+    g = (x - t) * __builtin_amdgcn_rcpf(fmaxf((1.f - x) * x, 1e-12f)) * (s * (1.f - s)) * gscale;
 }
 
 // The same for target == 0 (every element the GEMM epilogue sees), simplified analytically:

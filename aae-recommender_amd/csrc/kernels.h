@@ -185,6 +185,23 @@ __global__ __launch_bounds__(256) void bce_fixup_kernel(BatchView bv, const floa
     if (tid == 0) partials[b * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// first stage of a wide slab reduction: out[g][i] = sum of the slabs z = g, g+G, g+2G, ... of element i
+// (float4 per thread, the loads of one thread are independent and stay in flight together)
+__global__ __launch_bounds__(256) void slab_partial_kernel(const float* __restrict__ slabs, int nslab,
+                                                           size_t slab_stride, size_t n4,
+                                                           float* __restrict__ out, size_t out_stride) {
+    const int g = blockIdx.y, G = gridDim.y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int z = g; z < nslab; z += G) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)z * slab_stride)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)g * out_stride)[i] = acc;
+    }
+}
+
 // out = (sum_z slab[z]) * act'(y) * dropout_scale      (consumer of the split-K dA2 GEMM)
 __global__ void slab_reduce_actbwd_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
                                           int rows, int h, int ld, const float* __restrict__ y, int ldy,

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--code", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
     return ap.parse_args()
 
 
@@ -57,6 +58,9 @@ def kernel_models(N, h, B, nnz_per_batch):
         "dec_dv3_adam": dict(bytes=24 * P3 + 4 * B * N, flops=2 * B * P3),
         # deferred Adam: only the rows of the items in the batch move (read p,g,m,v; write p,m,v,g=0)
         "enc_w1_adam": dict(bytes=32 * nnz_per_batch * h, flops=0),
+        # fused decoder output layer: V3a read once (4 B) + m, v read (8 B) + p, m, v written (12 B) per
+        # parameter; logits/dL/dlogits never leave the chip; three GEMMs of 2*B*N*(h+1) flop each
+        "dec_fused": dict(bytes=24 * P3, flops=6 * B * P3),
     }
 
 
@@ -90,7 +94,7 @@ def main():
     csr = DeviceCSR(X, dev)
     params = init_params(N, h, c, seed=0)
     model = HipAAE(N, h, c, max_batch=B, rng_mode="device", seed=1 + rank,
-                   grad_mode="export" if world > 1 else "fused", device=dev)
+                   grad_mode="export" if world > 1 else "fused", device=dev, unfused_decoder=a.unfused_decoder)
     model.load_params(params)
     if world > 1:
         from aaerec.parallel import DataParallelAAE
@@ -121,7 +125,7 @@ def main():
         dt = float(t.item())
     docs_per_s = a.steps * B * world / dt
 
-    names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam"]
+    names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
     km = kernel_models(N, h, B, nnz_per_batch)
     kstats = {}
     for kid, name in enumerate(names):

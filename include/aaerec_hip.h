@@ -77,7 +77,8 @@ typedef struct aae_config {
     float prior_scale;        /* used when has_prior_scale != 0 (aae.py:717-718) */
     int32_t has_prior_scale;
     uint64_t seed;            /* device rng */
-    int32_t reserved[8];      /* must be zero */
+    int32_t reserved[8];      /* must be zero ([0] = 1: keep the decoder output layer on the unfused
+                                 three-kernel path, for A/B measurements) */
 } aae_config;
 
 typedef struct aae_model* aae_handle;
@@ -220,7 +221,8 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_DEC_BCE_FWD,      /* decoder output GEMM + sigmoid/BCE epilogue */
        AAE_K_DEC_DA2,          /* dL/dlogits * V3 (split-K) */
        AAE_K_DEC_DV3_ADAM,     /* dV3 GEMM + fused Adam on V3 */
-       AAE_K_ENC_W1_ADAM,      /* dense Adam over the encoder's first layer */
+       AAE_K_ENC_W1_ADAM,      /* Adam over the touched rows of the encoder's first layer */
+       AAE_K_DEC_FUSED,        /* fused decoder output layer: logits + BCE + dV3/Adam + dA2 (B <= ~104) */
        AAE_K_N };
 int aae_profile_enable(aae_handle h, int on);
 int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* launches);

@@ -150,3 +150,38 @@ def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps():
     st = dev.adam_state("gen")
     np.testing.assert_allclose(st["lin1.weight"][1], ora.opt_gen.v["enc.lin1.weight"], atol=1e-12, rtol=1e-3)
     assert st["step"] == steps
+
+
+@pytest.mark.parametrize("N,h,c,B", [(5000, 200, 50, 100), (3001, 100, 50, 37), (4096, 200, 50, 104)])
+def test_fused_decoder_equals_unfused_path_at_headline_width(N, h, c, B):
+    """The persistent fused decoder kernel (dec_fused.h, used for B <= ~104) against the
+    three-kernel path (GEMM + BCE epilogue, split-K dA2, dV3 GEMM + Adam epilogue) that the
+    golden fixtures also pin, at the headline layer widths the small fixtures do not reach."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle.dense_torch_port import init_params
+    from tools.synth import throughput_corpus
+    X = throughput_corpus(3 * B, N, median_len=12, max_len=60, seed=3)
+    params = init_params(N, h, c, seed=1)
+    rng = np.random.default_rng(0)
+    models = []
+    for unfused in (False, True):
+        m = HipAAE(N, h, c, max_batch=B, rng_mode="inject", dropout=(0.2, 0.2), unfused_decoder=unfused)
+        m.load_params(params)
+        models.append(m)
+    csr = [DeviceCSR(X, m.device) for m in models]
+    for s in range(3):
+        masks = [(rng.random((B, h)) > 0.2).astype(np.uint8) for _ in range(12)]
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        out = []
+        for m, cs in zip(models, csr):
+            m.step(cs, s * B, B, masks=masks, z_real=zr)
+            out.append(m.losses())
+        np.testing.assert_allclose(out[0], out[1], rtol=2e-6, atol=1e-7)
+    a, b = models[0].state_dict(), models[1].state_dict()
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], atol=2e-6, rtol=0, err_msg=k)
+    for which in ("dec", "enc"):
+        sa, sb = models[0].adam_state(which), models[1].adam_state(which)
+        for k in ("lin3.weight", "lin1.weight"):
+            np.testing.assert_allclose(sa[k][0], sb[k][0], atol=1e-9, rtol=1e-4)
+            np.testing.assert_allclose(sa[k][1], sb[k][1], atol=1e-13, rtol=1e-4)
