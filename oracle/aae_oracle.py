@@ -428,3 +428,94 @@ class OracleAAE:
         logits, _ = self._mlp_fwd("dec", z, None)
         return sigmoid(logits)
 
+
+
+# ---------------------------------------------------------------------------------------------
+# the same step cut into the phases of the C ABI with gradients EXPORTED instead of applied
+# (aae_ae_encode / aae_ae_decode_backward / aae_ae_encoder_backward / aae_disc_step /
+# aae_gen_step / aae_apply_updates / aae_set_grad_scale, include/aaerec_hip.h) - the stand-in
+# that lets the world_size-2 gloo tests drive aaerec.parallel.DataParallelAAE on CPU.
+# ---------------------------------------------------------------------------------------------
+class OraclePhases(OracleAAE):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.grad_scale = 1.0
+        self.G = {}          # optimiser id -> {param name: gradient}
+        self.losses = [0.0, 0.0, 0.0]
+
+    def set_grad_scale(self, s):
+        self.grad_scale = float(s)
+
+    def ae_encode(self, indptr, indices, values, masks=None, z_real=None):
+        self._b = (indptr, indices, values)
+        self._mk = masks if masks is not None else [None] * 12
+        self._zr = z_real
+        z, self._ec = self.encode(indptr, indices, values, (self._mk[0], self._mk[1]))
+        self._z = z
+        return z
+
+    def ae_decode_backward(self, zc):
+        indptr, indices, values = self._b
+        B, N = len(indptr) - 1, self.N
+        zc = np.asarray(zc, dtype=f32)
+        logits, dc = self._mlp_fwd("dec", zc, (self._mk[2], self._mk[3]))
+        xhat = sigmoid(logits)
+        T = np.zeros((B, N), dtype=f32)
+        for b in range(B):
+            T[b, indices[indptr[b]:indptr[b + 1]]] = values[indptr[b]:indptr[b + 1]]
+        x, t = xhat + TINY, T + TINY
+        with np.errstate(divide="ignore"):
+            lx = np.maximum(np.log(x), f32(-100))
+            l1x = np.maximum(np.log1p(-x), f32(-100))
+        self.losses[0] = float((-(t * lx + (f32(1) - t) * l1x)).mean(dtype=np.float64))
+        gx = (x - t) / np.maximum((f32(1) - x) * x, f32(1e-12)) * f32(self.grad_scale / (B * N))
+        glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
+        Gd, gda1, gzc = self._mlp_bwd("dec", glog, dc)
+        Gd["dec.lin1.weight"] = (gda1.T @ zc).astype(f32)
+        self.G[1] = Gd
+        return gzc
+
+    def ae_encoder_backward(self, dz):
+        indptr, indices, values = self._b
+        ga3 = self._enc_final_bwd(self._z, np.asarray(dz, dtype=f32))
+        Ge, ga1, _ = self._mlp_bwd("enc", ga3, self._ec, need_dx=False)
+        Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, self._ec["s"], ga1)
+        self.G[0] = Ge
+
+    def disc_step(self):
+        indptr, indices, values = self._b
+        mk = self._mk[4:8]
+        B = len(indptr) - 1
+        zr = np.asarray(self._zr, dtype=f32)
+        if self.prior_scale is not None:
+            zr = (zr * f32(self.prior_scale)).astype(f32)
+        zf, _ = self.encode(indptr, indices, values, None)
+        dr, cr = self._disc(zr, (mk[0], mk[1]))
+        df, cf = self._disc(zf, (mk[2], mk[3]))
+        self.losses[1] = float(-(np.log(dr + TINY) + np.log(f32(1) - df + TINY)).mean(dtype=np.float64))
+        gs = f32(self.grad_scale / B)
+        G = {}
+        for d, g, cache in ((dr, -gs / (dr + TINY), cr), (df, gs / (f32(1) - df + TINY), cf)):
+            ga3 = (g * d * (f32(1) - d)).astype(f32)
+            Gi, ga1, _ = self._mlp_bwd("disc", ga3, cache, need_dx=False)
+            Gi["disc.lin1.weight"] = (ga1.T @ cache["x0"]).astype(f32)
+            for k, v in Gi.items():
+                G[k] = v if k not in G else (G[k] + v).astype(f32)
+        self.G[3] = G
+
+    def gen_step(self):
+        indptr, indices, values = self._b
+        mk = self._mk[8:12]
+        B = len(indptr) - 1
+        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
+        d, cd = self._disc(z, (mk[2], mk[3]))
+        self.losses[2] = float(-np.log(d + TINY).mean(dtype=np.float64))
+        ga3d = ((f32(-self.grad_scale / B) / (d + TINY)) * d * (f32(1) - d)).astype(f32)
+        _, _, gz = self._mlp_bwd("disc", ga3d, cd, need_dx=True)
+        Ge, ga1, _ = self._mlp_bwd("enc", self._enc_final_bwd(z, gz), ec, need_dx=False)
+        Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, ec["s"], ga1)
+        self.G[2] = Ge
+
+    def apply_updates(self, which):
+        opt = {0: self.opt_enc, 1: self.opt_dec, 2: self.opt_gen, 3: self.opt_disc}[which]
+        opt.step(self.p, self.G[which])

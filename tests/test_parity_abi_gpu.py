@@ -185,3 +185,40 @@ def test_fused_decoder_equals_unfused_path_at_headline_width(N, h, c, B):
         for k in ("lin3.weight", "lin1.weight"):
             np.testing.assert_allclose(sa[k][0], sb[k][0], atol=1e-9, rtol=1e-4)
             np.testing.assert_allclose(sa[k][1], sb[k][1], atol=1e-13, rtol=1e-4)
+
+
+class _SoloDist:
+    """torch.distributed stand-in for one rank: the exchange points become no-ops."""
+    class ReduceOp:
+        SUM = 0
+
+    def get_world_size(self, group=None):
+        return 1
+
+    def get_rank(self, group=None):
+        return 0
+
+    def all_reduce(self, t, op=None, group=None):
+        return None
+
+
+@pytest.mark.parametrize("name", ["step_masks", "step_cond_concat", "step_sgd", "step_wide"])
+def test_export_mode_through_parallel_wrapper_matches_reference(name):
+    """grad_mode='export' (gradients materialised, aae_apply_updates after the exchange point) driven
+    by aaerec.parallel.DataParallelAAE must reproduce the same fixtures as the fused-optimiser path."""
+    from aaerec.parallel import DataParallelAAE
+    fx = Fixture(name)
+    m = make_model(fx, grad_mode="export")
+    dp = DataParallelAAE(m, _SoloDist())
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = fx.cond_inputs(s)
+        cond_fn = None
+        if cond:
+            ct = torch.as_tensor(cond[0], device=m.device)
+            cond_fn = lambda z, ct=ct: (torch.cat([z, ct], 1), lambda dzc: dzc[:, :fx.cfg["c"]].contiguous())  # noqa: E731
+        dp.step(csr, 0, B, global_rows=B, cond_fn=cond_fn, masks=fx.masks(s), z_real=fx.z[f"step{s}.z_real"])
+        np.testing.assert_allclose(m.losses(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
+        if fx.has_state(s):
+            check_state(fx, m, s, name)
