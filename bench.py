@@ -149,6 +149,14 @@ def main():
             roofline = dict(kernel=dom, bound="mfma", achieved=ks["TFLOPs"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                             frac=round(mfma_frac, 4), traffic=None)
         roofline["avg_us"] = ks["avg_us"]
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+        # MI355X_MICROARCH.md prescribes), collected separately and committed under profiles/
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if pmc["config"] == {"n_items": N, "n_hidden": h, "batch": B} and dom in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][dom]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
