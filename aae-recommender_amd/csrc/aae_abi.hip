@@ -28,6 +28,7 @@
 #include "gemm_f32.h"
 #include "kernels.h"
 #include "dec_fused.h"
+#include "chain.h"
 
 using namespace aae;
 
@@ -72,7 +73,11 @@ struct aae_model {
     // gradients (all in export mode, gW1T always)
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
     // activations
-    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gzc, ga3, zin, xh1, xh2, dout, zsave;
+    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave;
+    bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
+    bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
+    bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
+    bool enc_bwd_done;
     int max_slabs;
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
@@ -177,6 +182,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
         m->slabs = a.mat((int64_t)nslab * R, h, m->ldh);
     }
     m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
+    m->gb2 = a.mat(R2, h + 1, m->ldh); m->gb3 = a.mat(R2, h + 1, m->ldh);
     m->gzc = a.mat(R, cp + 1, m->ldc);
     m->ga3 = a.mat(R2, cc + 1, m->ldz);
     m->zin = a.mat(R2, cc + 1, m->ldz);
@@ -470,6 +476,265 @@ int stage_zc(aae_model* m, const float* src, int64_t ld, int rows, hipStream_t s
     return AAE_OK;
 }
 
+
+// ==========================================================================================
+// chain path (chain.h): the hidden stacks as row-blocked programs
+// ==========================================================================================
+ChainOp cop(int kind, int src, int dst, int N) {
+    ChainOp o; memset(&o, 0, sizeof(o));
+    o.kind = kind; o.src = src; o.dst = dst; o.N = N; o.one_col = -1; o.scale = 1.f; o.yslot = 0;
+    return o;
+}
+ChainOp cop_load(const float* g, int ld, int dst, int N, int row0 = 0) {
+    ChainOp o = cop(COP_LOAD, 0, dst, N); o.W = g; o.ldw = ld; o.out_row0 = row0; return o;
+}
+ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int epi) {
+    ChainOp o = cop(kind, src, dst, N); o.W = W.p; o.ldw = (int)W.ld; o.K = K; o.epi = epi; return o;
+}
+void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
+
+struct ChainBuilder {
+    ChainProgram P;
+    ChainBuilder(const aae_model* m, int rows) {
+        memset(&P, 0, sizeof(P));
+        P.rows = rows; P.act = m->cfg.activation; P.seed = m->cfg.seed; P.step_ctr = m->step_ctr;
+        P.loss_out = m->losses; P.loss_slot = 3;
+    }
+    ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
+};
+
+int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
+    if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
+    const int grid = (cb.P.rows + kCR - 1) / kCR;
+    hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    LAUNCHCHK("chain_kernel");
+    return AAE_OK;
+}
+
+// up to 4 weight-gradient jobs in one launch
+struct DwBuilder {
+    DwGroup g; int tiles;
+    DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
+    void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
+        DwJob& J = g.jobs[g.njobs++];
+        const Ten& W = m->P[pid];
+        const int set = (which == O_GEN) ? 1 : 0;
+        J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
+        J.p = W.p; J.m = m->M[set][pid].p; J.v = m->V[set][pid].p; J.ld = (int)W.ld; J.sc = m->sc + which;
+        J.grad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[pid].p : nullptr;
+        J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
+        tiles += ((J.M + 31) / 32) * J.tiles_n;
+    }
+    int launch(hipStream_t s) {
+        hipLaunchKernelGGL(grouped_dw_kernel, dim3(tiles), dim3(256), 0, s, g);
+        LAUNCHCHK("grouped_dw_kernel");
+        return AAE_OK;
+    }
+};
+
+// Encoder hidden stack from the gathered first layer (eh1 in global): lin2, lin3, output activation.
+// ops appended to `cb`; z ends in slot 2.
+void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_t* mk2, uint32_t sid2, int rows,
+                        float* eh2_out) {
+    const int h = m->h;
+    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    ChainOp& a = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_W2], h + 1, h, CEPI_DROPACT));
+    a.d = make_drop(m, 1, train, mk2, nullptr, rows, h, sid2); a.one_col = h;
+    if (eh2_out) cop_out(a, eh2_out, m->ldh);
+    cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W3], h + 1, m->c, CEPI_NONE));
+}
+
+// ae forward after the gather: encoder tail (+ optionally the decoder's two hidden layers)
+int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* z_out, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p);
+    ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final;
+    cop_out(f, m->zc.p, m->ldc); f.out2 = m->zsave.p; f.ldo2 = m->ldz;
+    if (z_out) { ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, z_out, c); }
+    if (with_dec) {
+        if (m->cfg.cond_inc > 0) {
+            ChainOp& cl = cb.add(cop_load(cond_dev, m->cfg.cond_inc, 2, m->cfg.cond_inc)); cl.dst_col0 = c; cl.one_col = cp;
+        } else {
+            f.one_col = cp;
+        }
+        ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+        v1.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
+        ChainOp& v2 = cb.add(cop_linear(COP_LINEAR, 3, 4, m->P[P_V2], h + 1, h, CEPI_DROPACT));
+        v2.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
+    }
+    m->dec_hidden_done = with_dec;
+    return launch_chain(m, cb, s);
+}
+
+// decoder hidden layers from zc (global): split API and predict
+int chain_dec_hidden(aae_model* m, bool train, int rows, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 0, cp)); l.one_col = cp;
+    ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+    v1.d = make_drop(m, 0, train, I.masks_dev[2], nullptr, rows, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
+    ChainOp& v2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_V2], h + 1, h, CEPI_DROPACT));
+    v2.d = make_drop(m, 1, train, I.masks_dev[3], nullptr, rows, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
+// decoder backward below the output layer (+ optionally the encoder backward) as one program.
+//   dec: sum of the 16 dA2 partial slabs -> act'/dropout -> V2 -> V1 -> gzc
+//   enc: dz (slot or external) -> output activation' -> W3 -> W2 -> ga1
+int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* part_slabs, size_t slab_stride,
+                      const float* gz_ext, int ld_gz, float* dzc_out, int which, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    if (dec_part) {
+        if (part_slabs) {
+            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+            cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
+            ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1;
+            ab.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); cop_out(ab, m->gb0.p, m->ldh);
+        } else {
+            cb.add(cop_load(m->gb0.p, m->ldh, 2, h));      // unfused decoder path: gb0 already holds dL/da2
+        }
+        cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
+        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 2, 4, m->P[P_V2], h, h, CEPI_ACTBWD)); x2.yslot = 3;
+        x2.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); cop_out(x2, m->gb1.p, m->ldh);
+        ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 4, 5, m->P[P_V1], h, cp, CEPI_NONE));
+        cop_out(x1, m->gzc.p, m->ldc);
+        if (dzc_out) { x1.out2 = dzc_out; x1.ldo2 = cp; }
+    }
+    if (enc_part) {
+        if (!dec_part || gz_ext) cb.add(cop_load(gz_ext ? gz_ext : m->gzc.p, gz_ext ? ld_gz : m->ldc, 5, c));
+        cb.add(cop_load(m->zsave.p, m->ldz, 6, c));
+        ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
+        cop_out(fb, m->ga3.p, m->ldz);
+        cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
+        ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 7, 9, m->P[P_W3], c, h, CEPI_ACTBWD)); x3.yslot = 8;
+        x3.d = make_drop(m, 1, true, I.masks_dev[which == O_GEN ? 9 : 1], nullptr, B, h, which == O_GEN ? 9 : 1);
+        cop_out(x3, m->gb2.p, m->ldh);
+        cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
+        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 9, 1, m->P[P_W2], h, h, CEPI_ACTBWD)); x2.yslot = 0;
+        x2.d = make_drop(m, 0, true, I.masks_dev[which == O_GEN ? 8 : 0], nullptr, B, h, which == O_GEN ? 8 : 0);
+        cop_out(x2, m->gb3.p, m->ldh);
+    }
+    return launch_chain(m, cb, s);
+}
+
+// first encoder layer's weight gradient (sparse scatter), bias gradient and their optimiser
+int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStream_t s) {
+    const int B = m->rows, h = m->h;
+    const int set = (which == O_GEN) ? 1 : 0;
+    const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
+                       m->Gr[P_W1T].p, m->ldw1, 0);
+    LAUNCHCHK("enc_scatter");
+    hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
+                       m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
+    LAUNCHCHK("colsum_adam");
+    if (m->lazy) {
+        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
+        int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
+                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
+                           m->tsync, m->step_ctr, which == O_GEN ? 1 : 0);
+        LAUNCHCHK("w1_sparse_adam");
+    } else if (!exportg) {
+        size_t n4 = m->P[P_W1T].floats() / 4;
+        hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
+                           m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
+        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
+                           m->Gr[P_W1T].p, m->ldw1, 1);
+        LAUNCHCHK("adam_dense W1T");
+    }
+    return AAE_OK;
+}
+
+int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t sid1, hipStream_t s) {
+    const int B = m->rows, h = m->h;
+    DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
+    ProfScope ps(m, AAE_K_ENC_GATHER, s);
+    size_t shm = (size_t)4 * r4(h) * sizeof(float);
+    hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1, m->P[P_B1].p, h,
+                       m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation, d1, m->cfg.seed,
+                       m->step_ctr, m->rscale);
+    LAUNCHCHK("enc_gather");
+    return AAE_OK;
+}
+
+// disc_step on the chain path
+int chain_disc_step(aae_model* m, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    const aae_rng_inject& I = m->inj;
+    TRY(gather_first_layer(m, false, nullptr, 0, s));
+    {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
+        ChainBuilder cb(m, B);
+        chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr);
+        ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final; cop_out(f, m->zin.p, m->ldz, B);
+        TRY(launch_chain(m, cb, s));
+    }
+    {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
+        ChainBuilder cb(m, 2 * B);
+        cb.P.loss_slot = 1;
+        ChainOp& l = cb.add(cop_load(m->zin.p, m->ldz, 0, c)); l.one_col = c;
+        ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_D1], c + 1, h, CEPI_DROPACT));
+        d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
+        ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_D2], h + 1, h, CEPI_DROPACT));
+        d2.d = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5); d2.one_col = h; cop_out(d2, m->xh2.p, m->ldh);
+        cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_D3], h + 1, 1, CEPI_SIGMOID));
+        ChainOp& adv = cb.add(cop(COP_ADV, 3, 4, 1)); adv.aux = 0; adv.row_split = B; adv.scale = m->grad_scale;
+        cop_out(adv, m->ga3.p, 4);
+        ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 4, 5, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
+        cop_out(x3, m->gb0.p, m->ldh);
+        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 5, 6, m->P[P_D2], h, h, CEPI_ACTBWD)); x2.yslot = 1; x2.d = d1.d;
+        cop_out(x2, m->gb1.p, m->ldh);
+        TRY(launch_chain(m, cb, s));
+    }
+    DwBuilder dw;
+    dw.add(m, m->ga3.p, 4, m->xh2.p, m->ldh, 2 * B, P_D3, O_DISC);
+    dw.add(m, m->gb0.p, m->ldh, m->xh1.p, m->ldh, 2 * B, P_D2, O_DISC);
+    dw.add(m, m->gb1.p, m->ldh, m->zin.p, m->ldz, 2 * B, P_D1, O_DISC);
+    return dw.launch(s);
+}
+
+// gen_step on the chain path: everything between the shared gather and the weight gradients is
+// row-local and runs as ONE program
+int chain_gen_step(aae_model* m, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 2;
+    cb.add(cop_load(m->a1.p, m->ldh, 0, h));
+    ChainOp& e1 = cb.add(cop(COP_DROPACT, 0, 1, h));
+    e1.d = make_drop(m, 0, true, I.masks_dev[8], nullptr, B, h, 8); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
+    ChainOp& e2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W2], h + 1, h, CEPI_DROPACT));
+    e2.d = make_drop(m, 1, true, I.masks_dev[9], nullptr, B, h, 9); e2.one_col = h; cop_out(e2, m->eh2.p, m->ldh);
+    cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_W3], h + 1, c, CEPI_NONE));
+    ChainOp& f = cb.add(cop(COP_FINAL_FWD, 3, 3, c)); f.aux = m->cfg.enc_final; f.one_col = c;
+    ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 3, 4, m->P[P_D1], c + 1, h, CEPI_DROPACT));
+    d1.d = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10); d1.one_col = h;
+    ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 4, 5, m->P[P_D2], h + 1, h, CEPI_DROPACT));
+    d2.d = make_drop(m, 1, true, I.masks_dev[11], nullptr, B, h, 11); d2.one_col = h;
+    cb.add(cop_linear(COP_LINEAR, 5, 6, m->P[P_D3], h + 1, 1, CEPI_SIGMOID));
+    ChainOp& adv = cb.add(cop(COP_ADV, 6, 7, 1)); adv.aux = 1; adv.row_split = B; adv.scale = m->grad_scale;
+    ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 7, 8, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
+    ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 8, 9, m->P[P_D2], h, h, CEPI_ACTBWD)); x2.yslot = 4; x2.d = d1.d;
+    cb.add(cop_linear(COP_LINEAR_DX, 9, 0, m->P[P_D1], h, c, CEPI_NONE));                    // dL/dz
+    ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;
+    cop_out(fb, m->ga3.p, m->ldz);
+    ChainOp& w3 = cb.add(cop_linear(COP_LINEAR_DX, 6, 7, m->P[P_W3], c, h, CEPI_ACTBWD)); w3.yslot = 2; w3.d = e2.d;
+    cop_out(w3, m->gb2.p, m->ldh);
+    ChainOp& w2 = cb.add(cop_linear(COP_LINEAR_DX, 7, 8, m->P[P_W2], h, h, CEPI_ACTBWD)); w2.yslot = 1; w2.d = e1.d;
+    cop_out(w2, m->gb3.p, m->ldh);
+    TRY(launch_chain(m, cb, s));
+    DwBuilder dw;
+    dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
+    dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
+    TRY(dw.launch(s));
+    return encoder_first_layer_update(m, m->gb3.p, O_GEN, s);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -508,6 +773,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         const int nb = (m->h + 1 + 15) / 16;
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
         m->fused_ok = m->fused_nb != 0 && m->ldh <= 256 && (m->ldh % 4) == 0 && m->ldh <= kSD - 2;
+        m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= 208) && getenv("AAE_NO_CHAIN") == nullptr;
+        if (m->use_chain && hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess)
+            m->use_chain = false;
         m->force_unfused = cfg->reserved[0] == 1;   // debugging / A-B switch: reserved[0] = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;
@@ -753,14 +1023,22 @@ static void remember_inject(aae_model* m, const aae_rng_inject* inj, bool reset)
     else if (reset) memset(&m->inj, 0, sizeof(m->inj));
 }
 
-int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* inj, float* z_out, void* stream) {
+static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_inject* inj, float* z_out, bool with_dec,
+                          const float* cond_dev, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
-                       m->stamp, m->ucount);
+                       m->stamp, m->ucount, m->losses);
     if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+    m->dec_hidden_done = false; m->enc_bwd_done = false;
+    if (m->use_chain) {
+        TRY(gather_first_layer(m, true, m->inj.masks_dev[0], 0, s));
+        TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
+        m->phase = 1;
+        return AAE_OK;
+    }
     TRY(encoder_forward(m, true, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, false, m->zc.p, m->ldc, s));
     // keep a copy of z for the encoder backward (condition plugins replace zc)
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
@@ -773,6 +1051,10 @@ int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* in
     return AAE_OK;
 }
 
+int aae_ae_encode(aae_handle m, const aae_batch* batch, const aae_rng_inject* inj, float* z_out, void* stream) {
+    return ae_encode_impl(m, batch, inj, z_out, false, nullptr, stream);
+}
+
 int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, const aae_rng_inject* inj,
                            float* dzc_out, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
@@ -783,11 +1065,13 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, B, s));
     const uint8_t* mk2 = m->inj.masks_dev[2];
     const uint8_t* mk3 = m->inj.masks_dev[3];
-    TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
+    if (m->use_chain) { if (!m->dec_hidden_done) TRY(chain_dec_hidden(m, true, B, s)); }
+    else TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
     const size_t fused_lds = dec_fused_lds_bytes(B, h);
+    const float* chain_part = nullptr; size_t chain_stride = 0;
     if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
         const int ntiles = (N + kTI - 1) / kTI;
@@ -824,10 +1108,14 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         const size_t n4 = (size_t)B * m->ldh / 4;
         hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
                            fa.slab_stride, n4, part, fa.slab_stride);
-        hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h, 64)), dim3(64), 0, s, part, 16,
-                           fa.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2, m->cfg.seed,
-                           m->step_ctr);
-        LAUNCHCHK("slab_reduce");
+        if (m->use_chain) {
+            chain_part = part; chain_stride = fa.slab_stride;
+        } else {
+            hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h, 64)), dim3(64), 0, s, part, 16,
+                               fa.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2,
+                               m->cfg.seed, m->step_ctr);
+            LAUNCHCHK("slab_reduce");
+        }
     } else {
     // ---- unfused path: output layer + BCE: G = dL/dlogits [B][N]
     {
@@ -866,6 +1154,23 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
     }
     }
+    if (m->use_chain) {
+        // decoder hidden backward (+ the encoder backward when called from aae_step) in one program,
+        // then every small weight gradient + optimiser update in one grouped launch
+        const bool enc_too = m->fuse_enc_bwd;
+        TRY(chain_ae_backward(m, true, enc_too, chain_part, chain_stride, nullptr, 0, dzc_out, O_ENC, s));
+        DwBuilder dw;
+        dw.add(m, m->gb0.p, m->ldh, m->dh1.p, m->ldh, B, P_V2, O_DEC);
+        dw.add(m, m->gb1.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
+        if (enc_too) {
+            dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
+            dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
+            m->enc_bwd_done = true;
+        }
+        TRY(dw.launch(s));
+        m->phase = 2;
+        return AAE_OK;
+    }
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
@@ -888,6 +1193,18 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->phase != 2) return fail(AAE_ESTATE, "aae_ae_encoder_backward without aae_ae_decode_backward");
     hipStream_t s = S(stream);
+    if (m->use_chain) {
+        if (!m->enc_bwd_done) {
+            TRY(chain_ae_backward(m, false, true, nullptr, 0, dz_dev, (int)dz_ld, nullptr, O_ENC, s));
+            DwBuilder dw;
+            dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, m->rows, P_W3, O_ENC);
+            dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, m->rows, P_W2, O_ENC);
+            TRY(dw.launch(s));
+        }
+        TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s));
+        m->phase = 3;
+        return AAE_OK;
+    }
     const float* gz = dz_dev ? dz_dev : m->gzc.p;
     int ld = dz_dev ? (int)dz_ld : m->ldc;
     TRY(encoder_backward(m, gz, ld, m->zsave.p, m->ldz, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, O_ENC, s));
@@ -914,6 +1231,11 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
                            m->ldz, B, cc, pscale);
     }
     LAUNCHCHK("prior");
+    if (m->use_chain) {
+        TRY(chain_disc_step(m, s));
+        m->phase = 4;
+        return AAE_OK;
+    }
     TRY(encoder_forward(m, false, nullptr, nullptr, 0, 0, false, m->zin.p + (size_t)B * m->ldz, m->ldz, s));
     TRY(disc_forward(m, 2 * B, I.masks_dev[4], I.masks_dev[6], I.masks_dev[5], I.masks_dev[7], B, 4, 5, s));
     hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, s, m->dout.p, 4, B, 0, m->grad_scale, m->ga3.p, 4,
@@ -944,6 +1266,11 @@ int aae_gen_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
     hipStream_t s = S(stream);
     const int B = m->rows, h = m->h, cc = m->c;
     const aae_rng_inject& I = m->inj;
+    if (m->use_chain) {
+        TRY(chain_gen_step(m, s));
+        m->phase = 0;
+        return AAE_OK;
+    }
     TRY(encoder_forward(m, true, I.masks_dev[8], I.masks_dev[9], 8, 9, true, m->zin.p, m->ldz, s));
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, m->zsave.p,
                        m->ldz, B, cc, 1.0f);
@@ -976,13 +1303,16 @@ int aae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const 
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
     hipStream_t s = S(stream);
-    TRY(aae_ae_encode(m, batch, inj, nullptr, stream));
+    TRY(ae_encode_impl(m, batch, inj, nullptr, true, cond_dev, stream));
     if (m->cfg.cond_inc > 0) {
         hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->cfg.cond_inc)), dim3(256), 0, s, cond_dev,
                            m->cfg.cond_inc, m->zc.p + m->c, m->ldc, m->rows, m->cfg.cond_inc, 1.0f);
         LAUNCHCHK("copy cond");
     }
-    TRY(aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream));
+    m->fuse_enc_bwd = true;
+    int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream);
+    m->fuse_enc_bwd = false;
+    TRY(rc);
     TRY(aae_ae_encoder_backward(m, nullptr, 0, stream));
     TRY(aae_disc_gen(m, nullptr, stream));
     return AAE_OK;
@@ -1003,6 +1333,16 @@ int aae_encode(aae_handle m, const aae_batch* batch, float* z_out, void* stream)
     TRY(set_batch(m, batch));
     hipStream_t s = S(stream);
     if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
+    if (m->use_chain) {
+        TRY(gather_first_layer(m, false, nullptr, 0, s));
+        ChainBuilder cb(m, m->rows);
+        chain_encoder_tail(m, cb, false, nullptr, 0, m->rows, nullptr);
+        ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, m->c)); f.aux = m->cfg.enc_final; cop_out(f, m->zc.p, m->ldc);
+        if (z_out) { f.out2 = z_out; f.ldo2 = m->c; }
+        TRY(launch_chain(m, cb, s));
+        m->phase = 0;
+        return AAE_OK;
+    }
     TRY(encoder_forward(m, false, nullptr, nullptr, 0, 0, false, m->zc.p, m->ldc, s));
     if (z_out) {
         hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->c)), dim3(256), 0, s, m->zc.p, m->ldc,
@@ -1021,7 +1361,8 @@ int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
         return fail(AAE_EINVAL, "out_dev must be 16-byte aligned with out_ld >= n_items and out_ld % 4 == 0");
     hipStream_t s = S(stream);
     if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, n_rows, s));
-    TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
+    if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
+    else TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
     TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s));
     return AAE_OK;

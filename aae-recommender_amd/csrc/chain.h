@@ -1,0 +1,338 @@
+// Row-blocked layer chains: the hidden stacks of Encoder / Decoder / Discriminator (forward and
+// the activation-gradient half of backward) are row-local, so a workgroup can carry 16 rows of
+// the batch through a whole sequence of layers without leaving the CU: activations sit in LDS
+// "slots" [16][kCL], weights stream from L2 straight into MFMA operand registers, and every layer
+// is a handful of v_mfma_f32_16x16x4_f32 per wave.  One launch replaces up to 14 tiny GEMM /
+// element-wise launches whose 5-8 us dispatch floor dominated the B=100 step.
+//
+// A chain is a small program of ChainOps executed in order by every workgroup on its own 16 rows
+// (barrier between ops).  The weight-gradient products (sums over the batch) are NOT row-local:
+// the chains store the per-layer gradients/activations they need and grouped_dw_kernel
+// (below) turns them into optimiser updates.
+#pragma once
+#include "device_common.h"
+#include "gemm_f32.h"
+#include "kernels.h"
+
+namespace aae {
+
+constexpr int kCR = 16;        // rows per workgroup
+constexpr int kCL = 212;       // slot row stride (floats): widths up to 208, 16-byte aligned rows
+constexpr int kCSlots = 10;
+constexpr int kCT = 512;       // threads per workgroup (8 waves)
+constexpr int kCMaxOps = 16;
+
+enum { COP_LOAD = 0,        // dst <- global src [rows][lds_] cols [0, N)            (zero padded)
+       COP_LINEAR,          // dst[16][N] = epi( src[16][K] * W[N][K]^T )             W k-contiguous rows
+       COP_LINEAR_DX,       // dst[16][N] = epi( src[16][K] * W[K][0:N] )             W n-contiguous rows
+       COP_FINAL_FWD,       // encoder output activation on dst (in place), width N
+       COP_FINAL_BWD,       // dst <- d(final act): src = dL/dz, yslot = z
+       COP_ADV,             // adversarial loss + gradient on the discriminator output (slot src col 0 -> dst col 0)
+       COP_DROPACT,         // dst <- act(dropout(src)), width N
+       COP_SLABSUM,         // dst <- sum_z slabs[z][row][0:N]
+       COP_ACTBWD,          // dst <- src * act'(y) * dropout_scale   (y from yslot)
+       COP_STORE };         // no compute: only the post-op global store(s) of dst[:, 0:N]
+
+enum { CEPI_NONE = 0, CEPI_DROPACT = 1, CEPI_ACTBWD = 2, CEPI_SIGMOID = 3 };
+
+struct ChainOp {
+    int kind, src, dst, K, N;
+    const float* W; int ldw;            // weights / global source (COP_LOAD, COP_SLABSUM)
+    int epi, yslot;                     // epilogue; slot holding y for ACTBWD / FINAL_BWD
+    DropSpec d;
+    float* out; int ldo; int out_row0;  // optional global store of dst[:, 0:N] at rows out_row0 + r
+    float* out2; int ldo2;              // optional second copy (e.g. z kept for the backward pass)
+    int one_col;                        // >= 0: set dst[:, one_col] = 1 (constant-1 column of augmented weights)
+    int aux;                            // COP_ADV: mode; COP_SLABSUM: number of slabs; COP_FINAL_*: kind
+    size_t stride;                      // COP_SLABSUM: slab stride (floats)
+    float scale;                        // COP_ADV: grad scale; COP_LOAD: multiplier
+    int row_split;                      // COP_ADV mode 0: rows >= row_split are "fake"
+    int dst_col0;                       // COP_LOAD: first destination column (appending a condition block)
+};
+
+struct ChainProgram {
+    int nops, rows, act;
+    uint64_t seed; const long long* step_ctr;
+    float* loss_out; int loss_slot;     // COP_ADV accumulates -mean(log ...) here (atomicAdd of per-row terms)
+    ChainOp ops[kCMaxOps];
+};
+
+__device__ __forceinline__ float chain_epi(int epi, const ChainOp& op, const ChainProgram& P, uint64_t key,
+                                           const float* slots, int grow, int lrow, int col, float v) {
+    if (epi == CEPI_DROPACT) {
+        if (op.d.enabled) v = drop_fwd(op.d, drop_keep(op.d, key, grow, col), v);
+        return act_fwd(P.act, v);
+    }
+    if (epi == CEPI_ACTBWD) {
+        const float y = slots[op.yslot * kCR * kCL + lrow * kCL + col];
+        v *= act_grad_from_y(P.act, y);
+        if (op.d.enabled) v *= drop_bwd_mul(op.d, drop_keep(op.d, key, grow, col));
+        return v;
+    }
+    if (epi == CEPI_SIGMOID) return sigmoidf_(v);
+    return v;
+}
+
+__global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
+    extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int r0 = blockIdx.x * kCR;
+    const int nrows = min(kCR, P.rows - r0);
+    const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
+
+    for (int i = tid; i < kCSlots * kCR * kCL; i += kCT) slots[i] = 0.f;
+    __syncthreads();
+
+    for (int oi = 0; oi < P.nops; ++oi) {
+        const ChainOp& op = P.ops[oi];
+        float* dst = slots + op.dst * kCR * kCL;
+        const float* src = slots + op.src * kCR * kCL;
+        const int kind = op.kind;
+
+        if (kind == COP_LINEAR || kind == COP_LINEAR_DX) {
+            // output blocks of 16 columns: wave w takes blocks w, w+8 (N <= 208 -> <= 13 blocks)
+            const int nblk = (op.N + 15) >> 4;
+            f32x4 acc[2];
+            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int b0 = min(wave, nblk - 1), b1 = min(wave + 8, nblk - 1);
+            if (kind == COP_LINEAR) {
+                // k-permutation: lane (fr, fk) holds k = kc + 4*fk + j in element j of one float4 for BOTH
+                // operands, so 16 k need one 16-byte load per operand and feed 4 MFMAs
+                const float* w0 = op.W + (size_t)min(b0 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
+                const float* w1 = op.W + (size_t)min(b1 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
+                const float* a = src + fr * kCL + 4 * fk;
+                const int kch = (op.K + 15) >> 4;
+                for (int c = 0; c < kch; c += 2) {
+                    float4 xa[2], y0[2], y1[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kc = min(c + j, kch - 1) * 16;
+                        y0[j] = *reinterpret_cast<const float4*>(w0 + kc);
+                        y1[j] = *reinterpret_cast<const float4*>(w1 + kc);
+                        xa[j] = *reinterpret_cast<const float4*>(a + kc);
+                        if (c + j >= kch) xa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, y0[j].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, y1[j].x, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, y0[j].y, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, y1[j].y, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, y0[j].z, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, y1[j].z, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, y0[j].w, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, y1[j].w, acc[1], 0, 0, 0);
+                    }
+                }
+            } else {
+                // W[k][n], n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes)
+                const float* w0 = op.W + (size_t)fk * op.ldw + min(b0 * 16 + fr, op.N - 1);
+                const float* w1 = op.W + (size_t)fk * op.ldw + min(b1 * 16 + fr, op.N - 1);
+                const float* a = src + fr * kCL + fk;
+                const int ks = (op.K + 3) >> 2;
+                for (int s = 0; s < ks; s += 4) {
+                    float xa[4], y0[4], y1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kk = (s + j) * 4;
+                        const int kr = min(kk + fk, op.K - 1) - fk;          // clamp the weight row, A is zero past K
+                        y0[j] = w0[(size_t)kr * op.ldw];
+                        y1[j] = w1[(size_t)kr * op.ldw];
+                        xa[j] = (kk + fk < op.K) ? a[min(kk, kCL - 4)] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], y0[j], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], y1[j], acc[1], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();      // dst may alias a slot other waves were still reading (src != dst is required)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int blk = wave + 8 * q;
+                if (blk < nblk) {
+                    const int col = blk * 16 + fr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lrow = fk * 4 + r;
+                        float v = 0.f;
+                        if (col < op.N && lrow < nrows) v = chain_epi(op.epi, op, P, key, slots, r0 + lrow, lrow, col, acc[q][r]);
+                        dst[lrow * kCL + col] = v;
+                    }
+                }
+            }
+            // columns [16*nblk, kCL) of dst keep their zeros: slots are only ever written inside [0, 16*nblk)
+        } else if (kind == COP_LOAD) {
+            for (int i = tid; i < kCR * op.N; i += kCT) {
+                const int lrow = i / op.N, col = i - lrow * op.N;
+                dst[lrow * kCL + op.dst_col0 + col] =
+                    lrow < nrows ? op.W[(size_t)(op.out_row0 + r0 + lrow) * op.ldw + col] * op.scale : 0.f;
+            }
+        } else if (kind == COP_SLABSUM) {
+            for (int i = tid; i < kCR * op.N; i += kCT) {
+                const int lrow = i / op.N, col = i - lrow * op.N;
+                float v = 0.f;
+                if (lrow < nrows)
+                    for (int z = 0; z < op.aux; ++z) v += op.W[(size_t)z * op.stride + (size_t)(r0 + lrow) * op.ldw + col];
+                dst[lrow * kCL + col] = v;
+            }
+        } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
+            const int epi = kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD;
+            for (int i = tid; i < kCR * op.N; i += kCT) {
+                const int lrow = i / op.N, col = i - lrow * op.N;
+                dst[lrow * kCL + col] =
+                    lrow < nrows ? chain_epi(epi, op, P, key, slots, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
+            }
+        } else if (kind == COP_FINAL_FWD) {
+            // one wave per pair of rows; softmax / sigmoid / identity over N columns, in place on dst
+            for (int lrow = wave; lrow < kCR; lrow += 8) {
+                float* zr = dst + lrow * kCL;
+                if (op.aux == 1) {
+                    float mx = -INFINITY;
+                    for (int j = lane; j < op.N; j += 64) mx = fmaxf(mx, zr[j]);
+                    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    float sum = 0.f;
+                    for (int j = lane; j < op.N; j += 64) sum += expf(zr[j] - mx);
+                    sum = wave_sum(sum);
+                    for (int j = lane; j < op.N; j += 64) zr[j] = expf(zr[j] - mx) / sum;
+                } else if (op.aux == 2) {
+                    for (int j = lane; j < op.N; j += 64) zr[j] = sigmoidf_(zr[j]);
+                }
+            }
+        } else if (kind == COP_FINAL_BWD) {
+            const float* zs = slots + op.yslot * kCR * kCL;
+            for (int lrow = wave; lrow < kCR; lrow += 8) {
+                const float* zr = zs + lrow * kCL;
+                const float* gr = src + lrow * kCL;
+                float* o = dst + lrow * kCL;
+                if (op.aux == 1) {
+                    float dot = 0.f;
+                    for (int j = lane; j < op.N; j += 64) dot += gr[j] * zr[j];
+                    dot = wave_sum(dot);
+                    for (int j = lane; j < op.N; j += 64) o[j] = zr[j] * (gr[j] - dot);
+                } else if (op.aux == 2) {
+                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j] * zr[j] * (1.f - zr[j]);
+                } else {
+                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
+                }
+            }
+        } else if (kind == COP_ADV) {
+            // src col 0 = D(x) of each row.  mode 0: rows < row_split real, others fake; mode 1: all fake(gen)
+            if (tid < kCR) {
+                const int lrow = tid, g = r0 + lrow;
+                float gv = 0.f;
+                if (lrow < nrows) {
+                    const float dv = src[lrow * kCL];
+                    const int B = op.row_split;
+                    const float invB = 1.f / (float)B;
+                    float l, gg;
+                    if (op.aux == 0 && g >= B) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
+                    else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
+                    gv = gg * dv * (1.f - dv) * op.scale;
+                    atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                }
+                dst[lrow * kCL] = gv;
+            }
+        }
+        __syncthreads();
+        // columns behind what this op wrote must read as zero for the next layer's k-padding
+        if (kind != COP_STORE && kind != COP_ADV && kind != COP_FINAL_FWD) {
+            const int c0 = (kind == COP_LINEAR || kind == COP_LINEAR_DX) ? ((op.N + 15) & ~15) : op.dst_col0 + op.N;
+            const int w = kCL - c0;
+            for (int i = tid; i < kCR * w; i += kCT) dst[(i / w) * kCL + c0 + i % w] = 0.f;
+            __syncthreads();
+        }
+        if (op.one_col >= 0) {
+            if (tid < kCR) dst[tid * kCL + op.one_col] = tid < nrows ? 1.f : 0.f;
+            __syncthreads();
+        }
+        if (op.out || op.out2) {
+            for (int i = tid; i < nrows * op.N; i += kCT) {
+                const int lrow = i / op.N, col = i - lrow * op.N;
+                const float v = dst[lrow * kCL + col];
+                if (op.out) op.out[(size_t)(op.out_row0 + r0 + lrow) * op.ldo + col] = v;
+                if (op.out2) op.out2[(size_t)(r0 + lrow) * op.ldo2 + col] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// grouped weight-gradient GEMMs: dW[out][in+1] = G[rows][out]^T * X[rows][in+1] for up to 4 layers
+// in one launch, 32x32 tiles, fused optimiser update (or gradient export).
+// -----------------------------------------------------------------------------------------------
+struct DwJob {
+    const float* G; int ldg; const float* X; int ldx; int rows;   // K = rows
+    int M, N;                                                      // out, in+1
+    float* p; float* m; float* v; float* grad; int ld;             // grad != NULL: export
+    const OptScalars* sc;
+    int tile0;                                                     // first linear tile id of this job
+    int tiles_n;                                                   // tiles along N
+};
+struct DwGroup { int njobs; DwJob jobs[4]; };
+
+__global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
+    constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
+    int j = 0;
+    for (int q = 1; q < grp.njobs; ++q) if ((int)blockIdx.x >= grp.jobs[q].tile0) j = q;
+    const DwJob& J = grp.jobs[j];
+    const int t = blockIdx.x - J.tile0;
+    const int m0 = (t / J.tiles_n) * TS, n0 = (t % J.tiles_n) * TS;
+    float* As = smem; float* Bs = smem + BK * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int K = J.rows;
+    const int mmax4 = ((J.M + 3) & ~3) - 4, nmax4 = ((J.N + 3) & ~3) - 4;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        float4 ra[NV], rb[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + 256 * q, kr = min(k0 + f / (TS / 4), K - 1), cq = (f % (TS / 4)) * 4;
+            ra[q] = *reinterpret_cast<const float4*>(J.G + (size_t)kr * J.ldg + min(m0 + cq, mmax4));
+            rb[q] = *reinterpret_cast<const float4*>(J.X + (size_t)kr * J.ldx + min(n0 + cq, nmax4));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + 256 * q, kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
+            const bool ok = k0 + kr < K;
+            float4 va, vb;
+            va.x = (ok && m0 + cq < J.M) ? ra[q].x : 0.f; va.y = (ok && m0 + cq + 1 < J.M) ? ra[q].y : 0.f;
+            va.z = (ok && m0 + cq + 2 < J.M) ? ra[q].z : 0.f; va.w = (ok && m0 + cq + 3 < J.M) ? ra[q].w : 0.f;
+            vb.x = (ok && n0 + cq < J.N) ? rb[q].x : 0.f; vb.y = (ok && n0 + cq + 1 < J.N) ? rb[q].y : 0.f;
+            vb.z = (ok && n0 + cq + 2 < J.N) ? rb[q].z : 0.f; vb.w = (ok && n0 + cq + 3 < J.N) ? rb[q].w : 0.f;
+            *reinterpret_cast<float4*>(&As[kr * LDT + cq]) = va;
+            *reinterpret_cast<float4*>(&Bs[kr * LDT + cq]) = vb;
+        }
+        __syncthreads();
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[(kk + fk) * LDT + wm + fr], Bs[(kk + fk) * LDT + wn + fr], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float* Cs = smem;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cs[(wm + (lane >> 4) * 4 + r) * LDC + wn + (lane & 15)] = acc[r];
+    __syncthreads();
+    const int row = tid / (TS / 4), col = (tid % (TS / 4)) * 4;
+    const int gm = m0 + row, gn = n0 + col;
+    if (gm < J.M && gn < J.N) {
+        const float4 g4 = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
+        if (J.grad) {
+            EpiStore e; e.out = J.grad; e.ld = J.ld;
+            EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
+        } else {
+            EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
+            EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
+        }
+    }
+}
+
+}  // namespace aae

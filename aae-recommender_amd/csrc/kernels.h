@@ -463,9 +463,10 @@ __global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucoun
 
 // once per step, one launch: rng step counter += 1 and the four optimisers' step counts ->
 // scalars (see OptScalars) + this step's row of the lazy-Adam table.  Thread i = optimiser i.
-__global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount) {
+__global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount,
+                                    float* losses) {
     const int i = threadIdx.x;
-    if (i == 0) { *ctr += 1; *stamp += 1; *ucount = 0; }
+    if (i == 0) { *ctr += 1; *stamp += 1; *ucount = 0; losses[1] = 0.f; losses[2] = 0.f; }
     if (i >= 4) return;
     OptScalars s = sc[i];
     s.t += 1;
