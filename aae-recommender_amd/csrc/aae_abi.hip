@@ -499,6 +499,7 @@ struct ChainBuilder {
         memset(&P, 0, sizeof(P));
         P.rows = rows; P.act = m->cfg.activation; P.seed = m->cfg.seed; P.step_ctr = m->step_ctr;
         P.loss_out = m->losses; P.loss_slot = 3;
+        { const char* e = getenv("AAE_CHAIN_SKIP"); P.dbg = e ? atoi(e) : 0; }
     }
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
 };

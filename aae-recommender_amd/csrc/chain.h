@@ -54,6 +54,7 @@ struct ChainProgram {
     int nops, rows, act;
     uint64_t seed; const long long* step_ctr;
     float* loss_out; int loss_slot;     // COP_ADV accumulates -mean(log ...) here (atomicAdd of per-row terms)
+    int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
     ChainOp ops[kCMaxOps];
 };
 
@@ -73,6 +74,61 @@ __device__ __forceinline__ float chain_epi(int epi, const ChainOp& op, const Cha
     return v;
 }
 
+// Element-wise work on a 16-row block uses a fixed thread -> (row, float4 column) map:
+// row = tid >> 5, column group c4 = (tid & 31) + 32*j (j = 0, 1): 64 float4 = 256 columns, no
+// integer division, and both of a thread's global loads are in flight before the first use (a
+// scalar element loop is a chain of dependent L2 round trips, ~1 us each).
+__device__ __forceinline__ void chain_load_block(const float* __restrict__ g, int ld, int row0, int nrows, int N,
+                                                 float* dst, int dst_col0, float scale) {
+    const int tid = threadIdx.x, lrow = tid >> 5;
+    const bool vec = (ld & 3) == 0 && (dst_col0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    const int rowc = min(lrow, max(nrows, 1) - 1);
+    const int nf4 = (N + 3) >> 2;
+    if (vec) {
+        float4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c4 = min((tid & 31) + 32 * j, nf4 - 1);
+            v[j] = *reinterpret_cast<const float4*>(g + (size_t)(row0 + rowc) * ld + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c4 = (tid & 31) + 32 * j;
+            if (c4 * 4 + dst_col0 < kCL) {                  // also clears the tail of the slot row
+                const bool ok = lrow < nrows;
+                float4 o;
+                o.x = (ok && c4 * 4 + 0 < N) ? v[j].x * scale : 0.f;
+                o.y = (ok && c4 * 4 + 1 < N) ? v[j].y * scale : 0.f;
+                o.z = (ok && c4 * 4 + 2 < N) ? v[j].z * scale : 0.f;
+                o.w = (ok && c4 * 4 + 3 < N) ? v[j].w * scale : 0.f;
+                *reinterpret_cast<float4*>(dst + lrow * kCL + dst_col0 + c4 * 4) = o;
+            }
+        }
+    } else {
+        for (int col = tid & 31; col + dst_col0 < kCL; col += 32)
+            dst[lrow * kCL + dst_col0 + col] =
+                (lrow < nrows && col < N) ? g[(size_t)(row0 + lrow) * ld + col] * scale : 0.f;
+    }
+}
+
+// LDS slot [16][0:N) -> global rows
+__device__ __forceinline__ void chain_store_block(const float* src, int nrows, int N, float* __restrict__ g, int ld,
+                                                  int row0) {
+    const int tid = threadIdx.x, lrow = tid >> 5;
+    if (lrow >= nrows) return;
+    if ((ld & 3) == 0 && (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c4 = (tid & 31) + 32 * j;
+            if (c4 * 4 < N)
+                *reinterpret_cast<float4*>(g + (size_t)(row0 + lrow) * ld + c4 * 4) =
+                    *reinterpret_cast<const float4*>(src + lrow * kCL + c4 * 4);
+        }
+    } else {
+        for (int col = tid & 31; col < N; col += 32) g[(size_t)(row0 + lrow) * ld + col] = src[lrow * kCL + col];
+    }
+}
+
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -81,9 +137,6 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     const int r0 = blockIdx.x * kCR;
     const int nrows = min(kCR, P.rows - r0);
     const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
-
-    for (int i = tid; i < kCSlots * kCR * kCL; i += kCT) slots[i] = 0.f;
-    __syncthreads();
 
     for (int oi = 0; oi < P.nops; ++oi) {
         const ChainOp& op = P.ops[oi];
@@ -97,57 +150,61 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             f32x4 acc[2];
             acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int b0 = min(wave, nblk - 1), b1 = min(wave + 8, nblk - 1);
+            if (!(P.dbg & 1)) {
+            // All weight loads of the layer are issued before its first MFMA (the arrays below are fully
+            // unrolled, i.e. registers): a layer then costs one L2 round trip, not one per k-group.
             if (kind == COP_LINEAR) {
                 // k-permutation: lane (fr, fk) holds k = kc + 4*fk + j in element j of one float4 for BOTH
                 // operands, so 16 k need one 16-byte load per operand and feed 4 MFMAs
+                constexpr int MC = 13;                         // K <= 208
                 const float* w0 = op.W + (size_t)min(b0 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
                 const float* w1 = op.W + (size_t)min(b1 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
                 const float* a = src + fr * kCL + 4 * fk;
                 const int kch = (op.K + 15) >> 4;
-                for (int c = 0; c < kch; c += 2) {
-                    float4 xa[2], y0[2], y1[2];
+                float4 y0[MC], y1[MC];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int kc = min(c + j, kch - 1) * 16;
-                        y0[j] = *reinterpret_cast<const float4*>(w0 + kc);
-                        y1[j] = *reinterpret_cast<const float4*>(w1 + kc);
-                        xa[j] = *reinterpret_cast<const float4*>(a + kc);
-                        if (c + j >= kch) xa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                for (int c = 0; c < MC; ++c) {
+                    const int kc = min(c, kch - 1) * 16;
+                    y0[c] = *reinterpret_cast<const float4*>(w0 + kc);
+                    y1[c] = *reinterpret_cast<const float4*>(w1 + kc);
+                }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, y0[j].x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, y1[j].x, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, y0[j].y, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, y1[j].y, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, y0[j].z, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, y1[j].z, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, y0[j].w, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, y1[j].w, acc[1], 0, 0, 0);
+                for (int c = 0; c < MC; ++c) {
+                    if (c < kch) {
+                        const float4 xa = *reinterpret_cast<const float4*>(a + c * 16);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y0[c].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c].x, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y0[c].y, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c].y, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y0[c].z, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c].z, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y0[c].w, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c].w, acc[1], 0, 0, 0);
                     }
                 }
             } else {
                 // W[k][n], n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes)
+                constexpr int MS = 52;                         // K <= 208
                 const float* w0 = op.W + (size_t)fk * op.ldw + min(b0 * 16 + fr, op.N - 1);
                 const float* w1 = op.W + (size_t)fk * op.ldw + min(b1 * 16 + fr, op.N - 1);
                 const float* a = src + fr * kCL + fk;
                 const int ks = (op.K + 3) >> 2;
-                for (int s = 0; s < ks; s += 4) {
-                    float xa[4], y0[4], y1[4];
+                float y0[MS], y1[MS];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int kk = (s + j) * 4;
-                        const int kr = min(kk + fk, op.K - 1) - fk;          // clamp the weight row, A is zero past K
-                        y0[j] = w0[(size_t)kr * op.ldw];
-                        y1[j] = w1[(size_t)kr * op.ldw];
-                        xa[j] = (kk + fk < op.K) ? a[min(kk, kCL - 4)] : 0.f;
-                    }
+                for (int j = 0; j < MS; ++j) {
+                    const int kr = min(min(j, ks - 1) * 4 + fk, op.K - 1) - fk;   // clamped weight row; A is zero past K
+                    y0[j] = w0[(size_t)kr * op.ldw];
+                    y1[j] = w1[(size_t)kr * op.ldw];
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], y0[j], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], y1[j], acc[1], 0, 0, 0);
+                for (int j = 0; j < MS; ++j) {
+                    if (j < ks) {
+                        const float xa = (j * 4 + fk < op.K) ? a[j * 4] : 0.f;
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
                     }
                 }
+            }
             }
             __syncthreads();      // dst may alias a slot other waves were still reading (src != dst is required)
 #pragma unroll
@@ -164,28 +221,41 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     }
                 }
             }
-            // columns [16*nblk, kCL) of dst keep their zeros: slots are only ever written inside [0, 16*nblk)
-        } else if (kind == COP_LOAD) {
-            for (int i = tid; i < kCR * op.N; i += kCT) {
-                const int lrow = i / op.N, col = i - lrow * op.N;
-                dst[lrow * kCL + op.dst_col0 + col] =
-                    lrow < nrows ? op.W[(size_t)(op.out_row0 + r0 + lrow) * op.ldw + col] * op.scale : 0.f;
+            // columns [16*nblk, kCL) must read as zero for the next layer's k-padding
+            {
+                const int c0 = nblk * 16, lrow = tid >> 5;
+                for (int col = c0 + (tid & 31); col < kCL; col += 32) dst[lrow * kCL + col] = 0.f;
             }
+        } else if (kind == COP_LOAD) {
+            chain_load_block(op.W, op.ldw, op.out_row0 + r0, nrows, op.N, dst, op.dst_col0, op.scale);
         } else if (kind == COP_SLABSUM) {
-            for (int i = tid; i < kCR * op.N; i += kCT) {
-                const int lrow = i / op.N, col = i - lrow * op.N;
-                float v = 0.f;
-                if (lrow < nrows)
-                    for (int z = 0; z < op.aux; ++z) v += op.W[(size_t)z * op.stride + (size_t)(r0 + lrow) * op.ldw + col];
-                dst[lrow * kCL + col] = v;
+            // sum of op.aux (<= 16) partial slabs: every slab load of a thread is in flight at once
+            const int lrow = tid >> 5, rowc = min(lrow, max(nrows, 1) - 1), nf4 = (op.N + 3) >> 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c4 = (tid & 31) + 32 * j, c4c = min(c4, nf4 - 1);
+                float4 v[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z)
+                    v[z] = *reinterpret_cast<const float4*>(op.W + (size_t)min(z, op.aux - 1) * op.stride +
+                                                            (size_t)(r0 + rowc) * op.ldw + c4c * 4);
+                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int z = 0; z < 16; ++z)
+                    if (z < op.aux) { acc4.x += v[z].x; acc4.y += v[z].y; acc4.z += v[z].z; acc4.w += v[z].w; }
+                const bool ok = lrow < nrows;
+                if (!ok || c4 * 4 + 0 >= op.N) acc4.x = 0.f;
+                if (!ok || c4 * 4 + 1 >= op.N) acc4.y = 0.f;
+                if (!ok || c4 * 4 + 2 >= op.N) acc4.z = 0.f;
+                if (!ok || c4 * 4 + 3 >= op.N) acc4.w = 0.f;
+                if (c4 * 4 < kCL) *reinterpret_cast<float4*>(dst + lrow * kCL + c4 * 4) = acc4;
             }
         } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
             const int epi = kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD;
-            for (int i = tid; i < kCR * op.N; i += kCT) {
-                const int lrow = i / op.N, col = i - lrow * op.N;
-                dst[lrow * kCL + col] =
-                    lrow < nrows ? chain_epi(epi, op, P, key, slots, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
-            }
+            const int lrow = tid >> 5;
+            for (int col = tid & 31; col < kCL; col += 32)
+                dst[lrow * kCL + col] = (lrow < nrows && col < op.N)
+                    ? chain_epi(epi, op, P, key, slots, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
         } else if (kind == COP_FINAL_FWD) {
             // one wave per pair of rows; softmax / sigmoid / identity over N columns, in place on dst
             for (int lrow = wave; lrow < kCR; lrow += 8) {
@@ -238,26 +308,12 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
         }
         __syncthreads();
-        // columns behind what this op wrote must read as zero for the next layer's k-padding
-        if (kind != COP_STORE && kind != COP_ADV && kind != COP_FINAL_FWD) {
-            const int c0 = (kind == COP_LINEAR || kind == COP_LINEAR_DX) ? ((op.N + 15) & ~15) : op.dst_col0 + op.N;
-            const int w = kCL - c0;
-            for (int i = tid; i < kCR * w; i += kCT) dst[(i / w) * kCL + c0 + i % w] = 0.f;
-            __syncthreads();
-        }
-        if (op.one_col >= 0) {
+        if (op.one_col >= 0) {      // written by the same lanes for every op kind: rows of the block
             if (tid < kCR) dst[tid * kCL + op.one_col] = tid < nrows ? 1.f : 0.f;
             __syncthreads();
         }
-        if (op.out || op.out2) {
-            for (int i = tid; i < nrows * op.N; i += kCT) {
-                const int lrow = i / op.N, col = i - lrow * op.N;
-                const float v = dst[lrow * kCL + col];
-                if (op.out) op.out[(size_t)(op.out_row0 + r0 + lrow) * op.ldo + col] = v;
-                if (op.out2) op.out2[(size_t)(r0 + lrow) * op.ldo2 + col] = v;
-            }
-        }
-        __syncthreads();
+        if (op.out) chain_store_block(dst, nrows, op.N, op.out, op.ldo, op.out_row0 + r0);
+        if (op.out2) chain_store_block(dst, nrows, op.N, op.out2, op.ldo2, r0);
     }
 }
 
