@@ -81,6 +81,8 @@ _PROTOS = {
     "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
     "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "aae_w1_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "aae_w1_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -158,7 +160,8 @@ class HipAAE:
     def __init__(self, n_items, n_hidden, n_code, cond_inc=0, max_batch=100, max_nnz=None,
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
-                 rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False):
+                 rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
+                 dp_world=1, w1_cap=None):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -185,6 +188,12 @@ class HipAAE:
         cfg.prior_scale = float(prior_scale) if prior_scale is not None else 1.0
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.reserved[0] = 1 if unfused_decoder else 0
+        cfg.reserved[1] = int(dp_world) if grad_mode == "export" else 0
+        self.dp_world = int(dp_world)
+        # rows of the packed first-layer gradient one rank may send per exchange
+        self.w1_cap = int(w1_cap if w1_cap is not None else min(cfg.max_nnz, n_items, 65536))
+        self._w1_hdr = (1 + self.w1_cap + 3) & ~3          # int32 words of the packet header (16-byte aligned)
+        self._w1_packet = None
         self.cfg = cfg
         self.N, self.h, self.c, self.cond_inc = n_items, n_hidden, n_code, cond_inc
         self.max_batch = max_batch
@@ -230,9 +239,10 @@ class HipAAE:
         return self.arena[a.byte_offset:end].view(torch.float32)
 
     def grad_buckets(self, which):
-        """Flat gradient views to all-reduce for optimiser `which` (export mode)."""
+        """Flat gradient views to all-reduce for optimiser `which` (export mode).  The first
+        encoder layer's row-sparse gradient is not among them: see w1_export / w1_import."""
         if which in (O_ENC, O_GEN):
-            return [self._span(T_GRAD + T_ENC_W1T, T_GRAD + T_ENC_W1T), self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
+            return [self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
         if which == O_DEC:
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2), self._span(T_GRAD + T_DEC_V3, T_GRAD + T_DEC_V3)]
         return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
@@ -395,6 +405,28 @@ class HipAAE:
     def apply_updates(self, which):
         with torch.cuda.device(self.device):
             _check(self.lib.aae_apply_updates(self.handle, which, self._stream()))
+
+    def w1_export(self):
+        """Pack this rank's first-layer gradient rows: one flat float32 tensor = int32 header
+        (count, item ids) + rows [cap, n_hidden]."""
+        n = self._w1_hdr + self.w1_cap * self.h
+        if self._w1_packet is None:
+            self._w1_packet = torch.zeros(n, dtype=torch.float32, device=self.device)
+        pk = self._w1_packet
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_w1_export(self.handle, C.c_void_p(pk.data_ptr()),
+                                          C.c_void_p(pk.data_ptr() + 4 * self._w1_hdr), self.w1_cap, self._stream()))
+        return pk
+
+    def w1_import(self, packets, n_peers, which):
+        """Sum the peers' packed rows (flat tensor of n_peers packets) and run optimiser `which` on them."""
+        stride = 4 * (self._w1_hdr + self.w1_cap * self.h)
+        assert packets.numel() * 4 >= n_peers * stride
+        self._keep.append(packets)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_w1_import(self.handle, C.c_void_p(packets.data_ptr()),
+                                          C.c_void_p(packets.data_ptr() + 4 * self._w1_hdr), self.w1_cap, n_peers,
+                                          stride, which, self._stream()))
 
     def set_grad_scale(self, scale):
         _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))

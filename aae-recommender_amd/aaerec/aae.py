@@ -143,13 +143,14 @@ class AdversarialAutoEncoder:
         return None
 
     # ---- construction: the nets + 4 optimisers of the reference's fit() (aae.py:782-804) ----
-    def _build(self, n_items, code_inc, max_row_nnz=None):
-        dist_group = None
+    def _build(self, n_items, code_inc, max_row_nnz=None, w1_cap=None):
+        dist_group, dist_world = None, 1
         if self.data_parallel is not None and self.data_parallel is not False:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("data_parallel needs torch.distributed to be initialised")
             dist_group = None if self.data_parallel is True else self.data_parallel
+            dist_world = dist.get_world_size(dist_group)
         seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
             if self.rng_mode == "device" else 0
         self.hip = _hip.HipAAE(
@@ -158,7 +159,8 @@ class AdversarialAutoEncoder:
             activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
-            grad_mode="export" if self.data_parallel else "fused", device=self.device)
+            grad_mode="export" if self.data_parallel else "fused", device=self.device,
+            dp_world=dist_world, w1_cap=w1_cap)
         # nn.Linear default initialisation, drawn from torch's global CPU generator in the
         # reference's construction order (Encoder, Decoder, Discriminator; lin1, lin2, lin3 each),
         # so equal seeds give equal initial weights
@@ -264,7 +266,11 @@ class AdversarialAutoEncoder:
               self.n_code + code_inc)
         X = X.tocsr()
         _validate_targets(X)
-        self._build(X.shape[1], code_inc, max_row_nnz=max(int(X.getnnz(1).max()) if X.shape[0] else 1, 4096))
+        row_nnz = np.sort(X.getnnz(1))[::-1]
+        # most distinct items any batch can touch: the batch_size longest rows (bounds the packed
+        # first-layer gradient a data-parallel rank sends)
+        w1_cap = int(min(X.shape[1], max(1, row_nnz[:self.batch_size].sum())))
+        self._build(X.shape[1], code_inc, max_row_nnz=max(int(row_nnz[0]) if X.shape[0] else 1, 4096), w1_cap=w1_cap)
         csr = _hip.DeviceCSR(X, self.hip.device)       # the corpus stays resident in HBM
         n_docs = X.shape[0]
         self.train()

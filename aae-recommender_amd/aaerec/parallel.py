@@ -7,10 +7,12 @@ local_rows / global_rows (aae_set_grad_scale) and the all-reduce is a plain SUM;
 rank runs the identical optimiser update, so replicas stay bit-identical.
 
 Exchange points per step (the order the reference's single-process step imposes):
-    after decoder backward      dec grads  (V3 [N,h+1] dense, V1, V2)      -> dec_optim
-    after encoder backward      enc grads  (W1T [N,h] row-sparse, small)   -> enc_optim
+    after decoder backward      dec grads  (V3 [N,h+1] dense, V1, V2): asynchronous all-reduce,
+                                waited for at the end of the step          -> dec_optim
+    after encoder backward      enc small grads all-reduce; W1T row-sparse:
+                                all-gather of packed rows                  -> enc_optim
     after disc_step             disc grads (~50 k floats)                  -> disc_optim
-    after gen_step              enc grads again                            -> gen_optim
+    after gen_step              enc grads again (small + packed rows)      -> gen_optim
 
 `model` is anything with the export-mode phase interface of aaerec._hip.HipAAE
 (ae_encode / ae_decode_backward / ae_encoder_backward / disc_step / gen_step / apply_updates /
@@ -25,6 +27,7 @@ class DataParallelAAE:
         self.model, self.dist, self.group = model, dist, group
         self.world = dist.get_world_size(group)
         self.global_rows = None
+        self._w1_all = None
 
     def shard(self, start, stop):
         """Contiguous share [lo, hi) of the global batch [start, stop) for this rank, or
@@ -37,9 +40,25 @@ class DataParallelAAE:
         lo = start + rank * base + min(rank, extra)
         return lo, lo + base + (1 if rank < extra else 0)
 
-    def _allreduce(self, which):
-        for t in self.model.grad_buckets(which):
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+    def _allreduce(self, which, async_op=False):
+        return [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                for t in self.model.grad_buckets(which)]
+
+    def _exchange_w1(self, which):
+        """First encoder layer: only the rows of the items in the global batch carry gradient, so the
+        ranks all-gather their packed rows (a few MB) instead of all-reducing the dense [N, h] tensor."""
+        m = self.model
+        if not hasattr(m, "w1_export"):
+            return                      # dense stand-in: the gradient is part of grad_buckets()
+        pk = m.w1_export()
+        if self.world == 1:
+            allp = pk
+        else:
+            if self._w1_all is None or self._w1_all.numel() != pk.numel() * self.world:
+                self._w1_all = pk.new_empty(pk.numel() * self.world)
+            self.dist.all_gather_into_tensor(self._w1_all, pk, group=self.group)
+            allp = self._w1_all
+        m.w1_import(allp, self.world, which)
 
     def step(self, csr, row_start, n_rows, global_rows=None, rows=None, cond_fn=None, masks=None, z_real=None):
         """cond_fn(z) -> (zc, backward(dzc) -> dz) for condition plugins; None = no condition."""
@@ -53,14 +72,21 @@ class DataParallelAAE:
         else:
             zc, back = cond_fn(z)
             dz = back(m.ae_decode_backward(zc))
-        self._allreduce(O_DEC)
-        m.apply_updates(O_DEC)
+        # the decoder is not touched again before the next step: its (large) gradient travels while
+        # the encoder backward, disc_step and gen_step run
+        dec_work = self._allreduce(O_DEC, async_op=True)
         m.ae_encoder_backward(dz)
         self._allreduce(O_ENC)
         m.apply_updates(O_ENC)
+        self._exchange_w1(O_ENC)
         m.disc_step()
         self._allreduce(O_DISC)
         m.apply_updates(O_DISC)
         m.gen_step()
         self._allreduce(O_GEN)
         m.apply_updates(O_GEN)
+        self._exchange_w1(O_GEN)
+        for w in dec_work:
+            if w is not None:
+                w.wait()
+        m.apply_updates(O_DEC)

@@ -133,7 +133,8 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 1; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 2; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[1] < 0 || c->reserved[1] > 64) return fail(AAE_EINVAL, "reserved[1] (data-parallel world size) out of range");
     if (c->reserved[0] != 0 && c->reserved[0] != 1) return fail(AAE_EINVAL, "reserved[0] must be 0 or 1");
     return AAE_OK;
 }
@@ -195,7 +196,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->rscale = a.take(R, nullptr);
     m->tsync = reinterpret_cast<int*>(a.take(N, nullptr));
     m->mark = reinterpret_cast<int*>(a.take(N, nullptr));
-    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz * (size_t)std::max(1, c.reserved[1]), nullptr));
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
     m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
@@ -410,6 +411,7 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
                        m->P[P_B1].p, m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr,
                        m->sc + which);
     LAUNCHCHK("colsum_adam");
+    if (exportg) return AAE_OK;
     if (m->lazy) {
         ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
         int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
@@ -634,20 +636,14 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
                        m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
     LAUNCHCHK("colsum_adam");
-    if (m->lazy) {
+    if (exportg) return AAE_OK;        // data parallel: aae_w1_export / exchange / aae_w1_import follow
+    {
         ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
         int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
         hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
                            m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
                            m->tsync, m->step_ctr, which == O_GEN ? 1 : 0);
         LAUNCHCHK("w1_sparse_adam");
-    } else if (!exportg) {
-        size_t n4 = m->P[P_W1T].floats() / 4;
-        hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
-                           m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
-        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
-                           m->Gr[P_W1T].p, m->ldw1, 1);
-        LAUNCHCHK("adam_dense W1T");
     }
     return AAE_OK;
 }
@@ -763,7 +759,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
-    m->lazy = cfg->grad_mode == AAE_GRAD_FUSED;
+    m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1382,6 +1378,49 @@ int aae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev, flo
     return aae_decode(m, nullptr, 0, m->rows, out_dev, out_ld, stream);
 }
 
+// ---- data parallel: row-sparse exchange of the first encoder layer's gradient -------------
+int aae_w1_export(aae_handle m, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream) {
+    if (!m || !hdr_dev || !vals_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_w1_export needs grad_mode=export");
+    if (cap < 1) return fail(AAE_EINVAL, "cap must be positive");
+    hipStream_t s = S(stream);
+    hipLaunchKernelGGL(w1_pack_kernel, dim3(std::min(cap, 4096)), dim3(256), 0, s, m->ulist, m->ucount, m->Gr[P_W1T].p,
+                       m->ldw1, m->h, cap, reinterpret_cast<int*>(hdr_dev), vals_dev);
+    LAUNCHCHK("w1_pack");
+    return AAE_OK;
+}
+
+int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, int32_t cap, int32_t n_peers,
+                  int64_t peer_stride_bytes, int which, void* stream) {
+    if (!m || !hdr_dev || !vals_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_w1_import needs grad_mode=export");
+    if (which != O_ENC && which != O_GEN) return fail(AAE_EINVAL, "which must be enc_optim (0) or gen_optim (2)");
+    if (n_peers < 1 || n_peers > std::max(1, m->cfg.reserved[1])) return fail(AAE_EINVAL, "n_peers exceeds cfg.reserved[1]");
+    hipStream_t s = S(stream);
+    hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, s, m->stamp, m->ucount);
+    for (int p = 0; p < n_peers; ++p) {
+        const char* hb = reinterpret_cast<const char*>(hdr_dev) + (size_t)p * peer_stride_bytes;
+        const char* vb = reinterpret_cast<const char*>(vals_dev) + (size_t)p * peer_stride_bytes;
+        hipLaunchKernelGGL(w1_unpack_kernel, dim3(std::min(cap, 4096)), dim3(256), 0, s, reinterpret_cast<const int*>(hb),
+                           reinterpret_cast<const float*>(vb), m->h, m->Gr[P_W1T].p, m->ldw1, m->mark, m->stamp,
+                           m->ulist, m->ucount);
+    }
+    LAUNCHCHK("w1_unpack");
+    const int set = which == O_GEN ? 1 : 0;
+    const int grid = std::min(m->cfg.max_nnz * std::max(1, m->cfg.reserved[1]), 8192);
+    if (m->cfg.optimizer == AAE_OPT_ADAM) {
+        hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->N, m->tsync,
+                           m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,
+                           m->ldw1, m->h, m->tab, m->step_ctr, -1);
+        LAUNCHCHK("w1_catchup union");
+    }
+    hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
+                       m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, m->h, m->sc + which, m->tsync,
+                       m->step_ctr, which == O_GEN ? 1 : 0);
+    LAUNCHCHK("w1_sparse_adam union");
+    return AAE_OK;
+}
+
 // ---- data parallel: optimiser step on all-reduced gradients ------------------------------
 int aae_apply_updates(aae_handle m, int which, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
@@ -1392,6 +1431,7 @@ int aae_apply_updates(aae_handle m, int which, void* stream) {
     int hi = which == O_DEC ? P_V3 : which == O_DISC ? P_D3 : P_W3;
     const int set = which == O_GEN ? 1 : 0;
     for (int pid = lo; pid <= hi; ++pid) {
+        if (pid == P_W1T) continue;        // row-sparse: aae_w1_import applies it
         size_t n4 = m->P[pid].floats() / 4;
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[pid].p, m->M[set][pid].p,
                            m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, pid == P_W1T ? 1 : 0);

@@ -454,6 +454,42 @@ __global__ __launch_bounds__(256) void w1_sparse_adam_kernel(const int* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// data parallel, row-sparse exchange of the first encoder layer's gradient.
+// pack:   hdr[0] = count, hdr[1 + r] = item id, vals[r][0:h] = gW1T[item][0:h]; the gradient row is
+//         cleared.  One workgroup per listed row.
+// unpack: gW1T[item] += vals[r] for one peer's packet (rows are unique inside a packet, so plain
+//         read-modify-write; peers are applied by consecutive launches in rank order, which makes
+//         the sum bitwise identical on every rank) and the item joins the union list.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void w1_pack_kernel(const int* __restrict__ ulist, const int* __restrict__ ucount,
+                                                      float* __restrict__ gW1T, int ldw, int h, int cap,
+                                                      int* __restrict__ hdr, float* __restrict__ vals) {
+    const int cnt = min(*ucount, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = (*ucount > cap) ? -1 : cnt;
+    for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const int row = ulist[r];
+        if (threadIdx.x == 0) hdr[1 + r] = row;
+        for (int c = threadIdx.x; c < h; c += 256) {
+            vals[(size_t)r * h + c] = gW1T[(size_t)row * ldw + c];
+            gW1T[(size_t)row * ldw + c] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void w1_unpack_kernel(const int* __restrict__ hdr, const float* __restrict__ vals,
+                                                        int h, float* __restrict__ gW1T, int ldw,
+                                                        int* __restrict__ mark, const int* __restrict__ stamp_p,
+                                                        int* __restrict__ ulist, int* __restrict__ ucount) {
+    const int cnt = hdr[0];
+    const int stamp = *stamp_p;
+    for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const int row = hdr[1 + r];
+        for (int c = threadIdx.x; c < h; c += 256) gW1T[(size_t)row * ldw + c] += vals[(size_t)r * h + c];
+        if (threadIdx.x == 0 && atomicExch(&mark[row], stamp) != stamp) ulist[atomicAdd(ucount, 1)] = row;
+    }
+}
+
 __global__ void fill_int_kernel(int* p, size_t n, int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

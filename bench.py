@@ -94,7 +94,8 @@ def main():
     csr = DeviceCSR(X, dev)
     params = init_params(N, h, c, seed=0)
     model = HipAAE(N, h, c, max_batch=B, rng_mode="device", seed=1 + rank,
-                   grad_mode="export" if world > 1 else "fused", device=dev, unfused_decoder=a.unfused_decoder)
+                   grad_mode="export" if world > 1 else "fused", device=dev, unfused_decoder=a.unfused_decoder,
+                   dp_world=world, w1_cap=int(X.getnnz(1).reshape(n_batches, B).sum(1).max()) + 8)
     model.load_params(params)
     if world > 1:
         from aaerec.parallel import DataParallelAAE

@@ -77,8 +77,9 @@ typedef struct aae_config {
     float prior_scale;        /* used when has_prior_scale != 0 (aae.py:717-718) */
     int32_t has_prior_scale;
     uint64_t seed;            /* device rng */
-    int32_t reserved[8];      /* must be zero ([0] = 1: keep the decoder output layer on the unfused
-                                 three-kernel path, for A/B measurements) */
+    int32_t reserved[8];      /* must be zero, except [0] = 1: keep the decoder output layer on the unfused
+                                 three-kernel path (A/B measurements); [1] = number of data-parallel
+                                 peers whose packed rows aae_w1_import may receive (0 = 1) */
 } aae_config;
 
 typedef struct aae_model* aae_handle;
@@ -210,6 +211,16 @@ int aae_decode(aae_handle h, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
 /* data parallel (AAE_GRAD_EXPORT): after the caller has all-reduced the AAE_T_GRAD tensors of
  * optimiser `which` (0 enc 1 dec 2 gen 3 disc), apply torch.optim.Adam/SGD.step to them. */
 int aae_apply_updates(aae_handle h, int which, void* stream);
+/* Row-sparse exchange of the first encoder layer's gradient (only the rows of the items in the
+ * batch are non-zero).  aae_w1_export packs this rank's rows into hdr_dev (int32[1 + cap]: count,
+ * then item ids) and vals_dev (float[cap][n_hidden]) and clears them; after an all-gather the
+ * caller hands the n_peers packets (peer p at byte offset p * peer_stride_bytes from both base
+ * pointers) to aae_w1_import, which sums them in peer order, brings the union of rows up to date
+ * and runs the optimiser `which` (0 enc_optim after the ae phases, 2 gen_optim after gen_step) on
+ * them.  cfg.reserved[1] must hold the number of peers. */
+int aae_w1_export(aae_handle h, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream);
+int aae_w1_import(aae_handle h, const int32_t* hdr_dev, const float* vals_dev, int32_t cap, int32_t n_peers,
+                  int64_t peer_stride_bytes, int which, void* stream);
 /* scale applied to this rank's loss gradients (local_rows / global_rows) so that the
  * all-reduced sum equals the single-process mean over the global batch. */
 int aae_set_grad_scale(aae_handle h, float scale);

@@ -108,3 +108,81 @@ def test_shard_bounds():
     spans = [DataParallelAAE(None, FakeDist(r, 4)).shard(10, 23) for r in range(4)]
     assert spans == [(10, 14), (14, 17), (17, 20), (20, 23)]
     assert DataParallelAAE(None, FakeDist(0, 4)).shard(0, 3) == (None, None)
+
+
+class SparseW1Replica(OracleReplica):
+    """Same stand-in, but the first encoder layer's gradient travels as packed rows
+    (w1_export / w1_import), the path the GPU model takes."""
+    CAP = 64
+
+    def grad_buckets(self, which):
+        return [torch.from_numpy(g) for k, g in self.o.G[which].items() if k != "enc.lin1.weight"]
+
+    def w1_export(self):
+        g = self.o.G[self._which]["enc.lin1.weight"]          # dense [h, N]
+        rows = np.flatnonzero(np.abs(g).sum(0))
+        h = g.shape[0]
+        pk = np.zeros(1 + self.CAP + self.CAP * h, dtype=np.float32)
+        pk[0] = len(rows)
+        pk[1:1 + len(rows)] = rows
+        pk[1 + self.CAP:1 + self.CAP + len(rows) * h] = g[:, rows].T.ravel()
+        return torch.from_numpy(pk)
+
+    def w1_import(self, packets, n_peers, which):
+        g = self.o.G[which]["enc.lin1.weight"]
+        h = g.shape[0]
+        g[:] = 0
+        per = 1 + self.CAP + self.CAP * h
+        for p in range(n_peers):
+            pk = packets[p * per:(p + 1) * per].numpy()
+            n = int(pk[0])
+            rows = pk[1:1 + n].astype(np.int64)
+            g[:, rows] += pk[1 + self.CAP:1 + self.CAP + n * h].reshape(n, h).T
+        self.o.opt_enc.step(self.o.p, {"enc.lin1.weight": g}) if which == 0 else \
+            self.o.opt_gen.step(self.o.p, {"enc.lin1.weight": g})
+
+    def ae_encoder_backward(self, dz):
+        super().ae_encoder_backward(dz)
+        self._which = 0
+
+    def gen_step(self):
+        super().gen_step()
+        self._which = 2
+
+    def apply_updates(self, which):
+        opt = {0: self.o.opt_enc, 1: self.o.opt_dec, 2: self.o.opt_gen, 3: self.o.opt_disc}[which]
+        opt.step(self.o.p, {k: v for k, v in self.o.G[which].items() if k != "enc.lin1.weight"})
+
+
+def _worker_sparse(rank, world, port, name, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.parallel import DataParallelAAE
+    fx = Fixture(name)
+    model = SparseW1Replica(fx.init_params(), **fx.model_kwargs())
+    dp = DataParallelAAE(model, dist)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        B = len(ip) - 1
+        lo, hi = dp.shard(0, B)
+        masks = fx.masks(s)
+        if masks is not None:
+            masks = [m[lo:hi] for m in masks]
+        dp.step((ip, idx, val), lo, hi - lo, global_rows=B, masks=masks, z_real=fx.z[f"step{s}.z_real"][lo:hi])
+    if rank == 0:
+        ret.update({k: v.copy() for k, v in model.o.p.items()})
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_packed_first_layer_rows_equal_single_process():
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_sparse, args=(2, port, "step_masks", ret), nprocs=2, join=True)
+        got = dict(ret)
+    fx = Fixture("step_masks")
+    for k, w in fx.expected_params(fx.steps - 1).items():
+        np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)

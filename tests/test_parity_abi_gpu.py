@@ -198,7 +198,7 @@ class _SoloDist:
     def get_rank(self, group=None):
         return 0
 
-    def all_reduce(self, t, op=None, group=None):
+    def all_reduce(self, t, op=None, group=None, async_op=False):
         return None
 
 
@@ -208,7 +208,7 @@ def test_export_mode_through_parallel_wrapper_matches_reference(name):
     by aaerec.parallel.DataParallelAAE must reproduce the same fixtures as the fused-optimiser path."""
     from aaerec.parallel import DataParallelAAE
     fx = Fixture(name)
-    m = make_model(fx, grad_mode="export")
+    m = make_model(fx, grad_mode="export", dp_world=1)
     dp = DataParallelAAE(m, _SoloDist())
     for s in range(fx.steps):
         csr = csr_of(fx, m, s)
