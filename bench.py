@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--code", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
     ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
     return ap.parse_args()
 
@@ -77,10 +78,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dp = world > 1 or a.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from aaerec._hip import HipAAE, DeviceCSR
     from aaerec import _hip
@@ -93,11 +96,17 @@ def main():
     nnz_per_batch = X.nnz / n_batches
     csr = DeviceCSR(X, dev)
     params = init_params(N, h, c, seed=0)
+    # rows of the packed first-layer gradient per exchange: must be the same on every rank
+    w1_cap = int(X.getnnz(1).reshape(n_batches, B).sum(1).max()) + 8
+    if use_dp and world > 1:
+        capt = torch.tensor([w1_cap], dtype=torch.int64, device=dev)
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+        w1_cap = int(capt.item())
     model = HipAAE(N, h, c, max_batch=B, rng_mode="device", seed=1 + rank,
-                   grad_mode="export" if world > 1 else "fused", device=dev, unfused_decoder=a.unfused_decoder,
-                   dp_world=world, w1_cap=int(X.getnnz(1).reshape(n_batches, B).sum(1).max()) + 8)
+                   grad_mode="export" if use_dp else "fused", device=dev, unfused_decoder=a.unfused_decoder,
+                   dp_world=world, w1_cap=w1_cap)
     model.load_params(params)
-    if world > 1:
+    if use_dp:
         from aaerec.parallel import DataParallelAAE
         runner = DataParallelAAE(model, dist)
         step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
@@ -208,9 +217,19 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(docs_per_s / cpu["value"], 1)
-        print(json.dumps(out))
+        result_line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a pipe and
+        # would otherwise land after the result: flush it first so the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
