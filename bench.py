@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--hidden", type=int, default=200)
     ap.add_argument("--code", type=int, default=50)
+    ap.add_argument("--cond-inc", type=int, default=0, help="width of a constant concatenated condition block (config C4: 300)")
+    ap.add_argument("--median-len", type=int, default=20, help="median items per synthetic doc")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
@@ -92,17 +94,20 @@ def main():
 
     N, h, c, B = a.items, a.hidden, a.code, a.batch
     n_batches = 64
-    X = throughput_corpus(n_batches * B, N, seed=1234 + rank)
+    X = throughput_corpus(n_batches * B, N, median_len=a.median_len, seed=1234 + rank)
     nnz_per_batch = X.nnz / n_batches
     csr = DeviceCSR(X, dev)
-    params = init_params(N, h, c, seed=0)
+    params = init_params(N, h, c, cond_inc=a.cond_inc, seed=0)
+    cond_all = None
+    if a.cond_inc:
+        cond_all = (torch.randn(n_batches * B, a.cond_inc, device=dev) * 0.1)
     # rows of the packed first-layer gradient per exchange: must be the same on every rank
     w1_cap = int(X.getnnz(1).reshape(n_batches, B).sum(1).max()) + 8
     if use_dp and world > 1:
         capt = torch.tensor([w1_cap], dtype=torch.int64, device=dev)
         dist.all_reduce(capt, op=dist.ReduceOp.MAX)
         w1_cap = int(capt.item())
-    model = HipAAE(N, h, c, max_batch=B, rng_mode="device", seed=1 + rank,
+    model = HipAAE(N, h, c, cond_inc=a.cond_inc, max_batch=B, rng_mode="device", seed=1 + rank,
                    grad_mode="export" if use_dp else "fused", device=dev, unfused_decoder=a.unfused_decoder,
                    dp_world=world, w1_cap=w1_cap)
     model.load_params(params)
@@ -111,7 +116,11 @@ def main():
         runner = DataParallelAAE(model, dist)
         step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
     else:
-        step = lambda i: model.step(csr, (i % n_batches) * B, B)   # noqa: E731
+        if cond_all is not None:
+            step = lambda i: model.step(csr, (i % n_batches) * B, B,   # noqa: E731
+                                        cond=cond_all[(i % n_batches) * B:(i % n_batches + 1) * B])
+        else:
+            step = lambda i: model.step(csr, (i % n_batches) * B, B)   # noqa: E731
 
     def barrier():
         if dist is not None:
@@ -211,7 +220,8 @@ def main():
             "config": {"workload": f"C3 PubMed-scale synthetic Bags: |items|={N}, hidden={h}, code={c}, fp32, "
                                    f"batch={B} docs/GPU/step, full partial_fit (ae+disc+gen, 4 Adam)",
                        "n_items": N, "n_hidden": h, "n_code": c, "batch_per_gpu": B, "global_batch": B * world,
-                       "nnz_per_batch": round(nnz_per_batch, 1), "rng": "device", "parallelism": f"dp{world}"},
+                       "cond_inc": a.cond_inc, "nnz_per_batch": round(nnz_per_batch, 1), "rng": "device",
+                       "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
             "losses_last_step": [round(x, 5) for x in losses],
         }
