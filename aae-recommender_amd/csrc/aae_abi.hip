@@ -354,8 +354,8 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
     DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, B, h, sid2);
     if (!reuse_a1) {
         ProfScope ps(m, AAE_K_ENC_GATHER, s);
-        size_t shm = (size_t)4 * r4(h) * sizeof(float);
-        hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
+        size_t shm = (size_t)16 * r4(h) * sizeof(float);
+        hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
                            m->P[P_B1].p, h, m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation,
                            d1, m->cfg.seed, m->step_ctr, m->rscale);
         LAUNCHCHK("enc_gather");
@@ -404,7 +404,7 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     // lin1: sparse scatter into gW1T, bias column sum
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
                        m->rscale, m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, m->gb1.p, B, h, m->ldh,
@@ -425,7 +425,7 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
                            m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
         LAUNCHCHK("adam_dense W1T");
-        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
+        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
                            m->rscale, m->Gr[P_W1T].p, m->ldw1, 1);
         LAUNCHCHK("enc_scatter zero");
     }
@@ -630,7 +630,7 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
     const int B = m->rows, h = m->h;
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
                        m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
@@ -652,8 +652,8 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
     const int B = m->rows, h = m->h;
     DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
     ProfScope ps(m, AAE_K_ENC_GATHER, s);
-    size_t shm = (size_t)4 * r4(h) * sizeof(float);
-    hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(256), shm, s, m->bv, m->P[P_W1T].p, m->ldw1, m->P[P_B1].p, h,
+    size_t shm = (size_t)16 * r4(h) * sizeof(float);
+    hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), shm, s, m->bv, m->P[P_W1T].p, m->ldw1, m->P[P_B1].p, h,
                        m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation, d1, m->cfg.seed,
                        m->step_ctr, m->rscale);
     LAUNCHCHK("enc_gather");

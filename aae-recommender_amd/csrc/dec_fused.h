@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     // k-steps rounded up to the unroll factor 4: the extra ones multiply zero padding (columns >= ldh
     // of both LDS images are zeroed once, G rows >= B are zero)
     const int ksteps1 = ((K1 + 3) / 4 + 3) & ~3;       // GEMM1: k over the h+1 hidden columns, <= (kSD-2)/4
-    const int ksteps2 = min(((B + 3) / 4 + 3) & ~3, 4 * kMB);   // GEMM2: k over docs, rows < 16*kMB
+    const int ksteps2 = min(((B + 3) / 4 + 1) & ~1, 4 * kMB);   // GEMM2: k over docs (2 per loop trip), rows < 16*kMB
+    const int nmb = (B + 15) >> 4;                      // 16-row blocks actually present (<= kMB)
     const int ntiles = (a.N + kTI - 1) / kTI;
     const int f4_per_row = ldv / 4;                    // ldv % 4 == 0
     const int tile_f4 = kTI * f4_per_row;              // float4 per tile span
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         // one block per wave (a wave past the last block re-does it and does not store): branch-free
         {
             f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int id0 = min(wave, 2 * kMB - 1);
+            const int id0 = min(wave, 2 * nmb - 1);
             const float* pa0 = dhs + min((id0 >> 1) * 16 + fr, B - 1) * kSD + fk;
             const float* pb0 = v3s + ((id0 & 1) * 16 + fr) * kSD + fk;
             // groups of 4 k-steps: all 8 LDS reads of a group are issued before its 4 MFMAs; two
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             }
             c0 += c1;
             // raw logits -> gs[b][n]   (C map: row = 4*(lane>>4) + r, col = lane & 15)
-            if (wave < 2 * kMB) {
+            if (wave < 2 * nmb) {
                 const int rb = (id0 >> 1) * 16 + fk * 4, cb = (id0 & 1) * 16 + fr;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 pg[q] = gs + fk * kSG + (id & 1) * 16 + fr;          // G[b = 4ks + fk][item]
                 pd[q] = dhs + (id >> 1) * 16 + fr;                   // dh2[b][col], row added below (clamped)
             }
-            for (int ks = 0; ks < ksteps2; ks += 2) {        // ksteps2 is a multiple of 4
+            for (int ks = 0; ks < ksteps2; ks += 2) {        // ksteps2 is even
                 float x[2][Q2], y[2][Q2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             const float* pg[Q3]; const float* pv[Q3];
 #pragma unroll
             for (int q = 0; q < Q3; ++q) {
-                const int id = min(wave + kNW * q, kMB * NB - 1);
+                const int id = min(wave + kNW * q, nmb * NB - 1);
                 const int mb = id / NB, nb = id - mb * NB;
                 pg[q] = gs + (mb * 16 + fr) * kSG + fk;             // G[b][n = 4ks + fk]
                 pv[q] = v3s + fk * kSD + nb * 16 + fr;               // V3a[n = 4ks + fk][col]
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
 #pragma unroll
     for (int q = 0; q < (kMB * NB + kNW - 1) / kNW; ++q) {
         const int id = wave + kNW * q;
-        if (id < kMB * NB) {
+        if (id < nmb * NB) {
             const int mb = id / NB, nb = id - mb * NB;
             const int rb = mb * 16 + fk * 4, cb = nb * 16 + fr;
 #pragma unroll

@@ -16,16 +16,17 @@ struct BatchView {
 // K2+K3 (+K4): sparse multi-hot -> first encoder Linear.  reference: F.normalize(inp, 1) +
 // enc.lin1 (+ drop1, act1), aae.py:132-137.
 //   a1[b,:] = b1 + sum_{e in row b} (v_e * s_b) * W1T[idx_e, :],  s_b = 1/max(sum|v|, 1e-12)
-// One workgroup per document; its 4 waves take every 4th entry, each lane a float4 of the
-// 800-byte (h=200) weight row, partial sums meet in LDS.
+// One workgroup per document; its 16 waves take every 16th entry (a typical document is one
+// dependent HBM round trip deep), each lane a float4 of the 800-byte (h=200) weight row, partial
+// sums meet in LDS.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const float* __restrict__ W1T, int ldw,
+__global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const float* __restrict__ W1T, int ldw,
                                                          const float* __restrict__ b1, int h, int normalize,
                                                          float* __restrict__ a1, float* __restrict__ y, int ld,
                                                          int act, DropSpec d, uint64_t seed, const long long* step_ctr,
                                                          float* __restrict__ rscale) {
-    extern __shared__ __attribute__((aligned(16))) float part[];   // [4][hp]
-    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [16][hp]
+    __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hp = (h + 3) & ~3;
     const int dc = bv.doc(b);
@@ -33,17 +34,19 @@ __global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const flo
     float s = 1.f;
     if (normalize) {
         float l1 = 0.f;
-        for (int64_t e = lo + tid; e < hi; e += 256) l1 += fabsf(bv.values[e]);
+        for (int64_t e = lo + tid; e < hi; e += 1024) l1 += fabsf(bv.values[e]);
         l1 = wave_sum(l1);
         if (lane == 0) red[wave] = l1;
         __syncthreads();
-        l1 = (red[0] + red[1]) + (red[2] + red[3]);
+        l1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) l1 += red[w];
         s = 1.f / fmaxf(l1, 1e-12f);
     }
     if (tid == 0) rscale[b] = s;
     for (int c0 = lane * 4; c0 < hp; c0 += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t e = lo + wave; e < hi; e += 4) {
+        for (int64_t e = lo + wave; e < hi; e += 16) {
             const int idx = bv.indices[e];
             float x = bv.values[e];
             if (normalize) x *= s;
@@ -54,8 +57,11 @@ __global__ __launch_bounds__(256) void enc_gather_kernel(BatchView bv, const flo
     }
     __syncthreads();
     const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
-    for (int c = tid; c < h; c += 256) {
-        float v = ((part[c] + part[hp + c]) + (part[2 * hp + c] + part[3 * hp + c])) + b1[c];
+    for (int c = tid; c < h; c += 1024) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += part[w * hp + c];
+        v += b1[c];
         a1[(size_t)b * ld + c] = v;
         if (y) {
             if (d.enabled) v = drop_fwd(d, drop_keep(d, key, b, c), v);
@@ -90,10 +96,9 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const fl
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
     const float s = zero ? 0.f : rscale[b];
-    for (int64_t e0 = lo + 16 * (int64_t)blockIdx.y; e0 < hi; e0 += 16 * (int64_t)gridDim.y) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t e = e0 + 4 * j + wave;
+    for (int64_t e0 = lo + 4 * (int64_t)blockIdx.y; e0 < hi; e0 += 4 * (int64_t)gridDim.y) {
+        {
+            const int64_t e = e0 + wave;
             if (e >= hi) break;
             const int idx = bv.indices[e];
             const float x = bv.values[e] * s;
