@@ -81,6 +81,8 @@ _PROTOS = {
     "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
     "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "aae_apply_updates_except": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "aae_apply_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "aae_w1_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "aae_w1_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
@@ -245,6 +247,8 @@ class HipAAE:
             return [self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
         if which == O_DEC:
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2), self._span(T_GRAD + T_DEC_V3, T_GRAD + T_DEC_V3)]
+        if which == "dec_small":
+            return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2)]
         return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
 
     # ---- state_dict in the reference layout ------------------------------------------
@@ -402,9 +406,20 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_gen_step(self.handle, None, self._stream()))
 
-    def apply_updates(self, which):
+    def apply_updates(self, which, skip=-1):
         with torch.cuda.device(self.device):
-            _check(self.lib.aae_apply_updates(self.handle, which, self._stream()))
+            _check(self.lib.aae_apply_updates_except(self.handle, which, skip, self._stream()))
+
+    def apply_shard(self, tid, row_begin, row_end, grad_shard, which):
+        self._keep.append(grad_shard)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_apply_shard(self.handle, tid, row_begin, row_end, C.c_void_p(grad_shard.data_ptr()),
+                                            which, self._stream()))
+
+    def big_grad(self):
+        """(tensor id, padded gradient view [rows, ld], padded parameter view [rows, ld]) of the one
+        tensor worth sharding across data-parallel ranks: the decoder's output layer."""
+        return T_DEC_V3, self.tensor(T_GRAD + T_DEC_V3, padded=True), self.tensor(T_DEC_V3, padded=True)
 
     def w1_export(self):
         """Pack this rank's first-layer gradient rows: one flat float32 tensor = int32 header

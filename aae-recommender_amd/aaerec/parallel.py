@@ -23,8 +23,10 @@ O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
 
 
 class DataParallelAAE:
-    def __init__(self, model, dist, group=None):
+    def __init__(self, model, dist, group=None, shard_decoder=True):
         self.model, self.dist, self.group = model, dist, group
+        self.shard_decoder = shard_decoder
+        self._shard_grad = self._shard_p = self._pending = None
         self.world = dist.get_world_size(group)
         self.global_rows = None
         self._w1_all = None
@@ -60,6 +62,51 @@ class DataParallelAAE:
             allp = self._w1_all
         m.w1_import(allp, self.world, which)
 
+    # ---- decoder output layer: reduce-scatter -> optimiser on this rank's rows -> all-gather ------
+    def _dec_start(self):
+        """Start the exchange of the decoder gradients; returns the state _dec_finish needs."""
+        m, d = self.model, self.dist
+        shardable = ((self.world > 1 or self.shard_decoder == "force") and self.shard_decoder and hasattr(m, "big_grad")
+                     and hasattr(d, "reduce_scatter_tensor"))
+        if shardable:
+            tid, g, p = m.big_grad()
+            if g.shape[0] % self.world == 0:
+                rows = g.shape[0] // self.world
+                if self._shard_grad is None:
+                    self._shard_grad = g.new_empty((rows, g.shape[1]))
+                    self._shard_p = g.new_empty((rows, g.shape[1]))
+                work = [d.reduce_scatter_tensor(self._shard_grad, g, op=d.ReduceOp.SUM, group=self.group, async_op=True)]
+                work += [d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group, async_op=True)
+                         for t in m.grad_buckets("dec_small")]
+                return ("shard", tid, p, rows, work)
+        return ("dense", self._allreduce(O_DEC, async_op=True))
+
+    def _dec_finish(self, st):
+        m, d = self.model, self.dist
+        if st[0] == "dense":
+            for w in st[1]:
+                if w is not None:
+                    w.wait()
+            m.apply_updates(O_DEC)
+            return
+        _, tid, p, rows, work = st
+        for w in work:
+            w.wait()
+        rank = d.get_rank(self.group)
+        m.apply_updates(O_DEC, skip=tid)                              # the small decoder layers
+        m.apply_shard(tid, rank * rows, (rank + 1) * rows, self._shard_grad, O_DEC)
+        self._shard_p.copy_(p[rank * rows:(rank + 1) * rows])
+        # the updated rows travel while the next step's encoder forward runs; waited for before the
+        # decoder is used again
+        self._pending = d.all_gather_into_tensor(p.view(-1), self._shard_p.view(-1), group=self.group, async_op=True)
+
+    def wait_pending(self):
+        """Block the stream until a still-travelling parameter all-gather has landed (call before
+        anything reads the decoder's output layer: next decode, predict, state export)."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
     def step(self, csr, row_start, n_rows, global_rows=None, rows=None, cond_fn=None, masks=None, z_real=None):
         """cond_fn(z) -> (zc, backward(dzc) -> dz) for condition plugins; None = no condition."""
         m = self.model
@@ -67,6 +114,7 @@ class DataParallelAAE:
             global_rows = n_rows * self.world
         m.set_grad_scale(n_rows / float(global_rows))
         z = m.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
+        self.wait_pending()
         if cond_fn is None:
             dz = m.ae_decode_backward(z)
         else:
@@ -74,7 +122,7 @@ class DataParallelAAE:
             dz = back(m.ae_decode_backward(zc))
         # the decoder is not touched again before the next step: its (large) gradient travels while
         # the encoder backward, disc_step and gen_step run
-        dec_work = self._allreduce(O_DEC, async_op=True)
+        dec_state = self._dec_start()
         m.ae_encoder_backward(dz)
         self._allreduce(O_ENC)
         m.apply_updates(O_ENC)
@@ -86,7 +134,4 @@ class DataParallelAAE:
         self._allreduce(O_GEN)
         m.apply_updates(O_GEN)
         self._exchange_w1(O_GEN)
-        for w in dec_work:
-            if w is not None:
-                w.wait()
-        m.apply_updates(O_DEC)
+        self._dec_finish(dec_state)

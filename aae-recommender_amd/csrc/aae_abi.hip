@@ -1421,8 +1421,30 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
     return AAE_OK;
 }
 
+// Adam/SGD of optimiser `which` on rows [row_begin, row_end) of parameter tensor `tensor_id` with
+// a gradient shard supplied by the caller (reduce-scatter output): the sharded-optimiser half of
+// reduce-scatter -> update 1/world of DEC_V3 -> all-gather.
+int aae_apply_shard(aae_handle m, int tensor_id, int64_t row_begin, int64_t row_end, const float* grad_shard_dev,
+                    int which, void* stream) {
+    if (!m || !grad_shard_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (tensor_id < 0 || tensor_id >= NP || tensor_id == P_W1T) return fail(AAE_EINVAL, "bad tensor id");
+    if (which < 0 || which > 3) return fail(AAE_EINVAL, "bad optimiser id");
+    const Ten& P = m->P[tensor_id];
+    if (row_begin < 0 || row_end > P.rows || row_begin >= row_end) return fail(AAE_EINVAL, "bad row range");
+    const int set = which == O_GEN ? 1 : 0;
+    const size_t off = (size_t)row_begin * P.ld, n4 = (size_t)(row_end - row_begin) * P.ld / 4;
+    hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, S(stream), P.p + off,
+                       m->M[set][tensor_id].p + off, m->V[set][tensor_id].p + off, const_cast<float*>(grad_shard_dev),
+                       n4, m->sc + which, 0);
+    LAUNCHCHK("adam shard");
+    return AAE_OK;
+}
+
 // ---- data parallel: optimiser step on all-reduced gradients ------------------------------
-int aae_apply_updates(aae_handle m, int which, void* stream) {
+int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* stream);
+int aae_apply_updates(aae_handle m, int which, void* stream) { return aae_apply_updates_except(m, which, -1, stream); }
+
+int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_apply_updates needs grad_mode=export");
     if (which < 0 || which > 3) return fail(AAE_EINVAL, "bad optimiser id");
@@ -1432,6 +1454,7 @@ int aae_apply_updates(aae_handle m, int which, void* stream) {
     const int set = which == O_GEN ? 1 : 0;
     for (int pid = lo; pid <= hi; ++pid) {
         if (pid == P_W1T) continue;        // row-sparse: aae_w1_import applies it
+        if (pid == skip_tensor_id) continue; // sharded by the caller: aae_apply_shard
         size_t n4 = m->P[pid].floats() / 4;
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[pid].p, m->M[set][pid].p,
                            m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, pid == P_W1T ? 1 : 0);

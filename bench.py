@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--median-len", type=int, default=20, help="median items per synthetic doc")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-shard", action="store_true", help="data parallel: all-reduce + replicated Adam for the decoder output layer")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
     ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
     return ap.parse_args()
@@ -113,7 +114,7 @@ def main():
     model.load_params(params)
     if use_dp:
         from aaerec.parallel import DataParallelAAE
-        runner = DataParallelAAE(model, dist)
+        runner = DataParallelAAE(model, dist, shard_decoder=False if a.no_shard else ("force" if world == 1 else True))
         step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
     else:
         if cond_all is not None:
@@ -134,6 +135,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    if use_dp:
+        runner.wait_pending()
     barrier()
     dt = time.perf_counter() - t0
     model.profile_enable(False)

@@ -221,6 +221,13 @@ int aae_apply_updates(aae_handle h, int which, void* stream);
 int aae_w1_export(aae_handle h, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream);
 int aae_w1_import(aae_handle h, const int32_t* hdr_dev, const float* vals_dev, int32_t cap, int32_t n_peers,
                   int64_t peer_stride_bytes, int which, void* stream);
+/* Sharded optimiser: aae_apply_updates_except is aae_apply_updates without tensor
+ * `skip_tensor_id`; aae_apply_shard runs optimiser `which` on rows [row_begin, row_end) of that
+ * tensor with the caller's gradient shard (e.g. a reduce-scatter result).  Used for DEC_V3:
+ * reduce-scatter -> update 1/world of the rows -> all-gather the updated rows. */
+int aae_apply_updates_except(aae_handle h, int which, int skip_tensor_id, void* stream);
+int aae_apply_shard(aae_handle h, int tensor_id, int64_t row_begin, int64_t row_end,
+                    const float* grad_shard_dev, int which, void* stream);
 /* scale applied to this rank's loss gradients (local_rows / global_rows) so that the
  * all-reduced sum equals the single-process mean over the global batch. */
 int aae_set_grad_scale(aae_handle h, float scale);

@@ -201,15 +201,28 @@ class _SoloDist:
     def all_reduce(self, t, op=None, group=None, async_op=False):
         return None
 
+    class _Done:
+        def wait(self):
+            return None
 
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        out.copy_(inp.reshape(out.shape))
+        return self._Done()
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        out.copy_(inp.reshape(out.shape))
+        return self._Done()
+
+
+@pytest.mark.parametrize("shard", [False, "force"])
 @pytest.mark.parametrize("name", ["step_masks", "step_cond_concat", "step_sgd", "step_wide"])
-def test_export_mode_through_parallel_wrapper_matches_reference(name):
+def test_export_mode_through_parallel_wrapper_matches_reference(name, shard):
     """grad_mode='export' (gradients materialised, aae_apply_updates after the exchange point) driven
     by aaerec.parallel.DataParallelAAE must reproduce the same fixtures as the fused-optimiser path."""
     from aaerec.parallel import DataParallelAAE
     fx = Fixture(name)
     m = make_model(fx, grad_mode="export", dp_world=1)
-    dp = DataParallelAAE(m, _SoloDist())
+    dp = DataParallelAAE(m, _SoloDist(), shard_decoder=shard)
     for s in range(fx.steps):
         csr = csr_of(fx, m, s)
         B = csr.shape[0]
@@ -219,6 +232,7 @@ def test_export_mode_through_parallel_wrapper_matches_reference(name):
             ct = torch.as_tensor(cond[0], device=m.device)
             cond_fn = lambda z, ct=ct: (torch.cat([z, ct], 1), lambda dzc: dzc[:, :fx.cfg["c"]].contiguous())  # noqa: E731
         dp.step(csr, 0, B, global_rows=B, cond_fn=cond_fn, masks=fx.masks(s), z_real=fx.z[f"step{s}.z_real"])
+        dp.wait_pending()
         np.testing.assert_allclose(m.losses(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
         if fx.has_state(s):
             check_state(fx, m, s, name)
