@@ -91,7 +91,8 @@ class DataParallelAAE:
             return
         _, tid, p, rows, work = st
         for w in work:
-            w.wait()
+            if w is not None:
+                w.wait()
         rank = d.get_rank(self.group)
         m.apply_updates(O_DEC, skip=tid)                              # the small decoder layers
         m.apply_shard(tid, rank * rows, (rank + 1) * rows, self._shard_grad, O_DEC)
