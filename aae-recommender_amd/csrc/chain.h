@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             f32x4 acc[2];
             acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int b0 = min(wave, nblk - 1), b1 = min(wave + 8, nblk - 1);
+            const bool two = nblk > 8;
             if (!(P.dbg & 1)) {
             // All weight loads of the layer are issued before its first MFMA (the arrays below are fully
             // unrolled, i.e. registers): a layer then costs one L2 round trip, not one per k-group.
@@ -173,13 +174,15 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     if (c < kch) {
                         const float4 xa = *reinterpret_cast<const float4*>(a + c * 16);
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y0[c].x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c].x, acc[1], 0, 0, 0);
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y0[c].y, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c].y, acc[1], 0, 0, 0);
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y0[c].z, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c].z, acc[1], 0, 0, 0);
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y0[c].w, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c].w, acc[1], 0, 0, 0);
+                        if (two) {          // layers of <= 128 columns need one block per wave only
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c].x, acc[1], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c].y, acc[1], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c].z, acc[1], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c].w, acc[1], 0, 0, 0);
+                        }
                     }
                 }
             } else {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     if (j < ks) {
                         const float xa = (j * 4 + fk < op.K) ? a[j * 4] : 0.f;
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
+                        if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
                     }
                 }
             }
