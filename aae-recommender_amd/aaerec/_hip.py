@@ -78,6 +78,7 @@ _PROTOS = {
     "aae_gen_step": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
     "aae_read_losses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.c_void_p]),
     "aae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_predict_topk": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
     "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -474,6 +475,18 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(out), out.shape[1], self._stream()))
         return out[:, :self.N]
+
+    def predict_topk(self, csr, row_start, n_rows, k, cond=None, exclude_known=True):
+        """(ids int32 [n_rows, k], scaled scores float32 [n_rows, k]) - device tensors."""
+        b = self._batch(csr, row_start, n_rows)
+        idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
+        val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_predict_topk(self.handle, C.byref(b), _ptr(cond), int(k), int(bool(exclude_known)),
+                                             _ptr(idx), _ptr(val), self._stream()))
+        return idx, val
 
     def encode(self, csr, row_start, n_rows):
         b = self._batch(csr, row_start, n_rows)

@@ -335,6 +335,33 @@ class AdversarialAutoEncoder:
         return np.vstack(pred)
 
 
+def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
+    """Top-k recommendations without materialising the [n, N] score matrix on the host: the
+    reference's predict -> remove_non_missing -> argtopk pipeline (aae.py:840-870,
+    evaluation.py:183-199, 20-58) with only [n, k] ids and scaled scores crossing PCIe.
+    Conditions must be of the constant-concatenation kind (or absent)."""
+    self.eval()
+    use_condition = _check_conditions(self.conditions, condition_data)
+    if use_condition and not self._is_constant_concat():
+        raise NotImplementedError("predict_topk supports constant concatenated conditions only")
+    Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
+    csr = _hip.DeviceCSR(Xs, self.hip.device)
+    ids, vals = [], []
+    for start in range(0, Xs.shape[0], self.batch_size):
+        n = min(self.batch_size, Xs.shape[0] - start)
+        cond = None
+        if use_condition:
+            c_batch = [_take(c, slice(start, start + n)) for c in condition_data]
+            cond = torch.cat([c.encode(x).to(self.hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
+        i, v = self.hip.predict_topk(csr, start, n, k, cond=cond, exclude_known=exclude_known)
+        ids.append(i)
+        vals.append(v)
+    return torch.cat(ids).cpu().numpy(), torch.cat(vals).cpu().numpy()
+
+
+AdversarialAutoEncoder.predict_topk = _predict_topk
+
+
 def _take(c, idx):
     """Row selection on whatever a condition's transform produced (ndarray, sparse, list)."""
     if isinstance(c, (list, tuple)):
@@ -397,3 +424,11 @@ class AAERecommender(Recommender):
         if self.conditions:
             condition_data = self.conditions.transform(test_set.get_attributes(self.conditions.keys()))
         return self.model.predict(X, condition_data=condition_data)
+
+    def predict_topk(self, test_set, k=10):
+        """(item ids [n, k], scaled scores [n, k]) of the k best new items per test bag."""
+        X = test_set.tocsr()
+        condition_data = None
+        if self.conditions:
+            condition_data = self.conditions.transform(test_set.get_attributes(self.conditions.keys()))
+        return self.model.predict_topk(X, k=k, condition_data=condition_data)

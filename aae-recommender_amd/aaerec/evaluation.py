@@ -124,6 +124,36 @@ def evaluate(ground_truth, predictions, metrics, batch_size=None):
     return [(np.mean(v), np.std(v)) for v in map(np.asarray, per_metric)]
 
 
+def evaluate_topk(ground_truth, topk_idx, metrics):
+    """The bounded ranking metrics ('mrr@k', 'map@k', 'p@k', 'P@1') from top-k item ids alone:
+    a metric at k only ever looks at the relevance of the k best predictions (RankingMetric above),
+    so [(mean, std)] equals evaluate() on the full score matrix.  topk_idx: [n, K] ids, best first,
+    K >= the largest k asked for; -1 entries count as irrelevant."""
+    gt = sp.csr_matrix(ground_truth)
+    topk_idx = np.asarray(topk_idx)
+    n, K = topk_idx.shape
+    assert gt.shape[0] == n
+    rel = np.zeros((n, K), dtype=np.int64)
+    for r in range(n):
+        truth = set(gt.indices[gt.indptr[r]:gt.indptr[r + 1]].tolist())
+        rel[r] = [1 if int(i) in truth else 0 for i in topk_idx[r]]
+    out = []
+    for name in metrics:
+        metric = METRICS[name]
+        k = metric.k
+        if k is None or k > K:
+            raise ValueError("metric {} needs the full ranking / more than the {} ids given".format(name, K))
+        rs = rel[:, :k]
+        if isinstance(metric, MRR):
+            out.append(rm.mean_reciprocal_rank(rs))
+        elif isinstance(metric, MAP):
+            out.append(rm.mean_average_precision(rs))
+        else:
+            ps = (rs > 0).mean(axis=1)
+            out.append((ps.mean(), ps.std()))
+    return out
+
+
 def reevaluate(gold_file, predictions_file, metrics):
     return evaluate(sp.load_npz(gold_file), np.load(predictions_file), metrics)
 

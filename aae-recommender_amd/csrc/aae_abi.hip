@@ -1378,6 +1378,27 @@ int aae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev, flo
     return aae_decode(m, nullptr, 0, m->rows, out_dev, out_ld, stream);
 }
 
+// predict + on-device remove_non_missing / argtopk (evaluation.py:183-199, 20-58): only the k best
+// items per row (ids and min-max-scaled scores) leave the GPU
+int aae_predict_topk(aae_handle m, const aae_batch* batch, const float* cond_dev, int32_t k, int32_t exclude_known,
+                     int32_t* idx_out_dev, float* val_out_dev, void* stream) {
+    if (!m || !idx_out_dev || !val_out_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (k < 1 || k > 32 || k > m->N) return fail(AAE_EINVAL, "k must be in [1, min(32, n_items)]");
+    TRY(aae_predict(m, batch, cond_dev, m->G.p, m->ldn, stream));      // scores into the [rows][N] scratch
+    hipStream_t s = S(stream);
+    if (k <= 10)
+        hipLaunchKernelGGL(topk_rows_kernel<10>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    else if (k <= 20)
+        hipLaunchKernelGGL(topk_rows_kernel<20>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    else
+        hipLaunchKernelGGL(topk_rows_kernel<32>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    LAUNCHCHK("topk_rows");
+    return AAE_OK;
+}
+
 // ---- data parallel: row-sparse exchange of the first encoder layer's gradient -------------
 int aae_w1_export(aae_handle m, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream) {
     if (!m || !hdr_dev || !vals_dev) return fail(AAE_EINVAL, "NULL argument");

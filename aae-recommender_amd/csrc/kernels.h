@@ -495,6 +495,86 @@ __global__ __launch_bounds__(256) void w1_unpack_kernel(const int* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// On-device tail of the evaluation path: what the reference does on the host
+// with the full [n_test, N] score matrix - remove_non_missing (row-wise min-max scaling, items
+// already in the input set to 0; evaluation.py:183-199) followed by argtopk (evaluation.py:20-58)
+// - reduced to the k best items per row, so only [rows, k] leaves the GPU.
+// One workgroup per row.  Known items are masked to -inf in place (their original scores still
+// enter the row minimum / maximum), every thread keeps a sorted top-K of its strided share in
+// registers, the 256 lists are merged by K rounds of block-wide argmax.
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ scores, int ld, int n_items, BatchView bv,
+                                                        int exclude_known, int k_out, int* __restrict__ idx_out,
+                                                        float* __restrict__ val_out) {
+    __shared__ float s_val[4]; __shared__ int s_idx[4]; __shared__ int s_who[4];
+    __shared__ float s_min[4], s_max[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sc = scores + (size_t)row * ld;
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (exclude_known) {
+        const int dc = bv.doc(row);
+        const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+        for (int64_t e = lo + tid; e < hi; e += 256) {
+            const int i = bv.indices[e];
+            const float v = sc[i];
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            sc[i] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    float tv[K]; int ti[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    for (int i = tid; i < n_items; i += 256) {
+        const float v = sc[i];
+        if (v != -INFINITY) { vmin = fminf(vmin, v); vmax = fmaxf(vmax, v); }
+        if (v > tv[K - 1]) {
+            tv[K - 1] = v; ti[K - 1] = i;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                if (tv[j] > tv[j - 1]) {
+                    const float fv = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = fv;
+                    const int iv = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = iv;
+                }
+            }
+        }
+    }
+    // row minimum / maximum
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); }
+    if (lane == 0) { s_min[wave] = vmin; s_max[wave] = vmax; }
+    __syncthreads();
+    vmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float span = vmax - vmin;
+    const float inv = span > 0.f ? 1.f / span : 1.f;
+    // K rounds: block-wide argmax over every thread's current head (lists are sorted descending)
+    for (int r = 0; r < k_out; ++r) {
+        float bv_ = tv[0]; int bi = ti[0]; int who = tid;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv_, o, 64); const int oi = __shfl_xor(bi, o, 64); const int ow = __shfl_xor(who, o, 64);
+            if (ov > bv_ || (ov == bv_ && (unsigned)oi < (unsigned)bi)) { bv_ = ov; bi = oi; who = ow; }
+        }
+        if (lane == 0) { s_val[wave] = bv_; s_idx[wave] = bi; s_who[wave] = who; }
+        __syncthreads();
+        float gv = s_val[0]; int gi = s_idx[0], gw = s_who[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > gv || (s_val[w] == gv && (unsigned)s_idx[w] < (unsigned)gi)) { gv = s_val[w]; gi = s_idx[w]; gw = s_who[w]; }
+        if (tid == 0) {
+            idx_out[(size_t)row * k_out + r] = gi;
+            val_out[(size_t)row * k_out + r] = gi >= 0 ? (gv - vmin) * inv : 0.f;
+        }
+        if (tid == gw) {            // pop the winner's head
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = -1;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void fill_int_kernel(int* p, size_t n, int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -203,6 +203,12 @@ int aae_read_losses(aae_handle h, float out_host[3], void* stream);
  * condition) -> decoder -> sigmoid, out_dev [rows][out_ld] float32. */
 int aae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, float* out_dev,
                 int64_t out_ld, void* stream);
+/* predict followed on the device by what Evaluation does on the host with the dense matrix:
+ * remove_non_missing (row-wise min-max scaling; items present in the input row excluded when
+ * exclude_known != 0; evaluation.py:183-199) and argtopk (evaluation.py:20-58).  Writes the k
+ * (<= 32) best item ids per row, best first, and their scaled scores: [rows][k]. */
+int aae_predict_topk(aae_handle h, const aae_batch* batch, const float* cond_dev, int32_t k,
+                     int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream);
 /* split form for generic conditions */
 int aae_encode(aae_handle h, const aae_batch* batch, float* z_out_dev, void* stream);
 int aae_decode(aae_handle h, const float* zc_dev, int64_t zc_ld, int32_t n_rows,

@@ -46,6 +46,14 @@ def main():
         m.partial_fit(d)
     torch.cuda.synchronize()
     out["partial_fit(host dense ndarray, as the reference passes it) docs/s"] = 16 * B / (time.perf_counter() - t0)
+    # predict: full [n, N] float32 matrix to the host vs. top-10 ids only
+    Xt = X[:2000]
+    m.predict(Xt[:200]); m.predict_topk(Xt[:200], k=10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); m.predict(Xt); torch.cuda.synchronize()
+    out["predict() docs/s (dense [n,N] scores to host)"] = Xt.shape[0] / (time.perf_counter() - t0)
+    t0 = time.perf_counter(); m.predict_topk(Xt, k=10); torch.cuda.synchronize()
+    out["predict_topk(k=10) docs/s (scaling, masking, top-k on device)"] = Xt.shape[0] / (time.perf_counter() - t0)
     for k, v in out.items():
         print(f"{k}: {v:,.0f}")
 
