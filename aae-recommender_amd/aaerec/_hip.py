@@ -164,7 +164,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None):
+                 dp_world=1, w1_cap=None, ae_only=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -192,6 +192,8 @@ class HipAAE:
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.reserved[0] = 1 if unfused_decoder else 0
         cfg.reserved[1] = int(dp_world) if grad_mode == "export" else 0
+        cfg.reserved[2] = 1 if ae_only else 0
+        self.ae_only = bool(ae_only)
         self.dp_world = int(dp_world)
         # rows of the packed first-layer gradient one rank may send per exchange
         self.w1_cap = int(w1_cap if w1_cap is not None else min(cfg.max_nnz, n_items, 65536))

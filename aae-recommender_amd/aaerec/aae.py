@@ -111,6 +111,7 @@ class AdversarialAutoEncoder:
         self.hip = None
         self._dp = None
         self.last_losses = None
+        self._ae_only = False
 
     def __str__(self):
         desc = "Adversarial Autoencoder"
@@ -160,7 +161,7 @@ class AdversarialAutoEncoder:
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
             grad_mode="export" if self.data_parallel else "fused", device=self.device,
-            dp_world=dist_world, w1_cap=w1_cap)
+            dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only)
         # nn.Linear default initialisation, drawn from torch's global CPU generator in the
         # reference's construction order (Encoder, Decoder, Discriminator; lin1, lin2, lin3 each),
         # so equal seeds give equal initial weights
@@ -218,7 +219,8 @@ class AdversarialAutoEncoder:
             z = hip.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
             zc, back = self._cond_fn(c_batch)(z)
             hip.ae_encoder_backward(back(hip.ae_decode_backward(zc)))
-            hip.disc_gen()
+            if not self._ae_only:
+                hip.disc_gen()
 
     def _cond_fn(self, c_batch):
         """z -> (zc, backward) through the condition plugins with torch autograd
@@ -335,6 +337,33 @@ class AdversarialAutoEncoder:
         return np.vstack(pred)
 
 
+class AutoEncoder(AdversarialAutoEncoder):
+    """The reference's plain (non-adversarial) autoencoder, aae.py:221-458: the same encoder and
+    decoder trained with the reconstruction step only, one learning rate for both optimisers.
+    Same kernels, the discriminator / generator phases are simply not run."""
+
+    def __init__(self, n_hidden=100, n_code=50, lr=0.001, batch_size=100, n_epochs=500, optimizer="adam",
+                 normalize_inputs=True, activation="ReLU", dropout=(.2, .2), conditions=None, verbose=True,
+                 device=None, rng_mode="device", seed=None):
+        super().__init__(n_hidden=n_hidden, n_code=n_code, gen_lr=lr, reg_lr=lr, prior="gauss", batch_size=batch_size,
+                         n_epochs=n_epochs, optimizer=optimizer, normalize_inputs=normalize_inputs,
+                         activation=activation, dropout=dropout, conditions=conditions, verbose=verbose,
+                         device=device, rng_mode=rng_mode, seed=seed)
+        self.lr = lr
+        self._ae_only = True
+
+    def __str__(self):
+        return "Autoencoder ({0}, {0}, {1}, {0}, {0}) optimized by {2} with learning rate {3}".format(
+            self.n_hidden, self.n_code, self.optimizer, self.lr)
+
+    def _host_randomness(self, B):
+        h, p1, p2 = self.n_hidden, self.dropout[0], self.dropout[1]
+
+        def mask(p):
+            return None if p == 0 else torch.empty(B, h).bernoulli_(1 - p).to(torch.uint8)
+        return [mask(p1), mask(p2), mask(p1), mask(p2)] + [None] * 8, None
+
+
 def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
     """Top-k recommendations without materialising the [n, N] score matrix on the host: the
     reference's predict -> remove_non_missing -> argtopk pipeline (aae.py:840-870,
@@ -410,10 +439,10 @@ class AAERecommender(Recommender):
         else:
             print("Start of training, not using condition...", self.conditions)
             condition_data = None
-        if not self.adversarial:
-            raise NotImplementedError("adversarial=False (the plain AutoEncoder, reference aae.py:221-458) is "
-                                      "outside the accelerated hot path of this build (SURVEY.md section 8f)")
-        self.model = AdversarialAutoEncoder(conditions=self.conditions, **self.model_params)
+        if self.adversarial:
+            self.model = AdversarialAutoEncoder(conditions=self.conditions, **self.model_params)
+        else:
+            self.model = AutoEncoder(conditions=self.conditions, **self.model_params)
         print(self.model)
         print(self.conditions)
         self.model.fit(X, condition_data=condition_data)

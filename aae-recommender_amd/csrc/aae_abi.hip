@@ -74,6 +74,7 @@ struct aae_model {
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave;
+    bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
     bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
     bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
@@ -133,7 +134,8 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 2; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 3; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[2] != 0 && c->reserved[2] != 1) return fail(AAE_EINVAL, "reserved[2] (autoencoder only) must be 0 or 1");
     if (c->reserved[1] < 0 || c->reserved[1] > 64) return fail(AAE_EINVAL, "reserved[1] (data-parallel world size) out of range");
     if (c->reserved[0] != 0 && c->reserved[0] != 1) return fail(AAE_EINVAL, "reserved[0] must be 0 or 1");
     return AAE_OK;
@@ -417,7 +419,7 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
         int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
         hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
                            m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
-                           m->tsync, m->step_ctr, which == O_GEN ? 1 : 0);
+                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
         LAUNCHCHK("w1_sparse_adam");
     } else if (!exportg) {
         size_t n4 = m->P[P_W1T].floats() / 4;
@@ -642,7 +644,7 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
         int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
         hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
                            m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
-                           m->tsync, m->step_ctr, which == O_GEN ? 1 : 0);
+                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
         LAUNCHCHK("w1_sparse_adam");
     }
     return AAE_OK;
@@ -759,6 +761,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
+    m->ae_only = cfg->reserved[2] == 1;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
         int dev = 0, cus = 0;
@@ -1212,6 +1215,7 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
 // disc_step (aae.py:713-732)
 int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->ae_only) return fail(AAE_ESTATE, "model was created as a plain autoencoder (no discriminator steps)");
     if (m->phase != 3) return fail(AAE_ESTATE, "aae_disc_step before the ae phases of the step");
     remember_inject(m, inj, false);
     hipStream_t s = S(stream);
@@ -1311,7 +1315,7 @@ int aae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const 
     m->fuse_enc_bwd = false;
     TRY(rc);
     TRY(aae_ae_encoder_backward(m, nullptr, 0, stream));
-    TRY(aae_disc_gen(m, nullptr, stream));
+    if (!m->ae_only) TRY(aae_disc_gen(m, nullptr, stream));
     return AAE_OK;
 }
 
@@ -1437,7 +1441,7 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
     }
     hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
                        m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, m->h, m->sc + which, m->tsync,
-                       m->step_ctr, which == O_GEN ? 1 : 0);
+                       m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
     LAUNCHCHK("w1_sparse_adam union");
     return AAE_OK;
 }

@@ -79,7 +79,9 @@ typedef struct aae_config {
     uint64_t seed;            /* device rng */
     int32_t reserved[8];      /* must be zero, except [0] = 1: keep the decoder output layer on the unfused
                                  three-kernel path (A/B measurements); [1] = number of data-parallel
-                                 peers whose packed rows aae_w1_import may receive (0 = 1) */
+                                 peers whose packed rows aae_w1_import may receive (0 = 1); [2] = 1:
+                                 plain AutoEncoder (reference aae.py:221-458): the step ends after the
+                                 encoder backward, aae_disc_step / aae_gen_step are errors */
 } aae_config;
 
 typedef struct aae_model* aae_handle;

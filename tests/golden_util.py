@@ -71,6 +71,8 @@ class Fixture:
         """{(optimiser, 'net.key'): (m, v, t)}"""
         out = {}
         for tag, net in (("A_enc", "enc"), ("A_dec", "dec"), ("A_gen", "enc"), ("A_disc", "disc")):
+            if f"step{s}.{tag}.0.m" not in self.z.files and f"step{s}.{tag}.2.m" not in self.z.files:
+                continue
             for i, k in enumerate(NET_KEYS):
                 key = f"step{s}.{tag}.{i}.m"
                 if key in self.z.files:

@@ -208,6 +208,9 @@ def test_aae_constructor_surface_and_errors():
         m.partial_fit(np.eye(3), y=[1, 2, 3])
     with pytest.raises(KeyError):
         AdversarialAutoEncoder(optimizer="rmsprop")
+    from aaerec.aae import AutoEncoder
+    ae = AutoEncoder(n_hidden=20, n_code=5, lr=0.01, verbose=False)
+    assert ae.gen_lr == ae.reg_lr == 0.01 and ae.encoder_activation == "linear" and str(ae).startswith("Autoencoder (20, 20, 5")
     rec = AAERecommender(n_hidden=10, n_epochs=1)
     assert isinstance(rec, Recommender) and str(rec).startswith("Adversarial Autoencoder\nModel Params:")
     with pytest.raises(RuntimeError):                # duplicate items -> 2.0 -> the reference's BCE error

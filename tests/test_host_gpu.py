@@ -202,3 +202,24 @@ def test_predict_topk_equals_host_pipeline():
     # known items never come back
     Xd = Xin.toarray()
     assert Xd[np.arange(Xin.shape[0])[:, None], ids].sum() == 0
+
+
+def test_autoencoder_recommender_learns():
+    """AAERecommender(adversarial=False) -> AutoEncoder (reference aae.py:221-458, 953-957)."""
+    from aaerec.aae import AAERecommender, AutoEncoder
+    from aaerec.evaluation import remove_non_missing, METRICS
+    z, Xtr, Xin, Yout = _e2e()
+
+    class Set:
+        def __init__(self, X):
+            self.X = X
+
+        def tocsr(self):
+            return self.X
+    torch.manual_seed(0)
+    np.random.seed(0)
+    rec = AAERecommender(adversarial=False, n_hidden=50, n_code=50, n_epochs=40, batch_size=100, lr=0.01, verbose=False)
+    rec.train(Set(Xtr))
+    assert isinstance(rec.model, AutoEncoder)
+    pred = remove_non_missing(rec.predict(Set(Xin)), Xin, copy=True)
+    assert METRICS["mrr@10"](Yout.toarray(), pred)[0] > 0.1

@@ -67,6 +67,18 @@ def test_oracle_predict(name):
     np.testing.assert_allclose(got, fx.z["predict.out"], atol=1e-6)
 
 
+def test_oracle_ae_step_matches_reference_autoencoder():
+    """The reference's plain AutoEncoder (aae.py:221-458) is the oracle's ae_step alone."""
+    fx = Fixture("step_ae_only")
+    m = build_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        loss = m.ae_step(ip, idx, val, fx.masks(s))
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        for k, w in fx.expected_params(s).items():
+            np.testing.assert_allclose(m.p[k], w, atol=TOL_PARAM, rtol=0, err_msg=k)
+
+
 def test_oracle_rejects_counts_above_one():
     """Reference behaviour (torch BCE): duplicate items give value 2.0 -> RuntimeError."""
     fx = Fixture("step_nodrop_gauss")

@@ -41,8 +41,9 @@ def check_state(fx, m, s, name):
     exp = fx.expected_adam(s)
     if not exp:
         return
-    states = {"A_enc": m.adam_state("enc"), "A_dec": m.adam_state("dec"),
-              "A_gen": m.adam_state("gen"), "A_disc": m.adam_state("disc")}
+    states = {"A_enc": m.adam_state("enc"), "A_dec": m.adam_state("dec")}
+    if any(t in ("A_gen", "A_disc") for t, _ in exp):
+        states.update({"A_gen": m.adam_state("gen"), "A_disc": m.adam_state("disc")})
     for (tag, k), (em, ev, et) in exp.items():
         st = states[tag]
         gm, gv = st[k.split(".", 1)[1]]
@@ -72,6 +73,24 @@ def test_step_matches_reference(name):
     pc_t = torch.as_tensor(pc[0], device=m.device) if pc else None
     out = m.predict(pcsr, 0, pcsr.shape[0], cond=pc_t).cpu().numpy()
     np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)
+
+
+def test_plain_autoencoder_matches_reference():
+    """cfg.reserved[2] = 1: the reference's non-adversarial AutoEncoder (aae.py:221-458) - only the
+    reconstruction step runs; fixture generated from the reference's AutoEncoder class."""
+    fx = Fixture("step_ae_only")
+    m = make_model(fx, ae_only=True)
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        m.step(csr, 0, csr.shape[0], masks=fx.masks(s) + [None] * 8)
+        got = m.losses()
+        np.testing.assert_allclose(got[0], fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        check_state(fx, m, s, "ae_only")
+    pcsr = csr_of(fx, m, 0, prefix="predict")
+    np.testing.assert_allclose(m.predict(pcsr, 0, pcsr.shape[0]).cpu().numpy(), fx.z["predict.out"], atol=TOL_RECON)
+    from aaerec._hip import AaeHipError
+    with pytest.raises(AaeHipError):
+        m.disc_step()
 
 
 def test_first_layer_and_code_match_reference():

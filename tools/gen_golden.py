@@ -321,6 +321,61 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
     return out
 
 
+def run_ae_only_case(ref_aae, name, N=300, h=20, c=10, B=16, steps=3, seed=0, dropout=(0.2, 0.2), lr=2e-3):
+    """The reference's plain AutoEncoder (aae.py:221-458): ae_step only, one learning rate."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(2000 + seed)
+    m = ref_aae.AutoEncoder(n_hidden=h, n_code=c, lr=lr, batch_size=B, n_epochs=1, dropout=dropout, verbose=True)
+    m.enc = ref_aae.Encoder(N, h, c, final_activation='linear', normalize_inputs=m.normalize_inputs,
+                            dropout=m.dropout, activation=m.activation)
+    m.dec = ref_aae.Decoder(c, h, N, dropout=m.dropout, activation=m.activation)
+    og = ref_aae.TORCH_OPTIMIZERS[m.optimizer]
+    m.enc_optim, m.dec_optim = og(m.enc.parameters(), lr=m.lr), og(m.dec.parameters(), lr=m.lr)
+    masks_log = []
+    for net_name, net in (("enc", m.enc), ("dec", m.dec)):
+        for li, attr in enumerate(("drop1", "drop2")):
+            setattr(net, attr, RecDropout(m.dropout[li], masks_log, f"{net_name}.{attr}"))
+    loss_log = []
+    ref_aae.log_losses = lambda *l: loss_log.append(l)
+    ref_aae.USE_WANDB = False
+    out = {}
+    cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="", cond_inc=0, n_hidden=h, n_code=c, ae_only=1,
+               gen_lr=lr, reg_lr=lr, dropout=list(dropout))
+    for net_name, net in (("enc", m.enc), ("dec", m.dec)):
+        for k, v in state_np(net).items():
+            out[f"init.{net_name}.{k}"] = v
+    # the kernels' model always has a discriminator; give it fixed (unused) weights
+    disc = ref_aae.Discriminator(c, h)
+    for k, v in state_np(disc).items():
+        out[f"init.disc.{k}"] = v
+    for s in range(steps):
+        X = make_batch(rng, B, N)
+        out[f"step{s}.indptr"] = X.indptr.astype(np.int64)
+        out[f"step{s}.indices"] = X.indices.astype(np.int32)
+        out[f"step{s}.values"] = X.data.astype(np.float32)
+        n0 = len(masks_log)
+        m.partial_fit(X.toarray(), step=s)
+        out[f"step{s}.losses"] = np.asarray(loss_log[-1], dtype=np.float64)
+        out[f"step{s}.z_real"] = np.zeros((B, c), dtype=np.float32)
+        for j, (tag, mk) in enumerate(masks_log[n0:]):
+            out[f"step{s}.mask{j}"] = mk
+        for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", disc)):
+            for k, v in state_np(net).items():
+                out[f"step{s}.{net_name}.{k}"] = v
+        ep, dp = list(m.enc.parameters()), list(m.dec.parameters())
+        for tag, opt, ps in (("A_enc", m.enc_optim, ep), ("A_dec", m.dec_optim, dp)):
+            for k, v in optim_np(opt, ps).items():
+                out[f"step{s}.{tag}.{k}"] = v
+    Xp = make_batch(rng, B, N)
+    out["predict.indptr"] = Xp.indptr.astype(np.int64)
+    out["predict.indices"] = Xp.indices.astype(np.int32)
+    out["predict.values"] = Xp.data.astype(np.float32)
+    out["predict.out"] = m.predict(Xp).astype(np.float32)
+    out["config_json"] = np.asarray(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses step0={out['step0.losses']}")
+
+
 def gen_metric_known_answers():
     """Known answers for the metric side, produced by calling the reference's own
     evaluation functions on literal inputs (evaluation.py:94-115,183-199)."""
@@ -425,6 +480,8 @@ def main():
         # one wider case so multi-tile kernel paths are pinned too
         run_case(ref_aae, ref_cond, "step_wide", seed=15, N=1100, h=72, c=24, B=40, steps=2,
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=20), capture_acts=False, states='last')
+    if want("ae_only"):
+        run_ae_only_case(ref_aae, "step_ae_only", seed=21)
     if want("metrics"):
         gen_metric_known_answers()
     if want("e2e"):
