@@ -171,7 +171,13 @@ class AdversarialAutoEncoder:
                   ("disc", (self.n_code, self.n_hidden, 1))]
         for net, (n_in, n_hid, n_out) in shapes:
             for layer, (i, o) in enumerate(((n_in, n_hid), (n_hid, n_hid), (n_hid, n_out)), start=1):
-                lin = torch.nn.Linear(i, o)
+                if net == "disc" and self._ae_only:
+                    # the reference's AutoEncoder builds no discriminator (aae.py:367-383): do not
+                    # consume the global generator for the (unused) one the kernels carry
+                    with torch.random.fork_rng():
+                        lin = torch.nn.Linear(i, o)
+                else:
+                    lin = torch.nn.Linear(i, o)
                 params["{}.lin{}.weight".format(net, layer)] = lin.weight.detach().numpy()
                 params["{}.lin{}.bias".format(net, layer)] = lin.bias.detach().numpy()
         self.hip.load_params(params)

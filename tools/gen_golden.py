@@ -448,6 +448,13 @@ def gen_e2e_c1(ref_aae):
                out_indptr=Yout.indptr, out_indices=Yout.indices,
                N=np.asarray(N), ref_mrr10=np.asarray(mrrs))
     np.savez_compressed(os.path.join(OUT, "e2e_c1.npz"), **out)
+    # the plain AutoEncoder (aae.py:221-458) on the same data, 3 epochs, for tests/test_host_gpu.py
+    torch.manual_seed(7)
+    np.random.seed(7)
+    ae = ref_aae.AutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100, lr=0.01, verbose=False)
+    ae.fit(Xtr)
+    np.savez_compressed(os.path.join(OUT, "e2e_ae_short.npz"), pred_short=ae.predict(Xin[:40]).astype(np.float32),
+                        seed=np.asarray(7))
 
 
 def main():
