@@ -85,6 +85,7 @@ _PROTOS = {
     "aae_apply_updates_except": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aae_apply_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "aae_w1_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "aae_w1_packet_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aae_w1_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -247,7 +248,7 @@ class HipAAE:
         """Flat gradient views to all-reduce for optimiser `which` (export mode).  The first
         encoder layer's row-sparse gradient is not among them: see w1_export / w1_import."""
         if which in (O_ENC, O_GEN):
-            return [self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
+            return []        # b1, W2, W3 ride in the w1_export packet and are applied by w1_import
         if which == O_DEC:
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2), self._span(T_GRAD + T_DEC_V3, T_GRAD + T_DEC_V3)]
         if which == "dec_small":
@@ -427,9 +428,11 @@ class HipAAE:
     def w1_export(self):
         """Pack this rank's first-layer gradient rows: one flat float32 tensor = int32 header
         (count, item ids) + rows [cap, n_hidden]."""
-        n = self._w1_hdr + self.w1_cap * self.h
         if self._w1_packet is None:
-            self._w1_packet = torch.zeros(n, dtype=torch.float32, device=self.device)
+            hw, tot = C.c_int64(), C.c_int64()
+            _check(self.lib.aae_w1_packet_floats(self.handle, self.w1_cap, C.byref(hw), C.byref(tot)))
+            assert hw.value == self._w1_hdr
+            self._w1_packet = torch.zeros(tot.value, dtype=torch.float32, device=self.device)
         pk = self._w1_packet
         with torch.cuda.device(self.device):
             _check(self.lib.aae_w1_export(self.handle, C.c_void_p(pk.data_ptr()),
@@ -438,7 +441,7 @@ class HipAAE:
 
     def w1_import(self, packets, n_peers, which):
         """Sum the peers' packed rows (flat tensor of n_peers packets) and run optimiser `which` on them."""
-        stride = 4 * (self._w1_hdr + self.w1_cap * self.h)
+        stride = 4 * self._w1_packet.numel()
         assert packets.numel() * 4 >= n_peers * stride
         self._keep.append(packets)
         with torch.cuda.device(self.device):

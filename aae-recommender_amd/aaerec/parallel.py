@@ -46,6 +46,15 @@ class DataParallelAAE:
         return [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
                 for t in self.model.grad_buckets(which)]
 
+    def _exchange_encoder(self, which):
+        """All encoder gradients of one optimiser step (enc_optim after the ae phases, gen_optim after
+        gen_step).  GPU model: one all-gather of packets (packed first-layer rows + the small layers).
+        Stand-ins without the packed path: all-reduce of dense buckets."""
+        if not hasattr(self.model, "w1_export") or getattr(self.model, "packet_has_small", True) is False:
+            self._allreduce(which)
+            self.model.apply_updates(which)
+        self._exchange_w1(which)
+
     def _exchange_w1(self, which):
         """First encoder layer: only the rows of the items in the global batch carry gradient, so the
         ranks all-gather their packed rows (a few MB) instead of all-reducing the dense [N, h] tensor."""
@@ -125,14 +134,10 @@ class DataParallelAAE:
         # the encoder backward, disc_step and gen_step run
         dec_state = self._dec_start()
         m.ae_encoder_backward(dz)
-        self._allreduce(O_ENC)
-        m.apply_updates(O_ENC)
-        self._exchange_w1(O_ENC)
+        self._exchange_encoder(O_ENC)
         m.disc_step()
         self._allreduce(O_DISC)
         m.apply_updates(O_DISC)
         m.gen_step()
-        self._allreduce(O_GEN)
-        m.apply_updates(O_GEN)
-        self._exchange_w1(O_GEN)
+        self._exchange_encoder(O_GEN)
         self._dec_finish(dec_state)

@@ -1404,6 +1404,12 @@ int aae_predict_topk(aae_handle m, const aae_batch* batch, const float* cond_dev
 }
 
 // ---- data parallel: row-sparse exchange of the first encoder layer's gradient -------------
+// floats from the start of Gr[B1] to the end of Gr[W3] (adjacent in the arena, 256-byte gaps included)
+static size_t enc_small_floats(const aae_model* m) {
+    const Ten& a = m->Gr[P_B1]; const Ten& b = m->Gr[P_W3];
+    return (b.off + b.floats() * sizeof(float) - a.off) / sizeof(float);
+}
+
 int aae_w1_export(aae_handle m, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream) {
     if (!m || !hdr_dev || !vals_dev) return fail(AAE_EINVAL, "NULL argument");
     if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_w1_export needs grad_mode=export");
@@ -1412,6 +1418,17 @@ int aae_w1_export(aae_handle m, int32_t* hdr_dev, float* vals_dev, int32_t cap, 
     hipLaunchKernelGGL(w1_pack_kernel, dim3(std::min(cap, 4096)), dim3(256), 0, s, m->ulist, m->ucount, m->Gr[P_W1T].p,
                        m->ldw1, m->h, cap, reinterpret_cast<int*>(hdr_dev), vals_dev);
     LAUNCHCHK("w1_pack");
+    // the encoder's small-layer gradients (b1, W2, W3: one contiguous arena span) ride behind the rows
+    const size_t nsmall = enc_small_floats(m);
+    HIPCHK(hipMemcpyAsync(vals_dev + (size_t)cap * m->h, m->Gr[P_B1].p, nsmall * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return AAE_OK;
+}
+
+int aae_w1_packet_floats(aae_handle m, int32_t cap, int64_t* hdr_words, int64_t* total_floats) {
+    if (!m || !hdr_words || !total_floats) return fail(AAE_EINVAL, "NULL argument");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "needs grad_mode=export");
+    *hdr_words = (1 + (int64_t)cap + 3) & ~(int64_t)3;
+    *total_floats = *hdr_words + (int64_t)cap * m->h + (int64_t)enc_small_floats(m);
     return AAE_OK;
 }
 
@@ -1431,6 +1448,17 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
                            m->ulist, m->ucount);
     }
     LAUNCHCHK("w1_unpack");
+    {   // small encoder layers: sum the peers' spans in rank order, then the optimiser on them
+        const size_t nsmall = enc_small_floats(m);
+        for (int p = 0; p < n_peers; ++p) {
+            const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(vals_dev) +
+                                                              (size_t)p * peer_stride_bytes) + (size_t)cap * m->h;
+            hipLaunchKernelGGL(accumulate_kernel, dim3(grid1d(nsmall)), dim3(256), 0, s, m->Gr[P_B1].p, src, nsmall,
+                               p == 0 ? 1 : 0);
+        }
+        LAUNCHCHK("accumulate small");
+        TRY(aae_apply_updates(m, which, stream));      // b1, W2, W3 (W1T is skipped there: sparse path below)
+    }
     const int set = which == O_GEN ? 1 : 0;
     const int grid = std::min(m->cfg.max_nnz * std::max(1, m->cfg.reserved[1]), 8192);
     if (m->cfg.optimizer == AAE_OPT_ADAM) {

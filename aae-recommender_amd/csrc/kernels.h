@@ -575,6 +575,12 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ scor
     }
 }
 
+// dst[i] = (first ? 0 : dst[i]) + src[i]   (summing the peers' small-layer gradients in rank order)
+__global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, int first) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (first ? 0.f : dst[i]) + src[i];
+}
+
 __global__ void fill_int_kernel(int* p, size_t n, int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

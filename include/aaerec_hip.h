@@ -227,6 +227,10 @@ int aae_apply_updates(aae_handle h, int which, void* stream);
  * and runs the optimiser `which` (0 enc_optim after the ae phases, 2 gen_optim after gen_step) on
  * them.  cfg.reserved[1] must hold the number of peers. */
 int aae_w1_export(aae_handle h, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream);
+/* packet layout for `cap` rows: hdr_words int32 words of header, then cap * n_hidden floats of
+ * rows, then the encoder's small-layer gradients (b1, W2, W3), which aae_w1_import also sums and
+ * applies - so one all-gather per exchange point carries everything the encoder optimisers need */
+int aae_w1_packet_floats(aae_handle h, int32_t cap, int64_t* hdr_words, int64_t* total_floats);
 int aae_w1_import(aae_handle h, const int32_t* hdr_dev, const float* vals_dev, int32_t cap, int32_t n_peers,
                   int64_t peer_stride_bytes, int which, void* stream);
 /* Sharded optimiser: aae_apply_updates_except is aae_apply_updates without tensor

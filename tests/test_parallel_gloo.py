@@ -112,8 +112,9 @@ def test_shard_bounds():
 
 class SparseW1Replica(OracleReplica):
     """Same stand-in, but the first encoder layer's gradient travels as packed rows
-    (w1_export / w1_import), the path the GPU model takes."""
+    (w1_export / w1_import), the path the GPU model takes (its small layers still all-reduce)."""
     CAP = 64
+    packet_has_small = False
 
     def grad_buckets(self, which):
         return [torch.from_numpy(g) for k, g in self.o.G[which].items() if k != "enc.lin1.weight"]
