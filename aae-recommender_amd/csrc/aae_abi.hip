@@ -511,8 +511,25 @@ struct ChainBuilder {
 int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
     const int grid = (cb.P.rows + kCR - 1) / kCR;
+    static const bool want_ts = getenv("AAE_CHAIN_TS") != nullptr;      // debug: per-op timeline of workgroup 0
+    static unsigned long long* ts_dev = nullptr;
+    if (want_ts) {
+        if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
+        cb.P.ts = ts_dev;
+    }
     hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     LAUNCHCHK("chain_kernel");
+    if (want_ts) {
+        unsigned long long h[32];
+        hipStreamSynchronize(s);
+        hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE"};
+        fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
+        for (int i = 0; i < cb.P.nops; ++i)
+            fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
+                    cb.P.ops[i].out ? ",st" : "", cb.P.ops[i].out2 ? ",st2" : "", (h[i + 1] - h[i]) * 0.01);
+        fprintf(stderr, "\n");
+    }
     return AAE_OK;
 }
 

@@ -55,22 +55,63 @@ struct ChainProgram {
     uint64_t seed; const long long* step_ctr;
     float* loss_out; int loss_slot;     // COP_ADV accumulates -mean(log ...) here (atomicAdd of per-row terms)
     int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
+    unsigned long long* ts;             // debug (AAE_CHAIN_TS): per-op 100 MHz timestamps of workgroup 0, else NULL
     ChainOp ops[kCMaxOps];
 };
 
-__device__ __forceinline__ float chain_epi(int epi, const ChainOp& op, const ChainProgram& P, uint64_t key,
-                                           const float* slots, int grow, int lrow, int col, float v) {
-    if (epi == CEPI_DROPACT) {
-        if (op.d.enabled) v = drop_fwd(op.d, drop_keep(op.d, key, grow, col), v);
-        return act_fwd(P.act, v);
+// Workgroup barrier that orders LDS traffic only: global stores of finished activations (consumed by
+// LATER kernels, never re-read inside this one) and weight loads in flight stay outstanding across
+// it, where __syncthreads() would drain them (s_waitcnt vmcnt(0)) once per op.
+__device__ __forceinline__ void chain_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Everything an epilogue needs from the op descriptor, read ONCE per op into scalar registers.  The
+// descriptor lives in the kernel-argument segment; hipcc treats such loads as free to repeat, and with
+// this kernel's scalar-register pressure it re-issued ~8 dependent s_load + s_waitcnt per ELEMENT
+// (~0.5 us per 16x16 block).  The empty asm makes each value opaque, i.e. it has to stay in a register.
+template <class T> __device__ __forceinline__ T chain_pin(T v) { asm volatile("" : "+s"(v)); return v; }
+
+struct EpiCtx {
+    int epi, act, den, drng, split, width;
+    uint32_t thr;
+    uint64_t dkey;
+    float mk, ak, ad;
+    const uint8_t* ma; const uint8_t* mb;
+    const float* y;                      // slot holding the forward activation (ACTBWD)
+};
+
+__device__ __forceinline__ EpiCtx chain_epi_ctx(int epi, const ChainOp& op, const ChainProgram& P, uint64_t key,
+                                                const float* slots) {
+    EpiCtx c;
+    c.epi = chain_pin(epi); c.act = chain_pin(P.act);
+    c.den = chain_pin(op.d.enabled); c.drng = chain_pin(op.d.device_rng);
+    c.split = chain_pin(op.d.split_row); c.width = chain_pin(op.d.width);
+    c.thr = chain_pin(op.d.keep_threshold);
+    c.dkey = chain_pin(key ^ ((uint64_t)op.d.stream_id * 0xA0761D6478BD642Full));
+    c.mk = chain_pin(op.d.mul_keep); c.ak = chain_pin(op.d.add_keep); c.ad = chain_pin(op.d.add_drop);
+    c.ma = chain_pin(op.d.mask_a); c.mb = chain_pin(op.d.mask_b);
+    c.y = slots + chain_pin(op.yslot) * kCR * kCL;
+    return c;
+}
+
+__device__ __forceinline__ int chain_keep(const EpiCtx& c, int row, int col) {      // drop_keep() on the pinned copy
+    if (c.drng) return hash_cell(c.dkey, (uint32_t)row, (uint32_t)col) >= c.thr;
+    const uint8_t* m = row < c.split ? c.ma : c.mb;
+    if (!m) return 1;
+    const int r = row < c.split ? row : row - c.split;
+    return m[(size_t)r * c.width + col] != 0;
+}
+
+__device__ __forceinline__ float chain_epi(const EpiCtx& c, int grow, int lrow, int col, float v) {
+    if (c.epi == CEPI_DROPACT) {
+        if (c.den) v = chain_keep(c, grow, col) ? v * c.mk + c.ak : c.ad;
+        return act_fwd(c.act, v);
     }
-    if (epi == CEPI_ACTBWD) {
-        const float y = slots[op.yslot * kCR * kCL + lrow * kCL + col];
-        v *= act_grad_from_y(P.act, y);
-        if (op.d.enabled) v *= drop_bwd_mul(op.d, drop_keep(op.d, key, grow, col));
+    if (c.epi == CEPI_ACTBWD) {
+        v *= act_grad_from_y(c.act, c.y[lrow * kCL + col]);
+        if (c.den) v *= chain_keep(c, grow, col) ? c.mk : 0.f;
         return v;
     }
-    if (epi == CEPI_SIGMOID) return sigmoidf_(v);
+    if (c.epi == CEPI_SIGMOID) return sigmoidf_(v);
     return v;
 }
 
@@ -129,6 +170,69 @@ __device__ __forceinline__ void chain_store_block(const float* src, int nrows, i
     }
 }
 
+// ---- one layer's MFMAs for the (up to) two 16-column blocks of a wave ---------------------------
+// All weight loads of the layer are issued before its first MFMA (the arrays are fully unrolled,
+// i.e. registers): a layer costs one L2 round trip, not one per k-group.  Loads are unconditional
+// from clamped addresses (a lane-conditional load makes hipcc wait for every load separately).
+// Forward, W[n][k] k-contiguous.  k-permutation: lane (fr, fk) holds k = kc + 4*fk + j in element j
+// of one float4 for BOTH operands, so 16 k need one 16-byte load per operand and feed 4 MFMAs.
+template <int MC, bool TWO>
+__device__ __forceinline__ void chain_linear_fwd(const ChainOp& op, const float* src, int b0, int b1, int fr, int fk,
+                                                 f32x4 (&acc)[2]) {
+    const float* w0 = op.W + (size_t)min(b0 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
+    const float* w1 = op.W + (size_t)min(b1 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
+    const float* a = src + fr * kCL + 4 * fk;
+    const int kch = (op.K + 15) >> 4;
+    float4 y0[MC], y1[TWO ? MC : 1];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        const int kc = min(c, kch - 1) * 16;
+        y0[c] = *reinterpret_cast<const float4*>(w0 + kc);
+        if (TWO) y1[c] = *reinterpret_cast<const float4*>(w1 + kc);
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        if (c < kch) {
+            const float4 xa = *reinterpret_cast<const float4*>(a + c * 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y0[c].x, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y0[c].y, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y0[c].z, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y0[c].w, acc[0], 0, 0, 0);
+            if (TWO) {
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c].x, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c].y, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c].z, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c].w, acc[1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// dX, W[k][n] n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes)
+template <int MS, bool TWO>
+__device__ __forceinline__ void chain_linear_dx(const ChainOp& op, const float* src, int b0, int b1, int fr, int fk,
+                                                f32x4 (&acc)[2]) {
+    const float* w0 = op.W + (size_t)fk * op.ldw + min(b0 * 16 + fr, op.N - 1);
+    const float* w1 = op.W + (size_t)fk * op.ldw + min(b1 * 16 + fr, op.N - 1);
+    const float* a = src + fr * kCL + fk;
+    const int ks = (op.K + 3) >> 2;
+    float y0[MS], y1[TWO ? MS : 1];
+#pragma unroll
+    for (int j = 0; j < MS; ++j) {
+        const int kr = min(min(j, ks - 1) * 4 + fk, op.K - 1) - fk;   // clamped weight row; A is zero past K
+        y0[j] = w0[(size_t)kr * op.ldw];
+        if (TWO) y1[j] = w1[(size_t)kr * op.ldw];
+    }
+#pragma unroll
+    for (int j = 0; j < MS; ++j) {
+        if (j < ks) {
+            const float xa = (j * 4 + fk < op.K) ? a[j * 4] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
+            if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -140,6 +244,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
 
     for (int oi = 0; oi < P.nops; ++oi) {
         const ChainOp& op = P.ops[oi];
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[oi] = wall_clock64();
         float* dst = slots + op.dst * kCR * kCL;
         const float* src = slots + op.src * kCR * kCL;
         const int kind = op.kind;
@@ -151,65 +256,23 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int b0 = min(wave, nblk - 1), b1 = min(wave + 8, nblk - 1);
             const bool two = nblk > 8;
-            if (!(P.dbg & 1)) {
-            // All weight loads of the layer are issued before its first MFMA (the arrays below are fully
-            // unrolled, i.e. registers): a layer then costs one L2 round trip, not one per k-group.
-            if (kind == COP_LINEAR) {
-                // k-permutation: lane (fr, fk) holds k = kc + 4*fk + j in element j of one float4 for BOTH
-                // operands, so 16 k need one 16-byte load per operand and feed 4 MFMAs
-                constexpr int MC = 13;                         // K <= 208
-                const float* w0 = op.W + (size_t)min(b0 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
-                const float* w1 = op.W + (size_t)min(b1 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
-                const float* a = src + fr * kCL + 4 * fk;
-                const int kch = (op.K + 15) >> 4;
-                float4 y0[MC], y1[MC];
-#pragma unroll
-                for (int c = 0; c < MC; ++c) {
-                    const int kc = min(c, kch - 1) * 16;
-                    y0[c] = *reinterpret_cast<const float4*>(w0 + kc);
-                    y1[c] = *reinterpret_cast<const float4*>(w1 + kc);
-                }
-#pragma unroll
-                for (int c = 0; c < MC; ++c) {
-                    if (c < kch) {
-                        const float4 xa = *reinterpret_cast<const float4*>(a + c * 16);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y0[c].x, acc[0], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y0[c].y, acc[0], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y0[c].z, acc[0], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y0[c].w, acc[0], 0, 0, 0);
-                        if (two) {          // layers of <= 128 columns need one block per wave only
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c].x, acc[1], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c].y, acc[1], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c].z, acc[1], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c].w, acc[1], 0, 0, 0);
-                        }
-                    }
-                }
-            } else {
-                // W[k][n], n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes)
-                constexpr int MS = 52;                         // K <= 208
-                const float* w0 = op.W + (size_t)fk * op.ldw + min(b0 * 16 + fr, op.N - 1);
-                const float* w1 = op.W + (size_t)fk * op.ldw + min(b1 * 16 + fr, op.N - 1);
-                const float* a = src + fr * kCL + fk;
-                const int ks = (op.K + 3) >> 2;
-                float y0[MS], y1[MS];
-#pragma unroll
-                for (int j = 0; j < MS; ++j) {
-                    const int kr = min(min(j, ks - 1) * 4 + fk, op.K - 1) - fk;   // clamped weight row; A is zero past K
-                    y0[j] = w0[(size_t)kr * op.ldw];
-                    y1[j] = w1[(size_t)kr * op.ldw];
-                }
-#pragma unroll
-                for (int j = 0; j < MS; ++j) {
-                    if (j < ks) {
-                        const float xa = (j * 4 + fk < op.K) ? a[j * 4] : 0.f;
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
-                        if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
-                    }
+            const EpiCtx ec = chain_epi_ctx(op.epi, op, P, key, slots);
+            const int epiN = chain_pin(op.N);
+            if (!(P.dbg & 1) && wave < nblk) {          // waves without a block (narrow layers) only meet the barriers
+                // Load volume follows the layer: short-K layers (K <= 64 forward, K <= 52 dX) take the 4-chunk /
+                // 13-step variant and layers of <= 128 columns skip the second block - the weight stream of a
+                // layer is bound by the CU's 64 B/clk vector-memory path, so unneeded (clamped) loads cost time.
+                if (kind == COP_LINEAR) {
+                    const int kch = (op.K + 15) >> 4;
+                    if (kch <= 4) { if (two) chain_linear_fwd<4, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<4, false>(op, src, b0, b1, fr, fk, acc); }
+                    else          { if (two) chain_linear_fwd<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<13, false>(op, src, b0, b1, fr, fk, acc); }
+                } else {
+                    const int ks = (op.K + 3) >> 2;
+                    if (ks <= 13) { if (two) chain_linear_dx<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<13, false>(op, src, b0, b1, fr, fk, acc); }
+                    else          { if (two) chain_linear_dx<52, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<52, false>(op, src, b0, b1, fr, fk, acc); }
                 }
             }
-            }
-            __syncthreads();      // dst may alias a slot other waves were still reading (src != dst is required)
+            chain_barrier();      // dst may alias a slot other waves were still reading (src != dst is required)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int blk = wave + 8 * q;
@@ -219,7 +282,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     for (int r = 0; r < 4; ++r) {
                         const int lrow = fk * 4 + r;
                         float v = 0.f;
-                        if (col < op.N && lrow < nrows) v = chain_epi(op.epi, op, P, key, slots, r0 + lrow, lrow, col, acc[q][r]);
+                        if (col < epiN && lrow < nrows) v = chain_epi(ec, r0 + lrow, lrow, col, acc[q][r]);
                         dst[lrow * kCL + col] = v;
                     }
                 }
@@ -254,11 +317,12 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 if (c4 * 4 < kCL) *reinterpret_cast<float4*>(dst + lrow * kCL + c4 * 4) = acc4;
             }
         } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
-            const int epi = kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD;
+            const EpiCtx ec = chain_epi_ctx(kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD, op, P, key, slots);
+            const int epiN = chain_pin(op.N);
             const int lrow = tid >> 5;
             for (int col = tid & 31; col < kCL; col += 32)
-                dst[lrow * kCL + col] = (lrow < nrows && col < op.N)
-                    ? chain_epi(epi, op, P, key, slots, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
+                dst[lrow * kCL + col] = (lrow < nrows && col < epiN)
+                    ? chain_epi(ec, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
         } else if (kind == COP_FINAL_FWD) {
             // one wave per pair of rows; softmax / sigmoid / identity over N columns, in place on dst
             for (int lrow = wave; lrow < kCR; lrow += 8) {
@@ -310,14 +374,15 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 dst[lrow * kCL] = gv;
             }
         }
-        __syncthreads();
+        chain_barrier();
         if (op.one_col >= 0) {      // written by the same lanes for every op kind: rows of the block
             if (tid < kCR) dst[tid * kCL + op.one_col] = tid < nrows ? 1.f : 0.f;
-            __syncthreads();
+            chain_barrier();
         }
         if (op.out) chain_store_block(dst, nrows, op.N, op.out, op.ldo, op.out_row0 + r0);
         if (op.out2) chain_store_block(dst, nrows, op.N, op.out2, op.ldo2, r0);
     }
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[P.nops] = wall_clock64();
 }
 
 // -----------------------------------------------------------------------------------------------

@@ -76,10 +76,22 @@ __device__ __forceinline__ uint64_t rng_key(uint64_t seed, uint64_t step, uint32
     return seed ^ (step * 0xD1B54A32D192ED03ull) ^ ((uint64_t)stream << 56);
 }
 
+// One 32-bit word per (row, col) cell of a dropout stream: the two key halves are offset by odd
+// multiples of row and col, then two multiply-xorshift rounds (the "lowbias32" constants).  Three
+// 32-bit multiplies per cell where the 64-bit mixer above needs sixteen (v_mul_*_u32 are
+// quarter-rate) - dropout masks are drawn inside the 16-row layer chain, on a single CU per block.
+__device__ __forceinline__ uint32_t hash_cell(uint64_t key, uint32_t row, uint32_t col) {
+    uint32_t x = ((uint32_t)key + row * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) + col * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
 // returns keep in {0,1}
 __device__ __forceinline__ int drop_keep(const DropSpec& d, uint64_t key, int row, int col) {
     if (d.device_rng)
-        return hash_u32(key ^ ((uint64_t)d.stream_id << 48), ((uint64_t)(uint32_t)row << 32) | (uint32_t)col) >= d.keep_threshold;
+        return hash_cell(key ^ ((uint64_t)d.stream_id * 0xA0761D6478BD642Full), (uint32_t)row, (uint32_t)col) >= d.keep_threshold;
     const uint8_t* m = row < d.split_row ? d.mask_a : d.mask_b;
     if (!m) return 1;
     int r = row < d.split_row ? row : row - d.split_row;
