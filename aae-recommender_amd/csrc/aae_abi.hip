@@ -112,9 +112,11 @@ struct Arena {
         if (off_out) *off_out = o;
         return dry ? nullptr : reinterpret_cast<float*>(base + o);
     }
-    Ten mat(int64_t rows, int64_t cols, int64_t ld) {
+    // pad_rows: extra rows behind the tensor that stay zero for the life of the arena (the layer-chain
+    // kernel reads whole 4-row k-steps of a weight matrix without clamping the row index)
+    Ten mat(int64_t rows, int64_t cols, int64_t ld, int64_t pad_rows = 0) {
         Ten t; t.rows = rows; t.cols = cols; t.ld = ld;
-        t.p = take((size_t)rows * ld, &t.off);
+        t.p = take((size_t)(rows + pad_rows) * ld, &t.off);
         return t;
     }
 };
@@ -151,14 +153,14 @@ size_t layout(aae_model* m, char* base, bool dry) {
     const int N = m->N, h = m->h, cc = m->c, cp = m->cp;
     m->P[P_W1T] = a.mat(N, h, m->ldw1);
     m->P[P_B1] = a.mat(1, h, m->ldw1);
-    m->P[P_W2] = a.mat(h, h + 1, m->ldh);
-    m->P[P_W3] = a.mat(cc, h + 1, m->ldh);
-    m->P[P_V1] = a.mat(h, cp + 1, m->ldc);
-    m->P[P_V2] = a.mat(h, h + 1, m->ldh);
+    m->P[P_W2] = a.mat(h, h + 1, m->ldh, 4);
+    m->P[P_W3] = a.mat(cc, h + 1, m->ldh, 4);
+    m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 4);
+    m->P[P_V2] = a.mat(h, h + 1, m->ldh, 4);
     m->P[P_V3] = a.mat(N, h + 1, m->ldh);
-    m->P[P_D1] = a.mat(h, cc + 1, m->ldz);
-    m->P[P_D2] = a.mat(h, h + 1, m->ldh);
-    m->P[P_D3] = a.mat(1, h + 1, m->ldh);
+    m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 4);
+    m->P[P_D2] = a.mat(h, h + 1, m->ldh, 4);
+    m->P[P_D3] = a.mat(1, h + 1, m->ldh, 4);
     for (int i = 0; i < NP; ++i) {
         m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
         m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);

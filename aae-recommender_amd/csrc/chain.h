@@ -95,7 +95,9 @@ __device__ __forceinline__ EpiCtx chain_epi_ctx(int epi, const ChainOp& op, cons
 
 __device__ __forceinline__ int chain_keep(const EpiCtx& c, int row, int col) {      // drop_keep() on the pinned copy
     if (c.drng) return hash_cell(c.dkey, (uint32_t)row, (uint32_t)col) >= c.thr;
-    const uint8_t* m = row < c.split ? c.ma : c.mb;
+    // (the pinned copies lost their address space: say "global" again, or these become flat loads)
+    typedef const __attribute__((address_space(1))) uint8_t* gmask_t;
+    gmask_t m = (gmask_t)(row < c.split ? c.ma : c.mb);
     if (!m) return 1;
     const int r = row < c.split ? row : row - c.split;
     return m[(size_t)r * c.width + col] != 0;
@@ -176,19 +178,23 @@ __device__ __forceinline__ void chain_store_block(const float* src, int nrows, i
 // from clamped addresses (a lane-conditional load makes hipcc wait for every load separately).
 // Forward, W[n][k] k-contiguous.  k-permutation: lane (fr, fk) holds k = kc + 4*fk + j in element j
 // of one float4 for BOTH operands, so 16 k need one 16-byte load per operand and feed 4 MFMAs.
+// Addressing: every load is  scalar base (op.W + uniform chunk offset)  +  one 32-bit per-lane byte
+// offset that is the same for all chunks, i.e. the SGPR-base form of global_load - no 64-bit VALU
+// address per load and no VGPR pair to hold it.
 template <int MC, bool TWO>
 __device__ __forceinline__ void chain_linear_fwd(const ChainOp& op, const float* src, int b0, int b1, int fr, int fk,
                                                  f32x4 (&acc)[2]) {
-    const float* w0 = op.W + (size_t)min(b0 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
-    const float* w1 = op.W + (size_t)min(b1 * 16 + fr, op.N - 1) * op.ldw + 4 * fk;
-    const float* a = src + fr * kCL + 4 * fk;
+    const int ldw = op.ldw, N = op.N;
     const int kch = (op.K + 15) >> 4;
+    const uint32_t o0 = (uint32_t)(min(b0 * 16 + fr, N - 1) * ldw + 4 * fk) * 4u;
+    const uint32_t o1 = (uint32_t)(min(b1 * 16 + fr, N - 1) * ldw + 4 * fk) * 4u;
+    const float* a = src + fr * kCL + 4 * fk;
     float4 y0[MC], y1[TWO ? MC : 1];
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
-        const int kc = min(c, kch - 1) * 16;
-        y0[c] = *reinterpret_cast<const float4*>(w0 + kc);
-        if (TWO) y1[c] = *reinterpret_cast<const float4*>(w1 + kc);
+        const char* base = reinterpret_cast<const char*>(op.W + min(c, kch - 1) * 16);     // uniform
+        y0[c] = *reinterpret_cast<const float4*>(base + o0);
+        if (TWO) y1[c] = *reinterpret_cast<const float4*>(base + o1);
     }
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
@@ -208,25 +214,28 @@ __device__ __forceinline__ void chain_linear_fwd(const ChainOp& op, const float*
     }
 }
 
-// dX, W[k][n] n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes)
+// dX, W[k][n] n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes).  The last
+// k-step may touch rows K .. K+2: its A operand is zero there and the arena keeps 4 zero rows behind
+// every weight matrix the chain reads (layout(): pad_rows), so the row index needs no clamp.
 template <int MS, bool TWO>
 __device__ __forceinline__ void chain_linear_dx(const ChainOp& op, const float* src, int b0, int b1, int fr, int fk,
                                                 f32x4 (&acc)[2]) {
-    const float* w0 = op.W + (size_t)fk * op.ldw + min(b0 * 16 + fr, op.N - 1);
-    const float* w1 = op.W + (size_t)fk * op.ldw + min(b1 * 16 + fr, op.N - 1);
+    const int ldw = op.ldw, N = op.N, K = op.K;
+    const int ks = (K + 3) >> 2;
+    const uint32_t o0 = (uint32_t)(fk * ldw + min(b0 * 16 + fr, N - 1)) * 4u;
+    const uint32_t o1 = (uint32_t)(fk * ldw + min(b1 * 16 + fr, N - 1)) * 4u;
     const float* a = src + fr * kCL + fk;
-    const int ks = (op.K + 3) >> 2;
     float y0[MS], y1[TWO ? MS : 1];
 #pragma unroll
     for (int j = 0; j < MS; ++j) {
-        const int kr = min(min(j, ks - 1) * 4 + fk, op.K - 1) - fk;   // clamped weight row; A is zero past K
-        y0[j] = w0[(size_t)kr * op.ldw];
-        if (TWO) y1[j] = w1[(size_t)kr * op.ldw];
+        const char* base = reinterpret_cast<const char*>(op.W + (size_t)(min(j, ks - 1) * 4) * ldw);   // uniform
+        y0[j] = *reinterpret_cast<const float*>(base + o0);
+        if (TWO) y1[j] = *reinterpret_cast<const float*>(base + o1);
     }
 #pragma unroll
     for (int j = 0; j < MS; ++j) {
         if (j < ks) {
-            const float xa = (j * 4 + fk < op.K) ? a[j * 4] : 0.f;
+            const float xa = (j * 4 + fk < K) ? a[j * 4] : 0.f;
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
             if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
         }
