@@ -1110,6 +1110,13 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.slabs = m->slabs.p; fa.slab_stride = (size_t)m->R * m->ldh; fa.ld_slab = m->ldh;
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
         { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
+        static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile
+        static unsigned long long* ts_dev = nullptr;
+        fa.ts = nullptr;
+        if (want_ts) {
+            if (!ts_dev && hipMalloc(&ts_dev, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
+            fa.ts = ts_dev;
+        }
         const int grid = std::min(ntiles, m->n_cu);
         {
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
@@ -1120,6 +1127,18 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             }
         }
         LAUNCHCHK("dec_fused");
+        if (want_ts) {
+            unsigned long long t[16];
+            hipStreamSynchronize(s);
+            hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[dec_fused tile 5] S0=%.2f GEMM1+BCE0=%.2f entries=%.2f GEMM2+GEMM3=%.2f S5=%.2f | tile=%.2f us, %.0f shader clocks -> %.2f GHz\n",
+                    (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
+                    (t[6] - t[4]) * 0.01, (t[6] - t[0]) * 0.01, (double)(t[9] - t[8]),
+                    (double)(t[9] - t[8]) / ((t[6] - t[0]) * 10.0));
+            fprintf(stderr, "[dec_fused wg 0] prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
+                    (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
+                    (t[12] - t[7]) * 0.01);
+        }
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, grid, m->fix_partials, 0,
                            1.0f / ((float)B * (float)N), m->losses, 0);
         // 256+ slabs -> 16 partial slabs (stored behind the per-workgroup ones) -> sum + act'/dropout

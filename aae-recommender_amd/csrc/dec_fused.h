@@ -1,22 +1,32 @@
 // Fused decoder output layer for reference-sized batches (B <= ~104 at h = 200):
 //
 //   per tile of 32 items, one persistent 1024-thread workgroup (16 waves, 4 per SIMD) per CU:
+//     S0     V3a tile (prefetched registers) -> LDS; request tile t+1's V3a and CSR entries
 //     GEMM1  logits[B x 32]   = dh2[B x (h+1)] * V3a[32 x (h+1)]^T          (dec.lin3, aae.py:176)
-//     BCE    G = dL/dlogits, loss                                            (aae.py:177, 693-695)
-//     GEMM2  dV3a[32 x (h+1)] = G^T * dh2            -> dec_optim (Adam) on this V3a tile, in place
+//            epilogue: BCE of every cell against a zero target -> G = dL/dlogits, loss (aae.py:177, 693-695)
+//     S2     the tile's CSR entries (non-zero targets) replace their cell's G and loss term
+//     GEMM2  dV3a[32 x (h+1)] = G^T * dh2
 //     GEMM3  dA2[B x (h+1)]  += G * V3a[32 x (h+1)]   (accumulated in registers across the tiles
 //                                                      of the workgroup, one slab per workgroup)
+//     S5     dec_optim (Adam) on this V3a tile, in place (or gradient export)
 //
 // The three GEMMs run on v_mfma_f32_16x16x4_f32 from LDS-resident operands: dh2 is loaded once
 // per workgroup (B x 210 floats), the V3a tile once per tile and serves GEMM1, GEMM3 and the
 // optimiser (p), so the layer's weights cross HBM exactly once per step: 4 B read + 8 B (m, v)
 // read + 12 B written per parameter = the 24 B/param floor of a fused Adam, and dL/dlogits
 // [B x N] never exists in HBM.  Next tile's V3a and this tile's m, v are in flight (registers)
-// while the matrix cores work.
+// while the matrix cores work; barriers order LDS only (lds_barrier) so they do not drain them.
+// All ds_read_b32 operand patterns are bank-conflict free: row-major reads by the 16 x 2 (row, k)
+// lanes of a half-wave rely on the strides (kSD, kSG == 2 mod 4, half odd), k-strided reads on
+// walking k in rows 8 apart (GEMM2) resp. on the V3a image keeping odd items 8 rows below their
+// even neighbour (GEMM3, v3_row()).
+//
+// Debug: AAE_DEC_SKIP (phase ablation mask) and AAE_DEC_TS (100 MHz phase timeline of workgroup 0).
 //
 // Non-zero BCE targets come as per-tile entry lists (items sorted into 32-item buckets by
 // tile_hist/scan/fill below, a counting sort over the batch's CSR entries).
 #pragma once
+#include <type_traits>
 #include "device_common.h"
 #include "gemm_f32.h"
 #include "kernels.h"
@@ -29,8 +39,15 @@ constexpr int kSD = 210;       // LDS row stride of dh2 / V3a images: == 2 (mod 
 constexpr int kSG = 34;        // LDS row stride of the G tile (same property for the b-major reads of GEMM3)
 constexpr int kSO = 212;       // LDS row stride of the dV3a tile (16-byte aligned rows for the float4 epilogue)
 constexpr int kMB = 7;         // 16-row blocks of the batch dimension (B <= 112)
+constexpr int kGR = 128;       // rows of the G tile in LDS: GEMM2 walks the batch in 32-row groups (rows >= B are zero)
 constexpr int kNT = 1024;      // threads per workgroup: 4 waves per SIMD hide the LDS-operand latency of the
 constexpr int kNW = kNT / 64;  // MFMA chains by wave switching (a wave's own chain is load -> wait -> MFMA)
+
+// LDS row of item n of the tile in the V3a image.  GEMM3 takes items (2t, 2t+1) for the two k of a
+// half-wave and reads one V3a row per k: the rows have to sit 8 (mod 16) apart for their 16 columns to
+// fall on disjoint banks at stride kSD, so odd items live 8 rows below their even neighbour.  GEMM1
+// reads 16 items = 16 distinct rows of one half of the image either way.
+__device__ __forceinline__ int v3_row(int n) { return ((n >> 1) & 7) + 16 * (n >> 4) + 8 * (n & 1); }
 
 struct TileEntries {           // CSR entries of the batch bucketed by item tile
     const int* start;          // [ntiles + 1]
@@ -50,31 +67,40 @@ struct DecFusedArgs {
     float* partials;                      // loss partial per workgroup
     const OptScalars* sc;
     int dbg_skip;                         // timing-only ablation mask (AAE_DEC_SKIP), 0 in production
+    unsigned long long* ts;               // debug (AAE_DEC_TS): 100 MHz phase timestamps of workgroup 0, tile 5; else NULL
 };
 
 // LDS bytes the kernel needs for (B, h)
 inline size_t dec_fused_lds_bytes(int B, int h) {
     (void)h;
-    return sizeof(float) * ((size_t)B * kSD + (size_t)kTI * kSD + (size_t)16 * kMB * kSG + (size_t)kTI * kSO + 64);
+    return sizeof(float) * ((size_t)B * kSD + (size_t)kTI * kSD + (size_t)kGR * kSG + (size_t)kTI * kSO + 64);
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. it would wait for the NEXT tile's V3a, this tile's m / v and the
+// previous tile's parameter stores at every phase boundary - exactly the traffic that is meant to
+// stay in flight behind the matrix cores.  Global data is never exchanged between waves inside this
+// kernel (each tile's rows are read and written by the same lanes), so LDS ordering is all it needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NB>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dhs = lds;                                  // [B][kSD]
     float* v3s = dhs + (size_t)a.B * kSD;              // [32][kSD]
-    float* gs = v3s + kTI * kSD;                       // [112][kSG]  logits, then dL/dlogits
-    float* os = gs + 16 * kMB * kSG;                   // [32][kSO]   dV3a tile
+    float* gs = v3s + kTI * kSD;                       // [128][kSG]  logits, then dL/dlogits
+    float* os = gs + kGR * kSG;                        // [32][kSO]   dV3a tile
     float* red = os + kTI * kSO;                       // [64]
+    float* raw = os;                                   // [16*kMB][kSG] raw logits of the tile, between GEMM1 and GEMM2
 
     const int tid = threadIdx.x, lane = tid & 63;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block ids below are scalars
     const int fr = lane & 15, fk = lane >> 4;
     const int B = a.B, K1 = a.h + 1, ldv = a.ldv;
     // k-steps rounded up to the unroll factor 4: the extra ones multiply zero padding (columns >= ldh
     // of both LDS images are zeroed once, G rows >= B are zero)
     const int ksteps1 = ((K1 + 3) / 4 + 3) & ~3;       // GEMM1: k over the h+1 hidden columns, <= (kSD-2)/4
-    const int ksteps2 = min(((B + 3) / 4 + 1) & ~1, 4 * kMB);   // GEMM2: k over docs (2 per loop trip), rows < 16*kMB
     const int nmb = (B + 15) >> 4;                      // 16-row blocks actually present (<= kMB)
     const int ntiles = (a.N + kTI - 1) / kTI;
     const int f4_per_row = ldv / 4;                    // ldv % 4 == 0
@@ -91,7 +117,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         *reinterpret_cast<float2*>(d) = make_float2(x.x, x.y);
         *reinterpret_cast<float2*>(d + 2) = make_float2(x.z, x.w);
     }
-    for (int i = tid; i < 16 * kMB * kSG; i += kNT) gs[i] = 0.f;
+    for (int i = tid; i < kGR * kSG; i += kNT) gs[i] = 0.f;
     for (int i = tid; i < (B + kTI) * (kSD - a.ldh); i += kNT) {      // pad columns of dhs and v3s (contiguous rows)
         const int r = i / (kSD - a.ldh), cidx = a.ldh + i % (kSD - a.ldh);
         dhs[r * kSD + cidx] = 0.f;
@@ -107,7 +133,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     // (vmcnt(0)) before the next one, which serialises the HBM round trips.
     const size_t last_f4 = ((size_t)a.N * ldv) / 4 - 1;
     auto load_span = [&](const float* base, int tile, float4* r) {
-        const size_t f0 = (size_t)tile * kTI * f4_per_row;
+        const size_t f0 = (size_t)((a.dbg_skip & 128) ? (int)blockIdx.x : tile) * kTI * f4_per_row;   // 128: L2-resident ablation
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const size_t f = f0 + (size_t)(tid + kNT * j);
@@ -117,34 +143,82 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         // hold finite values that are either never stored or multiplied by zero gradients
     };
 
+    // Software pipeline over the tiles of this workgroup.  Inside the loop no global load is consumed in
+    // the phase that issues it (hipcc would wait for it AND everything older with s_waitcnt vmcnt(0), and
+    // loads return in order - one such load exposes the whole prefetch):
+    //   V3a(t+1), the CSR entries of tile t+1 and the entry range of tile t+2 are requested in S0(t),
+    //   m/v(t) before GEMM2(t); parameter stores of S5(t) retire behind GEMM3(t).
     float4 vreg[NV], mreg[NV], sreg[NV];
     int tile = blockIdx.x;
-    if (tile < ntiles) load_span(a.V3a, tile, vreg);
+    const int stride = gridDim.x;
+    const int last_e = max(a.te.start[ntiles] - 1, 0);        // clamp for the unconditional entry loads
+    auto load_range = [&](int t, int& lo, int& hi) {
+        const int tc = min(t, ntiles - 1);
+        lo = a.te.start[tc]; hi = a.te.start[tc + 1];
+        if (t >= ntiles) hi = lo;
+    };
+    int ce0 = 0, ce1 = 0, ne0 = 0, ne1 = 0, fe0 = 0, fe1 = 0;  // entry ranges: current, next, the one after
+    int ent_b = 0, ent_n = 0; float ent_v = 0.f;               // this thread's entry of the NEXT tile
+    auto load_entry = [&](int lo) {
+        const int e = min(lo + tid, last_e);
+        ent_b = a.te.eb[e]; ent_n = a.te.en[e]; ent_v = a.te.ev[e];
+    };
+    if (tile < ntiles) {
+        load_span(a.V3a, tile, vreg);
+        load_range(tile, ne0, ne1);
+        load_range(tile + stride, fe0, fe1);
+        load_entry(ne0);
+    }
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    // tile-invariant addressing of this thread's NV float4 slots of a tile span (no division in the loop)
+    int s_rc[NV];                                       // row * 64 + float4 column (ldv <= 252)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+    }
+    auto slot_v3 = [&](int j) { return v3_row(s_rc[j] >> 6) * kSD + (s_rc[j] & 63) * 4; };
+    auto slot_os = [&](int j) { return (s_rc[j] >> 6) * kSO + (s_rc[j] & 63) * 4; };
+    int iter = 0;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[11] = wall_clock64();
+    auto stamp = [&](int k) { if (a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
+    for (; tile < ntiles; tile += stride, ++iter) {
         const int i0 = tile * kTI;
-        __syncthreads();                               // previous tile's readers of v3s / os are done
-        // ---- S0: V3a tile registers -> LDS; start this tile's m, v and the next tile's V3a
+        // A zero the compiler cannot see through: the LDS operand pointers of the three GEMMs are built from
+        // it, so they are recomputed per tile (~30 VALU) instead of being hoisted out of the tile loop and held
+        // in ~20 VGPRs across every phase - at 128 VGPRs (16 waves/CU) that hoisting spilled to scratch, and a
+        // scratch reload waits for every older global load in flight.
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int frz = fr + oz;
+        stamp(0);
+        lds_barrier();                                 // previous tile's readers of v3s / gs are done
+        // ---- S0: V3a tile registers -> LDS; rotate the pipeline registers and request the next stage
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int f = tid + kNT * j;
-            if (f < tile_f4) {
-                float* d = v3s + (f / f4_per_row) * kSD + (f % f4_per_row) * 4;
+            if (tid + kNT * j < tile_f4) {
+                float* d = v3s + slot_v3(j);
                 *reinterpret_cast<float2*>(d) = make_float2(vreg[j].x, vreg[j].y);
                 *reinterpret_cast<float2*>(d + 2) = make_float2(vreg[j].z, vreg[j].w);
             }
         }
-        if (tile + (int)gridDim.x < ntiles) load_span(a.V3a, tile + gridDim.x, vreg);
-        __syncthreads();
+        ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
+        const int my_p = ent_b * kSG + ent_n; const float my_v = ent_v;
+        load_span(a.V3a, min(tile + stride, ntiles - 1), vreg);
+        load_range(tile + 2 * stride, fe0, fe1);
+        load_entry(ne0);
+        lds_barrier();
+        stamp(1);
 
-        if (!(a.dbg_skip & 1))
+        if (!(a.dbg_skip & 1) && wave < 2 * nmb)
         // ---- S1: GEMM1 logits[b][n] = sum_k dh2[b][k] * V3a[n][k]; blocks (mb, nb2) id = mb*2 + nb2,
-        // one block per wave (a wave past the last block re-does it and does not store): branch-free
+        // one block per wave; `wave` is a scalar, so waves past the last block skip with a scalar branch and
+        // leave the matrix pipe of their SIMD to the others
         {
             f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int id0 = min(wave, 2 * nmb - 1);
-            const float* pa0 = dhs + min((id0 >> 1) * 16 + fr, B - 1) * kSD + fk;
-            const float* pb0 = v3s + ((id0 & 1) * 16 + fr) * kSD + fk;
+            const int id0 = wave;
+            const float* pa0 = dhs + min((id0 >> 1) * 16 + frz, B - 1) * kSD + fk;
+            const float* pb0 = v3s + v3_row((id0 & 1) * 16 + frz) * kSD + fk;
             // groups of 4 k-steps: all 8 LDS reads of a group are issued before its 4 MFMAs; two
             // accumulators (even / odd k-steps) break the dependent-accumulator latency
             f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -158,138 +232,184 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3], y[3], c1, 0, 0, 0);
             }
             c0 += c1;
-            // raw logits -> gs[b][n]   (C map: row = 4*(lane>>4) + r, col = lane & 15)
-            if (wave < 2 * nmb) {
+            // Epilogue = BCE with a zero target, the case of all but a handful of cells: dL/dlogit -> gs[b][n]
+            // (C map: row = 4*(lane>>4) + r, col = lane & 15).  The raw logit also goes to the (still unused)
+            // dV3a buffer for the cells that do have a target.
+            {
                 const int rb = (id0 >> 1) * 16 + fk * 4, cb = (id0 & 1) * 16 + fr;
+                const bool item_ok = i0 + cb < a.N && !(a.dbg_skip & 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (rb + r < B) gs[(rb + r) * kSG + cb] = c0[r];
+                    if (rb + r < B) {
+                        float g = 0.f, l = 0.f;
+                        if (item_ok) bce_elem_t0(c0[r], a.gscale, g, l);
+                        gs[(rb + r) * kSG + cb] = g;
+                        raw[(rb + r) * kSG + cb] = c0[r];
+                        loss += l;
+                    }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        stamp(2);
 
-        // ---- S2: BCE.  Entries with a non-zero target first (they need the raw logit); their
-        // corrected gradient waits in the (still unused) dV3a tile buffer ...
-        const int e0 = a.te.start[tile], e1 = (a.dbg_skip & 2) ? e0 : a.te.start[tile + 1];
-        int* fix_pos = reinterpret_cast<int*>(os);
-        float* fix_g = os + (kTI * kSO) / 2;
-        for (int e = e0 + tid; e < e1; e += kNT) {
-            const int p = a.te.eb[e] * kSG + a.te.en[e];
-            float g0, l0, g1, l1;
-            bce_elem_t0(gs[p], a.gscale, g0, l0);
-            bce_elem(gs[p], a.te.ev[e], a.gscale, g1, l1);
-            loss += l1 - l0;
-            fix_pos[e - e0] = p; fix_g[e - e0] = g1;
+        // ---- S2: the CSR entries of the tile (non-zero targets) replace their cell's gradient and loss term
+        {
+            const int e0 = ce0, e1 = (a.dbg_skip & 2) ? e0 : ce1;
+            if (tid < e1 - e0) {                        // the prefetched entry of this thread
+                float g0, l0, g1, l1;
+                bce_elem_t0(raw[my_p], a.gscale, g0, l0);
+                bce_elem(raw[my_p], my_v, a.gscale, g1, l1);
+                loss += l1 - l0;
+                gs[my_p] = g1;
+            }
+            for (int e = e0 + kNT + tid; e < e1; e += kNT) { // tiles with more than 1024 entries (tiny vocabularies)
+                const int p = a.te.eb[e] * kSG + a.te.en[e];
+                float g0, l0, g1, l1;
+                bce_elem_t0(raw[p], a.gscale, g0, l0);
+                bce_elem(raw[p], a.te.ev[e], a.gscale, g1, l1);
+                loss += l1 - l0;
+                gs[p] = g1;
+            }
         }
-        __syncthreads();
-        // ... then every element with the zero-target form, in place
-        for (int i = tid; i < ((a.dbg_skip & 2) ? 0 : B * kTI); i += kNT) {
-            const int b = i >> 5, n = i & 31;
-            float g = 0.f, l = 0.f;
-            if (i0 + n < a.N) bce_elem_t0(gs[b * kSG + n], a.gscale, g, l);
-            gs[b * kSG + n] = g;
-            loss += l;
-        }
-        __syncthreads();
-        for (int e = tid; e < e1 - e0; e += kNT) gs[fix_pos[e]] = fix_g[e];
-        __syncthreads();
+        lds_barrier();
 
+        stamp(3);
         // the optimiser moments of this tile travel while GEMM2 and GEMM3 run
         if (do_adam && !sc.is_sgd) { load_span(a.M, tile, mreg); load_span(a.V, tile, sreg); }
-        if (!(a.dbg_skip & 4))
-        // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib; every wave
-        // runs Q2 blocks (ids w + 8q, clamped), branch-free
-        {
-            constexpr int Q2 = (2 * NB + kNW - 1) / kNW;
-            f32x4 acc2[Q2];
-            const float* pg[Q2]; const float* pd[Q2];
+        // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib, a wave owns the ids
+        // wave + 16q: they share the item half ib (one G read serves them all) and differ in the column block.
+        // k runs over the batch rows in groups of 32: k-step (g, r) multiplies rows 32g + r + 8*fk.  Rows 8
+        // apart are 16 banks apart in both operands (8 * kSG = 16, 8 * kSD = 16 mod 32), so the two k of a
+        // half-wave never collide; the order of the rows inside the sum is free.
+        auto gemm2 = [&](auto NQ) {
+            constexpr int nq = decltype(NQ)::value;
+            constexpr int NA = nq == 1 ? 2 : 1;                       // one block: even / odd k-steps alternate accumulators
+            f32x4 acc2[nq][NA];
+            const float* pd[nq];
+            const float* pg = gs + 8 * fk * kSG + (wave & 1) * 16 + frz;      // G[b = 32g + r + 8fk][item]
 #pragma unroll
-            for (int q = 0; q < Q2; ++q) {
-                acc2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int id = min(wave + kNW * q, 2 * NB - 1);
-                pg[q] = gs + fk * kSG + (id & 1) * 16 + fr;          // G[b = 4ks + fk][item]
-                pd[q] = dhs + (id >> 1) * 16 + fr;                   // dh2[b][col], row added below (clamped)
+            for (int q = 0; q < nq; ++q) {
+                for (int u = 0; u < NA; ++u) acc2[q][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                pd[q] = dhs + ((wave + kNW * q) >> 1) * 16 + frz;      // dh2[b][col]
             }
-            for (int ks = 0; ks < ksteps2; ks += 2) {        // ksteps2 is even
-                float x[2][Q2], y[2][Q2];
+            const int nfull = B >> 5;                                 // groups whose 32 rows all exist: no row clamp,
+            for (int g = 0; g < nfull; ++g) {                         // every LDS address = base + constant
+                const float* xg = pg + 32 * g * kSG;
+                const int yoff = (32 * g + 8 * fk) * kSD;
+#pragma unroll 1
+                for (int r = 0; r < 8; r += 4) {
+                    float x[4], y[4][nq];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int rowc = min((ks + j) * 4 + fk, B - 1) * kSD;
+                    for (int j = 0; j < 4; ++j) {
+                        x[j] = xg[(r + j) * kSG];
 #pragma unroll
-                    for (int q = 0; q < Q2; ++q) { x[j][q] = pg[q][(ks + j) * 4 * kSG]; y[j][q] = pd[q][rowc]; }
+                        for (int q = 0; q < nq; ++q) y[j][q] = pd[q][yoff + (r + j) * kSD];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int q = 0; q < nq; ++q)
+                            acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
                 }
+            }
+            {   // the partial last group: rows past B - 1 are clamped (their G rows are zero)
+                const int g = nfull;
+                const int nr = min(8, (B - 32 * g + 3) & ~3);          // k-steps (4 per trip), <= 0: none
+                for (int r = 0; r < nr; r += 4) {
+                    float x[4], y[4][nq];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = 32 * g + r + j;
+                        const int rowc = min(row + 8 * fk, B - 1) * kSD;
+                        x[j] = pg[row * kSG];
 #pragma unroll
-                    for (int q = 0; q < Q2; ++q)
-                        acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][q], y[j][q], acc2[q], 0, 0, 0);
+                        for (int q = 0; q < nq; ++q) y[j][q] = pd[q][rowc];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int q = 0; q < nq; ++q)
+                            acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int q = 0; q < Q2; ++q) {
+            for (int q = 0; q < nq; ++q) {
                 const int id = wave + kNW * q;
-                if (id < 2 * NB) {
-                    const int rb = (id & 1) * 16 + fk * 4, cb = (id >> 1) * 16 + fr;
+                const int rb = (id & 1) * 16 + fk * 4, cb = (id >> 1) * 16 + fr;
+                const f32x4 c = NA == 2 ? acc2[q][0] + acc2[q][NA - 1] : acc2[q][0];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) os[(rb + r) * kSO + cb] = acc2[q][r];
-                }
+                for (int r = 0; r < 4; ++r) os[(rb + r) * kSO + cb] = c[r];
             }
+        };
+        if (!(a.dbg_skip & 4) && wave < 2 * NB) {
+            constexpr int Q2 = (2 * NB + kNW - 1) / kNW;
+            static_assert(kNW % 2 == 0, "a wave's blocks must share the item half");
+            if (wave + kNW * (Q2 - 1) < 2 * NB) gemm2(std::integral_constant<int, Q2>{});     // scalar branch
+            else gemm2(std::integral_constant<int, (Q2 > 1 ? Q2 - 1 : 1)>{});
         }
 
-        if (!(a.dbg_skip & 8))
-        // ---- S4: GEMM3 dA2[b][c] += sum_n G[b][n] * V3a[n][c]; blocks id = mb*NB + nb, Q3 per wave
-        {
+        // ---- S4: GEMM3 dA2[b][c] += sum_n G[b][n] * V3a[n][c]; blocks id = mb*NB + nb, ids wave + 16q.  It runs
+        // after S5 so that the parameter stores retire behind these MFMAs, not at the next tile's first wait.
+        if (!(a.dbg_skip & 8)) {
             constexpr int Q3 = (kMB * NB + kNW - 1) / kNW;
+            // scalar: the wave's last block exists, or is a duplicate that only keeps the code branch-free (small
+            // batches have several duplicates: they still run, and are never stored)
+            const bool full3 = wave + kNW * (Q3 - 1) < nmb * NB || nmb < kMB;
             const float* pg[Q3]; const float* pv[Q3];
 #pragma unroll
             for (int q = 0; q < Q3; ++q) {
                 const int id = min(wave + kNW * q, nmb * NB - 1);
                 const int mb = id / NB, nb = id - mb * NB;
-                pg[q] = gs + (mb * 16 + fr) * kSG + fk;             // G[b][n = 4ks + fk]
-                pv[q] = v3s + fk * kSD + nb * 16 + fr;               // V3a[n = 4ks + fk][col]
+                pg[q] = gs + (mb * 16 + frz) * kSG + fk;            // G[b][n = 4ks + fk]
+                pv[q] = v3s + ((fk >> 1) + 8 * (fk & 1)) * kSD + nb * 16 + frz;  // V3a[n = 4ks + fk][col] at v3_row(n)
             }
 #pragma unroll
             for (int ks = 0; ks < kTI / 4; ++ks) {
                 float x[Q3], y[Q3];
 #pragma unroll
-                for (int q = 0; q < Q3; ++q) { x[q] = pg[q][ks * 4]; y[q] = pv[q][ks * 4 * kSD]; }
+                for (int q = 0; q < Q3; ++q) { x[q] = pg[q][ks * 4]; y[q] = pv[q][(((2 * ks) & 7) + 16 * ((2 * ks) >> 3)) * kSD]; }
 #pragma unroll
-                for (int q = 0; q < Q3; ++q) acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[q], acc3[q], 0, 0, 0);
+                for (int q = 0; q < Q3; ++q)
+                    if (q < Q3 - 1 || full3)
+                        acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[q], acc3[q], 0, 0, 0);
             }
         }
-        __syncthreads();                               // os complete
+        lds_barrier();                               // os complete
+        stamp(4);
 
         // ---- S5: optimiser on the tile (or gradient export), whole rows, float4 per lane
         if (!(a.dbg_skip & 16))
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int f = tid + kNT * j;
-            if (f < tile_f4) {
-                const int row = f / f4_per_row, c4 = f % f4_per_row;
-                if (i0 + row < a.N) {
-                    const float4 g = *reinterpret_cast<const float4*>(os + row * kSO + c4 * 4);
-                    const size_t off = ((size_t)i0 + row) * ldv + (size_t)c4 * 4;
-                    if (!do_adam) {
-                        *reinterpret_cast<float4*>(a.gradV3 + off) = g;
-                    } else {
-                        const float* ps = v3s + row * kSD + c4 * 4;
-                        float4 p = make_float4(ps[0], ps[1], ps[2], ps[3]);
-                        float4 mm = mreg[j], vv = sreg[j];
-                        if (!(a.dbg_skip & 64)) {
-                        adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
-                        adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
-                        }
-                        if (a.dbg_skip & 32) { if (p.x + mm.x + vv.x == 123.f) a.partials[1] = 1.f; continue; }
-                        *reinterpret_cast<float4*>(a.V3a + off) = p;
-                        if (!sc.is_sgd) {
-                            *reinterpret_cast<float4*>(a.M + off) = mm;
-                            *reinterpret_cast<float4*>(a.V + off) = vv;
-                        }
+            if (tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < a.N) {
+                const float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
+                // the tile span is contiguous: element offset = i0 * ldv + 4 * slot
+                const size_t off = (size_t)((a.dbg_skip & 128) ? (int)blockIdx.x * kTI : i0) * ldv + (size_t)(tid + kNT * j) * 4;
+                if (!do_adam) {
+                    *reinterpret_cast<float4*>(a.gradV3 + off) = g;
+                } else {
+                    const float* ps = v3s + slot_v3(j);
+                    float4 p = make_float4(ps[0], ps[1], ps[2], ps[3]);
+                    float4 mm = mreg[j], vv = sreg[j];
+                    if (!(a.dbg_skip & 64)) {
+                    adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
+                    adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
+                    }
+                    if (a.dbg_skip & 32) { if (p.x + mm.x + vv.x == 123.f) a.partials[1] = 1.f; continue; }
+                    *reinterpret_cast<float4*>(a.V3a + off) = p;
+                    if (!sc.is_sgd) {
+                        *reinterpret_cast<float4*>(a.M + off) = mm;
+                        *reinterpret_cast<float4*>(a.V + off) = vv;
                     }
                 }
             }
         }
+
+        stamp(5);
+        stamp(6);
     }
 
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
     // ---- dA2 partial of this workgroup -> its slab; loss partial
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll
@@ -311,6 +431,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         float s = 0.f;
         for (int w = 0; w < kNW; ++w) s += red[w];
         a.partials[blockIdx.x] = s;
+        if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
     }
 }
 
