@@ -803,7 +803,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) m->fused_ok = false;
+            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 2048);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) m->fused_ok = false;
         }
     }
     m->grad_scale = 1.f;
@@ -1094,12 +1095,18 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
         const int ntiles = (N + kTI - 1) / kTI;
-        const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
-        hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
-        hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
-        hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten,
-                           m->tev);
+        if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
+            const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+            hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
+                               m->tev);
+        } else {
+            const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
+            hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
+            hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
+            hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten,
+                               m->tev);
+        }
         LAUNCHCHK("tile buckets");
         DecFusedArgs fa;
         fa.dh2 = m->dh2.p; fa.ldh = m->ldh;
