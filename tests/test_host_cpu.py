@@ -216,3 +216,17 @@ def test_aae_constructor_surface_and_errors():
     with pytest.raises(RuntimeError):                # duplicate items -> 2.0 -> the reference's BCE error
         from aaerec.aae import _validate_targets
         _validate_targets(sp.csr_matrix(np.array([[2.0, 0.0]])))
+
+
+def test_torch_custom_ops_are_registered_and_have_no_cpu_path():
+    """torch.ops.aaerec.* (aaerec/ops.py) exist after import and refuse host tensors: the product has no CPU
+    fallback (the dispatcher has no CPU kernel for them)."""
+    import torch
+    from aaerec import ops  # noqa: F401  (registers the library)
+    for name in ("step", "encode", "predict", "predict_topk"):
+        assert hasattr(torch.ops.aaerec, name)
+    ip = torch.zeros(2, dtype=torch.int64)
+    idx = torch.zeros(1, dtype=torch.int32)
+    val = torch.ones(1)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.aaerec.encode(1, ip, idx, val, 0, 1, 1)

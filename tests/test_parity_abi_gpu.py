@@ -255,3 +255,36 @@ def test_export_mode_through_parallel_wrapper_matches_reference(name, shard):
         np.testing.assert_allclose(m.losses(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
         if fx.has_state(s):
             check_state(fx, m, s, name)
+
+
+@pytest.mark.parametrize("name", ["step_nodrop_gauss", "step_masks"])
+def test_torch_custom_ops_replay_fixture(name):
+    """The same replay through torch.ops.aaerec.* (aaerec/ops.py), the torch-facing surface over the C ABI."""
+    from aaerec import ops
+    fx = Fixture(name)
+    m = make_model(fx)
+    mid = ops.register_model(m)
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        masks = [None if k is None else torch.as_tensor(np.ascontiguousarray(k, dtype=np.uint8), device=m.device)
+                 for k in (fx.masks(s) or [])]
+        z_real = torch.as_tensor(fx.z[f"step{s}.z_real"], device=m.device)
+        losses = torch.ops.aaerec.step(mid, csr.indptr, csr.indices, csr.values, None, 0, B, csr.nnz_per_row_max,
+                                       None, masks, z_real)
+        np.testing.assert_allclose(losses.cpu().numpy(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
+        if fx.has_state(s):
+            check_state(fx, m, s, name)
+    pcsr = csr_of(fx, m, 0, prefix="predict")
+    n = pcsr.shape[0]
+    out = torch.ops.aaerec.predict(mid, pcsr.indptr, pcsr.indices, pcsr.values, 0, n, pcsr.nnz_per_row_max, None)
+    np.testing.assert_allclose(out.cpu().numpy(), fx.z["predict.out"], atol=TOL_RECON)
+    ids, val = torch.ops.aaerec.predict_topk(mid, pcsr.indptr, pcsr.indices, pcsr.values, 0, n, pcsr.nnz_per_row_max,
+                                             None, 5, True)
+    ids2, val2 = m.predict_topk(pcsr, 0, n, 5)
+    assert torch.equal(ids, ids2) and torch.equal(val, val2)
+    z = torch.ops.aaerec.encode(mid, pcsr.indptr, pcsr.indices, pcsr.values, 0, n, pcsr.nnz_per_row_max)
+    assert z.shape == (n, fx.cfg["c"])
+    del m
+    with pytest.raises(RuntimeError):
+        torch.ops.aaerec.encode(mid, pcsr.indptr, pcsr.indices, pcsr.values, 0, n, pcsr.nnz_per_row_max)
