@@ -72,6 +72,8 @@ _PROTOS = {
     "aae_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
     "aae_ae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
     "aae_ae_decode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
+    "aae_decoder_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int64, C.POINTER(AaeRngInject),
+                                   C.c_void_p, C.c_void_p]),
     "aae_ae_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_disc_gen": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
     "aae_disc_step": (C.c_int, [C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
@@ -391,6 +393,21 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_ae_decode_backward(self.handle, _ptr(zc), zc.shape[1], None, _ptr(dzc), self._stream()))
         return dzc
+
+    def decoder_step(self, csr, row_start, n_rows, zin, rows=None, masks=None, want_grad=True):
+        """DecodingRecommender.partial_fit (aae.py:489-517): decoder forward on zin [n_rows, n_code + cond_inc],
+        BCE against the CSR rows, decoder backward + optimiser step.  masks: (dec.drop1, dec.drop2) keep-masks
+        in rng_mode='inject'.  Returns dL/dzin (device) or None."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        inj = self._inject([None, None, masks[0], masks[1]] if masks is not None else None, None)
+        zin = zin.detach().to(self.device, torch.float32).contiguous()
+        assert zin.shape == (n_rows, self.c + self.cond_inc), "decoder input width mismatch"
+        dz = torch.empty_like(zin) if want_grad else None
+        self._keep = getattr(self, "_keep", []) + [zin]
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_decoder_step(self.handle, C.byref(b), _ptr(zin), zin.shape[1],
+                                             C.byref(inj) if inj else None, _ptr(dz), self._stream()))
+        return dz
 
     def ae_encoder_backward(self, dz):
         dz = dz.detach().to(self.device, torch.float32).contiguous()

@@ -406,6 +406,156 @@ def _take(c, idx):
     return c[idx]
 
 
+class DecodingRecommender(Recommender):
+    """ Only the decoder part of the AAE, basically 2-MLP (reference aae.py:461-584): the encoded conditions
+    (the first one as is, the others imposed on it) -> Decoder -> BCE against the item rows.  The decoder runs
+    on the HIP kernels (aae_decoder_step / aae_decode); the condition plugins stay torch modules and receive
+    dL/d(inputs) through autograd, then take their own optimiser step. """
+
+    def __init__(self, conditions, n_epochs=100, batch_size=100, optimizer='adam', n_hidden=100, lr=0.001,
+                 verbose=True, device=None, rng_mode="device", seed=None, **mlp_params):
+        super().__init__()
+        self.n_epochs = n_epochs
+        self.batch_size = batch_size
+        self.lr = lr
+        self.optimizer = optimizer.lower()
+        self.model_params = mlp_params
+        self.verbose = verbose
+        self.n_hidden = n_hidden
+        assert len(conditions), "Minimum 1 condition is necessary for MLP"
+        self.conditions = conditions
+        unknown = set(mlp_params) - {"dropout", "activation"}
+        if unknown:        # the reference forwards **mlp_params to Decoder(...), which accepts exactly these
+            raise TypeError("__init__() got an unexpected keyword argument '{}'".format(sorted(unknown)[0]))
+        self.dropout = tuple(mlp_params.get("dropout", (.2, .2)))
+        self.activation = mlp_params.get("activation", "ReLU")
+        if rng_mode not in ("device", "reference"):
+            raise ValueError("rng_mode must be 'device' or 'reference'")
+        self.device, self.rng_mode, self.seed = device, rng_mode, seed
+        self.hip = None
+        self.mlp, self.mlp_optim, self.vect = None, None, None
+        self.last_loss = None
+
+    def __str__(self):
+        desc = "MLP-2 Decoder with " + str(self.n_hidden) + " hidden units"
+        desc += " training for " + str(self.n_epochs)
+        desc += " optimized by " + self.optimizer
+        desc += " with learning rate " + str(self.lr)
+        desc += " with %d conditions: %s " % (len(self.conditions), ', '.join(self.conditions.keys()))
+        desc += "\n MLP Params: " + str(self.model_params)
+        return desc
+
+    # ---- internals ---------------------------------------------------------------------------
+    def _build(self, n_items, max_row_nnz=None):
+        n_in = int(self.conditions.size_increment())
+        seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
+            if self.rng_mode == "device" else 0
+        self.hip = _hip.HipAAE(
+            n_items, self.n_hidden, n_in, cond_inc=0, max_batch=self.batch_size,
+            max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
+            activation=self.activation, optimizer=self.optimizer, dropout=self.dropout, gen_lr=self.lr,
+            reg_lr=self.lr, rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
+            device=self.device)
+        # Decoder(size_increment, n_hidden, n_items): nn.Linear default init in construction order (aae.py:521-524)
+        params = {}
+        for layer, (i, o) in enumerate(((n_in, self.n_hidden), (self.n_hidden, self.n_hidden),
+                                        (self.n_hidden, n_items)), start=1):
+            lin = torch.nn.Linear(i, o)
+            params["dec.lin{}.weight".format(layer)] = lin.weight.detach().numpy()
+            params["dec.lin{}.bias".format(layer)] = lin.bias.detach().numpy()
+        self.hip.load_params(params)
+        self.mlp, self.mlp_optim = _NetView(self, "dec"), _OptimView(self, "dec")
+
+    def _inputs(self, condition_data):
+        """ Encode ALL condition data with the respective condition, start with the first encoded condition
+        and impose all remaining ones (aae.py:494-502, 570-576) """
+        encoded = self.conditions.encode(condition_data)
+        inputs = encoded[0]
+        for cond, cdata in zip(list(self.conditions.values())[1:], encoded[1:]):
+            inputs = cond.impose(inputs, cdata)
+        return inputs
+
+    def _masks(self, B):
+        if self.rng_mode != "reference":
+            return None
+        return [None if p == 0 else torch.empty(B, self.n_hidden).bernoulli_(1 - p).to(torch.uint8)
+                for p in self.dropout]
+
+    def _step(self, csr, n_rows, rows, condition_data):
+        self.conditions.train()
+        inputs = self._inputs(condition_data)
+        masks = self._masks(n_rows)
+        dz = self.hip.decoder_step(csr, 0, n_rows, inputs, rows=rows, masks=masks, want_grad=inputs.requires_grad)
+        self.conditions.zero_grad()
+        if inputs.requires_grad:
+            inputs.backward(dz.to(inputs.device))
+        self.conditions.step()
+
+    # ---- public API ----------------------------------------------------------------------------
+    def partial_fit(self, condition_data, y, step=None):
+        ys = sp.csr_matrix(y.numpy() if torch.is_tensor(y) else y) if not sp.issparse(y) else y.tocsr()
+        if self.hip is None:
+            self._build(ys.shape[1])
+        _validate_targets(ys)
+        if ys.shape[0] > self.hip.max_batch:
+            raise ValueError("batch of {} rows exceeds batch_size={}".format(ys.shape[0], self.hip.max_batch))
+        csr = _hip.DeviceCSR(ys, self.hip.device)
+        self._step(csr, ys.shape[0], None, condition_data)
+        if self.verbose:
+            self.last_loss = self.hip.losses()[0]
+            print("\rLoss: {}".format(self.last_loss), flush=True, end='')
+        return self
+
+    def fit(self, condition_data, Y):
+        Y = Y.tocsr() if sp.issparse(Y) else sp.csr_matrix(Y)
+        _validate_targets(Y)
+        row_nnz = Y.getnnz(1)
+        self._build(Y.shape[1], max_row_nnz=max(int(row_nnz.max()) if Y.shape[0] else 1, 4096))
+        csr = _hip.DeviceCSR(Y, self.hip.device)       # the targets stay resident in HBM
+        n_docs = Y.shape[0]
+        step = 0
+        for __epoch in range(self.n_epochs):
+            # sklearn.utils.shuffle(Y, *condition_data): one permutation for all arrays (aae.py:530)
+            perm = np.arange(n_docs)
+            np.random.shuffle(perm)
+            perm_dev = torch.as_tensor(perm.astype(np.int32), device=self.hip.device)
+            for start in range(0, n_docs, self.batch_size):
+                idx = perm[start:start + self.batch_size]
+                c_batch = [_take(c, idx) for c in condition_data]
+                self._step(csr, len(idx), perm_dev[start:start + len(idx)], c_batch)
+                if self.verbose:
+                    self.last_loss = self.hip.losses()[0]
+                    print("\rLoss: {}".format(self.last_loss), flush=True, end='')
+                step += 1
+            if self.verbose:
+                print()
+        self.last_loss = self.hip.losses()[0]
+        return self
+
+    def train(self, training_set):
+        # Fit function from condition to X
+        Y = training_set.tocsr()
+        condition_data_raw = training_set.get_attributes(self.conditions.keys())
+        condition_data = self.conditions.fit_transform(condition_data_raw)
+        self.fit(condition_data, Y)
+
+    def _predict_conditions(self, condition_data, n_users):
+        self.conditions.eval()
+        batch_results = []
+        with torch.no_grad():
+            for start in range(0, n_users, self.batch_size):
+                c_batch = [_take(c, slice(start, start + self.batch_size)) for c in condition_data]
+                res = self.hip.decode(self._inputs(c_batch))
+                batch_results.append(res.cpu().numpy())
+        return np.vstack(batch_results)
+
+    def predict(self, test_set):
+        n_users = test_set.size(0)
+        condition_data_raw = test_set.get_attributes(self.conditions.keys())
+        condition_data = self.conditions.transform(condition_data_raw)
+        return self._predict_conditions(condition_data, n_users)
+
+
 def _validate_targets(X):
     """The reference's F.binary_cross_entropy rejects targets outside [0,1] (duplicate items in a
     bag give 2.0 after tocsr()); keep that error behaviour."""

@@ -1234,6 +1234,24 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     return AAE_OK;
 }
 
+int aae_decoder_step(aae_handle m, const aae_batch* batch, const float* zin_dev, int64_t zin_ld,
+                     const aae_rng_inject* inj, float* dzin_out, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (!zin_dev) return fail(AAE_EINVAL, "zin_dev is NULL");
+    if (zin_ld < m->cp) return fail(AAE_EINVAL, "zin_ld < n_code + cond_inc");
+    TRY(set_batch(m, batch));
+    remember_inject(m, inj, true);
+    hipStream_t s = S(stream);
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                       m->stamp, m->ucount, m->losses);
+    LAUNCHCHK("advance_step");
+    m->dec_hidden_done = false; m->enc_bwd_done = false; m->fuse_enc_bwd = false;
+    m->phase = 1;
+    TRY(aae_ae_decode_backward(m, zin_dev, zin_ld, nullptr, dzin_out, stream));
+    m->phase = 0;
+    return AAE_OK;
+}
+
 int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->phase != 2) return fail(AAE_ESTATE, "aae_ae_encoder_backward without aae_ae_decode_backward");

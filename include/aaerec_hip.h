@@ -192,6 +192,15 @@ int aae_ae_decode_backward(aae_handle h, const float* zc_dev, int64_t zc_ld,
                            const aae_rng_inject* inject, float* dzc_out_dev, void* stream);
 int aae_ae_encoder_backward(aae_handle h, const float* dz_dev, int64_t dz_ld, void* stream);
 int aae_disc_gen(aae_handle h, const aae_rng_inject* inject, void* stream);
+/* DecodingRecommender.partial_fit, aae.py:489-517 ("only the decoder part of the AAE, basically
+ * 2-MLP"): the decoder maps an input block computed by the host's condition plugins to the items.
+ *   zin_dev [batch->n_rows][n_code + cond_inc]  the encoded / imposed conditions (aae.py:494-502)
+ *   batch                                        the targets y as CSR rows (aae.py:506-507)
+ * Decoder forward in train mode, BCE against the batch, decoder backward + its optimiser step
+ * (learning rate = cfg.gen_lr); dzin_out_dev (may be NULL) receives dL/dzin for trainable
+ * conditions.  Uses masks_dev[2], masks_dev[3] of `inject`.  Predict = aae_decode. */
+int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev, int64_t zin_ld,
+                     const aae_rng_inject* inject, float* dzin_out_dev, void* stream);
 /* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
  * between them) */
 int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);

@@ -332,15 +332,10 @@ class OracleAAE:
         return sigmoid(a3), cache
 
     # -- the three sub-steps ----------------------------------------------
-    def ae_step(self, indptr, indices, values, masks, cond_inputs=None):
-        """masks = [enc.drop1, enc.drop2, dec.drop1, dec.drop2] keep-masks or None."""
-        mk = masks if masks is not None else [None] * 4
-        B, N = len(indptr) - 1, self.N
-        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
-        zc = z
-        for cond, inp in zip(self.conditions, cond_inputs or []):
-            zc = cond.fwd(zc, inp)
-        logits, dc = self._mlp_fwd("dec", zc, (mk[2], mk[3]))
+    def _bce(self, logits, indptr, indices, values):
+        """F.binary_cross_entropy(sigmoid(logits) + TINY, X + TINY), mean over B*N, and its gradient w.r.t. the
+        logits exactly as autograd forms it (aae.py:693-695; clamped logs, 1e-12 floor in the backward)."""
+        B, N = logits.shape
         xhat = sigmoid(logits)
         T = np.zeros((B, N), dtype=f32)
         for b in range(B):
@@ -353,6 +348,18 @@ class OracleAAE:
         loss = float((-(t * lx + (f32(1) - t) * l1x)).mean(dtype=np.float64))
         gx = (x - t) / np.maximum((f32(1) - x) * x, f32(1e-12)) / f32(B * N)
         glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
+        return loss, glog, xhat
+
+    def ae_step(self, indptr, indices, values, masks, cond_inputs=None):
+        """masks = [enc.drop1, enc.drop2, dec.drop1, dec.drop2] keep-masks or None."""
+        mk = masks if masks is not None else [None] * 4
+        B, N = len(indptr) - 1, self.N
+        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
+        zc = z
+        for cond, inp in zip(self.conditions, cond_inputs or []):
+            zc = cond.fwd(zc, inp)
+        logits, dc = self._mlp_fwd("dec", zc, (mk[2], mk[3]))
+        loss, glog, xhat = self._bce(logits, indptr, indices, values)
         Gd, gda1, gzc = self._mlp_bwd("dec", glog, dc)
         Gd["dec.lin1.weight"] = (gda1.T @ zc).astype(f32)
         gz = gzc
@@ -428,6 +435,46 @@ class OracleAAE:
         logits, _ = self._mlp_fwd("dec", z, None)
         return sigmoid(logits)
 
+
+
+class OracleDecoder(OracleAAE):
+    """DecodingRecommender (aae.py:461-584): the encoded conditions (first one as is, the others imposed on it,
+    aae.py:494-502) -> the 3-layer Decoder -> BCE against the item rows; one optimiser for the decoder, the
+    conditions step their own.  Condition stand-ins start from an empty code block."""
+
+    def __init__(self, params, lr=1e-3, optimizer="adam", activation="ReLU", dropout=(0.2, 0.2), conditions=None):
+        self.p = {k: np.array(v, dtype=f32) for k, v in params.items() if k.startswith("dec.")}
+        self.N = self.p["dec.lin3.weight"].shape[0]
+        self.act, self.dropout = activation, tuple(dropout)
+        self.alpha_mode = activation == "SELU"
+        self.opt_dec = (Adam if optimizer == "adam" else SGD)(lr)
+        self.conditions = conditions or []
+
+    def inputs(self, cond_inputs, train=True):
+        B = len(cond_inputs[0])
+        z = np.zeros((B, 0), dtype=f32)
+        for cond, inp in zip(self.conditions, cond_inputs):
+            z = cond.fwd(z, inp, train=train)
+        return z
+
+    def partial_fit(self, cond_inputs, indptr, indices, values, masks=None):
+        """masks = (dec.drop1, dec.drop2) keep-masks or None (aae.py:489-517)."""
+        zin = self.inputs(cond_inputs)
+        logits, dc = self._mlp_fwd("dec", zin, masks)
+        loss, glog, _ = self._bce(logits, indptr, indices, values)
+        Gd, gda1, gz = self._mlp_bwd("dec", glog, dc)
+        Gd["dec.lin1.weight"] = (gda1.T @ zin).astype(f32)
+        self.last_dzin = gz
+        for cond in reversed(self.conditions):
+            gz = cond.bwd(gz)
+        self.opt_dec.step(self.p, Gd)
+        for cond in self.conditions:
+            cond.step()
+        return loss
+
+    def predict(self, cond_inputs):
+        logits, _ = self._mlp_fwd("dec", self.inputs(cond_inputs, train=False), None)
+        return sigmoid(logits)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -112,3 +112,36 @@ def test_dense_port_reproduces_reference_steps(name):
             got = m.state_dict()
             for k, w in fx.expected_params(s).items():
                 np.testing.assert_allclose(got[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} step {s} {k}")
+
+
+DECODING_CASES = ["step_decoding", "step_decoding_trainable"]
+
+
+def build_decoding_oracle(fx):
+    c = fx.cfg
+    incs = c["incs"]
+    conds = [O.CategoricalSum(fx.z["init.cond.embedding"], lr=1e-2) if c["trainable"] else O.ConcatConst(incs[0])]
+    conds += [O.ConcatConst(i) for i in incs[1:]]
+    return O.OracleDecoder(fx.init_params(), lr=c["gen_lr"], dropout=tuple(c["dropout"]), conditions=conds)
+
+
+@pytest.mark.parametrize("name", DECODING_CASES)
+def test_oracle_reproduces_reference_decoding_recommender(name):
+    """DecodingRecommender.partial_fit / predict (aae.py:461-584) against fixtures made from the reference."""
+    fx = Fixture(name)
+    m = build_decoding_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        loss = m.partial_fit(fx.cond_inputs(s), ip, idx, val, fx.masks(s))
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS, atol=1e-7)
+        for k in ("lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"):
+            np.testing.assert_allclose(m.p["dec." + k], fx.z[f"step{s}.dec.{k}"], atol=TOL_PARAM, rtol=0,
+                                       err_msg=f"{name} step {s} {k}")
+        for (tag, k), (em, ev, et) in fx.expected_adam(s).items():
+            assert tag == "A_dec" and m.opt_dec.t[k] == et
+            np.testing.assert_allclose(m.opt_dec.m[k], em, atol=1e-9, rtol=2e-5)
+            np.testing.assert_allclose(m.opt_dec.v[k], ev, atol=1e-13, rtol=5e-5)
+        if fx.cfg["trainable"]:
+            np.testing.assert_allclose(m.conditions[0].params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
+    out = m.predict(fx.cond_inputs(0, prefix="predict"))
+    np.testing.assert_allclose(out, fx.z["predict.out"], atol=2e-6)

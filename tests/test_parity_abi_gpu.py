@@ -288,3 +288,41 @@ def test_torch_custom_ops_replay_fixture(name):
     del m
     with pytest.raises(RuntimeError):
         torch.ops.aaerec.encode(mid, pcsr.indptr, pcsr.indices, pcsr.values, 0, n, pcsr.nnz_per_row_max)
+
+
+@pytest.mark.parametrize("name", ["step_decoding", "step_decoding_trainable"])
+def test_decoder_step_matches_reference(name):
+    """aae_decoder_step (DecodingRecommender.partial_fit, aae.py:489-517) replayed against the reference's
+    fixtures; the condition side (host plugins in production) is played by the oracle's stand-ins, which also
+    check the dL/dzin the kernel hands back for trainable conditions."""
+    from aaerec._hip import HipAAE
+    from test_oracle_golden import build_decoding_oracle
+    fx = Fixture(name)
+    c = fx.cfg
+    orc = build_decoding_oracle(fx)
+    m = HipAAE(c["N"], c["h"], c["n_code"], cond_inc=0, max_batch=c["B"], rng_mode="inject", gen_lr=c["gen_lr"],
+               reg_lr=c["gen_lr"], dropout=tuple(c["dropout"]))
+    m.load_params(fx.init_params())
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = fx.cond_inputs(s)
+        zin = orc.inputs(cond)                                   # with the embeddings as they are before this step
+        dz = m.decoder_step(csr, 0, B, torch.as_tensor(zin, device=m.device), masks=fx.masks(s))
+        loss = orc.partial_fit(cond, *fx.batch(s), fx.masks(s))  # advances the oracle's conditions as well
+        np.testing.assert_allclose(m.losses()[0], fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS, atol=1e-6)
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS, atol=1e-6)
+        np.testing.assert_allclose(dz.cpu().numpy(), orc.last_dzin, rtol=2e-4, atol=2e-9, err_msg=f"{name} dzin {s}")
+        got = m.state_dict()
+        for k in ("lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"):
+            np.testing.assert_allclose(got["dec." + k], fx.z[f"step{s}.dec.{k}"], atol=TOL_PARAM, rtol=0,
+                                       err_msg=f"{name} step {s} {k}")
+        st = m.adam_state("dec")
+        for (tag, k), (em, ev, et) in fx.expected_adam(s).items():
+            gm, gv = st[k.split(".", 1)[1]]
+            assert st["step"] == et
+            np.testing.assert_allclose(gm, em, atol=2e-9, rtol=1e-4)
+            np.testing.assert_allclose(gv, ev, atol=1e-12, rtol=2e-4)
+    zp = orc.inputs(fx.cond_inputs(0, prefix="predict"), train=False)
+    out = m.decode(torch.as_tensor(zp, device=m.device)).cpu().numpy()
+    np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)

@@ -376,6 +376,114 @@ def run_ae_only_case(ref_aae, name, N=300, h=20, c=10, B=16, steps=3, seed=0, dr
     print(f"{name}: losses step0={out['step0.losses']}")
 
 
+def run_decoding_case(ref_aae, ref_cond, name, N=300, h=20, B=16, steps=3, seed=0, dropout=(0.2, 0.2), lr=2e-3,
+                      incs=(12, 8), trainable=False):
+    """The reference's DecodingRecommender (aae.py:461-584): conditions -> 3-layer decoder -> BCE against the
+    item rows.  Conditions: constant concatenated blocks (first one is the base input, the others are imposed,
+    aae.py:494-502); trainable=True makes the first one a CategoricalCondition (embedding sum, own optimiser)."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(3000 + seed)
+
+    def const_concat(inc):
+        class ConstConcat(ref_cond.ConcatenationBasedConditioning):
+            def size_increment(self):
+                return inc
+
+            def encode(self, inputs):
+                return torch.as_tensor(inputs, dtype=torch.float32)
+        return ConstConcat()
+    items = []
+    if trainable:
+        items.append(("authors", ref_cond.CategoricalCondition(incs[0], sparse=False, use_cuda=False, reduce="sum",
+                                                                lr=1e-2)))
+    else:
+        items.append(("title", const_concat(incs[0])))
+    for j, inc in enumerate(incs[1:]):
+        items.append((f"c{j}", const_concat(inc)))
+    conditions = ref_cond.ConditionList(items)
+    vocab = 40
+    if trainable:
+        conditions["authors"].fit([[f"a{i}"] for i in range(vocab)])
+    m = ref_aae.DecodingRecommender(conditions, n_epochs=1, batch_size=B, n_hidden=h, lr=lr, verbose=False,
+                                    dropout=dropout)
+    m.mlp = ref_aae.Decoder(conditions.size_increment(), h, N, **m.model_params)
+    m.mlp_optim = ref_aae.TORCH_OPTIMIZERS[m.optimizer](m.mlp.parameters(), lr=m.lr)
+    masks_log = []
+    for li, attr in enumerate(("drop1", "drop2")):
+        setattr(m.mlp, attr, RecDropout(dropout[li], masks_log, f"dec.{attr}"))
+    ref_aae.USE_WANDB = False
+    losses = []
+    orig_bce = ref_aae.F.binary_cross_entropy
+
+    def rec_bce(*a, **k):
+        out = orig_bce(*a, **k)
+        losses.append(float(out.detach()))
+        return out
+    out = {}
+    cfg = dict(N=N, h=h, c=int(conditions.size_increment()), B=B, steps=steps, cond="", cond_inc=0, n_hidden=h,
+               n_code=int(conditions.size_increment()), decoder_only=1, incs=list(incs), trainable=int(trainable),
+               gen_lr=lr, reg_lr=lr, dropout=list(dropout), vocab=vocab)
+    for k, v in state_np(m.mlp).items():
+        out[f"init.dec.{k}"] = v
+    if trainable:
+        out["init.cond.embedding"] = conditions["authors"].embedding.weight.detach().numpy().copy()
+
+    def cond_batch(n):
+        cb = []
+        if trainable:
+            raw = [[f"a{int(i)}" for i in rng.integers(0, vocab, size=int(rng.integers(1, 4)))] for _ in range(n)]
+            cb.append(conditions["authors"].transform(raw))       # list of index lists (0 = padding / unknown)
+        else:
+            cb.append(rng.normal(size=(n, incs[0])).astype(np.float32))
+        for inc in incs[1:]:
+            cb.append(rng.normal(size=(n, inc)).astype(np.float32))
+        return cb
+
+    def save_cond(prefix, cb):
+        for j, x in enumerate(cb):
+            if trainable and j == 0:
+                L = max(len(l) for l in x)      # padded exactly as CategoricalCondition._pad_batch does
+                out[f"{prefix}.cond{j}"] = np.asarray([l + [0] * (L - len(l)) for l in x], dtype=np.int64)
+            else:
+                out[f"{prefix}.cond{j}"] = np.asarray(x, dtype=np.float32)
+    ref_aae.F.binary_cross_entropy = rec_bce
+    try:
+        for s in range(steps):
+            Y = make_batch(rng, B, N)
+            cb = cond_batch(B)
+            out[f"step{s}.indptr"] = Y.indptr.astype(np.int64)
+            out[f"step{s}.indices"] = Y.indices.astype(np.int32)
+            out[f"step{s}.values"] = Y.data.astype(np.float32)
+            save_cond(f"step{s}", cb)
+            n0 = len(masks_log)
+            m.partial_fit(cb, torch.FloatTensor(Y.toarray()), step=s)
+            out[f"step{s}.losses"] = np.asarray([losses[-1], 0.0, 0.0], dtype=np.float64)
+            for j, (tag, mk) in enumerate(masks_log[n0:]):
+                out[f"step{s}.mask{j}"] = mk
+            for k, v in state_np(m.mlp).items():
+                out[f"step{s}.dec.{k}"] = v
+            for k, v in optim_np(m.mlp_optim, list(m.mlp.parameters())).items():
+                out[f"step{s}.A_dec.{k}"] = v
+            if trainable:
+                out[f"step{s}.cond.embedding"] = conditions["authors"].embedding.weight.detach().numpy().copy()
+    finally:
+        ref_aae.F.binary_cross_entropy = orig_bce
+    # predict (aae.py:560-583) on a fresh condition batch
+    cb = cond_batch(B)
+    save_cond("predict", cb)
+    m.mlp.eval()
+    conditions.eval()
+    with torch.no_grad():
+        enc = conditions.encode(cb)
+        inputs = enc[0]
+        for cnd, cd in zip(list(conditions.values())[1:], enc[1:]):
+            inputs = cnd.impose(inputs, cd)
+        out["predict.out"] = m.mlp(inputs).numpy().astype(np.float32)
+    out["config_json"] = np.asarray(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {[round(l, 6) for l in losses]}")
+
+
 def gen_metric_known_answers():
     """Known answers for the metric side, produced by calling the reference's own
     evaluation functions on literal inputs (evaluation.py:94-115,183-199)."""
@@ -489,6 +597,9 @@ def main():
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=20), capture_acts=False, states='last')
     if want("ae_only"):
         run_ae_only_case(ref_aae, "step_ae_only", seed=21)
+    if want("decoding"):
+        run_decoding_case(ref_aae, ref_cond, "step_decoding", seed=31)
+        run_decoding_case(ref_aae, ref_cond, "step_decoding_trainable", seed=32, incs=(8, 10), trainable=True)
     if want("metrics"):
         gen_metric_known_answers()
     if want("e2e"):
