@@ -279,7 +279,8 @@ class AdversarialAutoEncoder:
         # first-layer gradient a data-parallel rank sends)
         w1_cap = int(min(X.shape[1], max(1, row_nnz[:self.batch_size].sum())))
         self._build(X.shape[1], code_inc, max_row_nnz=max(int(row_nnz[0]) if X.shape[0] else 1, 4096), w1_cap=w1_cap)
-        csr = _hip.DeviceCSR(X, self.hip.device)       # the corpus stays resident in HBM
+        csr0 = _hip.DeviceCSR(X, self.hip.device)      # the corpus stays resident in HBM
+        self._fit_X = X                                 # (host copy; subclasses with host-side randomness use it)
         n_docs = X.shape[0]
         self.train()
         step = 0
@@ -291,6 +292,7 @@ class AdversarialAutoEncoder:
             perm = np.arange(n_docs)
             np.random.shuffle(perm)
             perm_dev = torch.as_tensor(perm.astype(np.int32), device=self.hip.device)
+            csr = self._epoch_csr(csr0)
             for start in range(0, n_docs, self.batch_size):
                 stop = min(start + self.batch_size, n_docs)
                 if self._dp is not None:
@@ -316,6 +318,10 @@ class AdversarialAutoEncoder:
                 print()
         self.last_losses = self.hip.losses()
         return self
+
+    def _epoch_csr(self, csr):
+        """The resident corpus as this epoch's batches see it (hook: DenoisingAutoEncoder thins it)."""
+        return csr
 
     def predict(self, X, condition_data=None):
         self.eval()

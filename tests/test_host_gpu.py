@@ -358,3 +358,66 @@ def test_decoding_recommender_learns_from_conditions():
     pred = rec.predict(Set(Y[1000:], cond[1000:]))
     assert pred.shape == (200, N)
     assert METRICS["mrr@10"](Y[1000:].toarray(), pred)[0] > 0.5
+
+
+def test_denoising_autoencoder_tracks_reference():
+    """aaerec.dae.DenoisingAutoEncoder against the reference's dae.py: (a) recorded steps with the recorded
+    corruption and dropout masks injected; (b) 3 epochs of fit() with rng_mode='reference' and the reference's
+    seeds reproduce the reference's predictions (fixture e2e_dae_short.npz: corruption mask, shuffles, dropout
+    draws all come off the same generators in the same order)."""
+    from aaerec.dae import DenoisingAutoEncoder, DAERecommender
+    fx = Fixture("step_dae")
+    cfg = fx.cfg
+    m = DenoisingAutoEncoder(n_hidden=cfg["h"], n_code=cfg["c"], lr=cfg["gen_lr"], batch_size=cfg["B"],
+                             dropout=tuple(cfg["dropout"]), noise_factor=cfg["noise_factor"], verbose=True,
+                             rng_mode="reference")
+    m._build(cfg["N"], 0)
+    m.hip.load_params(fx.init_params())
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+        masks = fx.masks(s)
+        m._host_randomness = lambda B, masks=masks: (masks + [None] * 8, None)
+        m.partial_fit(X, keep=fx.z[f"step{s}.keep"])
+        np.testing.assert_allclose(m.last_losses[0], fx.z[f"step{s}.losses"][0], rtol=1e-5)
+        got = m.hip.state_dict()
+        for k, w in fx.expected_params(s).items():
+            if not k.startswith("disc."):
+                np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=f"dae step {s} {k}")
+    with pytest.raises(ValueError):
+        m.partial_fit(X, y=1)
+    with pytest.raises(NotImplementedError):
+        DenoisingAutoEncoder(corrupt="gauss")
+    with pytest.raises(KeyError):
+        DenoisingAutoEncoder(corrupt="salt")
+    # (b)
+    z, Xtr, Xin, Yout = _e2e()
+    want = np.load(os.path.join(GOLDEN, "e2e_dae_short.npz"))["pred_short"]
+    torch.manual_seed(7)
+    np.random.seed(7)
+    d = DenoisingAutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100, lr=0.01, verbose=False,
+                             rng_mode="reference")
+    d.fit(Xtr)
+    np.testing.assert_allclose(d.predict(Xin[:40]), want, atol=1e-4)
+    # (c) production randomness through the recommender surface: it learns, and thins ~noise_factor of the entries
+    from aaerec.evaluation import remove_non_missing, METRICS
+
+    class Set:
+        def __init__(self, X):
+            self.X = X
+
+        def tocsr(self):
+            return self.X
+    mrr = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        rec = DAERecommender(n_hidden=50, n_code=50, n_epochs=150, batch_size=100, lr=0.01, verbose=False)
+        rec.train(Set(Xtr))
+        pred = remove_non_missing(rec.predict(Set(Xin)), Xin, copy=True)
+        mrr.append(METRICS["mrr@10"](Yout.toarray(), pred)[0])
+    assert np.median(mrr) > 0.05, mrr
+    from aaerec import _hip
+    csr = _hip.DeviceCSR(Xtr, rec.dae.hip.device)
+    kept = float((rec.dae._epoch_csr(csr).values != 0).float().mean())
+    assert abs(kept - 0.8) < 0.02

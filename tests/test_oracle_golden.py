@@ -145,3 +145,18 @@ def test_oracle_reproduces_reference_decoding_recommender(name):
             np.testing.assert_allclose(m.conditions[0].params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
     out = m.predict(fx.cond_inputs(0, prefix="predict"))
     np.testing.assert_allclose(out, fx.z["predict.out"], atol=2e-6)
+
+
+def test_oracle_ae_step_matches_reference_denoising_autoencoder():
+    """DenoisingAutoEncoder, corrupt='zeros' (dae.py:48-52, 189-210): the reference thins the batch tensor in
+    place, so its step is ae_step on the thinned bag - the fixture records which CSR entries survived."""
+    fx = Fixture("step_dae")
+    m = build_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        loss = m.ae_step(ip, idx, val * fx.z[f"step{s}.keep"], fx.masks(s))
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        for k, w in fx.expected_params(s).items():
+            np.testing.assert_allclose(m.p[k], w, atol=TOL_PARAM, rtol=0, err_msg=k)
+    ip, idx, val = fx.batch(0, prefix="predict")
+    np.testing.assert_allclose(m.predict(ip, idx, val), fx.z["predict.out"], atol=2e-6)

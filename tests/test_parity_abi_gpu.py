@@ -326,3 +326,19 @@ def test_decoder_step_matches_reference(name):
     zp = orc.inputs(fx.cond_inputs(0, prefix="predict"), train=False)
     out = m.decode(torch.as_tensor(zp, device=m.device)).cpu().numpy()
     np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)
+
+
+def test_denoising_autoencoder_step_matches_reference():
+    """DenoisingAutoEncoder (dae.py:144-314, corrupt='zeros'): the plain autoencoder step on the thinned bag -
+    entries the reference's zeros_noise removed carry value 0 (they gather nothing and are zero targets)."""
+    from aaerec._hip import DeviceCSR
+    fx = Fixture("step_dae")
+    m = make_model(fx, ae_only=True)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        csr = DeviceCSR.from_arrays(ip, idx, val * fx.z[f"step{s}.keep"], fx.cfg["N"], m.device)
+        m.step(csr, 0, csr.shape[0], masks=fx.masks(s) + [None] * 8)
+        np.testing.assert_allclose(m.losses()[0], fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        check_state(fx, m, s, "dae")
+    pcsr = csr_of(fx, m, 0, prefix="predict")
+    np.testing.assert_allclose(m.predict(pcsr, 0, pcsr.shape[0]).cpu().numpy(), fx.z["predict.out"], atol=TOL_RECON)

@@ -565,6 +565,90 @@ def gen_e2e_c1(ref_aae):
                         seed=np.asarray(7))
 
 
+def gen_dae():
+    """The reference's DenoisingAutoEncoder (dae.py:144-314), corrupt='zeros' (its default): the batch tensor is
+    thinned IN PLACE by zeros_noise (dae.py:48-52), so encoder input and BCE target are both the thinned batch.
+    step_dae.npz: three recorded steps (per-entry keep flags, dropout masks, losses, parameters, Adam state);
+    e2e_dae_short.npz: 3 epochs of DenoisingAutoEncoder.fit on the C1 corpus -> predictions."""
+    import_reference()
+    import aaerec.dae as ref_dae
+    N, h, c, B, steps, seed, lr, nf, dropout = 300, 20, 10, 16, 3, 41, 2e-3, 0.3, (0.2, 0.2)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(4000 + seed)
+    m = ref_dae.DenoisingAutoEncoder(n_hidden=h, n_code=c, lr=lr, batch_size=B, n_epochs=1, dropout=dropout,
+                                     noise_factor=nf, corrupt='zeros', verbose=True)
+    m.enc = ref_dae.Encoder(N, h, c, final_activation='linear', normalize_inputs=m.normalize_inputs,
+                            dropout=m.dropout, activation=m.activation)
+    m.dec = ref_dae.Decoder(c, h, N, dropout=m.dropout, activation=m.activation)
+    og = ref_dae.TORCH_OPTIMIZERS[m.optimizer]
+    m.enc_optim, m.dec_optim = og(m.enc.parameters(), lr=m.lr), og(m.dec.parameters(), lr=m.lr)
+    masks_log, corrupted, loss_log = [], [], []
+    for net_name, net in (("enc", m.enc), ("dec", m.dec)):
+        for li, attr in enumerate(("drop1", "drop2")):
+            setattr(net, attr, RecDropout(m.dropout[li], masks_log, f"{net_name}.{attr}"))
+    orig_corrupt = m.corrupt
+
+    def rec_corrupt(batch, noise_factor):
+        out = orig_corrupt(batch, noise_factor)
+        corrupted.append(out.detach().numpy().copy())
+        return out
+    m.corrupt = rec_corrupt
+    ref_dae.log_losses = lambda *l: loss_log.append(l)
+    out = {}
+    cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="", cond_inc=0, n_hidden=h, n_code=c, ae_only=1, gen_lr=lr,
+               reg_lr=lr, dropout=list(dropout), noise_factor=nf, corrupt="zeros")
+    import aaerec.aae as ref_aae
+    disc = ref_aae.Discriminator(c, h)            # the kernels' model always carries one (unused here)
+    for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", disc)):
+        for k, v in state_np(net).items():
+            out[f"init.{net_name}.{k}"] = v
+    for s in range(steps):
+        X = make_batch(rng, B, N, max_len=12)
+        out[f"step{s}.indptr"] = X.indptr.astype(np.int64)
+        out[f"step{s}.indices"] = X.indices.astype(np.int32)
+        out[f"step{s}.values"] = X.data.astype(np.float32)
+        n0 = len(masks_log)
+        m.partial_fit(X.toarray())
+        C = corrupted[-1]
+        rows = np.repeat(np.arange(B), np.diff(X.indptr))
+        out[f"step{s}.keep"] = (C[rows, X.indices] != 0).astype(np.uint8)       # per CSR entry
+        assert np.count_nonzero(C) == int(out[f"step{s}.keep"].sum())           # noise only removes entries
+        out[f"step{s}.losses"] = np.asarray(loss_log[-1], dtype=np.float64)
+        out[f"step{s}.z_real"] = np.zeros((B, c), dtype=np.float32)
+        for j, (tag, mk) in enumerate(masks_log[n0:]):
+            out[f"step{s}.mask{j}"] = mk
+        for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", disc)):
+            for k, v in state_np(net).items():
+                out[f"step{s}.{net_name}.{k}"] = v
+        ep, dp = list(m.enc.parameters()), list(m.dec.parameters())
+        for tag, opt, ps in (("A_enc", m.enc_optim, ep), ("A_dec", m.dec_optim, dp)):
+            for k, v in optim_np(opt, ps).items():
+                out[f"step{s}.{tag}.{k}"] = v
+    Xp = make_batch(rng, B, N)
+    out["predict.indptr"] = Xp.indptr.astype(np.int64)
+    out["predict.indices"] = Xp.indices.astype(np.int32)
+    out["predict.values"] = Xp.data.astype(np.float32)
+    out["predict.out"] = m.predict(Xp).astype(np.float32)
+    out["config_json"] = np.asarray(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, "step_dae.npz"), **out)
+    print("step_dae: losses", [l[0] for l in loss_log], "kept", [int(out[f'step{s}.keep'].sum()) for s in range(steps)],
+          "of", [len(out[f'step{s}.keep']) for s in range(steps)])
+    # 3 epochs of fit() on the C1 corpus (tests/golden/e2e_c1.npz holds it)
+    z = np.load(os.path.join(OUT, "e2e_c1.npz"))
+    Nc = int(z["N"])
+
+    def csr(ip, idx):
+        return sp.csr_matrix((np.ones(len(idx)), idx, ip), shape=(len(ip) - 1, Nc))
+    Xtr, Xin = csr(z["train_indptr"], z["train_indices"]), csr(z["in_indptr"], z["in_indices"])
+    torch.manual_seed(7)
+    np.random.seed(7)
+    d = ref_dae.DenoisingAutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100, lr=0.01, verbose=False)
+    d.fit(Xtr)
+    np.savez_compressed(os.path.join(OUT, "e2e_dae_short.npz"), pred_short=d.predict(Xin[:40]).astype(np.float32),
+                        seed=np.asarray(7))
+    print("e2e_dae_short written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_aae, ref_cond = import_reference()
@@ -600,6 +684,8 @@ def main():
     if want("decoding"):
         run_decoding_case(ref_aae, ref_cond, "step_decoding", seed=31)
         run_decoding_case(ref_aae, ref_cond, "step_decoding_trainable", seed=32, incs=(8, 10), trainable=True)
+    if want("dae"):
+        gen_dae()
     if want("metrics"):
         gen_metric_known_answers()
     if want("e2e"):
