@@ -1568,13 +1568,28 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
     int lo = which == O_DEC ? P_V1 : which == O_DISC ? P_D1 : P_W1T;
     int hi = which == O_DEC ? P_V3 : which == O_DISC ? P_D3 : P_W3;
     const int set = which == O_GEN ? 1 : 0;
+    // small tensors (every hidden layer) share one launch; a vocabulary-sized one (DEC_V3 when the caller does
+    // not shard it) streams through the plain grid-stride kernel
+    AdamGroup grp; grp.njobs = 0;
+    unsigned blocks = 0;
     for (int pid = lo; pid <= hi; ++pid) {
         if (pid == P_W1T) continue;        // row-sparse: aae_w1_import applies it
         if (pid == skip_tensor_id) continue; // sharded by the caller: aae_apply_shard
-        size_t n4 = m->P[pid].floats() / 4;
+        const size_t n4 = m->P[pid].floats() / 4;
+        if (n4 <= (size_t)1 << 18 && grp.njobs < 8) {
+            AdamJob& j = grp.jobs[grp.njobs++];
+            j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p; j.g = m->Gr[pid].p;
+            j.n4 = (unsigned)n4; j.blk0 = blocks;
+            blocks += (unsigned)((n4 + 255) / 256);
+            continue;
+        }
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[pid].p, m->M[set][pid].p,
-                           m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, pid == P_W1T ? 1 : 0);
+                           m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, 0);
         LAUNCHCHK("adam_dense");
+    }
+    if (grp.njobs) {
+        hipLaunchKernelGGL(adam_group_kernel, dim3(blocks), dim3(256), 0, s, grp, m->sc + which);
+        LAUNCHCHK("adam_group");
     }
     return AAE_OK;
 }

@@ -128,6 +128,30 @@ __global__ void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, 
     }
 }
 
+// The same update for up to 8 small tensors of one optimiser in ONE launch (data-parallel replicas apply the
+// all-reduced gradients of every hidden layer after each phase: twelve ~4 us launches per step otherwise).
+struct AdamJob { float* p; float* m; float* v; float* g; unsigned n4; unsigned blk0; };   // blk0: first block of the job
+struct AdamGroup { int njobs; AdamJob jobs[8]; };
+
+__global__ __launch_bounds__(256) void adam_group_kernel(AdamGroup grp, const OptScalars* sc) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < grp.njobs && blockIdx.x >= grp.jobs[i].blk0) j = i;
+    const AdamJob job = grp.jobs[j];
+    const OptScalars s = *sc;
+    const unsigned i = (blockIdx.x - job.blk0) * 256u + threadIdx.x;
+    if (i >= job.n4) return;
+    float4 pp = reinterpret_cast<float4*>(job.p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(job.g)[i];
+    float4 mm = make_float4(0, 0, 0, 0), vv = mm;
+    if (!s.is_sgd) { mm = reinterpret_cast<float4*>(job.m)[i]; vv = reinterpret_cast<float4*>(job.v)[i]; }
+    adam_update(pp.x, mm.x, vv.x, gg.x, s); adam_update(pp.y, mm.y, vv.y, gg.y, s);
+    adam_update(pp.z, mm.z, vv.z, gg.z, s); adam_update(pp.w, mm.w, vv.w, gg.w, s);
+    reinterpret_cast<float4*>(job.p)[i] = pp;
+    if (!s.is_sgd) { reinterpret_cast<float4*>(job.m)[i] = mm; reinterpret_cast<float4*>(job.v)[i] = vv; }
+}
+
 // bias gradient of the first encoder layer: db1[c] = sum_b ga1[b][c], then its optimiser
 // update (or export).  Block = 64 columns x 16 waves striding the rows, LDS tree over waves.
 __global__ __launch_bounds__(1024) void colsum_adam_kernel(const float* __restrict__ ga, int rows, int h, int ld,
