@@ -72,6 +72,9 @@ _PROTOS = {
     "aae_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
     "aae_ae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
     "aae_ae_decode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AaeRngInject), C.c_void_p, C.c_void_p]),
+    "aae_vae_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aae_vae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
     "aae_decoder_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int64, C.POINTER(AaeRngInject),
                                    C.c_void_p, C.c_void_p]),
     "aae_ae_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -167,7 +170,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -195,8 +198,8 @@ class HipAAE:
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.reserved[0] = 1 if unfused_decoder else 0
         cfg.reserved[1] = int(dp_world) if grad_mode == "export" else 0
-        cfg.reserved[2] = 1 if ae_only else 0
-        self.ae_only = bool(ae_only)
+        cfg.reserved[2] = 3 if vae else 1 if ae_only else 0
+        self.ae_only, self.vae = bool(ae_only or vae), bool(vae)
         self.dp_world = int(dp_world)
         # rows of the packed first-layer gradient one rank may send per exchange
         self.w1_cap = int(w1_cap if w1_cap is not None else min(cfg.max_nnz, n_items, 65536))
@@ -408,6 +411,30 @@ class HipAAE:
             _check(self.lib.aae_decoder_step(self.handle, C.byref(b), _ptr(zin), zin.shape[1],
                                              C.byref(inj) if inj else None, _ptr(dz), self._stream()))
         return dz
+
+    def vae_step(self, csr, row_start, n_rows, rows=None, cond=None, eps=None):
+        """VAE.partial_fit (vae.py:147-186).  eps: [n_rows, n_code] standard-normal draws (rng_mode='inject')."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        keep = []
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous(); keep.append(cond)
+        if eps is not None:
+            eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous(); keep.append(eps)
+        self._keep = keep
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_vae_step(self.handle, C.byref(b), _ptr(cond), _ptr(eps), self._stream()))
+
+    def vae_predict(self, csr, row_start, n_rows, cond=None, eps=None):
+        b = self._batch(csr, row_start, n_rows)
+        out = self._out_buffer(n_rows)
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous()
+        if eps is not None:
+            eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_vae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(eps), _ptr(out), out.shape[1],
+                                            self._stream()))
+        return out[:, :self.N]
 
     def ae_encoder_backward(self, dz):
         dz = dz.detach().to(self.device, torch.float32).contiguous()

@@ -75,6 +75,9 @@ struct aae_model {
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave;
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
+    bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
+    bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
+    Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
     bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
     bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
@@ -137,7 +140,10 @@ int validate(const aae_config* c) {
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
     for (int i = 3; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
-    if (c->reserved[2] != 0 && c->reserved[2] != 1) return fail(AAE_EINVAL, "reserved[2] (autoencoder only) must be 0 or 1");
+    if (c->reserved[2] < 0 || c->reserved[2] > 3 || c->reserved[2] == 2)
+        return fail(AAE_EINVAL, "reserved[2] must be 0 (AAE), 1 (plain autoencoder) or 3 (VAE)");
+    if (c->reserved[2] == 3 && (c->n_hidden + 1 > 208 || c->n_code + c->cond_inc + 1 > 208 || 2 * c->n_code > 208))
+        return fail(AAE_EINVAL, "VAE mode needs n_hidden <= 207, n_code + cond_inc <= 207, 2 * n_code <= 208");
     if (c->reserved[1] < 0 || c->reserved[1] > 64) return fail(AAE_EINVAL, "reserved[1] (data-parallel world size) out of range");
     if (c->reserved[0] != 0 && c->reserved[0] != 1) return fail(AAE_EINVAL, "reserved[0] must be 0 or 1");
     return AAE_OK;
@@ -154,7 +160,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->P[P_W1T] = a.mat(N, h, m->ldw1);
     m->P[P_B1] = a.mat(1, h, m->ldw1);
     m->P[P_W2] = a.mat(h, h + 1, m->ldh, 4);
-    m->P[P_W3] = a.mat(cc, h + 1, m->ldh, 4);
+    m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 4);   // VAE: [fc21; fc22]
     m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 4);
     m->P[P_V2] = a.mat(h, h + 1, m->ldh, 4);
     m->P[P_V3] = a.mat(N, h + 1, m->ldh);
@@ -194,6 +200,9 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
+    if (c.reserved[2] == 3) {
+        m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
+    }
     m->bce_partials_cap = std::max(512, ((N + 31) / 32) * ((R + 31) / 32));
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
     m->fix_partials = a.take((size_t)R * 64, nullptr);
@@ -525,7 +534,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         unsigned long long h[32];
         hipStreamSynchronize(s);
         hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE"};
+        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD"};
         fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
         for (int i = 0; i < cb.P.nops; ++i)
             fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
@@ -681,6 +690,50 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
     return AAE_OK;
 }
 
+// ---- VAE (reference vae.py:47-266) -----------------------------------------------------------
+// forward: eh1 (the gather's act(fc1 x)) -> [mu | logvar] = [fc21; fc22] eh1 -> z = mu + eps * exp(logvar/2)
+// -> (constant condition block) -> dh2 = act(fc3 z): the input of the vocabulary-wide output layer fc4
+int chain_vae_forward(aae_model* m, const float* cond_dev, const float* eps_dev, int rows, hipStream_t s) {
+    const int h = m->h, c = m->c, cp = m->cp;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    ChainOp& ml = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_W3], h + 1, 2 * c, CEPI_NONE));
+    cop_out(ml, m->mulv.p, (int)m->mulv.ld);
+    ChainOp& rp = cb.add(cop(COP_REPARAM, 1, 2, c));
+    rp.W = eps_dev; rp.ldw = c; rp.aux = 12; rp.aux_ptr = m->veps.p; rp.aux_ld = (int)m->veps.ld;
+    if (m->cfg.cond_inc > 0) {
+        ChainOp& cl = cb.add(cop_load(cond_dev, m->cfg.cond_inc, 2, m->cfg.cond_inc)); cl.dst_col0 = c; cl.one_col = cp;
+    } else {
+        rp.one_col = cp;
+    }
+    ChainOp& st = cb.add(cop(COP_STORE, 2, 2, cp)); cop_out(st, m->zc.p, m->ldc);
+    ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+    v1.one_col = h; cop_out(v1, m->dh2.p, m->ldh);        // no dropout in the VAE: DropSpec stays disabled
+    return launch_chain(m, cb, s);
+}
+
+// backward below the output layer: dL/d(dh2) -> fc3 -> dz -> (dmu, dlogvar) incl. the KL term -> [fc21; fc22] -> ga1
+int chain_vae_backward(aae_model* m, const float* part_slabs, size_t slab_stride, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 1;                                   // KL sum -> losses[1]
+    if (part_slabs) {
+        ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+        cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
+        ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1; cop_out(ab, m->gb0.p, m->ldh);
+    } else {
+        cb.add(cop_load(m->gb0.p, m->ldh, 2, h));         // unfused decoder path: gb0 already holds dL/d(pre-activation)
+    }
+    cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    cb.add(cop_load(m->mulv.p, (int)m->mulv.ld, 4, 2 * c));
+    ChainOp& rb = cb.add(cop(COP_REPARAM_BWD, 3, 5, 2 * c)); rb.yslot = 4; rb.scale = m->grad_scale;
+    rb.aux_ptr = m->veps.p; rb.aux_ld = (int)m->veps.ld; cop_out(rb, m->gmulv.p, (int)m->gmulv.ld);
+    cb.add(cop_load(m->eh1.p, m->ldh, 6, h));
+    ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 5, 7, m->P[P_W3], 2 * c, h, CEPI_ACTBWD)); x1.yslot = 6;
+    cop_out(x1, m->gb3.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
 // disc_step on the chain path
 int chain_disc_step(aae_model* m, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c;
@@ -780,7 +833,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
-    m->ae_only = cfg->reserved[2] == 1;
+    m->vae = cfg->reserved[2] == 3; m->vae_bwd = false;
+    m->ae_only = cfg->reserved[2] == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
         int dev = 0, cus = 0;
@@ -1199,6 +1253,15 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
     }
     }
+    if (m->use_chain && m->vae_bwd) {
+        TRY(chain_vae_backward(m, chain_part, chain_stride, s));
+        DwBuilder dw;
+        dw.add(m, m->gb0.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
+        dw.add(m, m->gmulv.p, (int)m->gmulv.ld, m->eh1.p, m->ldh, B, P_W3, O_ENC);
+        TRY(dw.launch(s));
+        m->phase = 2;
+        return AAE_OK;
+    }
     if (m->use_chain) {
         // decoder hidden backward (+ the encoder backward when called from aae_step) in one program,
         // then every small weight gradient + optimiser update in one grouped launch
@@ -1248,6 +1311,52 @@ int aae_decoder_step(aae_handle m, const aae_batch* batch, const float* zin_dev,
     m->dec_hidden_done = false; m->enc_bwd_done = false; m->fuse_enc_bwd = false;
     m->phase = 1;
     TRY(aae_ae_decode_backward(m, zin_dev, zin_ld, nullptr, dzin_out, stream));
+    m->phase = 0;
+    return AAE_OK;
+}
+
+// VAE.partial_fit (vae.py:147-186): loss = mean BCE + KL sum (vae.py:132-145), one Adam over all five Linears
+int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (!m->vae) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (!m->use_chain) return fail(AAE_ESTATE, "VAE mode needs the layer-chain kernels");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
+    TRY(set_batch(m, batch));
+    remember_inject(m, nullptr, true);
+    hipStream_t s = S(stream);
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                       m->stamp, m->ucount, m->losses);
+    LAUNCHCHK("advance_step");
+    if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+    TRY(gather_first_layer(m, false, nullptr, 0, s));                 // eh1 = act(fc1(normalize(x))), vae.py:111-113
+    TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
+    m->dec_hidden_done = true; m->enc_bwd_done = false; m->fuse_enc_bwd = false;
+    m->vae_bwd = true; m->phase = 1;
+    const int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream);
+    m->vae_bwd = false;
+    if (rc != AAE_OK) return rc;
+    TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s));
+    m->phase = 0;
+    return AAE_OK;
+}
+
+// VAE.predict (vae.py:229-266): the same stochastic forward (the reference samples eps in eval mode too)
+int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev, const float* eps_dev, float* out_dev,
+                    int64_t out_ld, void* stream) {
+    if (!m || !out_dev) return fail(AAE_EINVAL, "handle/out is NULL");
+    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
+    if (out_ld < m->N || (out_ld & 3) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
+        return fail(AAE_EINVAL, "out_dev must be 16-byte aligned with out_ld >= n_items and out_ld % 4 == 0");
+    TRY(set_batch(m, batch));
+    hipStream_t s = S(stream);
+    if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
+    TRY(gather_first_layer(m, false, nullptr, 0, s));
+    TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
+    EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
+    TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s));
     m->phase = 0;
     return AAE_OK;
 }

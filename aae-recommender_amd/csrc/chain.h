@@ -31,7 +31,11 @@ enum { COP_LOAD = 0,        // dst <- global src [rows][lds_] cols [0, N)       
        COP_DROPACT,         // dst <- act(dropout(src)), width N
        COP_SLABSUM,         // dst <- sum_z slabs[z][row][0:N]
        COP_ACTBWD,          // dst <- src * act'(y) * dropout_scale   (y from yslot)
-       COP_STORE };         // no compute: only the post-op global store(s) of dst[:, 0:N]
+       COP_STORE,           // no compute: only the post-op global store(s) of dst[:, 0:N]
+       COP_REPARAM,         // VAE (vae.py:115-118): src = [mu | logvar] (2N cols) -> dst[:, 0:N) = mu + eps * exp(logvar / 2);
+                            //   eps: W (global [rows][ldw], injected) or the counter generator; always written to aux_ptr
+       COP_REPARAM_BWD };   // src = dL/dz (N/2 cols), yslot = [mu | logvar], eps from aux_ptr -> dst = [dL/dmu | dL/dlogvar] (N cols)
+                            //   incl. the KL term's own gradient (vae.py:141-145), whose value goes to the loss slot
 
 enum { CEPI_NONE = 0, CEPI_DROPACT = 1, CEPI_ACTBWD = 2, CEPI_SIGMOID = 3 };
 
@@ -48,6 +52,7 @@ struct ChainOp {
     float scale;                        // COP_ADV: grad scale; COP_LOAD: multiplier
     int row_split;                      // COP_ADV mode 0: rows >= row_split are "fake"
     int dst_col0;                       // COP_LOAD: first destination column (appending a condition block)
+    float* aux_ptr; int aux_ld;         // COP_REPARAM*: the eps buffer [rows][aux_ld] in global memory
 };
 
 struct ChainProgram {
@@ -365,6 +370,50 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
                 }
             }
+        } else if (kind == COP_REPARAM) {
+            const int lrow = tid >> 5, n = op.N;
+            for (int col = tid & 31; col < kCL; col += 32) {
+                float zv = 0.f;
+                if (lrow < nrows && col < n) {
+                    float eps;
+                    if (op.W) eps = op.W[(size_t)(r0 + lrow) * op.ldw + col];
+                    else {      // Box-Muller on two words of the counter generator (stream id = op.aux)
+                        const uint64_t k = key ^ ((uint64_t)(uint32_t)op.aux * 0xA0761D6478BD642Full);
+                        const uint32_t u1 = hash_cell(k, (uint32_t)(r0 + lrow), (uint32_t)(2 * col));
+                        const uint32_t u2 = hash_cell(k, (uint32_t)(r0 + lrow), (uint32_t)(2 * col + 1));
+                        const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+                        const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
+                        eps = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2);
+                    }
+                    op.aux_ptr[(size_t)(r0 + lrow) * op.aux_ld + col] = eps;
+                    const float mu = src[lrow * kCL + col], lv = src[lrow * kCL + n + col];
+                    zv = mu + eps * expf(0.5f * lv);
+                }
+                dst[lrow * kCL + col] = zv;
+            }
+        } else if (kind == COP_REPARAM_BWD) {
+            const float* ml = slots + op.yslot * kCR * kCL;
+            const int lrow = tid >> 5, n = op.N >> 1;          // op.N = 2n columns are produced (and stored)
+            float kl = 0.f;
+            for (int col = tid & 31; col < kCL; col += 32) {
+                float o = 0.f;
+                if (lrow < nrows && col < 2 * n) {
+                    const int j = col < n ? col : col - n;
+                    const float mu = ml[lrow * kCL + j], lv = ml[lrow * kCL + n + j];
+                    const float gz = src[lrow * kCL + j];
+                    const float ev = expf(lv);
+                    if (col < n) {
+                        o = gz + op.scale * mu;
+                        kl += -0.5f * (1.f + lv - mu * mu - ev);
+                    } else {
+                        const float eps = op.aux_ptr[(size_t)(r0 + lrow) * op.aux_ld + j];
+                        o = gz * eps * 0.5f * expf(0.5f * lv) + op.scale * 0.5f * (ev - 1.f);
+                    }
+                }
+                dst[lrow * kCL + col] = o;
+            }
+            kl = wave_sum(kl);
+            if (lane == 0 && kl != 0.f) atomicAdd(P.loss_out + P.loss_slot, kl);
         } else if (kind == COP_ADV) {
             // src col 0 = D(x) of each row.  mode 0: rows < row_split real, others fake; mode 1: all fake(gen)
             if (tid < kCR) {

@@ -81,7 +81,8 @@ typedef struct aae_config {
                                  three-kernel path (A/B measurements); [1] = number of data-parallel
                                  peers whose packed rows aae_w1_import may receive (0 = 1); [2] = 1:
                                  plain AutoEncoder (reference aae.py:221-458): the step ends after the
-                                 encoder backward, aae_disc_step / aae_gen_step are errors */
+                                 encoder backward, aae_disc_step / aae_gen_step are errors; [2] = 3: VAE
+                                 (reference vae.py:47-266): see aae_vae_step */
 } aae_config;
 
 typedef struct aae_model* aae_handle;
@@ -201,6 +202,16 @@ int aae_disc_gen(aae_handle h, const aae_rng_inject* inject, void* stream);
  * conditions.  Uses masks_dev[2], masks_dev[3] of `inject`.  Predict = aae_decode. */
 int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev, int64_t zin_ld,
                      const aae_rng_inject* inject, float* dzin_out_dev, void* stream);
+/* VAE.partial_fit / VAE.predict, vae.py:147-186, 229-266.  The model must have been created with
+ * cfg.reserved[2] = 3: ENC_W1T/B1 = fc1, ENC_W3 = [fc21; fc22] (2 * n_code rows: mu, then logvar), DEC_V1 = fc3,
+ * DEC_V3 = fc4; ENC_W2 / DEC_V2 / the discriminator are unused; cfg.gen_lr is the single learning rate and
+ * cfg.dropout must be (0, 0).  loss = mean BCE (losses[0]) + KL sum (losses[1]), vae.py:132-145.
+ *   cond_dev  constant concatenated condition block [rows][cond_inc] or NULL
+ *   eps_dev   [rows][n_code] standard-normal draws of reparametrize() (vae.py:115-118); NULL = counter generator
+ *             (required when cfg.rng_mode == AAE_RNG_INJECT).  The reference samples eps in predict as well. */
+int aae_vae_step(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream);
+int aae_vae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev,
+                    float* out_dev, int64_t out_ld, void* stream);
 /* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
  * between them) */
 int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);

@@ -477,6 +477,77 @@ class OracleDecoder(OracleAAE):
         return sigmoid(logits)
 
 
+class OracleVAE(OracleAAE):
+    """VAE (vae.py:47-266): x -> L1 normalise -> fc1 -> act -> (fc21 = mu, fc22 = logvar) -> z = mu + eps*exp(logvar/2)
+    -> [conditions] -> fc3 -> act -> fc4 -> sigmoid; loss = nn.BCELoss() (mean: the `size_average = False` the
+    reference sets afterwards is not read by torch, vae.py:133-136) + KL sum (vae.py:141-145); ONE optimiser over
+    all five Linears.  Parameters are keyed fc1 / fc21 / fc22 / fc3 / fc4 (.weight [out,in], .bias)."""
+    NAMES = ("fc1", "fc21", "fc22", "fc3", "fc4")
+
+    def __init__(self, params, lr=1e-3, optimizer="adam", normalize_inputs=True, activation="ReLU", conditions=None):
+        self.p = {k: np.array(v, dtype=f32) for k, v in params.items()}
+        self.p["enc.lin1.weight"], self.p["enc.lin1.bias"] = self.p["fc1.weight"], self.p["fc1.bias"]   # aliases
+        self.N = self.p["fc1.weight"].shape[1]
+        self.normalize, self.act = normalize_inputs, activation
+        self.opt = (Adam if optimizer == "adam" else SGD)(lr)
+        self.conditions = conditions or []
+
+    def forward(self, indptr, indices, values, eps, cond_inputs=None, train=True):
+        P = self.p
+        s = self._row_scale(indptr, values)
+        a1 = self._first_layer(indptr, indices, values, s)
+        h1 = act_fwd(self.act, a1)
+        mu, lv = _lin(h1, P["fc21.weight"], P["fc21.bias"]), _lin(h1, P["fc22.weight"], P["fc22.bias"])
+        std = np.exp(f32(0.5) * lv).astype(f32)
+        z = (np.asarray(eps, dtype=f32) * std + mu).astype(f32)
+        zc = z
+        for cond, inp in zip(self.conditions, cond_inputs or []):
+            zc = cond.fwd(zc, inp, train=train)
+        a3 = _lin(zc, P["fc3.weight"], P["fc3.bias"])
+        h3 = act_fwd(self.act, a3)
+        logits = _lin(h3, P["fc4.weight"], P["fc4.bias"])
+        return sigmoid(logits), dict(s=s, a1=a1, h1=h1, mu=mu, lv=lv, std=std, eps=np.asarray(eps, dtype=f32), zc=zc,
+                                     a3=a3, h3=h3)
+
+    def partial_fit(self, indptr, indices, values, eps, cond_inputs=None):
+        """Returns (BCE mean + KL sum) / B, the number the reference logs (vae.py:185)."""
+        P = self.p
+        B, N = len(indptr) - 1, self.N
+        xhat, c = self.forward(indptr, indices, values, eps, cond_inputs)
+        T = np.zeros((B, N), dtype=f32)
+        for b in range(B):
+            T[b, indices[indptr[b]:indptr[b + 1]]] = values[indptr[b]:indptr[b + 1]]
+        with np.errstate(divide="ignore"):
+            lx = np.maximum(np.log(xhat), f32(-100))
+            l1x = np.maximum(np.log1p(-xhat), f32(-100))
+        bce = float((-(T * lx + (f32(1) - T) * l1x)).mean(dtype=np.float64))
+        mu, lv = c["mu"], c["lv"]
+        kld = float(-0.5 * (1.0 + lv.astype(np.float64) - mu.astype(np.float64) ** 2 - np.exp(lv.astype(np.float64))).sum())
+        gx = (xhat - T) / np.maximum((f32(1) - xhat) * xhat, f32(1e-12)) / f32(B * N)
+        glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
+        G = {"fc4.weight": (glog.T @ c["h3"]).astype(f32), "fc4.bias": glog.sum(0).astype(f32)}
+        ga3 = act_bwd(self.act, c["a3"], c["h3"], (glog @ P["fc4.weight"]).astype(f32))
+        G["fc3.weight"], G["fc3.bias"] = (ga3.T @ c["zc"]).astype(f32), ga3.sum(0).astype(f32)
+        gz = (ga3 @ P["fc3.weight"]).astype(f32)
+        for cond in reversed(self.conditions):
+            gz = cond.bwd(gz)
+        gmu = (gz + mu).astype(f32)
+        glv = (gz * c["eps"] * f32(0.5) * c["std"] + f32(0.5) * (np.exp(lv) - f32(1))).astype(f32)
+        G["fc21.weight"], G["fc21.bias"] = (gmu.T @ c["h1"]).astype(f32), gmu.sum(0).astype(f32)
+        G["fc22.weight"], G["fc22.bias"] = (glv.T @ c["h1"]).astype(f32), glv.sum(0).astype(f32)
+        ga1 = act_bwd(self.act, c["a1"], c["h1"], (gmu @ P["fc21.weight"] + glv @ P["fc22.weight"]).astype(f32))
+        G["fc1.weight"] = self._enc_w1_grad(indptr, indices, values, c["s"], ga1)
+        G["fc1.bias"] = ga1.sum(0).astype(f32)
+        self.opt.step(self.p, G)
+        for cond in self.conditions:
+            cond.step()
+        self.last = dict(bce=bce, kld=kld)
+        return (bce + kld) / B
+
+    def predict(self, indptr, indices, values, eps, cond_inputs=None):
+        return self.forward(indptr, indices, values, eps, cond_inputs, train=False)[0]
+
+
 # ---------------------------------------------------------------------------------------------
 # the same step cut into the phases of the C ABI with gradients EXPORTED instead of applied
 # (aae_ae_encode / aae_ae_decode_backward / aae_ae_encoder_backward / aae_disc_step /

@@ -421,3 +421,95 @@ def test_denoising_autoencoder_tracks_reference():
     csr = _hip.DeviceCSR(Xtr, rec.dae.hip.device)
     kept = float((rec.dae._epoch_csr(csr).values != 0).float().mean())
     assert abs(kept - 0.8) < 0.02
+
+
+@pytest.mark.parametrize("name", ["step_vae", "step_vae_cond"])
+def test_vae_tracks_reference(name):
+    """aaerec.vae.VAE against the reference's vae.py fixtures: recorded steps with the recorded eps."""
+    from aaerec.vae import VAE
+    from aaerec import condition as C
+    from test_parity_abi_gpu import _vae_params
+    fx = Fixture(name)
+    cfg = fx.cfg
+    conds = None
+    if cfg["cond"] == "concat30":
+        class ConstConcat(C.ConcatenationBasedConditioning):
+            constant_concat = True
+
+            def size_increment(self):
+                return 30
+
+            def encode(self, inputs):
+                return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
+        conds = C.ConditionList([("title", ConstConcat())])
+    m = VAE(cfg["N"], cfg["N"], n_hidden=cfg["h"], n_code=cfg["c"], lr=cfg["gen_lr"], batch_size=cfg["B"],
+            conditions=conds, verbose=True, rng_mode="reference")
+    m.hip.load_params(_vae_params(fx, "init"))
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+        eps = fx.z[f"step{s}.eps"]
+        m._eps = lambda B, eps=eps: torch.from_numpy(eps)
+        m.partial_fit(X, condition_data=fx.cond_inputs(s) or None)
+        np.testing.assert_allclose(m.last_loss, fx.z[f"step{s}.losses"][0], rtol=2e-5)
+        sd = m.state_dict()
+        for n in ("fc1", "fc21", "fc22", "fc3", "fc4"):
+            for t in ("weight", "bias"):
+                np.testing.assert_allclose(sd[f"{n}.{t}"].numpy(), fx.z[f"step{s}.{n}.{t}"], atol=1e-5, rtol=0,
+                                           err_msg=f"{name} step {s} {n}.{t}")
+    ip, idx, val = fx.batch(0, prefix="predict")
+    Xp = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+    m._eps = lambda B: torch.from_numpy(fx.z["predict.eps"])
+    np.testing.assert_allclose(m.predict(Xp, condition_data=fx.cond_inputs(0, prefix="predict") or None),
+                               fx.z["predict.out"], atol=1e-5)
+    with pytest.raises(ValueError):
+        m.partial_fit(X, y=1, condition_data=fx.cond_inputs(0) or None)
+    with pytest.raises(NotImplementedError):
+        VAE(cfg["N"], cfg["N"], final_activation="Tanh")
+
+
+def test_vae_fit_with_reference_rng_and_recommender():
+    """(a) 3 epochs of VAE.fit with rng_mode='reference' and the reference's seeds give the reference's trained
+    encoder/decoder: fixture e2e_vae_short.npz holds mu, logvar and decode(mu) of 40 test rows computed by the
+    reference from ITS weights; here they are computed from OUR weights.  (b) VAERecommender learns."""
+    from aaerec.vae import VAE, VAERecommender
+    from aaerec.evaluation import remove_non_missing, METRICS
+    z, Xtr, Xin, Yout = _e2e()
+    want = np.load(os.path.join(GOLDEN, "e2e_vae_short.npz"))
+    N = Xtr.shape[1]
+    torch.manual_seed(7)
+    np.random.seed(7)
+    v = VAE(N, N, n_hidden=50, n_code=50, n_epochs=3, batch_size=100, lr=0.01, verbose=False, rng_mode="reference")
+    v.fit(Xtr)
+    sd = {k: t.numpy().astype(np.float64) for k, t in v.state_dict().items()}
+    x = Xin[:40].toarray().astype(np.float64)
+    x /= np.maximum(np.abs(x).sum(1, keepdims=True), 1e-12)
+    h1 = np.maximum(x @ sd["fc1.weight"].T + sd["fc1.bias"], 0)
+    mu = h1 @ sd["fc21.weight"].T + sd["fc21.bias"]
+    lv = h1 @ sd["fc22.weight"].T + sd["fc22.bias"]
+    h3 = np.maximum(mu @ sd["fc3.weight"].T + sd["fc3.bias"], 0)
+    rec = 1.0 / (1.0 + np.exp(-(h3 @ sd["fc4.weight"].T + sd["fc4.bias"])))
+    np.testing.assert_allclose(mu, want["mu"], atol=2e-4)
+    np.testing.assert_allclose(lv, want["logvar"], atol=2e-4)
+    np.testing.assert_allclose(rec, want["recon_mu"], atol=1e-4)
+
+    class Set:
+        def __init__(self, X):
+            self.X = X
+
+        def tocsr(self):
+            return self.X
+    mrr = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        rec = VAERecommender(n_hidden=50, n_code=50, n_epochs=60, batch_size=100, lr=0.01, verbose=False)
+        rec.train(Set(Xtr))
+        pred = remove_non_missing(rec.predict(Set(Xin)), Xin, copy=True)
+        mrr.append(METRICS["mrr@10"](Yout.toarray(), pred)[0])
+    print("VAE MRR@10", mrr)
+    # The reference's VAE adds a MEAN BCE to a SUMMED KL term (vae.py:133-145), so the KL term dominates and the
+    # posterior collapses: on this corpus the reference itself reaches MRR@10 0.010 / 0.018 / 0.020 after 60 epochs
+    # and 0.020 / 0.014 / 0.013 after 200 (seeds 1..3, measured with the reference in this repo's container;
+    # chance is ~0.003).  Parity with that behaviour is the point, not a good recommender.
+    assert 0.006 < np.median(mrr) < 0.1, mrr

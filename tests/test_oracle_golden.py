@@ -160,3 +160,34 @@ def test_oracle_ae_step_matches_reference_denoising_autoencoder():
             np.testing.assert_allclose(m.p[k], w, atol=TOL_PARAM, rtol=0, err_msg=k)
     ip, idx, val = fx.batch(0, prefix="predict")
     np.testing.assert_allclose(m.predict(ip, idx, val), fx.z["predict.out"], atol=2e-6)
+
+
+VAE_CASES = ["step_vae", "step_vae_cond"]
+VAE_NAMES = ("fc1", "fc21", "fc22", "fc3", "fc4")
+
+
+def build_vae_oracle(fx):
+    conds = [O.ConcatConst(30)] if fx.cfg["cond"] == "concat30" else []
+    params = {f"{n}.{t}": fx.z[f"init.{n}.{t}"] for n in VAE_NAMES for t in ("weight", "bias")}
+    return O.OracleVAE(params, lr=fx.cfg["gen_lr"], conditions=conds)
+
+
+@pytest.mark.parametrize("name", VAE_CASES)
+def test_oracle_reproduces_reference_vae(name):
+    """VAE.partial_fit / predict (vae.py:47-266) with the recorded eps of reparametrize()."""
+    fx = Fixture(name)
+    m = build_vae_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        loss = m.partial_fit(ip, idx, val, fx.z[f"step{s}.eps"], fx.cond_inputs(s))
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=5e-6)
+        for n in VAE_NAMES:
+            for t in ("weight", "bias"):
+                k = f"{n}.{t}"
+                np.testing.assert_allclose(m.p[k], fx.z[f"step{s}.{k}"], atol=TOL_PARAM, rtol=0, err_msg=f"{name} {s} {k}")
+                assert m.opt.t[k] == float(fx.z[f"step{s}.A.{k}.t"])
+                np.testing.assert_allclose(m.opt.m[k], fx.z[f"step{s}.A.{k}.m"], atol=2e-8, rtol=2e-4)
+                np.testing.assert_allclose(m.opt.v[k], fx.z[f"step{s}.A.{k}.v"], atol=1e-12, rtol=2e-4)
+    ip, idx, val = fx.batch(0, prefix="predict")
+    out = m.predict(ip, idx, val, fx.z["predict.eps"], fx.cond_inputs(0, prefix="predict"))
+    np.testing.assert_allclose(out, fx.z["predict.out"], atol=2e-6)

@@ -342,3 +342,54 @@ def test_denoising_autoencoder_step_matches_reference():
         check_state(fx, m, s, "dae")
     pcsr = csr_of(fx, m, 0, prefix="predict")
     np.testing.assert_allclose(m.predict(pcsr, 0, pcsr.shape[0]).cpu().numpy(), fx.z["predict.out"], atol=TOL_RECON)
+
+
+def _vae_params(fx, prefix):
+    g = lambda n, t: fx.z[f"{prefix}.{n}.{t}"]                                      # noqa: E731
+    return {"enc.lin1.weight": g("fc1", "weight"), "enc.lin1.bias": g("fc1", "bias"),
+            "enc.lin3.weight": np.vstack([g("fc21", "weight"), g("fc22", "weight")]),
+            "enc.lin3.bias": np.concatenate([g("fc21", "bias"), g("fc22", "bias")]),
+            "dec.lin1.weight": g("fc3", "weight"), "dec.lin1.bias": g("fc3", "bias"),
+            "dec.lin3.weight": g("fc4", "weight"), "dec.lin3.bias": g("fc4", "bias")}
+
+
+@pytest.mark.parametrize("name", ["step_vae", "step_vae_cond"])
+def test_vae_step_matches_reference(name):
+    """aae_vae_step / aae_vae_predict (VAE, reference vae.py:47-266) with the recorded eps of reparametrize():
+    loss = (mean BCE + KL sum) / B as the reference logs it, all five Linears and their Adam moments after every
+    step.  ENC_W3 holds [fc21; fc22]."""
+    from aaerec._hip import HipAAE
+    fx = Fixture(name)
+    c = fx.cfg
+    m = HipAAE(c["N"], c["h"], c["c"], cond_inc=c["cond_inc"], max_batch=c["B"], rng_mode="inject", gen_lr=c["gen_lr"],
+               reg_lr=c["gen_lr"], dropout=(0.0, 0.0), vae=True)
+    m.load_params(_vae_params(fx, "init"))
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = fx.cond_inputs(s)
+        cond_t = torch.as_tensor(cond[0], device=m.device) if cond else None
+        m.vae_step(csr, 0, B, cond=cond_t, eps=fx.z[f"step{s}.eps"])
+        l = m.losses()
+        np.testing.assert_allclose((l[0] + l[1]) / B, fx.z[f"step{s}.losses"][0], rtol=2e-5)
+        got, want = m.state_dict(), _vae_params(fx, f"step{s}")
+        for k, w in want.items():
+            np.testing.assert_allclose(got[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} step {s} {k}")
+        enc, dec = m.adam_state("enc"), m.adam_state("dec")
+        for st, key, names in ((enc, "lin1", ("fc1",)), (enc, "lin3", ("fc21", "fc22")), (dec, "lin1", ("fc3",)),
+                               (dec, "lin3", ("fc4",))):
+            for t, idx in (("weight", 0), ("bias", 1)):
+                em = np.concatenate([fx.z[f"step{s}.A.{n}.{t}.m"] for n in names])
+                ev = np.concatenate([fx.z[f"step{s}.A.{n}.{t}.v"] for n in names])
+                gm, gv = st[f"{key}.{t}"]
+                np.testing.assert_allclose(gm, em, atol=2e-8, rtol=2e-4, err_msg=f"{name} {s} m {key}.{t}")
+                np.testing.assert_allclose(gv, ev, atol=1e-12, rtol=2e-4, err_msg=f"{name} {s} v {key}.{t}")
+            assert st["step"] == float(fx.z[f"step{s}.A.{names[0]}.weight.t"])
+    pcsr = csr_of(fx, m, 0, prefix="predict")
+    pc = fx.cond_inputs(0, prefix="predict")
+    pc_t = torch.as_tensor(pc[0], device=m.device) if pc else None
+    out = m.vae_predict(pcsr, 0, pcsr.shape[0], cond=pc_t, eps=fx.z["predict.eps"]).cpu().numpy()
+    np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)
+    from aaerec._hip import AaeHipError
+    with pytest.raises(AaeHipError):
+        m.vae_step(csr, 0, B, cond=cond_t, eps=None)        # inject mode needs eps

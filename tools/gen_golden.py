@@ -28,6 +28,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -649,6 +650,112 @@ def gen_dae():
     print("e2e_dae_short written")
 
 
+def gen_vae():
+    """The reference's VAE (vae.py:47-266): step_vae.npz (no condition) and step_vae_cond.npz (30-d constant
+    concatenated condition): recorded eps of reparametrize(), losses (loss.item() / B as the reference logs it),
+    parameters and Adam state after every step, a (stochastic: eps recorded) predict; e2e_vae_short.npz: 3
+    epochs of VAE.fit on the C1 corpus and the eps-free part of the prediction pipeline (mu of the first rows)."""
+    _, ref_cond = import_reference()
+    import aaerec.vae as ref_vae
+    names = ("fc1", "fc21", "fc22", "fc3", "fc4")
+
+    def run(name, seed, cond):
+        N, h, c, B, steps, lr = 300, 20, 10, 16, 3, 2e-3
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(5000 + seed)
+        conditions, inc = None, 0
+        if cond:
+            class ConstConcat(ref_cond.ConcatenationBasedConditioning):
+                def size_increment(self):
+                    return 30
+
+                def encode(self, inputs):
+                    return torch.as_tensor(inputs, dtype=torch.float32)
+            conditions, inc = ref_cond.ConditionList([("title", ConstConcat())]), 30
+        m = ref_vae.VAE(N, N, n_hidden=h, n_code=c, lr=lr, batch_size=B, n_epochs=1, conditions=conditions,
+                        verbose=True, device=torch.device("cpu"))
+        eps_log, loss_log = [], []
+        orig_randn_like = torch.randn_like
+
+        def rec_randn_like(*a, **k):
+            e = orig_randn_like(*a, **k)
+            eps_log.append(e.detach().numpy().copy())
+            return e
+        ref_vae.log_losses = lambda l: loss_log.append(l)
+        out = {}
+        cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="concat30" if cond else "", cond_inc=inc, n_hidden=h,
+                   n_code=c, vae=1, gen_lr=lr, reg_lr=lr, dropout=[0.0, 0.0])
+        for n in names:
+            lin = getattr(m, n)
+            out[f"init.{n}.weight"] = lin.weight.detach().numpy().copy()
+            out[f"init.{n}.bias"] = lin.bias.detach().numpy().copy()
+        torch.randn_like = rec_randn_like
+        try:
+            for s in range(steps):
+                X = make_batch(rng, B, N)
+                out[f"step{s}.indptr"] = X.indptr.astype(np.int64)
+                out[f"step{s}.indices"] = X.indices.astype(np.int32)
+                out[f"step{s}.values"] = X.data.astype(np.float32)
+                cb = None
+                if cond:
+                    cv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+                    out[f"step{s}.cond0"] = cv
+                    cb = [cv]
+                m.partial_fit(X, condition_data=cb)
+                out[f"step{s}.eps"] = eps_log[-1]
+                out[f"step{s}.losses"] = np.asarray([loss_log[-1], 0.0, 0.0], dtype=np.float64)   # (BCE + KLD) / B
+                params = list(m.parameters())
+                for n in names:
+                    lin = getattr(m, n)
+                    out[f"step{s}.{n}.weight"] = lin.weight.detach().numpy().copy()
+                    out[f"step{s}.{n}.bias"] = lin.bias.detach().numpy().copy()
+                    for tag, t in (("weight", lin.weight), ("bias", lin.bias)):
+                        st = m.optimizer.state[t]
+                        out[f"step{s}.A.{n}.{tag}.m"] = st["exp_avg"].numpy().copy()
+                        out[f"step{s}.A.{n}.{tag}.v"] = st["exp_avg_sq"].numpy().copy()
+                        out[f"step{s}.A.{n}.{tag}.t"] = np.asarray(float(st["step"]))
+            Xp = make_batch(rng, B, N)
+            out["predict.indptr"] = Xp.indptr.astype(np.int64)
+            out["predict.indices"] = Xp.indices.astype(np.int32)
+            out["predict.values"] = Xp.data.astype(np.float32)
+            pc = None
+            if cond:
+                pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+                out["predict.cond0"] = pcv
+                pc = [pcv]
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                out["predict.out"] = m.predict(Xp, condition_data=pc).astype(np.float32)
+            out["predict.eps"] = eps_log[-1]
+        finally:
+            torch.randn_like = orig_randn_like
+        out["config_json"] = np.asarray(json.dumps(cfg))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(f"{name}: losses {[round(float(l), 5) for l in loss_log]}")
+    run("step_vae", 51, False)
+    run("step_vae_cond", 52, True)
+    # 3 epochs of fit() on the C1 corpus with the reference's seeds; predict() itself is stochastic, so the pinned
+    # quantity is the encoder mean of the first rows (deterministic given the trained weights)
+    z = np.load(os.path.join(OUT, "e2e_c1.npz"))
+    Nc = int(z["N"])
+
+    def csr(ip, idx):
+        return sp.csr_matrix((np.ones(len(idx)), idx, ip), shape=(len(ip) - 1, Nc))
+    Xtr, Xin = csr(z["train_indptr"], z["train_indices"]), csr(z["in_indptr"], z["in_indices"])
+    torch.manual_seed(7)
+    np.random.seed(7)
+    v = ref_vae.VAE(Nc, Nc, n_hidden=50, n_code=50, n_epochs=3, batch_size=100, lr=0.01, verbose=False,
+                    device=torch.device("cpu"))
+    v.fit(Xtr)
+    with torch.no_grad():
+        x = torch.as_tensor(Xin[:40].toarray(), dtype=torch.float32)
+        mu, logvar = v.encode(F.normalize(x, 1))
+        recon_mu = v.decode(mu)                       # the prediction with eps = 0
+    np.savez_compressed(os.path.join(OUT, "e2e_vae_short.npz"), mu=mu.numpy(), logvar=logvar.numpy(),
+                        recon_mu=recon_mu.numpy().astype(np.float32), seed=np.asarray(7))
+    print("e2e_vae_short written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_aae, ref_cond = import_reference()
@@ -686,6 +793,8 @@ def main():
         run_decoding_case(ref_aae, ref_cond, "step_decoding_trainable", seed=32, incs=(8, 10), trainable=True)
     if want("dae"):
         gen_dae()
+    if want("vae"):
+        gen_vae()
     if want("metrics"):
         gen_metric_known_answers()
     if want("e2e"):
