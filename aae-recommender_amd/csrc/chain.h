@@ -19,7 +19,12 @@ namespace aae {
 constexpr int kCR = 16;        // rows per workgroup
 constexpr int kCL = 212;       // slot row stride (floats): widths up to 208, 16-byte aligned rows
 constexpr int kCSlots = 10;
-constexpr int kCT = 512;       // threads per workgroup (8 waves)
+constexpr int kCT = 1024;      // threads per workgroup
+constexpr int kCW = kCT / 64;  // waves: 16 (one 16-column block of a layer per wave) or 8 (two blocks per wave)
+constexpr int kCQ = (13 + kCW - 1) / kCW;   // blocks per wave (N <= 208 -> 13 blocks)
+constexpr int kTPR = kCT / 16; // threads per row of the 16-row block in element-wise work
+constexpr int kRS = kCT == 1024 ? 6 : 5;    // log2(kTPR)
+constexpr int kJ = 64 / kTPR;  // float4 column groups per thread (64 float4 = 256 columns per row)
 constexpr int kCMaxOps = 16;
 
 enum { COP_LOAD = 0,        // dst <- global src [rows][lds_] cols [0, N)            (zero padded)
@@ -123,25 +128,25 @@ __device__ __forceinline__ float chain_epi(const EpiCtx& c, int grow, int lrow, 
 }
 
 // Element-wise work on a 16-row block uses a fixed thread -> (row, float4 column) map:
-// row = tid >> 5, column group c4 = (tid & 31) + 32*j (j = 0, 1): 64 float4 = 256 columns, no
+// row = tid >> kRS, column group c4 = (tid & (kTPR-1)) + kTPR*j (j < kJ): 64 float4 = 256 columns, no
 // integer division, and both of a thread's global loads are in flight before the first use (a
 // scalar element loop is a chain of dependent L2 round trips, ~1 us each).
 __device__ __forceinline__ void chain_load_block(const float* __restrict__ g, int ld, int row0, int nrows, int N,
                                                  float* dst, int dst_col0, float scale) {
-    const int tid = threadIdx.x, lrow = tid >> 5;
+    const int tid = threadIdx.x, lrow = tid >> kRS;
     const bool vec = (ld & 3) == 0 && (dst_col0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     const int rowc = min(lrow, max(nrows, 1) - 1);
     const int nf4 = (N + 3) >> 2;
     if (vec) {
         float4 v[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c4 = min((tid & 31) + 32 * j, nf4 - 1);
+        for (int j = 0; j < kJ; ++j) {
+            const int c4 = min((tid & (kTPR - 1)) + kTPR * j, nf4 - 1);
             v[j] = *reinterpret_cast<const float4*>(g + (size_t)(row0 + rowc) * ld + c4 * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c4 = (tid & 31) + 32 * j;
+        for (int j = 0; j < kJ; ++j) {
+            const int c4 = (tid & (kTPR - 1)) + kTPR * j;
             if (c4 * 4 + dst_col0 < kCL) {                  // also clears the tail of the slot row
                 const bool ok = lrow < nrows;
                 float4 o;
@@ -153,7 +158,7 @@ __device__ __forceinline__ void chain_load_block(const float* __restrict__ g, in
             }
         }
     } else {
-        for (int col = tid & 31; col + dst_col0 < kCL; col += 32)
+        for (int col = tid & (kTPR - 1); col + dst_col0 < kCL; col += kTPR)
             dst[lrow * kCL + dst_col0 + col] =
                 (lrow < nrows && col < N) ? g[(size_t)(row0 + lrow) * ld + col] * scale : 0.f;
     }
@@ -162,18 +167,18 @@ __device__ __forceinline__ void chain_load_block(const float* __restrict__ g, in
 // LDS slot [16][0:N) -> global rows
 __device__ __forceinline__ void chain_store_block(const float* src, int nrows, int N, float* __restrict__ g, int ld,
                                                   int row0) {
-    const int tid = threadIdx.x, lrow = tid >> 5;
+    const int tid = threadIdx.x, lrow = tid >> kRS;
     if (lrow >= nrows) return;
     if ((ld & 3) == 0 && (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c4 = (tid & 31) + 32 * j;
+        for (int j = 0; j < kJ; ++j) {
+            const int c4 = (tid & (kTPR - 1)) + kTPR * j;
             if (c4 * 4 < N)
                 *reinterpret_cast<float4*>(g + (size_t)(row0 + lrow) * ld + c4 * 4) =
                     *reinterpret_cast<const float4*>(src + lrow * kCL + c4 * 4);
         }
     } else {
-        for (int col = tid & 31; col < N; col += 32) g[(size_t)(row0 + lrow) * ld + col] = src[lrow * kCL + col];
+        for (int col = tid & (kTPR - 1); col < N; col += kTPR) g[(size_t)(row0 + lrow) * ld + col] = src[lrow * kCL + col];
     }
 }
 
@@ -267,9 +272,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             // output blocks of 16 columns: wave w takes blocks w, w+8 (N <= 208 -> <= 13 blocks)
             const int nblk = (op.N + 15) >> 4;
             f32x4 acc[2];
-            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int b0 = min(wave, nblk - 1), b1 = min(wave + 8, nblk - 1);
-            const bool two = nblk > 8;
+            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (acc[1] unused when a wave owns one block)
+            const int b0 = min(wave, nblk - 1), b1 = min(wave + kCW, nblk - 1);
+            const bool two = kCQ > 1 && nblk > kCW;
             const EpiCtx ec = chain_epi_ctx(op.epi, op, P, key, slots);
             const int epiN = chain_pin(op.N);
             if (!(P.dbg & 1) && wave < nblk) {          // waves without a block (narrow layers) only meet the barriers
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
             chain_barrier();      // dst may alias a slot other waves were still reading (src != dst is required)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int blk = wave + 8 * q;
+            for (int q = 0; q < kCQ; ++q) {
+                const int blk = wave + kCW * q;
                 if (blk < nblk) {
                     const int col = blk * 16 + fr;
 #pragma unroll
@@ -303,17 +308,17 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
             // columns [16*nblk, kCL) must read as zero for the next layer's k-padding
             {
-                const int c0 = nblk * 16, lrow = tid >> 5;
-                for (int col = c0 + (tid & 31); col < kCL; col += 32) dst[lrow * kCL + col] = 0.f;
+                const int c0 = nblk * 16, lrow = tid >> kRS;
+                for (int col = c0 + (tid & (kTPR - 1)); col < kCL; col += kTPR) dst[lrow * kCL + col] = 0.f;
             }
         } else if (kind == COP_LOAD) {
             chain_load_block(op.W, op.ldw, op.out_row0 + r0, nrows, op.N, dst, op.dst_col0, op.scale);
         } else if (kind == COP_SLABSUM) {
             // sum of op.aux (<= 16) partial slabs: every slab load of a thread is in flight at once
-            const int lrow = tid >> 5, rowc = min(lrow, max(nrows, 1) - 1), nf4 = (op.N + 3) >> 2;
+            const int lrow = tid >> kRS, rowc = min(lrow, max(nrows, 1) - 1), nf4 = (op.N + 3) >> 2;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c4 = (tid & 31) + 32 * j, c4c = min(c4, nf4 - 1);
+            for (int j = 0; j < kJ; ++j) {
+                const int c4 = (tid & (kTPR - 1)) + kTPR * j, c4c = min(c4, nf4 - 1);
                 float4 v[16];
 #pragma unroll
                 for (int z = 0; z < 16; ++z)
@@ -333,13 +338,13 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
         } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
             const EpiCtx ec = chain_epi_ctx(kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD, op, P, key, slots);
             const int epiN = chain_pin(op.N);
-            const int lrow = tid >> 5;
-            for (int col = tid & 31; col < kCL; col += 32)
+            const int lrow = tid >> kRS;
+            for (int col = tid & (kTPR - 1); col < kCL; col += kTPR)
                 dst[lrow * kCL + col] = (lrow < nrows && col < epiN)
                     ? chain_epi(ec, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
         } else if (kind == COP_FINAL_FWD) {
             // one wave per pair of rows; softmax / sigmoid / identity over N columns, in place on dst
-            for (int lrow = wave; lrow < kCR; lrow += 8) {
+            for (int lrow = wave; lrow < kCR; lrow += kCW) {
                 float* zr = dst + lrow * kCL;
                 if (op.aux == 1) {
                     float mx = -INFINITY;
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
         } else if (kind == COP_FINAL_BWD) {
             const float* zs = slots + op.yslot * kCR * kCL;
-            for (int lrow = wave; lrow < kCR; lrow += 8) {
+            for (int lrow = wave; lrow < kCR; lrow += kCW) {
                 const float* zr = zs + lrow * kCL;
                 const float* gr = src + lrow * kCL;
                 float* o = dst + lrow * kCL;
@@ -371,8 +376,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 }
             }
         } else if (kind == COP_REPARAM) {
-            const int lrow = tid >> 5, n = op.N;
-            for (int col = tid & 31; col < kCL; col += 32) {
+            const int lrow = tid >> kRS, n = op.N;
+            for (int col = tid & (kTPR - 1); col < kCL; col += kTPR) {
                 float zv = 0.f;
                 if (lrow < nrows && col < n) {
                     float eps;
@@ -393,9 +398,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
         } else if (kind == COP_REPARAM_BWD) {
             const float* ml = slots + op.yslot * kCR * kCL;
-            const int lrow = tid >> 5, n = op.N >> 1;          // op.N = 2n columns are produced (and stored)
+            const int lrow = tid >> kRS, n = op.N >> 1;          // op.N = 2n columns are produced (and stored)
             float kl = 0.f;
-            for (int col = tid & 31; col < kCL; col += 32) {
+            for (int col = tid & (kTPR - 1); col < kCL; col += kTPR) {
                 float o = 0.f;
                 if (lrow < nrows && col < 2 * n) {
                     const int j = col < n ? col : col - n;
