@@ -393,3 +393,47 @@ def test_vae_step_matches_reference(name):
     from aaerec._hip import AaeHipError
     with pytest.raises(AaeHipError):
         m.vae_step(csr, 0, B, cond=cond_t, eps=None)        # inject mode needs eps
+
+
+@pytest.mark.parametrize("N,h,c,B,inc", [(3000, 200, 50, 100, 0), (2500, 100, 50, 37, 30), (2000, 207, 120, 64, 0)])
+def test_layer_chain_equals_per_layer_path_at_headline_width(N, h, c, B, inc):
+    """The row-blocked layer-chain kernel (chain.h: every hidden layer of the three phases, 13 column blocks at
+    h = 200) against the per-layer GEMM path (AAE_NO_CHAIN=1 at creation; the path the small golden fixtures were
+    first pinned on), at widths the fixtures do not reach, with dropout masks, a condition block and a ragged
+    last row block."""
+    import os
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle.dense_torch_port import init_params
+    from tools.synth import throughput_corpus
+    X = throughput_corpus(3 * B, N, median_len=12, max_len=60, seed=4)
+    params = init_params(N, h, c, seed=2, cond_inc=inc) if inc else init_params(N, h, c, seed=2)
+    rng = np.random.default_rng(1)
+    models = []
+    for no_chain in (False, True):
+        if no_chain:
+            os.environ["AAE_NO_CHAIN"] = "1"
+        try:
+            m = HipAAE(N, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", dropout=(0.2, 0.2), gen_lr=2e-3,
+                       reg_lr=1e-3)
+        finally:
+            os.environ.pop("AAE_NO_CHAIN", None)
+        m.load_params(params)
+        models.append(m)
+    csr = [DeviceCSR(X, m.device) for m in models]
+    for s in range(3):
+        masks = [(rng.random((B, h)) > 0.2).astype(np.uint8) for _ in range(12)]
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        cond = torch.as_tensor(rng.standard_normal((B, inc)).astype(np.float32) * 0.3) if inc else None
+        out = []
+        for m, cs in zip(models, csr):
+            m.step(cs, s * B, B, masks=masks, z_real=zr, cond=None if cond is None else cond.to(m.device))
+            out.append(m.losses())
+        np.testing.assert_allclose(out[0], out[1], rtol=3e-6, atol=1e-7, err_msg=f"step {s}")
+    a, b = models[0].state_dict(), models[1].state_dict()
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], atol=3e-6, rtol=0, err_msg=k)
+    for which in ("enc", "gen", "dec", "disc"):
+        sa, sb = models[0].adam_state(which), models[1].adam_state(which)
+        for k in ("lin2.weight", "lin3.weight", "lin1.bias"):
+            np.testing.assert_allclose(sa[k][0], sb[k][0], atol=2e-9, rtol=2e-4, err_msg=f"{which} m {k}")
+            np.testing.assert_allclose(sa[k][1], sb[k][1], atol=1e-13, rtol=2e-4, err_msg=f"{which} v {k}")
