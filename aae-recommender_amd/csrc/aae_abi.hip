@@ -186,7 +186,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
-        m->max_slabs = std::max(1, std::min(128, 512 / tiles));
+        m->max_slabs = std::max(1, std::min(128, 2048 / tiles));
         // the fused decoder kernel writes one dA2 slab per workgroup (<= 304 CUs assumed for sizing)
         int nslab = m->max_slabs;
         if (R <= 16 * kMB && dec_fused_lds_bytes(R, h) <= 160 * 1024) nslab = std::max(nslab, 304 + 16);
@@ -1232,14 +1232,14 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // dA2 = G * V3 (K = N items, split-K slabs), then back through act2/drop2
     {
         int tiles = ((B + 63) / 64) * ((h + 63) / 64);
-        int splits = std::max(1, std::min(m->max_slabs, 512 / tiles));
+        int splits = std::max(1, std::min(m->max_slabs, 2048 / tiles));
         int kps = ((N + splits - 1) / splits + 63) / 64 * 64;
         splits = (N + kps - 1) / kps;
         GemmShape g{m->G.p, m->P[P_V3].p, B, h, N, m->ldn, m->ldh, kps};
         EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
         {
             ProfScope ps(m, AAE_K_DEC_DA2, s);
-            (void)launch_gemm<0, 0, 64, 64>(g, e, splits, s);
+            (void)launch_gemm<0, 0, 16, 64>(g, e, splits, s);
         }
         LAUNCHCHK("dA2 gemm");
         hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
