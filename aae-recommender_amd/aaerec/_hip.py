@@ -496,7 +496,10 @@ class HipAAE:
     def set_grad_scale(self, scale):
         _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=True, kernels=None):
+        """kernels: iterable of kernel ids to time (None = all)."""
+        if on and kernels is not None:
+            on = sum(1 << (k + 1) for k in kernels)
         _check(self.lib.aae_profile_enable(self.handle, int(on)))
 
     def profile_read(self, kernel_id):

@@ -100,7 +100,7 @@ struct aae_model {
     BatchView bv; bool have_batch; int rows; int phase;
     aae_rng_inject inj;      // randomness of the running step (inject mode)
     // optional per-kernel timing (hipEvent pairs on the launch stream)
-    bool prof_on;
+    bool prof_on; unsigned prof_mask;   // bit k: time kernel id k
     std::vector<std::pair<hipEvent_t, hipEvent_t>>* prof_ev;   // [AAE_K_N]
     size_t prof_used[8];
 };
@@ -232,7 +232,7 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 // scoped hipEvent pair around one kernel launch when profiling is enabled
 struct ProfScope {
     aae_model* m; int k; hipStream_t s; bool on;
-    ProfScope(aae_model* m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_), on(m_->prof_on) {
+    ProfScope(aae_model* m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_), on(m_->prof_on && ((m_->prof_mask >> k_) & 1)) {
         if (!on) return;
         auto& v = m->prof_ev[k];
         if (m->prof_used[k] == v.size()) {
@@ -534,7 +534,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         unsigned long long h[32];
         hipStreamSynchronize(s);
         hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD"};
+        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "PRIOR"};
         fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
         for (int i = 0; i < cb.P.nops; ++i)
             fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
@@ -748,7 +748,12 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
         ChainBuilder cb(m, 2 * B);
         cb.P.loss_slot = 1;
-        ChainOp& l = cb.add(cop_load(m->zin.p, m->ldz, 0, c)); l.one_col = c;
+        // rows [0, B): z_real drawn (or injected) right here; rows [B, 2B): z_fake of the program above
+        ChainOp& l = cb.add(cop(COP_PRIOR, 0, 0, c)); l.one_col = c;
+        l.W = m->zin.p; l.ldw = m->ldz; l.row_split = B; l.aux = m->cfg.prior;
+        l.scale = m->cfg.has_prior_scale ? m->cfg.prior_scale : 1.0f;
+        l.aux_ptr = m->cfg.rng_mode == AAE_RNG_DEVICE ? nullptr : const_cast<float*>(I.z_real_dev); l.aux_ld = c;
+        cop_out(l, m->zin.p, m->ldz);                      // the weight-gradient GEMM of D1 reads all 2B rows
         ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_D1], c + 1, h, CEPI_DROPACT));
         d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
         ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_D2], h + 1, h, CEPI_DROPACT));
@@ -899,6 +904,7 @@ int aae_profile_enable(aae_handle h, int on) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     if (on && !h->prof_ev) h->prof_ev = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[AAE_K_N];
     h->prof_on = on != 0;
+    h->prof_mask = on == 1 ? ~0u : ((unsigned)on >> 1);     // 1 = every kernel id; else bit (k + 1) selects id k
     return AAE_OK;
 }
 
@@ -1200,13 +1206,13 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
                     (t[12] - t[7]) * 0.01);
         }
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, m->bce_partials, grid, m->fix_partials, 0,
-                           1.0f / ((float)B * (float)N), m->losses, 0);
-        // 256+ slabs -> 16 partial slabs (stored behind the per-workgroup ones) -> sum + act'/dropout
+        // 256+ slabs -> 16 partial slabs (stored behind the per-workgroup ones) -> sum + act'/dropout; the same
+        // launch reduces the per-workgroup loss partials
         float* part = m->slabs.p + (size_t)304 * fa.slab_stride;
         const size_t n4 = (size_t)B * m->ldh / 4;
         hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
-                           fa.slab_stride, n4, part, fa.slab_stride);
+                           fa.slab_stride, n4, part, fa.slab_stride, m->bce_partials, grid,
+                           1.0f / ((float)B * (float)N), m->losses, 0);
         if (m->use_chain) {
             chain_part = part; chain_stride = fa.slab_stride;
         } else {
@@ -1395,15 +1401,17 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
     const aae_rng_inject& I = m->inj;
     const float pscale = m->cfg.has_prior_scale ? m->cfg.prior_scale : 1.0f;
     // ---- disc_step: z_real rows [0,B), z_fake = Enc_eval(X) rows [B,2B)
-    if (m->cfg.rng_mode == AAE_RNG_DEVICE) {
-        hipLaunchKernelGGL(prior_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, B, cc,
-                           m->cfg.prior, pscale, m->cfg.seed, m->step_ctr);
-    } else {
-        if (!I.z_real_dev) return fail(AAE_EINVAL, "rng_mode=inject needs z_real_dev");
-        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, I.z_real_dev, cc, m->zin.p,
-                           m->ldz, B, cc, pscale);
+    if (m->cfg.rng_mode != AAE_RNG_DEVICE && !I.z_real_dev) return fail(AAE_EINVAL, "rng_mode=inject needs z_real_dev");
+    if (!m->use_chain) {                 // (the layer-chain program draws / copies z_real itself: COP_PRIOR)
+        if (m->cfg.rng_mode == AAE_RNG_DEVICE) {
+            hipLaunchKernelGGL(prior_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, B, cc,
+                               m->cfg.prior, pscale, m->cfg.seed, m->step_ctr);
+        } else {
+            hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, I.z_real_dev, cc, m->zin.p,
+                               m->ldz, B, cc, pscale);
+        }
+        LAUNCHCHK("prior");
     }
-    LAUNCHCHK("prior");
     if (m->use_chain) {
         TRY(chain_disc_step(m, s));
         m->phase = 4;

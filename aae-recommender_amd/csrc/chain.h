@@ -39,7 +39,9 @@ enum { COP_LOAD = 0,        // dst <- global src [rows][lds_] cols [0, N)       
        COP_STORE,           // no compute: only the post-op global store(s) of dst[:, 0:N]
        COP_REPARAM,         // VAE (vae.py:115-118): src = [mu | logvar] (2N cols) -> dst[:, 0:N) = mu + eps * exp(logvar / 2);
                             //   eps: W (global [rows][ldw], injected) or the counter generator; always written to aux_ptr
-       COP_REPARAM_BWD };   // src = dL/dz (N/2 cols), yslot = [mu | logvar], eps from aux_ptr -> dst = [dL/dmu | dL/dlogvar] (N cols)
+       COP_REPARAM_BWD,
+       COP_PRIOR };         // disc_step input rows: r < row_split: z_real = prior sample (aux = kind; aux_ptr = injected draws
+                            //   [row_split][aux_ld] instead) * scale (aae.py:716-718); r >= row_split: W[r] (z_fake)   // src = dL/dz (N/2 cols), yslot = [mu | logvar], eps from aux_ptr -> dst = [dL/dmu | dL/dlogvar] (N cols)
                             //   incl. the KL term's own gradient (vae.py:141-145), whose value goes to the loss slot
 
 enum { CEPI_NONE = 0, CEPI_DROPACT = 1, CEPI_ACTBWD = 2, CEPI_SIGMOID = 3 };
@@ -374,6 +376,27 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 } else {
                     for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
                 }
+            }
+        } else if (kind == COP_PRIOR) {
+            const int lrow = tid >> kRS, grow = r0 + lrow, n = op.N;
+            const uint64_t k = key ^ (100ull * 0xA0761D6478BD642Full);
+            for (int col = tid & (kTPR - 1); col < kCL; col += kTPR) {
+                float v = 0.f;
+                if (lrow < nrows && col < n) {
+                    if (grow >= op.row_split) v = op.W[(size_t)grow * op.ldw + col];
+                    else if (op.aux_ptr) v = op.aux_ptr[(size_t)grow * op.aux_ld + col] * op.scale;
+                    else if (op.aux == 0) {          // gauss: Box-Muller on two words of the counter generator
+                        const uint32_t u1 = hash_cell(k, (uint32_t)grow, (uint32_t)(2 * col));
+                        const uint32_t u2 = hash_cell(k, (uint32_t)grow, (uint32_t)(2 * col + 1));
+                        const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+                        const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
+                        v = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2) * op.scale;
+                    } else if (op.aux == 1) {        // categorical: one-hot of a uniform class per row
+                        const uint32_t u = hash_cell(k, (uint32_t)grow, 0xFFFFFFFFu);
+                        v = ((int)(u % (uint32_t)n) == col) ? op.scale : 0.f;
+                    }                                // bernoulli: the reference's randint(0, 1) is always 0 (aae.py:86-88)
+                }
+                dst[lrow * kCL + col] = v;
             }
         } else if (kind == COP_REPARAM) {
             const int lrow = tid >> kRS, n = op.N;

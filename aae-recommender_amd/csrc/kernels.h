@@ -216,10 +216,26 @@ __global__ __launch_bounds__(256) void bce_fixup_kernel(BatchView bv, const floa
 
 // first stage of a wide slab reduction: out[g][i] = sum of the slabs z = g, g+G, g+2G, ... of element i
 // (float4 per thread, the loads of one thread are independent and stay in flight together)
+// The last workgroup also folds the fused decoder's per-workgroup loss partials into losses[slot]
+// (fixed order, double accumulation: what loss_finalize_kernel does as a launch of its own).
 __global__ __launch_bounds__(256) void slab_partial_kernel(const float* __restrict__ slabs, int nslab,
                                                            size_t slab_stride, size_t n4,
-                                                           float* __restrict__ out, size_t out_stride) {
+                                                           float* __restrict__ out, size_t out_stride,
+                                                           const float* __restrict__ loss_partials, int n_partials,
+                                                           float loss_scale, float* losses, int slot) {
     const int g = blockIdx.y, G = gridDim.y;
+    if (loss_partials && blockIdx.x == gridDim.x - 1 && g == G - 1) {
+        __shared__ double red[256];
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 256) acc += (double)loss_partials[i];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) losses[slot] = (float)(red[0] * (double)loss_scale);
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8

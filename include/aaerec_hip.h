@@ -274,6 +274,8 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_ENC_W1_ADAM,      /* Adam over the touched rows of the encoder's first layer */
        AAE_K_DEC_FUSED,        /* fused decoder output layer: logits + BCE + dV3/Adam + dA2 (B <= ~104) */
        AAE_K_N };
+/* on = 0: off; 1: every kernel id above; otherwise a selection: bit (k + 1) of `on` times kernel id k
+ * (an event pair costs a few microseconds of stream time, so a timed run selects only what it reports) */
 int aae_profile_enable(aae_handle h, int on);
 int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* launches);
 
