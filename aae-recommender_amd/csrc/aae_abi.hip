@@ -86,6 +86,7 @@ struct aae_model {
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
     float* rscale;           // [R] 1/L1 of the rows of the running batch
+    bool buckets_valid;      // the per-tile entry buckets (tstart/teb/ten/tev) describe the running batch
     // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
     bool lazy;
     // fused decoder output layer (dec_fused.h): tile-bucketed batch entries, eligibility
@@ -322,7 +323,7 @@ int set_batch(aae_model* m, const aae_batch* b) {
     if (b->nnz_bound > m->cfg.max_nnz) return fail(AAE_EINVAL, "batch nnz_bound > max_nnz");
     m->bv.indptr = b->indptr_dev; m->bv.indices = b->indices_dev; m->bv.values = b->values_dev;
     m->bv.rows = b->rows_dev; m->bv.row_start = b->row_start; m->bv.n_rows = b->n_rows;
-    m->rows = b->n_rows; m->have_batch = true;
+    m->rows = b->n_rows; m->have_batch = true; m->buckets_valid = false;
     {   // 16 entries per workgroup pass; unknown row bound -> 64 strided chunks
         int mr = b->max_row_nnz > 0 ? b->max_row_nnz : 1024;
         m->chunks = std::max(1, std::min(64, (mr + 15) / 16));
@@ -521,7 +522,7 @@ struct ChainBuilder {
 
 int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
-    const int grid = (cb.P.rows + kCR - 1) / kCR;
+    const int grid = (cb.P.rows + kCR - 1) / kCR + (cb.P.bk.enabled ? 1 : 0);
     static const bool want_ts = getenv("AAE_CHAIN_TS") != nullptr;      // debug: per-op timeline of workgroup 0
     static unsigned long long* ts_dev = nullptr;
     if (want_ts) {
@@ -577,11 +578,28 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
     cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W3], h + 1, m->c, CEPI_NONE));
 }
 
+// The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
+// as one extra workgroup (chain.h), off the critical path.
+static bool fused_decoder_applies(const aae_model* m) {
+    return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB && dec_fused_lds_bytes(m->rows, m->h) <= 160 * 1024;
+}
+static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
+    const int ntiles = (m->N + kTI - 1) / kTI;
+    const size_t need = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+    if (m->buckets_valid || !fused_decoder_applies(m) || ntiles > kBucketMaxTiles || m->rows > kBucketMaxDocs ||
+        need > (size_t)kCSlots * kCR * kCL * sizeof(float) || getenv("AAE_NO_PIGGYBACK"))
+        return;
+    BucketJob& b = cb.P.bk;
+    b.bv = m->bv; b.ntiles = ntiles; b.tstart = m->tstart; b.eb = m->teb; b.en = m->ten; b.ev = m->tev; b.enabled = 1;
+    m->buckets_valid = true;
+}
+
 // ae forward after the gather: encoder tail (+ optionally the decoder's two hidden layers)
 int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* z_out, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
+    piggyback_buckets(m, cb);
     chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p);
     ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final;
     cop_out(f, m->zc.p, m->ldc); f.out2 = m->zsave.p; f.ldo2 = m->ldz;
@@ -1155,7 +1173,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
         const int ntiles = (N + kTI - 1) / kTI;
-        if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
+        if (m->buckets_valid) {
+            // built by the extra workgroup of this step's first chain launch
+        } else if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
             const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
             hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
                                m->tev);
@@ -1168,6 +1188,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                                m->tev);
         }
         LAUNCHCHK("tile buckets");
+        m->buckets_valid = true;
         DecFusedArgs fa;
         fa.dh2 = m->dh2.p; fa.ldh = m->ldh;
         fa.V3a = m->P[P_V3].p; fa.M = m->M[0][P_V3].p; fa.V = m->V[0][P_V3].p; fa.ldv = m->ldh;

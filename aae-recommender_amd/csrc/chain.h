@@ -13,6 +13,7 @@
 #include "device_common.h"
 #include "gemm_f32.h"
 #include "kernels.h"
+#include "buckets.h"
 
 namespace aae {
 
@@ -68,6 +69,7 @@ struct ChainProgram {
     float* loss_out; int loss_slot;     // COP_ADV accumulates -mean(log ...) here (atomicAdd of per-row terms)
     int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
     unsigned long long* ts;             // debug (AAE_CHAIN_TS): per-op 100 MHz timestamps of workgroup 0, else NULL
+    BucketJob bk;                       // enabled: one extra workgroup builds the fused decoder's tile buckets
     ChainOp ops[kCMaxOps];
 };
 
@@ -256,6 +258,10 @@ __device__ __forceinline__ void chain_linear_dx(const ChainOp& op, const float* 
 
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
+    if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
+        tile_bucket_body(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;

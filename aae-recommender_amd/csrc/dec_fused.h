@@ -30,15 +30,14 @@
 #include "device_common.h"
 #include "gemm_f32.h"
 #include "kernels.h"
+#include "buckets.h"
 
 namespace aae {
 
-constexpr int kTI = 32;        // items per tile
 constexpr int kSD = 210;       // LDS row stride of dh2 / V3a images: == 2 (mod 4) and /2 odd, so the 16 rows x 2 k
                                // that one ds_read_b32 half-wave touches fall on 32 distinct banks
 constexpr int kSG = 34;        // LDS row stride of the G tile (same property for the b-major reads of GEMM3)
 constexpr int kSO = 212;       // LDS row stride of the dV3a tile (16-byte aligned rows for the float4 epilogue)
-constexpr int kMB = 7;         // 16-row blocks of the batch dimension (B <= 112)
 constexpr int kGR = 128;       // rows of the G tile in LDS: GEMM2 walks the batch in 32-row groups (rows >= B are zero)
 constexpr int kNT = 1024;      // threads per workgroup: 4 waves per SIMD hide the LDS-operand latency of the
 constexpr int kNW = kNT / 64;  // MFMA chains by wave switching (a wave's own chain is load -> wait -> MFMA)
@@ -483,86 +482,6 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(BatchView bv, const int*
         const int idx = bv.indices[e], tile = idx / kTI;
         const int pos = tstart[tile] + atomicAdd(&tcursor[tile], 1);
         eb[pos] = b; en[pos] = idx - tile * kTI; ev[pos] = bv.values[e];
-    }
-}
-
-// The same counting sort in ONE launch for batches whose tile counters fit the LDS of a workgroup (the
-// four kernels above are ~5 us of launch latency each and sit on the step's critical path).  Document
-// bounds go to LDS first so that the entries form one flat index space: every thread then needs two
-// independent global round trips per pass (indices, values) instead of a chain through indptr.
-constexpr int kBucketMaxDocs = 16 * kMB;     // the fused decoder's batch limit
-constexpr int kBucketMaxTiles = 32 * 1024;   // LDS: (tiles + 1 + docs + 1 + 1024) ints <= 160 KB
-
-__global__ __launch_bounds__(1024) void tile_bucket_kernel(BatchView bv, int ntiles, int* __restrict__ tstart,
-                                                           int* __restrict__ eb, int* __restrict__ en,
-                                                           float* __restrict__ ev) {
-    extern __shared__ int bk_lds[];
-    int* cnt = bk_lds;                               // [ntiles + 1]  histogram, then fill cursor
-    int* dbeg = cnt + ntiles + 1;                    // [docs + 1]    first flat entry of each document
-    int* part = dbeg + kBucketMaxDocs + 1;           // [1024]        scan scratch
-    __shared__ long long dlo[kBucketMaxDocs];        // CSR offset of each document's first entry
-    const int t = threadIdx.x, docs = bv.n_rows;
-    for (int i = t; i <= ntiles; i += 1024) cnt[i] = 0;
-    int len = 0;
-    if (t < docs) {
-        const int dc = bv.doc(t);
-        const long long lo = bv.indptr[dc];
-        dlo[t] = lo;
-        len = (int)(bv.indptr[dc + 1] - lo);
-    }
-    // exclusive scan of the document lengths (docs <= 112 <= 2 waves): plain Hillis-Steele in LDS
-    part[t] = len;
-    __syncthreads();
-    for (int o = 1; o < kBucketMaxDocs; o <<= 1) {
-        const int v = (t >= o && t < kBucketMaxDocs) ? part[t - o] : 0;
-        __syncthreads();
-        if (t < kBucketMaxDocs) part[t] += v;
-        __syncthreads();
-    }
-    if (t < docs) dbeg[t] = part[t] - len;
-    if (t == 0) dbeg[docs] = part[kBucketMaxDocs - 1];
-    __syncthreads();
-    const int total = dbeg[docs];
-    auto doc_of = [&](int f) {                       // largest d with dbeg[d] <= f
-        int lo = 0, hi = docs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (dbeg[mid] <= f) lo = mid; else hi = mid - 1; }
-        return lo;
-    };
-    // pass 1: histogram over the tiles
-    for (int f = t; f < total; f += 1024) {
-        const int d = doc_of(f);
-        atomicAdd(&cnt[bv.indices[dlo[d] + (f - dbeg[d])] / kTI], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the tile counters -> tstart (global) and the fill cursors (LDS)
-    const int per = (ntiles + 1023) / 1024;
-    const int lo = min(t * per, ntiles), hi = min(ntiles, lo + per);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cnt[i];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = part[t] - sum;
-    for (int i = lo; i < hi; ++i) {
-        const int c = cnt[i];
-        tstart[i] = run;
-        cnt[i] = run;
-        run += c;
-    }
-    if (t == 1023) tstart[ntiles] = part[1023];
-    __syncthreads();
-    // pass 2: fill
-    for (int f = t; f < total; f += 1024) {
-        const int d = doc_of(f);
-        const long long e = dlo[d] + (f - dbeg[d]);
-        const int idx = bv.indices[e], tile = idx / kTI;
-        const int pos = atomicAdd(&cnt[tile], 1);
-        eb[pos] = d; en[pos] = idx - tile * kTI; ev[pos] = bv.values[e];
     }
 }
 
