@@ -86,6 +86,7 @@ struct aae_model {
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
     float* rscale;           // [R] 1/L1 of the rows of the running batch
+    bool w1_merged;          // the first-layer scatter + bias update of this phase rode in the grouped dW launch
     bool buckets_valid;      // the per-tile entry buckets (tstart/teb/ten/tev) describe the running batch
     // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
     bool lazy;
@@ -323,7 +324,7 @@ int set_batch(aae_model* m, const aae_batch* b) {
     if (b->nnz_bound > m->cfg.max_nnz) return fail(AAE_EINVAL, "batch nnz_bound > max_nnz");
     m->bv.indptr = b->indptr_dev; m->bv.indices = b->indices_dev; m->bv.values = b->values_dev;
     m->bv.rows = b->rows_dev; m->bv.row_start = b->row_start; m->bv.n_rows = b->n_rows;
-    m->rows = b->n_rows; m->have_batch = true; m->buckets_valid = false;
+    m->rows = b->n_rows; m->have_batch = true; m->buckets_valid = false; m->w1_merged = false;
     {   // 16 entries per workgroup pass; unknown row bound -> 64 strided chunks
         int mr = b->max_row_nnz > 0 ? b->max_row_nnz : 1024;
         m->chunks = std::max(1, std::min(64, (mr + 15) / 16));
@@ -559,8 +560,21 @@ struct DwBuilder {
         J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
         tiles += ((J.M + 31) / 32) * J.tiles_n;
     }
+    // the first encoder layer's scatter + bias update of optimiser `which` ride along (their sparse-row Adam follows
+    // as a launch of its own: encoder_first_layer_update(..., merged = true))
+    void add_first_layer(aae_model* m, const float* ga1, int which) {
+        const int set = (which == O_GEN) ? 1 : 0;
+        W1Job& w = g.w1;
+        w.enabled = 1; w.bv = m->bv; w.ga1 = ga1; w.ld = m->ldh; w.h = m->h; w.rows = m->rows;
+        w.rscale = m->rscale; w.gW1T = m->Gr[P_W1T].p; w.ldw = m->ldw1; w.ny = m->chunks * 4;
+        w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
+        w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
+        w.ncol = (m->h + 63) / 64;
+    }
     int launch(hipStream_t s) {
-        hipLaunchKernelGGL(grouped_dw_kernel, dim3(tiles), dim3(256), 0, s, g);
+        int blocks = tiles;
+        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.rows * g.w1.ny + g.w1.ncol; }
+        hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
         return AAE_OK;
     }
@@ -674,16 +688,18 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
 }
 
 // first encoder layer's weight gradient (sparse scatter), bias gradient and their optimiser
-int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStream_t s) {
+int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStream_t s, bool merged = false) {
     const int B = m->rows, h = m->h;
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    if (!merged) {
     hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
                        m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
                        m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
     LAUNCHCHK("colsum_adam");
+    }
     if (exportg) return AAE_OK;        // data parallel: aae_w1_export / exchange / aae_w1_import follow
     {
         ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
@@ -825,8 +841,9 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     DwBuilder dw;
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
+    dw.add_first_layer(m, m->gb3.p, O_GEN);
     TRY(dw.launch(s));
-    return encoder_first_layer_update(m, m->gb3.p, O_GEN, s);
+    return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
 }
 
 }  // namespace
@@ -1285,6 +1302,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         DwBuilder dw;
         dw.add(m, m->gb0.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
         dw.add(m, m->gmulv.p, (int)m->gmulv.ld, m->eh1.p, m->ldh, B, P_W3, O_ENC);
+        dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
         TRY(dw.launch(s));
         m->phase = 2;
         return AAE_OK;
@@ -1300,6 +1318,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         if (enc_too) {
             dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
             dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
+            dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
             m->enc_bwd_done = true;
         }
         TRY(dw.launch(s));
@@ -1363,7 +1382,7 @@ int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, co
     const int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream);
     m->vae_bwd = false;
     if (rc != AAE_OK) return rc;
-    TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s));
+    TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
     m->phase = 0;
     return AAE_OK;
 }
@@ -1398,9 +1417,10 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
             DwBuilder dw;
             dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, m->rows, P_W3, O_ENC);
             dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, m->rows, P_W2, O_ENC);
+            dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
             TRY(dw.launch(s));
         }
-        TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s));
+        TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
         m->phase = 3;
         return AAE_OK;
     }

@@ -89,26 +89,52 @@ __global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__
 // atomics run at full rate for).  zero != 0: store zeros instead (resets the touched rows after
 // the optimiser consumed them).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
-                                                          int h, const float* __restrict__ rscale,
-                                                          float* __restrict__ gW1T, int ldw, int zero) {
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void enc_scatter_body(const BatchView& bv, const float* __restrict__ ga1, int ld, int h,
+                                                 const float* __restrict__ rscale, float* __restrict__ gW1T, int ldw,
+                                                 int zero, int b, int by, int ny) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
     const float s = zero ? 0.f : rscale[b];
-    for (int64_t e0 = lo + 4 * (int64_t)blockIdx.y; e0 < hi; e0 += 4 * (int64_t)gridDim.y) {
-        {
-            const int64_t e = e0 + wave;
-            if (e >= hi) break;
-            const int idx = bv.indices[e];
-            const float x = bv.values[e] * s;
-            float* dst = gW1T + (size_t)idx * ldw;
-            for (int c = lane; c < h; c += 64) {
-                if (zero) dst[c] = 0.f;
-                else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
-            }
+    for (int64_t e0 = lo + 4 * (int64_t)by; e0 < hi; e0 += 4 * (int64_t)ny) {
+        const int64_t e = e0 + wave;
+        if (e >= hi) break;
+        const int idx = bv.indices[e];
+        const float x = bv.values[e] * s;
+        float* dst = gW1T + (size_t)idx * ldw;
+        for (int c = lane; c < h; c += 64) {
+            if (zero) dst[c] = 0.f;
+            else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
+                                                          int h, const float* __restrict__ rscale,
+                                                          float* __restrict__ gW1T, int ldw, int zero) {
+    enc_scatter_body(bv, ga1, ld, h, rscale, gW1T, ldw, zero, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// bias gradient of the first encoder layer for 64 columns, 256 threads (4 waves stride the rows), then its
+// optimiser update or export: the body of colsum_adam_kernel for use inside the grouped update launch
+__device__ __forceinline__ void colsum_adam_body(const float* __restrict__ ga, int rows, int h, int ld, float* p,
+                                                 float* m, float* v, float* gout, const OptScalars* sc, int cblock,
+                                                 float* red /* [4][64] LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cblock * 64 + lane;
+    float g = 0.f;
+    if (c < h)
+        for (int r = wave; r < rows; r += 4) g += ga[(size_t)r * ld + c];
+    red[wave * 64 + lane] = g;
+    __syncthreads();
+    if (wave != 0 || c >= h) return;
+    g = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+    if (gout) { gout[c] = g; return; }
+    const OptScalars s = *sc;
+    float pp = p[c], mm = s.is_sgd ? 0.f : m[c], vv = s.is_sgd ? 0.f : v[c];
+    adam_update(pp, mm, vv, g, s);
+    p[c] = pp;
+    if (!s.is_sgd) { m[c] = mm; v[c] = vv; }
 }
 
 // dense torch.optim.Adam/SGD over a flat tensor with a materialised gradient (K10)
