@@ -453,13 +453,14 @@ __global__ __launch_bounds__(256) void uniq_items_kernel(BatchView bv, int* __re
     }
 }
 
+// stab: the per-step scalars of steps t0+1 .. t0+nl, staged in LDS by the caller (a chain of dependent scalar
+// loads from the global table cost ~50 ns per replayed step - the whole kernel's time at 192 steps)
 __device__ __forceinline__ void lazy_replay(float& p, float& m1, float& v1, float& m3, float& v3, int t0, int upto,
-                                            const LazyTab* __restrict__ tab) {
+                                            const LazyTab* stab) {
     const int n = upto - t0;
     const int nl = n < kLazyReplay ? n : kLazyReplay;
     for (int j = 1; j <= nl; ++j) {
-        const int tt = t0 + j;
-        const LazyTab T = tab[tt < kLazyTabCap ? tt : kLazyTabCap - 1];
+        const LazyTab T = stab[j - 1];
         m1 = m1 + 0.1f * (0.f - m1);
         v1 = v1 * 0.999f;
         p = p + (T.nss_gen * m1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v1) * T.ibc2 + 1e-8f);
@@ -484,16 +485,20 @@ __global__ __launch_bounds__(256) void w1_catchup_kernel(const int* __restrict__
                                                          float* __restrict__ V3, int ld, int h,
                                                          const LazyTab* __restrict__ tab, const long long* step_ctr,
                                                          int upto_off) {
+    __shared__ LazyTab stab[kLazyReplay];
     const int upto = (int)*step_ctr + upto_off;
     const int cnt = ulist ? *ucount : n_rows_all;
     for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
         const int row = ulist ? ulist[r] : r;
         const int t0 = tsync[row];
         if (t0 < upto) {
+            const int nl = min(upto - t0, kLazyReplay);
+            for (int j = threadIdx.x; j < nl; j += 256) stab[j] = tab[min(t0 + 1 + j, kLazyTabCap - 1)];
+            __syncthreads();
             for (int c = threadIdx.x; c < h; c += 256) {
                 const size_t o = (size_t)row * ld + c;
                 float p = W[o], m1 = M1[o], v1 = V1[o], m3 = M3[o], v3 = V3[o];
-                lazy_replay(p, m1, v1, m3, v3, t0, upto, tab);
+                lazy_replay(p, m1, v1, m3, v3, t0, upto, stab);
                 W[o] = p; M1[o] = m1; V1[o] = v1; M3[o] = m3; V3[o] = v3;
             }
         }
