@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void adv_loss_kernel(const float* __restrict__
 // touched rows.
 // ---------------------------------------------------------------------------------------
 constexpr int kLazyReplay = 192;
-constexpr int kLazyTabCap = 65536;   // beyond it bc1 = bc2 = 1 exactly in fp32: the last row is the limit
+constexpr int kLazyTabCap = 65536;   // ring of the last 65536 steps' scalars (power of two; a replay reads <= kLazyReplay of them,
+                                     // so a learning rate changed by aae_set_lr at any step is honoured)
 
 struct LazyTab { float nss_gen, nss_reg, ibc2, pad; };   // per step t: -lr_gen/bc1, -lr_reg/bc1, 1/sqrt(bc2)
 
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256) void w1_catchup_kernel(const int* __restrict__
         const int t0 = tsync[row];
         if (t0 < upto) {
             const int nl = min(upto - t0, kLazyReplay);
-            for (int j = threadIdx.x; j < nl; j += 256) stab[j] = tab[min(t0 + 1 + j, kLazyTabCap - 1)];
+            for (int j = threadIdx.x; j < nl; j += 256) stab[j] = tab[(t0 + 1 + j) & (kLazyTabCap - 1)];
             __syncthreads();
             for (int c = threadIdx.x; c < h; c += 256) {
                 const size_t o = (size_t)row * ld + c;
@@ -676,9 +677,10 @@ __global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab
         s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
     sc[i] = s;
-    if (tab && s.t < kLazyTabCap) {        // optimiser 0 = enc_optim (gen_lr), 2 = gen_optim (reg_lr)
-        if (i == 0) { tab[s.t].nss_gen = s.neg_step_size; tab[s.t].ibc2 = s.inv_bc2_sqrt; }
-        if (i == 2) tab[s.t].nss_reg = s.neg_step_size;
+    if (tab) {                             // optimiser 0 = enc_optim (gen_lr), 2 = gen_optim (reg_lr)
+        const int slot = (int)(s.t & (kLazyTabCap - 1));
+        if (i == 0) { tab[slot].nss_gen = s.neg_step_size; tab[slot].ibc2 = s.inv_bc2_sqrt; }
+        if (i == 2) tab[slot].nss_reg = s.neg_step_size;
     }
 }
 
