@@ -16,10 +16,10 @@
 // read + 12 B written per parameter = the 24 B/param floor of a fused Adam, and dL/dlogits
 // [B x N] never exists in HBM.  Next tile's V3a and this tile's m, v are in flight (registers)
 // while the matrix cores work; barriers order LDS only (lds_barrier) so they do not drain them.
-// All ds_read_b32 operand patterns are bank-conflict free: row-major reads by the 16 x 2 (row, k)
-// lanes of a half-wave rely on the strides (kSD, kSG == 2 mod 4, half odd), k-strided reads on
-// walking k in rows 8 apart (GEMM2) resp. on the V3a image keeping odd items 8 rows below their
-// even neighbour (GEMM3, v3_row()).
+// All LDS operand patterns are bank-conflict free: row-major operands (k contiguous) are read two k at a
+// time with ds_read_b64 and rely on the strides (kSD, kSG = 4 * odd); k-strided operands (ds_read_b32) on
+// walking k in rows 4 apart (GEMM2) resp. on the V3a image keeping items i and i + 2 four rows apart
+// (GEMM3, v3_row()).
 //
 // Debug: AAE_DEC_SKIP (phase ablation mask) and AAE_DEC_TS (100 MHz phase timeline of workgroup 0).
 //
@@ -34,19 +34,22 @@
 
 namespace aae {
 
-constexpr int kSD = 210;       // LDS row stride of dh2 / V3a images: == 2 (mod 4) and /2 odd, so the 16 rows x 2 k
-                               // that one ds_read_b32 half-wave touches fall on 32 distinct banks
-constexpr int kSG = 34;        // LDS row stride of the G tile (same property for the b-major reads of GEMM3)
+constexpr int kSD = 212;       // LDS row stride of the dh2 / V3a images: 4 * odd.  Row-major operand reads are ds_read_b64
+                               // (2 k per lane, 256 B/clk instead of the 128 B/clk of ds_read_b32 - the matrix phases
+                               // are LDS-bound: doubling GEMM1's reads costs +2.4 us per tile): 16 rows x 2 lanes x
+                               // 8 bytes of a half-wave fall on 64 distinct banks
+constexpr int kSG = 36;        // LDS row stride of the G tile (4 * odd: the same property for GEMM3's row-major reads)
 constexpr int kSO = 212;       // LDS row stride of the dV3a tile (16-byte aligned rows for the float4 epilogue)
-constexpr int kGR = 128;       // rows of the G tile in LDS: GEMM2 walks the batch in 32-row groups (rows >= B are zero)
+constexpr int kGR = 16 * kMB;  // rows of the G tile in LDS (rows >= B are zero)
 constexpr int kNT = 1024;      // threads per workgroup: 4 waves per SIMD hide the LDS-operand latency of the
 constexpr int kNW = kNT / 64;  // MFMA chains by wave switching (a wave's own chain is load -> wait -> MFMA)
 
-// LDS row of item n of the tile in the V3a image.  GEMM3 takes items (2t, 2t+1) for the two k of a
-// half-wave and reads one V3a row per k: the rows have to sit 8 (mod 16) apart for their 16 columns to
-// fall on disjoint banks at stride kSD, so odd items live 8 rows below their even neighbour.  GEMM1
-// reads 16 items = 16 distinct rows of one half of the image either way.
-__device__ __forceinline__ int v3_row(int n) { return ((n >> 1) & 7) + 16 * (n >> 4) + 8 * (n & 1); }
+// LDS row of item n of the tile in the V3a image.  GEMM3 walks the items (its k) in chunks of 8, lane fk of a
+// k-quad taking items 8c + 2fk + j (j = 0, 1: one ds_read_b64 of G feeds two MFMAs), and reads one V3a row per
+// k with ds_read_b32: the rows of fk = 0 / 1 (and 2 / 3), i.e. of items i and i + 2, have to sit 4 (mod 8) rows
+// apart for their 16 columns to fall on disjoint banks at stride kSD (4 * 212 = 16 mod 32).  Swapping bits 1 and
+// 2 of the item index does that; GEMM1 reads 16 consecutive items = 16 distinct rows (mod 16) either way.
+__device__ __forceinline__ int v3_row(int n) { return (n & ~6) | ((n & 2) << 1) | ((n & 4) >> 1); }
 
 struct TileEntries {           // CSR entries of the batch bucketed by item tile
     const int* start;          // [ntiles + 1]
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dhs = lds;                                  // [B][kSD]
     float* v3s = dhs + (size_t)a.B * kSD;              // [32][kSD]
-    float* gs = v3s + kTI * kSD;                       // [128][kSG]  logits, then dL/dlogits
+    float* gs = v3s + kTI * kSD;                       // [kGR][kSG]  logits, then dL/dlogits
     float* os = gs + kGR * kSG;                        // [32][kSO]   dV3a tile
     float* red = os + kTI * kSO;                       // [64]
     float* raw = os;                                   // [16*kMB][kSG] raw logits of the tile, between GEMM1 and GEMM2
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     const int B = a.B, K1 = a.h + 1, ldv = a.ldv;
     // k-steps rounded up to the unroll factor 4: the extra ones multiply zero padding (columns >= ldh
     // of both LDS images are zeroed once, G rows >= B are zero)
-    const int ksteps1 = ((K1 + 3) / 4 + 3) & ~3;       // GEMM1: k over the h+1 hidden columns, <= (kSD-2)/4
+    const int kch1 = (((K1 + 7) >> 3) + 1) & ~1;       // GEMM1: 8-k chunks over the h+1 hidden columns (even count;
+                                                       // columns >= ldh of both LDS images are zero), 8 * kch1 <= kSD
     const int nmb = (B + 15) >> 4;                      // 16-row blocks actually present (<= kMB)
     const int ntiles = (a.N + kTI - 1) / kTI;
     const int f4_per_row = ldv / 4;                    // ldv % 4 == 0
@@ -216,19 +220,20 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         {
             f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int id0 = wave;
-            const float* pa0 = dhs + min((id0 >> 1) * 16 + frz, B - 1) * kSD + fk;
-            const float* pb0 = v3s + v3_row((id0 & 1) * 16 + frz) * kSD + fk;
-            // groups of 4 k-steps: all 8 LDS reads of a group are issued before its 4 MFMAs; two
-            // accumulators (even / odd k-steps) break the dependent-accumulator latency
+            // k-permutation: lane (fr, fk) supplies k = 8c + 2fk + j to MFMA j of chunk c for BOTH operands, so one
+            // 8-byte LDS read per operand feeds two MFMAs; two chunks per trip, even / odd accumulators
+            const float* pa0 = dhs + min((id0 >> 1) * 16 + frz, B - 1) * kSD + 2 * fk;
+            const float* pb0 = v3s + v3_row((id0 & 1) * 16 + frz) * kSD + 2 * fk;
             f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < ksteps1; ks += 4) {
-                float x[4], y[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { x[j] = pa0[(ks + j) * 4]; y[j] = pb0[(ks + j) * 4]; }
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0], y[0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[1], y[1], c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2], y[2], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3], y[3], c1, 0, 0, 0);
+            for (int c = 0; c < kch1; c += 2) {
+                const float2 xa = *reinterpret_cast<const float2*>(pa0 + 8 * c);
+                const float2 ya = *reinterpret_cast<const float2*>(pb0 + 8 * c);
+                const float2 xb = *reinterpret_cast<const float2*>(pa0 + 8 * c + 8);
+                const float2 yb = *reinterpret_cast<const float2*>(pb0 + 8 * c + 8);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, ya.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, ya.y, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.x, yb.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.y, yb.y, c1, 0, 0, 0);
             }
             c0 += c1;
             // Epilogue = BCE with a zero target, the case of all but a handful of cells: dL/dlogit -> gs[b][n]
@@ -277,59 +282,53 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         if (do_adam && !sc.is_sgd) { load_span(a.M, tile, mreg); load_span(a.V, tile, sreg); }
         // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib, a wave owns the ids
         // wave + 16q: they share the item half ib (one G read serves them all) and differ in the column block.
-        // k runs over the batch rows in groups of 32: k-step (g, r) multiplies rows 32g + r + 8*fk.  Rows 8
-        // apart are 16 banks apart in both operands (8 * kSG = 16, 8 * kSD = 16 mod 32), so the two k of a
+        // k runs over the batch rows in groups of 16: k-step (g, j) multiplies rows 16g + j + 4*fk.  Rows 4
+        // apart are 16 banks apart in both operands (4 * kSG = 4 * kSD = 16 mod 32), so the two k of a
         // half-wave never collide; the order of the rows inside the sum is free.
         auto gemm2 = [&](auto NQ) {
             constexpr int nq = decltype(NQ)::value;
             constexpr int NA = nq == 1 ? 2 : 1;                       // one block: even / odd k-steps alternate accumulators
             f32x4 acc2[nq][NA];
             const float* pd[nq];
-            const float* pg = gs + 8 * fk * kSG + (wave & 1) * 16 + frz;      // G[b = 32g + r + 8fk][item]
+            const float* pg = gs + 4 * fk * kSG + (wave & 1) * 16 + frz;      // G[b = 16g + j + 4fk][item]
 #pragma unroll
             for (int q = 0; q < nq; ++q) {
                 for (int u = 0; u < NA; ++u) acc2[q][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 pd[q] = dhs + ((wave + kNW * q) >> 1) * 16 + frz;      // dh2[b][col]
             }
-            const int nfull = B >> 5;                                 // groups whose 32 rows all exist: no row clamp,
+            const int nfull = B >> 4;                                 // groups whose 16 rows all exist: no row clamp,
             for (int g = 0; g < nfull; ++g) {                         // every LDS address = base + constant
-                const float* xg = pg + 32 * g * kSG;
-                const int yoff = (32 * g + 8 * fk) * kSD;
-#pragma unroll 1
-                for (int r = 0; r < 8; r += 4) {
-                    float x[4], y[4][nq];
+                const float* xg = pg + 16 * g * kSG;
+                const int yoff = (16 * g + 4 * fk) * kSD;
+                float x[4], y[4][nq];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        x[j] = xg[(r + j) * kSG];
+                for (int j = 0; j < 4; ++j) {
+                    x[j] = xg[j * kSG];
 #pragma unroll
-                        for (int q = 0; q < nq; ++q) y[j][q] = pd[q][yoff + (r + j) * kSD];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int q = 0; q < nq; ++q)
-                            acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
+                    for (int q = 0; q < nq; ++q) y[j][q] = pd[q][yoff + j * kSD];
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < nq; ++q)
+                        acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
             }
-            {   // the partial last group: rows past B - 1 are clamped (their G rows are zero)
+            if (B & 15) {   // the partial last group: rows past B - 1 are clamped (their G rows are zero)
                 const int g = nfull;
-                const int nr = min(8, (B - 32 * g + 3) & ~3);          // k-steps (4 per trip), <= 0: none
-                for (int r = 0; r < nr; r += 4) {
-                    float x[4], y[4][nq];
+                float x[4], y[4][nq];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int row = 32 * g + r + j;
-                        const int rowc = min(row + 8 * fk, B - 1) * kSD;
-                        x[j] = pg[row * kSG];
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 16 * g + j;
+                    const int rowc = min(row + 4 * fk, B - 1) * kSD;
+                    x[j] = pg[row * kSG];
 #pragma unroll
-                        for (int q = 0; q < nq; ++q) y[j][q] = pd[q][rowc];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int q = 0; q < nq; ++q)
-                            acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
+                    for (int q = 0; q < nq; ++q) y[j][q] = pd[q][rowc];
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < nq; ++q)
+                        acc2[q][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], y[j][q], acc2[q][j & (NA - 1)], 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < nq; ++q) {
@@ -359,18 +358,23 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             for (int q = 0; q < Q3; ++q) {
                 const int id = min(wave + kNW * q, nmb * NB - 1);
                 const int mb = id / NB, nb = id - mb * NB;
-                pg[q] = gs + (mb * 16 + frz) * kSG + fk;            // G[b][n = 4ks + fk]
-                pv[q] = v3s + ((fk >> 1) + 8 * (fk & 1)) * kSD + nb * 16 + frz;  // V3a[n = 4ks + fk][col] at v3_row(n)
+                pg[q] = gs + (mb * 16 + frz) * kSG + 2 * fk;        // G[b][n = 8c + 2fk + j]: float2 per chunk
+                pv[q] = v3s + (((fk & 1) << 2) | (fk & 2)) * kSD + nb * 16 + frz;   // V3a row v3_row(8c + 2fk + j) = 8c + this + j
             }
 #pragma unroll
-            for (int ks = 0; ks < kTI / 4; ++ks) {
-                float x[Q3], y[Q3];
+            for (int c = 0; c < kTI / 8; ++c) {
+                float2 x[Q3]; float y0[Q3], y1[Q3];
 #pragma unroll
-                for (int q = 0; q < Q3; ++q) { x[q] = pg[q][ks * 4]; y[q] = pv[q][(((2 * ks) & 7) + 16 * ((2 * ks) >> 3)) * kSD]; }
+                for (int q = 0; q < Q3; ++q) {
+                    x[q] = *reinterpret_cast<const float2*>(pg[q] + 8 * c);
+                    y0[q] = pv[q][(8 * c) * kSD]; y1[q] = pv[q][(8 * c + 1) * kSD];
+                }
 #pragma unroll
                 for (int q = 0; q < Q3; ++q)
-                    if (q < Q3 - 1 || full3)
-                        acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[q], acc3[q], 0, 0, 0);
+                    if (q < Q3 - 1 || full3) {
+                        acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].x, y0[q], acc3[q], 0, 0, 0);
+                        acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].y, y1[q], acc3[q], 0, 0, 0);
+                    }
             }
         }
         lds_barrier();                               // os complete
