@@ -161,14 +161,14 @@ size_t layout(aae_model* m, char* base, bool dry) {
     const int N = m->N, h = m->h, cc = m->c, cp = m->cp;
     m->P[P_W1T] = a.mat(N, h, m->ldw1);
     m->P[P_B1] = a.mat(1, h, m->ldw1);
-    m->P[P_W2] = a.mat(h, h + 1, m->ldh, 4);
-    m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 4);   // VAE: [fc21; fc22]
-    m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 4);
-    m->P[P_V2] = a.mat(h, h + 1, m->ldh, 4);
+    m->P[P_W2] = a.mat(h, h + 1, m->ldh, 16);
+    m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
+    m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 16);
+    m->P[P_V2] = a.mat(h, h + 1, m->ldh, 16);
     m->P[P_V3] = a.mat(N, h + 1, m->ldh);
-    m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 4);
-    m->P[P_D2] = a.mat(h, h + 1, m->ldh, 4);
-    m->P[P_D3] = a.mat(1, h + 1, m->ldh, 4);
+    m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 16);
+    m->P[P_D2] = a.mat(h, h + 1, m->ldh, 16);
+    m->P[P_D3] = a.mat(1, h + 1, m->ldh, 16);
     for (int i = 0; i < NP; ++i) {
         m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
         m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);

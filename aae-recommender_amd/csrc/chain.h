@@ -228,30 +228,48 @@ __device__ __forceinline__ void chain_linear_fwd(const ChainOp& op, const float*
     }
 }
 
-// dX, W[k][n] n-contiguous: one dword per lane and k-step (16 lanes = 64 contiguous bytes).  The last
-// k-step may touch rows K .. K+2: its A operand is zero there and the arena keeps 4 zero rows behind
-// every weight matrix the chain reads (layout(): pad_rows), so the row index needs no clamp.
-template <int MS, bool TWO>
+// dX, W[k][n] n-contiguous: one dword per lane and k (16 lanes = 64 contiguous bytes).  The same k-permutation
+// as forward - lane (fr, fk) takes k = 16c + 4*fk + e - so the A operand comes from LDS as one 16-byte read per
+// 4 MFMAs; A is masked to zero for k >= K (the slot may hold stale columns there), the weight rows up to
+// 16 * ceil(K / 16) - 1 exist because the arena keeps 16 zero rows behind every weight matrix the chain reads
+// (layout(): pad_rows), so the row index needs no clamp.
+template <int MC, bool TWO>
 __device__ __forceinline__ void chain_linear_dx(const ChainOp& op, const float* src, int b0, int b1, int fr, int fk,
                                                 f32x4 (&acc)[2]) {
     const int ldw = op.ldw, N = op.N, K = op.K;
-    const int ks = (K + 3) >> 2;
-    const uint32_t o0 = (uint32_t)(fk * ldw + min(b0 * 16 + fr, N - 1)) * 4u;
-    const uint32_t o1 = (uint32_t)(fk * ldw + min(b1 * 16 + fr, N - 1)) * 4u;
-    const float* a = src + fr * kCL + fk;
-    float y0[MS], y1[TWO ? MS : 1];
+    const int kch = (K + 15) >> 4;
+    const uint32_t o0 = (uint32_t)(4 * fk * ldw + min(b0 * 16 + fr, N - 1)) * 4u;
+    const uint32_t o1 = (uint32_t)(4 * fk * ldw + min(b1 * 16 + fr, N - 1)) * 4u;
+    const float* a = src + fr * kCL + 4 * fk;
+    float y0[MC * 4], y1[TWO ? MC * 4 : 1];
 #pragma unroll
-    for (int j = 0; j < MS; ++j) {
-        const char* base = reinterpret_cast<const char*>(op.W + (size_t)(min(j, ks - 1) * 4) * ldw);   // uniform
-        y0[j] = *reinterpret_cast<const float*>(base + o0);
-        if (TWO) y1[j] = *reinterpret_cast<const float*>(base + o1);
+    for (int c = 0; c < MC; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const char* base = reinterpret_cast<const char*>(op.W + (size_t)(min(c, kch - 1) * 16 + e) * ldw);   // uniform
+            y0[c * 4 + e] = *reinterpret_cast<const float*>(base + o0);
+            if (TWO) y1[c * 4 + e] = *reinterpret_cast<const float*>(base + o1);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < MS; ++j) {
-        if (j < ks) {
-            const float xa = (j * 4 + fk < K) ? a[j * 4] : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y0[j], acc[0], 0, 0, 0);
-            if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, y1[j], acc[1], 0, 0, 0);
+    for (int c = 0; c < MC; ++c) {
+        if (c < kch) {
+            float4 xa = *reinterpret_cast<const float4*>(a + c * 16);
+            const int k0 = c * 16 + 4 * fk;
+            if (k0 + 0 >= K) xa.x = 0.f;
+            if (k0 + 1 >= K) xa.y = 0.f;
+            if (k0 + 2 >= K) xa.z = 0.f;
+            if (k0 + 3 >= K) xa.w = 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y0[c * 4 + 0], acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y0[c * 4 + 1], acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y0[c * 4 + 2], acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y0[c * 4 + 3], acc[0], 0, 0, 0);
+            if (TWO) {
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, y1[c * 4 + 0], acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, y1[c * 4 + 1], acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, y1[c * 4 + 2], acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, y1[c * 4 + 3], acc[1], 0, 0, 0);
+            }
         }
     }
 }
@@ -286,17 +304,17 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             const EpiCtx ec = chain_epi_ctx(op.epi, op, P, key, slots);
             const int epiN = chain_pin(op.N);
             if (!(P.dbg & 1) && wave < nblk) {          // waves without a block (narrow layers) only meet the barriers
-                // Load volume follows the layer: short-K layers (K <= 64 forward, K <= 52 dX) take the 4-chunk /
-                // 13-step variant and layers of <= 128 columns skip the second block - the weight stream of a
+                // Load volume follows the layer: short-K layers (K <= 64) take the 4-chunk /
+                // chunk variant and layers of <= 128 columns skip the second block - the weight stream of a
                 // layer is bound by the CU's 64 B/clk vector-memory path, so unneeded (clamped) loads cost time.
                 if (kind == COP_LINEAR) {
                     const int kch = (op.K + 15) >> 4;
                     if (kch <= 4) { if (two) chain_linear_fwd<4, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<4, false>(op, src, b0, b1, fr, fk, acc); }
                     else          { if (two) chain_linear_fwd<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<13, false>(op, src, b0, b1, fr, fk, acc); }
                 } else {
-                    const int ks = (op.K + 3) >> 2;
-                    if (ks <= 13) { if (two) chain_linear_dx<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<13, false>(op, src, b0, b1, fr, fk, acc); }
-                    else          { if (two) chain_linear_dx<52, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<52, false>(op, src, b0, b1, fr, fk, acc); }
+                    const int kch = (op.K + 15) >> 4;
+                    if (kch <= 4) { if (two) chain_linear_dx<4, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<4, false>(op, src, b0, b1, fr, fk, acc); }
+                    else          { if (two) chain_linear_dx<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_dx<13, false>(op, src, b0, b1, fr, fk, acc); }
                 }
             }
             chain_barrier();      // dst may alias a slot other waves were still reading (src != dst is required)
