@@ -94,6 +94,7 @@ struct aae_model {
     int n_cu; bool fused_ok; int fused_nb; bool force_unfused;
     int* tcount; int* tstart; int* teb; int* ten; float* tev;
     int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
+    int* pslot; int* ptag;   // data parallel, peers > 1: [N][peers] slot of an item's row in each peer's packet / its stamp
     int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
     OptScalars* sc;          // [4]
@@ -212,6 +213,11 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->tsync = reinterpret_cast<int*>(a.take(N, nullptr));
     m->mark = reinterpret_cast<int*>(a.take(N, nullptr));
     m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz * (size_t)std::max(1, c.reserved[1]), nullptr));
+    m->pslot = m->ptag = nullptr;
+    if (c.grad_mode == AAE_GRAD_EXPORT && c.reserved[1] > 1) {
+        m->pslot = reinterpret_cast<int*>(a.take((size_t)N * c.reserved[1], nullptr));
+        m->ptag = reinterpret_cast<int*>(a.take((size_t)N * c.reserved[1], nullptr));
+    }
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
     m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
@@ -1661,23 +1667,39 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
     if (n_peers < 1 || n_peers > std::max(1, m->cfg.reserved[1])) return fail(AAE_EINVAL, "n_peers exceeds cfg.reserved[1]");
     hipStream_t s = S(stream);
     hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, s, m->stamp, m->ucount);
-    for (int p = 0; p < n_peers; ++p) {
-        const char* hb = reinterpret_cast<const char*>(hdr_dev) + (size_t)p * peer_stride_bytes;
-        const char* vb = reinterpret_cast<const char*>(vals_dev) + (size_t)p * peer_stride_bytes;
-        hipLaunchKernelGGL(w1_unpack_kernel, dim3(std::min(cap, 4096)), dim3(256), 0, s, reinterpret_cast<const int*>(hb),
-                           reinterpret_cast<const float*>(vb), m->h, m->Gr[P_W1T].p, m->ldw1, m->mark, m->stamp,
-                           m->ulist, m->ucount);
-    }
-    LAUNCHCHK("w1_unpack");
-    {   // small encoder layers: sum the peers' spans in rank order, then the optimiser on them
-        const size_t nsmall = enc_small_floats(m);
+    const size_t nsmall = enc_small_floats(m);
+    const char* small0 = reinterpret_cast<const char*>(vals_dev + (size_t)cap * m->h);
+    if (n_peers > 1 && m->pslot && !getenv("AAE_W1_SERIAL")) {
+        // every peer in one launch each: slot map + union list, rank-ordered row sums, rank-ordered small-layer sums
+        const int W = m->cfg.reserved[1];
+        hipLaunchKernelGGL(w1_map_kernel, dim3(std::max(1, std::min((cap + 255) / 256, 64)), n_peers), dim3(256), 0, s,
+                           reinterpret_cast<const char*>(hdr_dev), (long long)peer_stride_bytes, W, m->pslot, m->ptag,
+                           m->mark, m->stamp, m->ulist, m->ucount);
+        hipLaunchKernelGGL(w1_sum_kernel, dim3(std::min(cap * n_peers, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const char*>(vals_dev), (long long)peer_stride_bytes, m->h, n_peers, W, m->pslot,
+                           m->ptag, m->stamp, m->ulist, m->ucount, m->Gr[P_W1T].p, m->ldw1);
+        LAUNCHCHK("w1_map/sum");
+        hipLaunchKernelGGL(accumulate_peers_kernel, dim3(grid1d(nsmall)), dim3(256), 0, s, m->Gr[P_B1].p, small0,
+                           (long long)peer_stride_bytes, n_peers, nsmall);
+        LAUNCHCHK("accumulate peers");
+    } else {
         for (int p = 0; p < n_peers; ++p) {
-            const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(vals_dev) +
-                                                              (size_t)p * peer_stride_bytes) + (size_t)cap * m->h;
+            const char* hb = reinterpret_cast<const char*>(hdr_dev) + (size_t)p * peer_stride_bytes;
+            const char* vb = reinterpret_cast<const char*>(vals_dev) + (size_t)p * peer_stride_bytes;
+            hipLaunchKernelGGL(w1_unpack_kernel, dim3(std::min(cap, 4096)), dim3(256), 0, s, reinterpret_cast<const int*>(hb),
+                               reinterpret_cast<const float*>(vb), m->h, m->Gr[P_W1T].p, m->ldw1, m->mark, m->stamp,
+                               m->ulist, m->ucount);
+        }
+        LAUNCHCHK("w1_unpack");
+        // small encoder layers: sum the peers' spans in rank order
+        for (int p = 0; p < n_peers; ++p) {
+            const float* src = reinterpret_cast<const float*>(small0 + (size_t)p * peer_stride_bytes);
             hipLaunchKernelGGL(accumulate_kernel, dim3(grid1d(nsmall)), dim3(256), 0, s, m->Gr[P_B1].p, src, nsmall,
                                p == 0 ? 1 : 0);
         }
         LAUNCHCHK("accumulate small");
+    }
+    {
         TRY(aae_apply_updates(m, which, stream));      // b1, W2, W3 (W1T is skipped there: sparse path below)
     }
     const int set = which == O_GEN ? 1 : 0;

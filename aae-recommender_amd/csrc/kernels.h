@@ -657,6 +657,54 @@ __global__ void fill_int_kernel(int* p, size_t n, int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// ---- all peers in ONE launch each (a launch per peer is ~17 us x world, twice per step) ----------------------
+// map:  for every packed row of every peer: pslot / ptag [item][peer] = its slot in that peer's packet (tag = the
+//       exchange's stamp, so nothing has to be cleared), and the item joins the union list.  grid (x, peers).
+// sum:  one workgroup per item of the union list adds the peers' rows IN RANK ORDER (bitwise the same sum on every
+//       rank, and the same as consecutive per-peer launches) into the gradient image.
+__global__ __launch_bounds__(256) void w1_map_kernel(const char* __restrict__ pk, long long stride_bytes, int W,
+                                                     int* __restrict__ pslot, int* __restrict__ ptag,
+                                                     int* __restrict__ mark, const int* __restrict__ stamp_p,
+                                                     int* __restrict__ ulist, int* __restrict__ ucount) {
+    const int p = blockIdx.y;
+    const int* hdr = reinterpret_cast<const int*>(pk + (size_t)p * stride_bytes);
+    const int cnt = hdr[0], stamp = *stamp_p;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < cnt; r += gridDim.x * 256) {
+        const int row = hdr[1 + r];
+        pslot[(size_t)row * W + p] = r;
+        ptag[(size_t)row * W + p] = stamp;
+        if (atomicExch(&mark[row], stamp) != stamp) ulist[atomicAdd(ucount, 1)] = row;
+    }
+}
+
+__global__ __launch_bounds__(256) void w1_sum_kernel(const char* __restrict__ vals0, long long stride_bytes, int h,
+                                                     int n_peers, int W, const int* __restrict__ pslot,
+                                                     const int* __restrict__ ptag, const int* __restrict__ stamp_p,
+                                                     const int* __restrict__ ulist, const int* __restrict__ ucount,
+                                                     float* __restrict__ gW1T, int ldw) {
+    const int cnt = *ucount, stamp = *stamp_p;
+    for (int u = blockIdx.x; u < cnt; u += gridDim.x) {
+        const int row = ulist[u];
+        for (int c = threadIdx.x; c < h; c += 256) {
+            float acc = gW1T[(size_t)row * ldw + c];
+            for (int p = 0; p < n_peers; ++p)
+                if (ptag[(size_t)row * W + p] == stamp)
+                    acc += reinterpret_cast<const float*>(vals0 + (size_t)p * stride_bytes)[(size_t)pslot[(size_t)row * W + p] * h + c];
+            gW1T[(size_t)row * ldw + c] = acc;
+        }
+    }
+}
+
+// dst[i] = sum over peers (rank order) of src_p[i]: the small encoder layers behind the packed rows
+__global__ void accumulate_peers_kernel(float* __restrict__ dst, const char* __restrict__ src0, long long stride_bytes,
+                                        int n_peers, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int p = 0; p < n_peers; ++p) acc += reinterpret_cast<const float*>(src0 + (size_t)p * stride_bytes)[i];
+        dst[i] = acc;
+    }
+}
+
 // predict-time prologue of the unique-row pass: new stamp, empty list
 __global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucount = 0; }
 

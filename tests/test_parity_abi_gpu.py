@@ -437,3 +437,54 @@ def test_layer_chain_equals_per_layer_path_at_headline_width(N, h, c, B, inc):
         for k in ("lin2.weight", "lin3.weight", "lin1.bias"):
             np.testing.assert_allclose(sa[k][0], sb[k][0], atol=2e-9, rtol=2e-4, err_msg=f"{which} m {k}")
             np.testing.assert_allclose(sa[k][1], sb[k][1], atol=1e-13, rtol=2e-4, err_msg=f"{which} v {k}")
+
+
+def test_w1_import_all_peers_in_one_launch_equals_the_per_peer_launches():
+    """Data parallel, world > 1: aae_w1_import folds every peer's packed first-layer rows (and the small encoder
+    layers behind them) in one launch each, in rank order; the result must be BITWISE what consecutive per-peer
+    launches give (AAE_W1_SERIAL=1), or replicas would drift apart.  Peers share some items and not others."""
+    import os
+    from aaerec._hip import HipAAE
+    from oracle.dense_torch_port import init_params
+    W, N, h, c, B, cap = 4, 1500, 40, 10, 16, 96
+    params = init_params(N, h, c, seed=5)
+    rng = np.random.default_rng(9)
+    models = []
+    for _ in range(2):
+        m = HipAAE(N, h, c, max_batch=B, rng_mode="inject", grad_mode="export", dp_world=W, w1_cap=cap)
+        m.load_params(params)
+        models.append(m)
+    for m in models:
+        pk0 = m.w1_export()                            # allocates the packet: layout = header | rows | small layers
+    n, hw = pk0.numel(), models[0]._w1_hdr
+    host = np.zeros((W, n), dtype=np.float32)
+    common = rng.choice(N, size=20, replace=False)
+    for p in range(W):
+        own = rng.choice(N, size=int(rng.integers(30, 60)), replace=False)
+        items = np.unique(np.concatenate([common[: 5 + 4 * p], own]))[:cap]
+        hdr = np.zeros(hw, dtype=np.int32)
+        hdr[0] = len(items)
+        hdr[1:1 + len(items)] = items
+        host[p, :hw] = hdr.view(np.float32)
+        host[p, hw:hw + len(items) * h] = rng.standard_normal(len(items) * h).astype(np.float32) * 1e-3
+        host[p, hw + cap * h:] = rng.standard_normal(n - hw - cap * h).astype(np.float32) * 1e-3
+    out = []
+    for m, serial in zip(models, (False, True)):
+        if serial:
+            os.environ["AAE_W1_SERIAL"] = "1"
+        try:
+            m.w1_import(torch.as_tensor(host, device=m.device).reshape(-1), W, 0)
+            st = m.adam_state("enc")
+        finally:
+            os.environ.pop("AAE_W1_SERIAL", None)
+        out.append(st)
+    for k in ("lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"):
+        for j in (0, 1):
+            assert np.array_equal(out[0][k][j], out[1][k][j]), k
+    # and the sums are what they should be: first moment = 0.1 * summed gradient (fresh optimiser state)
+    dense = np.zeros((N, h), dtype=np.float64)
+    for p in range(W):
+        cnt = int(host[p, :1].view(np.int32)[0])
+        ids = host[p, 1:1 + cnt].view(np.int32)
+        dense[ids] += host[p, hw:hw + cnt * h].reshape(cnt, h)
+    np.testing.assert_allclose(out[0]["lin1.weight"][0].T, 0.1 * dense, rtol=1e-5, atol=1e-9)
