@@ -786,6 +786,11 @@ def main():
         # one wider case so multi-tile kernel paths are pinned too
         run_case(ref_aae, ref_cond, "step_wide", seed=15, N=1100, h=72, c=24, B=40, steps=2,
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=20), capture_acts=False, states='last')
+    if want("headline"):
+        # the headline layer widths (h=200, c=50, batch 100: 13 column blocks in the layer chains and in the fused
+        # decoder output layer, 7 row blocks) on a small vocabulary, straight from the reference
+        run_case(ref_aae, ref_cond, "step_headline", seed=16, N=330, h=200, c=50, B=100, steps=2,
+                 dropout=(0.2, 0.2), batch_kw=dict(max_len=24), capture_acts=False, states='last')
     if want("ae_only"):
         run_ae_only_case(ref_aae, "step_ae_only", seed=21)
     if want("decoding"):
