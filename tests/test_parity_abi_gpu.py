@@ -488,3 +488,31 @@ def test_w1_import_all_peers_in_one_launch_equals_the_per_peer_launches():
         ids = host[p, 1:1 + cnt].view(np.int32)
         dense[ids] += host[p, hw:hw + cnt * h].reshape(cnt, h)
     np.testing.assert_allclose(out[0]["lin1.weight"][0].T, 0.1 * dense, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,B,h,c", [(20, 1, 8, 4), (33, 2, 8, 4), (64, 3, 16, 5), (31, 17, 12, 3)])
+def test_tiny_shapes_match_oracle(N, B, h, c):
+    """Degenerate sizes: one document, a vocabulary smaller than one 32-item decoder tile, a batch that ends one
+    row into a second 16-row block - the kernels' clamped / masked lanes against the oracle (computed here)."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    rng = np.random.default_rng(N * 100 + B)
+    params = init_params(N, h, c, seed=N)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.2, 0.2))
+    dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+    dev.load_params(params)
+    ora = O.OracleAAE(params, **kw)
+    for s in range(3):
+        rows = [np.sort(rng.choice(N, size=int(rng.integers(1, min(N, 6))), replace=False)) for _ in range(B)]
+        ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        idx = np.concatenate(rows).astype(np.int32)
+        val = np.ones(len(idx), dtype=np.float32)
+        masks = [(rng.random((B, h)) > 0.2).astype(np.uint8) for _ in range(12)]
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        dev.step(DeviceCSR.from_arrays(ip, idx, val, N, dev.device), 0, B, masks=masks, z_real=zr)
+        want = ora.partial_fit(ip, idx, val, zr, masks)
+        np.testing.assert_allclose(dev.losses(), want, rtol=2e-5, atol=1e-6, err_msg=f"step {s}")
+    got = dev.state_dict()
+    for k, w in ora.p.items():
+        np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
