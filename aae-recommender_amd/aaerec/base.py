@@ -1,20 +1,28 @@
-"""Recommender plugin protocol (mirrors reference aaerec/base.py:5-19)."""
-from abc import ABC, abstractmethod
+"""Recommender plugin protocol: the surface the evaluation drivers call (reference aaerec/base.py:5-19).
+
+A plugin is trained on one ``Bags`` and asked to score every item for the rows of another; the HIP-backed
+recommenders (``AAERecommender``, ``DecodingRecommender``, ``DAERecommender``, ``VAERecommender``) all subclass
+this.  Like the reference's abstract base, a class that leaves ``train`` or ``predict`` undefined cannot be
+instantiated (TypeError).
+"""
+
+_REQUIRED = ("train", "predict")
 
 
-class Recommender(ABC):
-    """A recommender is trained on a Bags instance and scores every item for the rows of another."""
-    use_wandb = False
+class Recommender:
+    use_wandb = False           # the reference's drivers read this flag; experiment tracking is out of scope here
 
-    def __init__(self):
-        super().__init__()
+    def __new__(cls, *args, **kwargs):
+        missing = [name for name in _REQUIRED if getattr(cls, name) is getattr(Recommender, name)]
+        if missing:
+            raise TypeError("Can't instantiate {} without an implementation of: {}".format(
+                cls.__name__, ", ".join(missing)))
+        return super().__new__(cls)
 
-    @abstractmethod
     def train(self, X_train):
         """Fit on the training Bags."""
         raise NotImplementedError
 
-    @abstractmethod
     def predict(self, X_test):
-        """Return an [n_docs, n_items] score matrix (ndarray or scipy sparse)."""
+        """Score every item for every row of the test Bags: [n_docs, n_items], ndarray or scipy sparse."""
         raise NotImplementedError
