@@ -27,7 +27,9 @@ GRAD_FUSED, GRAD_EXPORT = 0, 1
 # tensor ids (aaerec_hip.h)
 T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3 = range(10)
 T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, T_GRAD = 16, 32, 48, 64, 80
-T_ACT_Z, T_ACT_LOSSES, T_ACT_A1 = 96, 97, 98
+T_ACT_Z, T_ACT_LOSSES, T_ACT_A1, T_ACT_DZC = 96, 97, 98, 99
+CAT_SUM, CAT_MEAN = 0, 1
+CAT_SPARSE_ADAM, CAT_ADAM = 0, 1
 O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
 
 
@@ -93,6 +95,10 @@ _PROTOS = {
     "aae_w1_packet_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aae_w1_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
+    "aae_cat_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_int64, C.c_void_p]),
+    "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_void_p]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -131,6 +137,44 @@ def _check(rc):
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _cat_args(table, idx, block):
+    """Argument checks shared by cat_encode / cat_update (operand shapes must match what the kernels index)."""
+    if not (table.is_cuda and idx.is_cuda and block.is_cuda):
+        raise RuntimeError("aaerec: the categorical condition kernels take GPU tensors (there is no CPU path)")
+    if table.dtype != torch.float32 or not table.is_contiguous() or table.dim() != 2:
+        raise TypeError("aaerec: embedding table must be a contiguous float32 [vocab, dim] tensor")
+    if idx.dtype != torch.int32 or idx.dim() != 2 or not idx.is_contiguous():
+        raise TypeError("aaerec: idx must be a contiguous int32 [rows, width] tensor")
+    if block.dtype != torch.float32 or block.dim() != 2 or block.stride(1) != 1 or block.shape[0] != idx.shape[0] \
+            or block.shape[1] != table.shape[1]:
+        raise TypeError("aaerec: block must be a float32 [rows, dim] view with unit column stride")
+
+
+def cat_encode(table, idx, out, mean=False):
+    """CategoricalCondition.encode on the device: out[r] = sum (or mean over the padded width) of table[idx[r, w]];
+    index 0 reads as zero.  `out` may be a column slice of the step's condition block."""
+    _cat_args(table, idx, out)
+    with torch.cuda.device(table.device):
+        _check(load_library().aae_cat_encode(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.shape[0],
+                                             idx.shape[1], CAT_MEAN if mean else CAT_SUM, _ptr(out), out.stride(0),
+                                             C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)))
+
+
+def cat_update(table, exp_avg, exp_avg_sq, idx, dout, lr, step, mean=False, grad_scratch=None):
+    """Backward of cat_encode from dout [rows, dim] plus the condition's optimiser step: SparseAdam over the rows the
+    batch names, or (grad_scratch given: zeros [vocab, dim]) dense Adam over the whole table.  step counts from 1."""
+    _cat_args(table, idx, dout)
+    for t in (exp_avg, exp_avg_sq) + ((grad_scratch,) if grad_scratch is not None else ()):
+        if t.shape != table.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != table.device:
+            raise TypeError("aaerec: optimiser state must match the embedding table")
+    with torch.cuda.device(table.device):
+        _check(load_library().aae_cat_update(_ptr(table), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad_scratch),
+                                             table.shape[0], table.shape[1], _ptr(idx), idx.shape[0], idx.shape[1],
+                                             CAT_MEAN if mean else CAT_SUM, _ptr(dout), dout.stride(0),
+                                             CAT_ADAM if grad_scratch is not None else CAT_SPARSE_ADAM, float(lr), int(step),
+                                             C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)))
 
 
 class DeviceCSR:
@@ -379,6 +423,10 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_step(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
                                      self._stream()))
+
+    def cond_grad(self, n_rows):
+        """dL/d(cond) of the last step's autoencoder phase: [n_rows, cond_inc] view (trainable conditions)."""
+        return self.tensor(T_ACT_DZC)[:n_rows, self.c:]
 
     def ae_encode(self, csr, row_start, n_rows, rows=None, masks=None, z_real=None):
         b = self._batch(csr, row_start, n_rows, rows)

@@ -204,6 +204,38 @@ class AdversarialAutoEncoder:
     def _is_constant_concat(self):
         return all(getattr(c, "constant_concat", False) for c in self.conditions.values())
 
+    def _is_device_native(self):
+        """Every condition is a concatenated block the kernels can produce and train themselves: a constant block or
+        a CategoricalCondition with its table on this GPU."""
+        dev = self.hip.device
+        return all(getattr(c, "constant_concat", False) or (hasattr(c, "device_native") and c.device_native(dev))
+                   for c in self.conditions.values())
+
+    def _native_cond_block(self, c_batch, n_rows):
+        """[n_rows, size_increment] block of the encoded conditions, in ConditionList order (encode_impose's
+        concatenation order, condition.py:90-99)."""
+        dev = self.hip.device
+        block = torch.empty(n_rows, self.hip.cond_inc, dtype=torch.float32, device=dev)
+        off = 0
+        for cond, x in zip(self.conditions.values(), c_batch):
+            w = cond.size_increment()
+            if getattr(cond, "constant_concat", False):
+                block[:, off:off + w] = cond.encode(x).to(dev)
+            else:
+                cond.encode_into(block[:, off:off + w], x)
+            off += w
+        return block
+
+    def _native_cond_update(self, n_rows):
+        """conditions.zero_grad / backward / step (aae.py:699-709) from the step's dL/d(condition block)."""
+        dblock = self.hip.cond_grad(n_rows)
+        off = 0
+        for cond in self.conditions.values():
+            w = cond.size_increment()
+            if not getattr(cond, "constant_concat", False):
+                cond.update_from(dblock[:, off:off + w])
+            off += w
+
     def _run_step(self, csr, row_start, n_rows, rows, c_batch):
         """One partial_fit on rows of a device-resident CSR."""
         masks = z_real = None
@@ -221,6 +253,10 @@ class AdversarialAutoEncoder:
             blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
             hip.step(csr, row_start, n_rows, rows=rows, cond=torch.cat([b.to(hip.device) for b in blocks], 1),
                      masks=masks, z_real=z_real)
+        elif self._is_device_native():
+            hip.step(csr, row_start, n_rows, rows=rows, cond=self._native_cond_block(c_batch, n_rows), masks=masks,
+                     z_real=z_real)
+            self._native_cond_update(n_rows)
         else:
             z = hip.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
             zc, back = self._cond_fn(c_batch)(z)
@@ -331,6 +367,7 @@ class AdversarialAutoEncoder:
         Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         csr = _hip.DeviceCSR(Xs, self.hip.device)
         fused = (not use_condition) or self._is_constant_concat()
+        native = use_condition and not fused and self._is_device_native()
         pred = []
         with torch.no_grad():
             for start in range(0, Xs.shape[0], self.batch_size):
@@ -342,6 +379,8 @@ class AdversarialAutoEncoder:
                         cond = torch.cat([c.encode(x).to(self.hip.device)
                                           for c, x in zip(self.conditions.values(), c_batch)], 1)
                     out = self.hip.predict(csr, start, n, cond=cond)
+                elif native:
+                    out = self.hip.predict(csr, start, n, cond=self._native_cond_block(c_batch, n))
                 else:
                     z = self.hip.encode(csr, start, n)
                     out = self.hip.decode(self.conditions.encode_impose(z, c_batch))

@@ -10,7 +10,9 @@ graph so trainable conditions (embedding tables with their own optimiser) keep l
 
 Conditions whose encoded input is a constant block that is concatenated
 (`PretrainedWordEmbeddingCondition`, anything with `constant_concat = True`) take the fully
-fused kernel path instead: their block is copied next to z on the device.
+fused kernel path instead: their block is copied next to z on the device.  So does a
+`CategoricalCondition` whose table lives on the GPU: its lookup, backward and SparseAdam / Adam step
+are two small kernels of the library around the fused step (`device_native`).
 """
 import itertools as it
 from abc import ABC, abstractmethod
@@ -256,16 +258,21 @@ class EmbeddingBagCondition(ConcatenationBasedConditioning):
 
 class CategoricalCondition(ConcatenationBasedConditioning):
     """Trainable embedding of a categorical attribute; index 0 = padding / out of vocabulary
-    (reference 397-508)."""
+    (reference 397-508).
+
+    embedding_on_gpu: the reference keeps the table in host memory unless asked (False) "to save GPU memory" and
+    pays a host round trip per step; with 288 GB of HBM the default here (None) is the GPU whenever use_cuda, which
+    also lets the AAE step train the condition with the library's own kernels (device_native).  An explicit False
+    is honoured."""
     padding_idx = 0
 
-    def __init__(self, embedding_dim, vocab_size=None, sparse=True, use_cuda=None, embedding_on_gpu=False,
+    def __init__(self, embedding_dim, vocab_size=None, sparse=True, use_cuda=None, embedding_on_gpu=None,
                  lr=1e-3, reduce=None, **embedding_params):
         self.vocab_size, self.embedding_dim = vocab_size, embedding_dim
         self.vocab = self.embedding = self.optimizer = None
         self.lr, self.sparse = lr, sparse
         self.use_cuda = torch.cuda.is_available() if use_cuda is None else use_cuda
-        self.embedding_on_gpu = embedding_on_gpu
+        self.embedding_on_gpu = self.use_cuda if embedding_on_gpu is None else embedding_on_gpu
         assert "padding_idx" not in embedding_params, "Padding is fixed with token 0"
         self.embedding_params = embedding_params
         assert reduce is None or reduce in ("mean", "sum", "max"), "Reduce neither None nor in 'mean','sum','max'"
@@ -319,6 +326,48 @@ class CategoricalCondition(ConcatenationBasedConditioning):
 
     def size_increment(self):
         return self.embedding_dim
+
+    # ---- device-native training path (libaaerec_hip: aae_cat_encode / aae_cat_update) ------------------------
+    # With the table in HBM the whole condition - lookup + reduction, its backward and its SparseAdam / Adam step -
+    # runs in two small kernels around aae_step instead of cutting the step at the condition boundary for autograd.
+    # The optimiser state lives in self.optimizer.state (torch's own layout), so state_dict() / a later torch-side
+    # step see the same tensors.
+    def device_native(self, device):
+        w = self.embedding.weight if self.embedding is not None else None
+        return (w is not None and w.is_cuda and w.device == torch.device(device) and self.reduce in (None, "sum", "mean")
+                and not self.embedding_params and self.embedding_dim <= 256)
+
+    def _index_block(self, inputs, device):
+        if self.reduce is None:
+            arr = np.asarray(inputs, dtype=np.int32).reshape(-1, 1)
+        else:
+            width = max(1, max(len(row) for row in inputs))
+            arr = np.zeros((len(inputs), width), dtype=np.int32)
+            for r, row in enumerate(inputs):
+                arr[r, :len(row)] = row
+        return torch.from_numpy(arr).to(device)
+
+    def encode_into(self, out, inputs):
+        """encode(inputs) written into `out` ([rows, embedding_dim], may be a column slice of a wider block)."""
+        from . import _hip
+        w = self.embedding.weight
+        self._idx = self._index_block(inputs, w.device)
+        _hip.cat_encode(w.data, self._idx, out, mean=self.reduce == "mean")
+
+    def update_from(self, dout):
+        """zero_grad + backward + step from dL/d(encoded block) of the rows last handed to encode_into."""
+        from . import _hip
+        w = self.embedding.weight
+        st = self.optimizer.state[w]
+        if "exp_avg" not in st:
+            st["step"] = 0 if self.sparse else torch.tensor(0.0)
+            st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(w.data), torch.zeros_like(w.data)
+        if not self.sparse and getattr(self, "_grad_scratch", None) is None:
+            self._grad_scratch = torch.zeros_like(w.data)
+        st["step"] += 1
+        _hip.cat_update(w.data, st["exp_avg"], st["exp_avg_sq"], self._idx, dout, self.optimizer.param_groups[0]["lr"],
+                        int(st["step"]), mean=self.reduce == "mean",
+                        grad_scratch=None if self.sparse else self._grad_scratch)
 
 
 class Condition(ConditionBase):

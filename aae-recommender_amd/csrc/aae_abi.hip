@@ -29,6 +29,7 @@
 #include "kernels.h"
 #include "dec_fused.h"
 #include "chain.h"
+#include "cond_embed.h"
 
 using namespace aae;
 
@@ -941,6 +942,56 @@ int aae_destroy(aae_handle h) {
     return AAE_OK;
 }
 
+// ---- CategoricalCondition (cond_embed.h): stateless entry points over caller-owned tables --------------------
+static int cat_check(int32_t vocab, int32_t dim, const int32_t* idx_dev, int32_t rows, int32_t width, int32_t reduce) {
+    if (vocab < 1 || dim < 1 || dim > kCatMaxDim) return fail(AAE_EINVAL, "categorical condition: need vocab >= 1 and 1 <= dim <= 256");
+    if (!idx_dev || rows < 1 || width < 1) return fail(AAE_EINVAL, "categorical condition: empty index block");
+    if ((int64_t)rows * width > (1 << 22)) return fail(AAE_EINVAL, "categorical condition: rows * width > 2^22");
+    if (reduce != AAE_CAT_SUM && reduce != AAE_CAT_MEAN) return fail(AAE_EINVAL, "categorical condition: reduce must be sum or mean");
+    return AAE_OK;
+}
+
+int aae_cat_encode(const float* table_dev, int32_t vocab, int32_t dim, const int32_t* idx_dev, int32_t rows,
+                   int32_t width, int32_t reduce, float* out_dev, int64_t out_ld, void* stream) {
+    TRY(cat_check(vocab, dim, idx_dev, rows, width, reduce));
+    if (!table_dev || !out_dev || out_ld < dim) return fail(AAE_EINVAL, "aae_cat_encode: table/out is NULL or out_ld < dim");
+    hipLaunchKernelGGL(cat_encode_kernel, dim3(rows, (dim + 63) / 64), dim3(64), 0, S(stream), table_dev, vocab, dim,
+                       idx_dev, width, reduce == AAE_CAT_MEAN, out_dev, (long long)out_ld);
+    LAUNCHCHK("cat_encode");
+    return AAE_OK;
+}
+
+int aae_cat_update(float* table_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* grad_scratch_dev, int32_t vocab,
+                   int32_t dim, const int32_t* idx_dev, int32_t rows, int32_t width, int32_t reduce,
+                   const float* dout_dev, int64_t dout_ld, int32_t optimizer, double lr, int64_t step, void* stream) {
+    TRY(cat_check(vocab, dim, idx_dev, rows, width, reduce));
+    if (!table_dev || !exp_avg_dev || !exp_avg_sq_dev || !dout_dev || dout_ld < dim)
+        return fail(AAE_EINVAL, "aae_cat_update: table/state/dout is NULL or dout_ld < dim");
+    if (optimizer != AAE_CAT_SPARSE_ADAM && optimizer != AAE_CAT_ADAM) return fail(AAE_EINVAL, "aae_cat_update: unknown optimizer");
+    if (optimizer == AAE_CAT_ADAM && !grad_scratch_dev) return fail(AAE_EINVAL, "aae_cat_update: dense Adam needs grad_scratch_dev");
+    if (step < 1) return fail(AAE_EINVAL, "aae_cat_update: step counts from 1");
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    CatUpdate a;
+    a.table = table_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev;
+    a.gdense = optimizer == AAE_CAT_ADAM ? grad_scratch_dev : nullptr;
+    a.idx = idx_dev; a.d = dout_dev; a.ldd = dout_ld; a.vocab = vocab; a.dim = dim; a.rows = rows; a.width = width;
+    a.mean = reduce == AAE_CAT_MEAN;
+    a.neg_step_size = (float)(-(lr * sqrt(bc2) / bc1));
+    const int n = rows * width;
+    hipLaunchKernelGGL(cat_update_kernel, dim3((n + kCatWaves - 1) / kCatWaves), dim3(64 * kCatWaves), 0, S(stream), a);
+    LAUNCHCHK("cat_update");
+    if (optimizer == AAE_CAT_ADAM) {
+        OptScalars sc; memset(&sc, 0, sizeof(sc));
+        sc.t = step; sc.neg_step_size = (float)(-(lr / bc1)); sc.bc2_sqrt = (float)sqrt(bc2); sc.lr = lr;
+        sc.inv_bc2_sqrt = 1.0f / sc.bc2_sqrt;
+        const size_t total = (size_t)vocab * dim;
+        hipLaunchKernelGGL(cat_dense_adam_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), table_dev,
+                           exp_avg_dev, exp_avg_sq_dev, grad_scratch_dev, total, sc);
+        LAUNCHCHK("cat_dense_adam");
+    }
+    return AAE_OK;
+}
+
 int aae_profile_enable(aae_handle h, int on) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     if (on && !h->prof_ev) h->prof_ev = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[AAE_K_N];
@@ -997,6 +1048,7 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
     else if (id >= AAE_T_GRAD && id < AAE_T_GRAD + NP) { t = &h->Gr[id - AAE_T_GRAD]; if (!t->rows) t = nullptr; }
     else if (id == AAE_T_ACT_Z) t = &h->zsave;
     else if (id == AAE_T_ACT_A1) t = &h->a1;
+    else if (id == AAE_T_ACT_DZC) { tmp = h->gzc; tmp.cols = h->cp; t = &tmp; }
     else if (id == AAE_T_ACT_LOSSES) {
         tmp.rows = 1; tmp.cols = 4; tmp.ld = 4; tmp.off = (size_t)((char*)h->losses - h->base); t = &tmp;
     }

@@ -132,7 +132,9 @@ enum {
     /* activations useful to callers */
     AAE_T_ACT_Z = 96,      /* encoder output of the last encode call [rows][n_code] */
     AAE_T_ACT_LOSSES = 97, /* float[4]: R, D, G of the last step, spare */
-    AAE_T_ACT_A1 = 98      /* first-layer pre-activations of the last encode [rows][n_hidden] */
+    AAE_T_ACT_A1 = 98,     /* first-layer pre-activations of the last encode [rows][n_hidden] */
+    AAE_T_ACT_DZC = 99     /* dL/d(decoder input) of the last ae phase [rows][n_code + cond_inc]: columns n_code.. are
+                            * the gradient of the condition block handed to aae_step (trainable conditions) */
 };
 
 typedef struct aae_tensor {
@@ -212,6 +214,27 @@ int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev,
 int aae_vae_step(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream);
 int aae_vae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev,
                     float* out_dev, int64_t out_ld, void* stream);
+/* CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute, reduced over the
+ * document's (batch-padded) value list and concatenated to the code.  The table and its optimiser state belong to
+ * the caller (plain device arrays [vocab][dim], row-major, dim <= 256); index 0 is the padding / out-of-vocabulary
+ * token: it reads as zero and never receives a gradient (nn.Embedding(padding_idx=0)).
+ *   idx_dev [rows][width] int32; reduce: sum (also "no reduction" with width = 1) or mean over the padded width
+ *   (hid.mean(1), condition.py:485-487, padding included).
+ * aae_cat_encode   out_dev[r][0:dim] = reduce_w table[idx[r][w]]   - write it into the cond block of aae_step
+ * aae_cat_update   the embedding's backward from dout_dev [rows][>= dim] (AAE_T_ACT_DZC columns of this condition)
+ *                  followed by the condition's own optimiser step (condition.py:491-497), default betas / eps:
+ *                  AAE_CAT_SPARSE_ADAM  torch.optim.SparseAdam (nn.Embedding(sparse=True), the reference's default):
+ *                                       only rows named by the batch move;
+ *                  AAE_CAT_ADAM         torch.optim.Adam over the whole table; grad_scratch_dev [vocab][dim] must be
+ *                                       zero on the first call and is left zero.
+ *                  `step` is the 1-based count of this update (the optimiser's state['step'] after it). */
+enum { AAE_CAT_SUM = 0, AAE_CAT_MEAN = 1 };
+enum { AAE_CAT_SPARSE_ADAM = 0, AAE_CAT_ADAM = 1 };
+int aae_cat_encode(const float* table_dev, int32_t vocab, int32_t dim, const int32_t* idx_dev, int32_t rows,
+                   int32_t width, int32_t reduce, float* out_dev, int64_t out_ld, void* stream);
+int aae_cat_update(float* table_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* grad_scratch_dev, int32_t vocab,
+                   int32_t dim, const int32_t* idx_dev, int32_t rows, int32_t width, int32_t reduce,
+                   const float* dout_dev, int64_t dout_ld, int32_t optimizer, double lr, int64_t step, void* stream);
 /* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
  * between them) */
 int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);

@@ -194,33 +194,84 @@ class BiasConst:
         pass
 
 
-class CategoricalSum:
-    """CategoricalCondition(reduce='sum', sparse=False): embedding rows summed per
-    doc, padding row 0 frozen at zero, own dense Adam (condition.py:441-505)."""
+class SparseAdam:
+    """torch.optim.SparseAdam defaults on one row-sparse tensor: only the rows present in the (coalesced) gradient
+    move, and eps is added to sqrt(exp_avg_sq) before the bias corrections are applied as one step size
+    (torch/optim/_functional.py sparse_adam)."""
 
-    def __init__(self, weight, lr):
+    def __init__(self, lr):
+        self.lr, self.m, self.v, self.t = float(lr), None, None, 0
+
+    def step(self, p, rows, g):
+        """p [vocab, dim] updated in place; rows: unique indices; g [len(rows), dim] their summed gradients."""
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        if self.m is None:
+            self.m, self.v = np.zeros_like(p), np.zeros_like(p)
+        self.t += 1
+        if len(rows) == 0:
+            return
+        m_old, v_old = self.m[rows], self.v[rows]
+        mu = ((g - m_old) * f32(1 - b1)).astype(f32)
+        self.m[rows] = m_old + mu
+        vu = ((g * g - v_old) * f32(1 - b2)).astype(f32)
+        self.v[rows] = v_old + vu
+        numer = mu + m_old
+        denom = np.sqrt(vu + v_old) + f32(eps)
+        step_size = self.lr * (1 - b2 ** self.t) ** 0.5 / (1 - b1 ** self.t)
+        p[rows] += f32(-step_size) * (numer / denom)
+
+
+class CategoricalEmbedding:
+    """CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute concatenated
+    to the code.  Index 0 = padding / out of vocabulary: its row stays zero and gets no gradient.
+      reduce  None: one index per document;  'sum' / 'mean': over the batch-padded list (mean divides by the padded
+              width, padding included - hid.mean(1) in the reference)
+      sparse  True: nn.Embedding(sparse=True) + SparseAdam (the reference's default);  False: dense Adam."""
+
+    def __init__(self, weight, lr, reduce="sum", sparse=False):
         self.params = {"w": weight.astype(f32).copy()}
-        self.opt = Adam(lr)
+        self.reduce, self.sparse = reduce, sparse
+        self.opt = SparseAdam(lr) if sparse else Adam(lr)
         self.inc = weight.shape[1]
 
+    def encode(self, idx):
+        idx = np.asarray(idx)
+        if idx.ndim == 1:
+            idx = idx[:, None]
+        self._idx = idx
+        e = self.params["w"][idx].sum(axis=1).astype(f32)
+        if self.reduce == "mean":
+            e = (e / f32(idx.shape[1])).astype(f32)
+        return e
+
     def fwd(self, z, idx, train=True):
-        self._idx = np.asarray(idx)
         self._c = z.shape[1]
-        e = self.params["w"][self._idx].sum(axis=1).astype(f32)
-        return np.concatenate([z, e], axis=1)
+        return np.concatenate([z, self.encode(idx)], axis=1)
 
     def bwd(self, dz):
-        de = dz[:, self._c:]
+        de = dz[:, self._c:self._c + self.inc]
+        if self.reduce == "mean":
+            de = (de / f32(self._idx.shape[1])).astype(f32)
         g = np.zeros_like(self.params["w"])
+        touched = np.zeros(len(g), dtype=bool)
         for b in range(self._idx.shape[0]):
             for j in self._idx[b]:
                 if j != 0:
                     g[j] += de[b]
-        self._g = g
+                    touched[j] = True
+        self._g, self._rows = g, np.nonzero(touched)[0]
         return dz[:, :self._c]
 
     def step(self):
-        self.opt.step(self.params, {"w": self._g})
+        if self.sparse:
+            self.opt.step(self.params["w"], self._rows, self._g[self._rows])
+        else:
+            self.opt.step(self.params, {"w": self._g})
+
+
+def CategoricalSum(weight, lr):
+    """CategoricalCondition(reduce='sum', sparse=False)."""
+    return CategoricalEmbedding(weight, lr, reduce="sum", sparse=False)
 
 
 # ---------------------------------------------------------------------------

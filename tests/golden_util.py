@@ -14,6 +14,9 @@ STEP_CASES = [
     "step_tanh", "step_lrs", "step_wide", "step_headline",
 ]
 
+# trainable CategoricalCondition variants (SparseAdam / mean / single index / behind a constant block)
+CAT_CASES = ["step_cat_sparse_sum", "step_cat_sparse_mean", "step_cat_single", "step_concat_cat"]
+
 NET_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
 
 

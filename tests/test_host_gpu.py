@@ -7,7 +7,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from golden_util import Fixture
+from golden_util import CAT_CASES, Fixture
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -144,6 +144,84 @@ def test_condition_plugins_through_autograd_bridge(name):
         pc = [[[int(j) for j in row if j != 0] or [0] for row in pc[0]]]
     m.batch_size = 7
     np.testing.assert_allclose(m.predict(Xp, condition_data=pc), fx.z["predict.out"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["step_cond_categorical"] + CAT_CASES)
+def test_categorical_condition_device_native(name):
+    """A CategoricalCondition with its table on the GPU is trained by the library's own kernels (aae_cat_encode before
+    the fused step, aae_cat_update = backward + SparseAdam / Adam after it) instead of the autograd bridge: same
+    fixtures from the reference, including the condition's optimiser state."""
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec import condition as C
+    fx = Fixture(name)
+    cfg = fx.cfg
+    kind = cfg.get("cat", dict(sparse=False, reduce="sum", concat=False, lr=1e-2))
+
+    class ConstConcat(C.ConcatenationBasedConditioning):
+        constant_concat = True
+
+        def size_increment(self):
+            return 30
+
+        def encode(self, inputs):
+            return torch.as_tensor(inputs, dtype=torch.float32, device="cuda")
+
+    cat = C.CategoricalCondition(8, sparse=kind["sparse"], use_cuda=True, reduce=kind["reduce"], lr=kind["lr"])
+    assert cat.embedding_on_gpu
+    V = fx.z["init.cond.embedding"].shape[0]
+    cat.vocab = {"a%d" % i: i for i in range(1, V)}               # indices are given pre-transformed
+    cat.embedding = torch.nn.Embedding(V, 8, padding_idx=0, sparse=kind["sparse"]).cuda()
+    with torch.no_grad():
+        cat.embedding.weight.copy_(torch.from_numpy(fx.z["init.cond.embedding"]))
+    opt = torch.optim.SparseAdam if kind["sparse"] else torch.optim.Adam
+    cat.optimizer = opt(cat.embedding.parameters(), lr=kind["lr"])
+    items = [("authors", cat)]
+    if kind["concat"]:
+        items.insert(0, ("title", ConstConcat()))
+    conds = C.ConditionList(items)
+
+    def cat_inputs(arr):
+        if kind["reduce"] is None:
+            return [int(j) for j in arr]
+        # the fixture stores the batch-padded lists; strip the padding again but keep the padded width (one row
+        # always spans it), which 'mean' divides by
+        return [[int(j) for j in row if j != 0] or [0] for row in arr]
+
+    m = AdversarialAutoEncoder(n_hidden=cfg["h"], n_code=cfg["c"], batch_size=cfg["B"], conditions=conds,
+                               verbose=True, rng_mode="reference", **fx.model_kwargs())
+    m._build(cfg["N"], cfg["cond_inc"])
+    assert m._is_device_native() and not m._is_constant_concat()
+    m.hip.load_params(fx.init_params())
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+        cin = fx.cond_inputs(s)
+        cin[-1] = cat_inputs(cin[-1])
+        masks, zr = fx.masks(s), fx.z[f"step{s}.z_real"]
+        m._host_randomness = lambda B, masks=masks, zr=zr: (masks, torch.from_numpy(zr))
+        m.partial_fit(X, condition_data=cin)
+        np.testing.assert_allclose(m.last_losses, fx.z[f"step{s}.losses"], rtol=1e-5, atol=1e-6)
+        got = m.hip.state_dict()
+        for k, w in fx.expected_params(s).items():
+            np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=f"{name} step {s} {k}")
+        np.testing.assert_allclose(cat.embedding.weight.detach().cpu().numpy(), fx.z[f"step{s}.cond.embedding"],
+                                   atol=1e-5, err_msg=f"{name} step {s} embedding")
+        if f"step{s}.cond.m" in fx.z.files:
+            st = cat.optimizer.state[cat.embedding.weight]
+            assert float(st["step"]) == float(fx.z[f"step{s}.cond.t"])
+            np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), fx.z[f"step{s}.cond.m"], atol=1e-8, rtol=1e-4)
+            np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), fx.z[f"step{s}.cond.v"], atol=1e-12, rtol=1e-4)
+    # the padding row never moves
+    assert float(cat.embedding.weight.detach()[0].abs().max()) == 0.0
+    ip, idx, val = fx.batch(0, prefix="predict")
+    Xp = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+    pc = fx.cond_inputs(0, prefix="predict")
+    pc[-1] = cat_inputs(pc[-1])
+    m.batch_size = 7
+    np.testing.assert_allclose(m.predict(Xp, condition_data=pc), fx.z["predict.out"], atol=1e-5)
+    # the optimiser state is torch's own: the same condition keeps training through the autograd bridge
+    sd = cat.optimizer.state_dict()
+    assert sd["state"][0]["exp_avg"].shape == (V, 8)
 
 
 def test_recommender_with_bags_and_evaluation_harness(capsys):

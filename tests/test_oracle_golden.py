@@ -3,7 +3,7 @@ real reference (tools/gen_golden.py).  Runs without a GPU."""
 import numpy as np
 import pytest
 
-from golden_util import STEP_CASES, Fixture
+from golden_util import CAT_CASES, STEP_CASES, Fixture
 from oracle import aae_oracle as O
 
 TOL_LOSS = 2e-6     # relative, fp32 summation order only
@@ -22,10 +22,15 @@ def build_oracle(fx):
         conds.append(O.BiasConst())
     if cond == "categorical":
         conds.append(O.CategoricalSum(fx.z["init.cond.embedding"], lr=1e-2))
+    elif "cat" in fx.cfg:
+        k = fx.cfg["cat"]
+        if k["concat"]:
+            conds.append(O.ConcatConst(30))
+        conds.append(O.CategoricalEmbedding(fx.z["init.cond.embedding"], lr=k["lr"], reduce=k["reduce"], sparse=k["sparse"]))
     return O.OracleAAE(fx.init_params(), conditions=conds, **fx.model_kwargs())
 
 
-@pytest.mark.parametrize("name", STEP_CASES)
+@pytest.mark.parametrize("name", STEP_CASES + CAT_CASES)
 def test_oracle_reproduces_reference_steps(name):
     fx = Fixture(name)
     m = build_oracle(fx)
@@ -50,12 +55,17 @@ def test_oracle_reproduces_reference_steps(name):
             assert o.t[k] == et
             np.testing.assert_allclose(o.m[k], em, atol=1e-9, rtol=2e-5, err_msg=f"{name} {tag} m {k}")
             np.testing.assert_allclose(o.v[k], ev, atol=1e-13, rtol=5e-5, err_msg=f"{name} {tag} v {k}")
-        if fx.cfg["cond"] == "categorical":
-            np.testing.assert_allclose(m.conditions[0].params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
+        if fx.cfg["cond"] == "categorical" or "cat" in fx.cfg:
+            cat = m.conditions[-1]
+            np.testing.assert_allclose(cat.params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
+            if f"step{s}.cond.m" in fx.z.files:       # the condition's own optimiser (SparseAdam: touched rows only)
+                assert cat.opt.t == float(fx.z[f"step{s}.cond.t"])
+                np.testing.assert_allclose(cat.opt.m, fx.z[f"step{s}.cond.m"], atol=1e-9, rtol=2e-5)
+                np.testing.assert_allclose(cat.opt.v, fx.z[f"step{s}.cond.v"], atol=1e-13, rtol=5e-5)
 
 
 @pytest.mark.parametrize("name", ["step_nodrop_gauss", "step_cond_concat", "step_cond_concat_bias",
-                                  "step_selu", "step_categorical_prior", "step_ragged"])
+                                  "step_selu", "step_categorical_prior", "step_ragged"] + CAT_CASES)
 def test_oracle_predict(name):
     fx = Fixture(name)
     m = build_oracle(fx)

@@ -516,3 +516,70 @@ def test_tiny_shapes_match_oracle(N, B, h, c):
     got = dev.state_dict()
     for k, w in ora.p.items():
         np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("rows,width,vocab,dim,mean", [(100, 9, 300, 200, False), (37, 4, 50, 33, True),
+                                                       (64, 1, 40, 64, False), (3, 70, 9, 256, True)])
+def test_categorical_condition_kernels_match_oracle(rows, width, vocab, dim, mean, sparse):
+    """aae_cat_encode / aae_cat_update against the oracle's CategoricalEmbedding (itself pinned to the reference's
+    CategoricalCondition fixtures): wide tables, values shared by many documents and repeated inside one list,
+    padding in the middle of a list, a strided output block; five optimiser steps."""
+    from aaerec import _hip
+    from oracle import aae_oracle as O
+    rng = np.random.default_rng(rows * 7 + width)
+    table0 = (rng.standard_normal((vocab, dim)) * 0.1).astype(np.float32)
+    table0[0] = 0
+    ora = O.CategoricalEmbedding(table0, lr=3e-3, reduce="mean" if mean else "sum", sparse=sparse)
+    dev = torch.device("cuda:0")
+    table = torch.from_numpy(table0.copy()).to(dev)
+    m, v = torch.zeros_like(table), torch.zeros_like(table)
+    scratch = None if sparse else torch.zeros_like(table)
+    off = 5                                                      # the block is a column slice of a wider buffer
+    for step in range(1, 6):
+        idx = rng.integers(0, vocab, size=(rows, width))
+        idx[rng.random((rows, width)) < 0.3] = 0                 # padding / out of vocabulary anywhere in the list
+        if width > 1:
+            idx[:, 1] = idx[:, 0]                                # the same value twice in one document
+        d = (rng.standard_normal((rows, dim)) * 0.05).astype(np.float32)
+        idx_dev = torch.from_numpy(idx.astype(np.int32)).to(dev)
+        block = torch.full((rows, dim + 11), 7.0, device=dev)
+        _hip.cat_encode(table, idx_dev, block[:, off:off + dim], mean=mean)
+        want = ora.encode(idx)
+        np.testing.assert_allclose(block[:, off:off + dim].cpu().numpy(), want, atol=1e-6, rtol=1e-6)
+        assert float(block[:, :off].min()) == 7.0 and float(block[:, off + dim:].min()) == 7.0
+        dblock = torch.zeros(rows, dim + 11, device=dev)
+        dblock[:, off:off + dim] = torch.from_numpy(d).to(dev)
+        _hip.cat_update(table, m, v, idx_dev, dblock[:, off:off + dim], 3e-3, step, mean=mean, grad_scratch=scratch)
+        ora._c = 0
+        ora.bwd(d)
+        ora.step()
+        np.testing.assert_allclose(table.cpu().numpy(), ora.params["w"], atol=2e-6, rtol=0, err_msg=f"step {step}")
+        om, ov = (ora.opt.m, ora.opt.v) if sparse else (ora.opt.m["w"], ora.opt.v["w"])
+        np.testing.assert_allclose(m.cpu().numpy(), om, atol=1e-9, rtol=1e-5)
+        np.testing.assert_allclose(v.cpu().numpy(), ov, atol=1e-13, rtol=1e-5)
+        if scratch is not None:
+            assert float(scratch.abs().max()) == 0.0             # consumed and cleared
+    assert float(table[0].abs().max()) == 0.0
+
+
+def test_categorical_condition_abi_rejects_bad_operands():
+    from aaerec import _hip
+    dev = torch.device("cuda:0")
+    table = torch.zeros(10, 8, device=dev)
+    idx = torch.zeros(4, 2, dtype=torch.int32, device=dev)
+    with pytest.raises(TypeError):
+        _hip.cat_encode(table, idx.long(), torch.zeros(4, 8, device=dev))
+    with pytest.raises(TypeError):
+        _hip.cat_encode(table, idx, torch.zeros(4, 9, device=dev))
+    with pytest.raises(RuntimeError):
+        _hip.cat_encode(table.cpu(), idx, torch.zeros(4, 8, device=dev))
+    with pytest.raises(_hip.AaeHipError):                        # dim > 256
+        _hip.cat_encode(torch.zeros(10, 300, device=dev), idx, torch.zeros(4, 300, device=dev))
+    with pytest.raises(_hip.AaeHipError):                        # step counts from 1
+        _hip.cat_update(table, torch.zeros_like(table), torch.zeros_like(table), idx, torch.zeros(4, 8, device=dev), 1e-3, 0)
+    # out-of-range indices read as padding instead of faulting
+    bad = torch.tensor([[11, -3], [1, 2], [0, 0], [9, 10]], dtype=torch.int32, device=dev)
+    out = torch.empty(4, 8, device=dev)
+    _hip.cat_encode(table + 1.0, bad, out)
+    assert out.cpu().numpy()[:, 0].tolist() == [0.0, 2.0, 0.0, 1.0]

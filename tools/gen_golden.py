@@ -142,6 +142,24 @@ def optim_np(opt, params):
     return out
 
 
+# CategoricalCondition variants (condition.py:397-508): optimiser (sparse=True -> SparseAdam), reduction over the
+# padded list (None = one value per document), and whether a constant 30-wide block precedes it in the ConditionList
+CAT_KINDS = {
+    "categorical": dict(sparse=False, reduce="sum", concat=False),
+    "cat_sparse_sum": dict(sparse=True, reduce="sum", concat=False),
+    "cat_sparse_mean": dict(sparse=True, reduce="mean", concat=False),
+    "cat_single": dict(sparse=True, reduce=None, concat=False),
+    "concat30+cat": dict(sparse=True, reduce="sum", concat=True),
+}
+
+
+def _pad_lists(lists):
+    if not isinstance(lists[0], list):
+        return np.asarray(lists, dtype=np.int64)
+    L = max(len(l) for l in lists)
+    return np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
+
+
 ENC_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
 
 
@@ -163,10 +181,21 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
                 return torch.as_tensor(inputs, dtype=torch.float32)
         conditions = ref_cond.ConditionList([("title", ConstConcat())])
         cond_inc = 30
-    elif cond == "categorical":
-        cc = ref_cond.CategoricalCondition(8, sparse=False, use_cuda=False, reduce="sum", lr=1e-2)
-        conditions = ref_cond.ConditionList([("authors", cc)])
+    elif cond in CAT_KINDS:
+        kind = CAT_KINDS[cond]
+        cc = ref_cond.CategoricalCondition(8, sparse=kind["sparse"], use_cuda=False, reduce=kind["reduce"], lr=1e-2)
+        items = [("authors", cc)]
         cond_inc = 8
+        if kind["concat"]:
+            class ConstConcat(ref_cond.ConcatenationBasedConditioning):
+                def size_increment(self):
+                    return 30
+
+                def encode(self, inputs):
+                    return torch.as_tensor(inputs, dtype=torch.float32)
+            items.insert(0, ("title", ConstConcat()))
+            cond_inc = 38
+        conditions = ref_cond.ConditionList(items)
     elif cond == "concat30+bias":
         class ConstConcat(ref_cond.ConcatenationBasedConditioning):
             def size_increment(self):
@@ -226,12 +255,16 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
         for k, v in state_np(net).items():
             out[f"init.{net_name}.{k}"] = v
 
-    if cond == "categorical":
+    if cond in CAT_KINDS:
         # fit the vocabulary on all raw inputs first (AAERecommender.train -> fit_transform)
         raw_all = [[f"a{int(x)}" for x in rng.integers(0, 12, size=int(rng.integers(1, 4)))]
                    for _ in range(B * steps)]
-        cdata = conditions.fit_transform([raw_all])[0]
+        if kind["reduce"] is None:
+            raw_all = [r[0] for r in raw_all]
+        cc.fit(raw_all)
+        cdata = cc.transform(raw_all)
         out["init.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+        cfg["cat"] = dict(kind, lr=1e-2)
 
     acts = {}
     if capture_acts:
@@ -260,11 +293,14 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
             out[f"step{s}.cond0"] = cv
             out[f"step{s}.cond1"] = bv
             cbatch = [cv, bv]
-        elif cond == "categorical":
+        elif cond in CAT_KINDS:
             lists = cdata[s * B: s * B + Bs]
-            L = max(len(l) for l in lists)
-            out[f"step{s}.cond0"] = np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
             cbatch = [lists]
+            if kind["concat"]:
+                cv = (rng.standard_normal((Bs, 30)) * 0.5).astype(np.float32)
+                out[f"step{s}.cond0"] = cv
+                cbatch = [cv, lists]
+            out[f"step{s}.cond{len(cbatch) - 1}"] = _pad_lists(lists)
         n_masks0, n_z0 = len(masks_log), len(z_log)
         m.partial_fit(X.toarray(), condition_data=cbatch, step=s)
         out[f"step{s}.losses"] = np.asarray(loss_log[-1], dtype=np.float64)
@@ -282,8 +318,12 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
                              ("A_gen", m.gen_optim, ep), ("A_disc", m.disc_optim, xp)):
             for k, v in optim_np(opt, ps).items():
                 out[f"step{s}.{tag}.{k}"] = v
-        if cond == "categorical":
+        if cond in CAT_KINDS:
             out[f"step{s}.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+            st = cc.optimizer.state[cc.embedding.weight]
+            out[f"step{s}.cond.m"] = st["exp_avg"].numpy().copy()
+            out[f"step{s}.cond.v"] = st["exp_avg_sq"].numpy().copy()
+            out[f"step{s}.cond.t"] = np.asarray(float(st["step"]))
         if capture_acts and s == 0:
             # forward order inside partial_fit: ae (train), disc (eval), gen (train)
             out["step0.act.enc_a1_ae"] = acts["enc_a1"][0]
@@ -307,11 +347,14 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
         pbv = (rng.standard_normal((B, c + 30)) * 0.1).astype(np.float32)
         out["predict.cond0"], out["predict.cond1"] = pcv, pbv
         pc = [pcv, pbv]
-    elif cond == "categorical":
+    elif cond in CAT_KINDS:
         lists = cdata[:B]
-        L = max(len(l) for l in lists)
-        out["predict.cond0"] = np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
         pc = [lists]
+        if kind["concat"]:
+            pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+            out["predict.cond0"] = pcv
+            pc = [pcv, lists]
+        out[f"predict.cond{len(pc) - 1}"] = _pad_lists(lists)
     m.batch_size = 7   # exercises the ragged last predict batch
     out["predict.out"] = m.predict(Xp, condition_data=pc).astype(np.float32)
     out["config_json"] = np.asarray(json.dumps(cfg))
@@ -791,6 +834,13 @@ def main():
         # decoder output layer, 7 row blocks) on a small vocabulary, straight from the reference
         run_case(ref_aae, ref_cond, "step_headline", seed=16, N=330, h=200, c=50, B=100, steps=2,
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=24), capture_acts=False, states='last')
+    if want("catcond"):
+        # trainable CategoricalCondition variants: SparseAdam (the reference's default), mean / no reduction, and
+        # behind a constant concatenated block
+        run_case(ref_aae, ref_cond, "step_cat_sparse_sum", seed=41, cond="cat_sparse_sum", dropout=(0.2, 0.2), steps=4)
+        run_case(ref_aae, ref_cond, "step_cat_sparse_mean", seed=42, cond="cat_sparse_mean", steps=4)
+        run_case(ref_aae, ref_cond, "step_cat_single", seed=43, cond="cat_single", steps=4)
+        run_case(ref_aae, ref_cond, "step_concat_cat", seed=44, cond="concat30+cat", dropout=(0.2, 0.2), steps=4)
     if want("ae_only"):
         run_ae_only_case(ref_aae, "step_ae_only", seed=21)
     if want("decoding"):
