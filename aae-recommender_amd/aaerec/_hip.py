@@ -139,6 +139,31 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_UPLOAD_STREAMS = {}
+
+
+def upload(x, device, dtype=None):
+    """Host -> HBM copy of a small per-batch operand (condition inputs, index blocks) that does not drain the queue.
+
+    A blocking copy from pageable memory on the compute stream waits for every kernel already enqueued there, so a
+    training loop that uploads something per batch runs host and GPU in lock-step.  The copy goes through a side
+    stream instead: the host waits for the copy alone, and because it has completed before this function returns,
+    whatever is enqueued afterwards on the compute stream sees the data.  Device tensors pass through."""
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+    dev = torch.device(device)
+    if t.is_cuda or dev.type != "cuda":
+        return t.to(dev, dtype) if dtype is not None else t.to(dev)
+    if dtype is not None:
+        t = t.to(dtype)
+    side = _UPLOAD_STREAMS.get(dev)
+    if side is None:
+        side = _UPLOAD_STREAMS[dev] = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        out = t.to(dev)
+    out.record_stream(torch.cuda.current_stream(dev))
+    return out
+
+
 def _cat_args(table, idx, block):
     """Argument checks shared by cat_encode / cat_update (operand shapes must match what the kernels index)."""
     if not (table.is_cuda and idx.is_cuda and block.is_cuda):
@@ -418,7 +443,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows, rows)
         inj = self._inject(masks, z_real)
         if cond is not None:
-            cond = cond.to(self.device, torch.float32).contiguous()
+            cond = upload(cond, self.device, torch.float32).contiguous()
             self._keep.append(cond)
         with torch.cuda.device(self.device):
             _check(self.lib.aae_step(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
@@ -465,7 +490,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows, rows)
         keep = []
         if cond is not None:
-            cond = cond.to(self.device, torch.float32).contiguous(); keep.append(cond)
+            cond = upload(cond, self.device, torch.float32).contiguous(); keep.append(cond)
         if eps is not None:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous(); keep.append(eps)
         self._keep = keep
@@ -476,7 +501,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows)
         out = self._out_buffer(n_rows)
         if cond is not None:
-            cond = cond.to(self.device, torch.float32).contiguous()
+            cond = upload(cond, self.device, torch.float32).contiguous()
         if eps is not None:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
         with torch.cuda.device(self.device):
@@ -571,7 +596,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows)
         out = self._out_buffer(n_rows)
         if cond is not None:
-            cond = cond.to(self.device, torch.float32).contiguous()
+            cond = upload(cond, self.device, torch.float32).contiguous()
         with torch.cuda.device(self.device):
             _check(self.lib.aae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(out), out.shape[1], self._stream()))
         return out[:, :self.N]
@@ -582,7 +607,7 @@ class HipAAE:
         idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
         if cond is not None:
-            cond = cond.to(self.device, torch.float32).contiguous()
+            cond = upload(cond, self.device, torch.float32).contiguous()
         with torch.cuda.device(self.device):
             _check(self.lib.aae_predict_topk(self.handle, C.byref(b), _ptr(cond), int(k), int(bool(exclude_known)),
                                              _ptr(idx), _ptr(val), self._stream()))

@@ -220,7 +220,7 @@ class AdversarialAutoEncoder:
         for cond, x in zip(self.conditions.values(), c_batch):
             w = cond.size_increment()
             if getattr(cond, "constant_concat", False):
-                block[:, off:off + w] = cond.encode(x).to(dev)
+                block[:, off:off + w] = _hip.upload(cond.encode(x), dev)
             else:
                 cond.encode_into(block[:, off:off + w], x)
             off += w
@@ -251,7 +251,7 @@ class AdversarialAutoEncoder:
             hip.step(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
         elif self._is_constant_concat():
             blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
-            hip.step(csr, row_start, n_rows, rows=rows, cond=torch.cat([b.to(hip.device) for b in blocks], 1),
+            hip.step(csr, row_start, n_rows, rows=rows, cond=torch.cat([_hip.upload(b, hip.device) for b in blocks], 1),
                      masks=masks, z_real=z_real)
         elif self._is_device_native():
             hip.step(csr, row_start, n_rows, rows=rows, cond=self._native_cond_block(c_batch, n_rows), masks=masks,
@@ -376,7 +376,7 @@ class AdversarialAutoEncoder:
                 if fused:
                     cond = None
                     if use_condition:
-                        cond = torch.cat([c.encode(x).to(self.hip.device)
+                        cond = torch.cat([_hip.upload(c.encode(x), self.hip.device)
                                           for c, x in zip(self.conditions.values(), c_batch)], 1)
                     out = self.hip.predict(csr, start, n, cond=cond)
                 elif native:
@@ -432,7 +432,7 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
         cond = None
         if use_condition:
             c_batch = [_take(c, slice(start, start + n)) for c in condition_data]
-            cond = torch.cat([c.encode(x).to(self.hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
+            cond = torch.cat([_hip.upload(c.encode(x), self.hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
         i, v = self.hip.predict_topk(csr, start, n, k, cond=cond, exclude_known=exclude_known)
         ids.append(i)
         vals.append(v)

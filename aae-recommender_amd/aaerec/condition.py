@@ -229,6 +229,9 @@ class PretrainedWordEmbeddingCondition(ConcatenationBasedConditioning):
         return self.vect.fit_transform(raw_inputs)
 
     def encode(self, inputs):
+        if self.device.type == "cuda":
+            from . import _hip
+            return _hip.upload(inputs, self.device, torch.float32)
         return torch.as_tensor(inputs, dtype=torch.float32, device=self.device)
 
     def size_increment(self):
@@ -345,7 +348,8 @@ class CategoricalCondition(ConcatenationBasedConditioning):
             arr = np.zeros((len(inputs), width), dtype=np.int32)
             for r, row in enumerate(inputs):
                 arr[r, :len(row)] = row
-        return torch.from_numpy(arr).to(device)
+        from . import _hip
+        return _hip.upload(arr, device)
 
     def encode_into(self, out, inputs):
         """encode(inputs) written into `out` ([rows, embedding_dim], may be a column slice of a wider block)."""

@@ -101,7 +101,7 @@ class VAE:
 
     def _cond(self, c_batch):
         blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
-        return torch.cat([b.to(self.device) for b in blocks], 1)
+        return torch.cat([_hip.upload(b, self.device) for b in blocks], 1)
 
     def _step(self, csr, n_rows, rows, c_batch):
         self.hip.vae_step(csr, 0, n_rows, rows=rows, cond=self._cond(c_batch) if c_batch is not None else None,

@@ -68,3 +68,9 @@ for on_gpu in (False, True):
         32, use_cuda=True, embedding_on_gpu=on_gpu, reduce="sum"))])
     d2 = both.fit_transform([vec, authors])
     rate(f"concat + categorical (emb on {'gpu' if on_gpu else 'cpu'})", both, d2, epochs=25 if on_gpu else 2)
+
+# the same condition forced through the torch-autograd bridge (the step cut at the condition boundary)
+cat = C.CategoricalCondition(32, use_cuda=True, reduce="sum")
+cat.device_native = lambda device: False
+cl = C.ConditionList([("authors", cat)])
+rate("categorical (emb on gpu, autograd bridge)", cl, cl.fit_transform([authors]))
