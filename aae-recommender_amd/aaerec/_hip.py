@@ -210,18 +210,18 @@ class DeviceCSR:
         X.sum_duplicates()
         self.shape = X.shape
         self.nnz_per_row_max = int(np.diff(X.indptr).max()) if X.shape[0] else 0
-        self.indptr = torch.as_tensor(X.indptr.astype(np.int64), device=device)
-        self.indices = torch.as_tensor(X.indices.astype(np.int32), device=device)
-        self.values = torch.as_tensor(X.data.astype(np.float32), device=device)
+        self.indptr = upload(X.indptr.astype(np.int64), device)
+        self.indices = upload(X.indices.astype(np.int32), device)
+        self.values = upload(X.data.astype(np.float32), device)
 
     @classmethod
     def from_arrays(cls, indptr, indices, values, n_cols, device):
         self = cls.__new__(cls)
         self.shape = (len(indptr) - 1, n_cols)
         self.nnz_per_row_max = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
-        self.indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64), device=device)
-        self.indices = torch.as_tensor(np.asarray(indices, dtype=np.int32), device=device)
-        self.values = torch.as_tensor(np.asarray(values, dtype=np.float32), device=device)
+        self.indptr = upload(np.asarray(indptr, dtype=np.int64), device)
+        self.indices = upload(np.asarray(indices, dtype=np.int32), device)
+        self.values = upload(np.asarray(values, dtype=np.float32), device)
         return self
 
 
