@@ -368,7 +368,7 @@ class AdversarialAutoEncoder:
         csr = _hip.DeviceCSR(Xs, self.hip.device)
         fused = (not use_condition) or self._is_constant_concat()
         native = use_condition and not fused and self._is_device_native()
-        pred = []
+        pred = _hip.HostRows(Xs.shape[0], Xs.shape[1], self.hip.device)
         with torch.no_grad():
             for start in range(0, Xs.shape[0], self.batch_size):
                 n = min(self.batch_size, Xs.shape[0] - start)
@@ -384,8 +384,8 @@ class AdversarialAutoEncoder:
                 else:
                     z = self.hip.encode(csr, start, n)
                     out = self.hip.decode(self.conditions.encode_impose(z, c_batch))
-                pred.append(out.cpu().numpy())
-        return np.vstack(pred)
+                pred.put(start, out)
+        return pred.numpy()
 
 
 class AutoEncoder(AdversarialAutoEncoder):
@@ -586,13 +586,12 @@ class DecodingRecommender(Recommender):
 
     def _predict_conditions(self, condition_data, n_users):
         self.conditions.eval()
-        batch_results = []
+        batch_results = _hip.HostRows(n_users, self.hip.N, self.hip.device)
         with torch.no_grad():
             for start in range(0, n_users, self.batch_size):
                 c_batch = [_take(c, slice(start, start + self.batch_size)) for c in condition_data]
-                res = self.hip.decode(self._inputs(c_batch))
-                batch_results.append(res.cpu().numpy())
-        return np.vstack(batch_results)
+                batch_results.put(start, self.hip.decode(self._inputs(c_batch)))
+        return batch_results.numpy()
 
     def predict(self, test_set):
         n_users = test_set.size(0)

@@ -164,15 +164,15 @@ class VAE:
             self.conditions.eval()
         Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         csr = _hip.DeviceCSR(Xs, self.device)
-        pred = []
+        pred = _hip.HostRows(Xs.shape[0], Xs.shape[1], self.device)
         with torch.no_grad():
             for start in range(0, Xs.shape[0], self.batch_size):
                 n = min(self.batch_size, Xs.shape[0] - start)
                 cond = None
                 if use_condition:
                     cond = self._cond([_take(c, slice(start, start + n)) for c in condition_data])
-                pred.append(self.hip.vae_predict(csr, start, n, cond=cond, eps=self._eps(n)).cpu().numpy())
-        return np.vstack(pred)
+                pred.put(start, self.hip.vae_predict(csr, start, n, cond=cond, eps=self._eps(n)))
+        return pred.numpy()
 
 
 class VAERecommender(Recommender):
