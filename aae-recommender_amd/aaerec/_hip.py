@@ -99,6 +99,8 @@ _PROTOS = {
                                  C.c_int64, C.c_void_p]),
     "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_void_p]),
+    "aae_csr_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -228,6 +230,22 @@ def cat_update(table, exp_avg, exp_avg_sq, idx, dout, lr, step, mean=False, grad
                                              CAT_MEAN if mean else CAT_SUM, _ptr(dout), dout.stride(0),
                                              CAT_ADAM if grad_scratch is not None else CAT_SPARSE_ADAM, float(lr), int(step),
                                              C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)))
+
+
+def csr_embed(csr, table):
+    """[rows, dim] device tensor: row r = sum of csr.values[e] * table[csr.indices[e]] over the entries of row r
+    (EmbeddedVectorizer.transform's `sparse_scores @ embedding`, reference ub.py:52-57)."""
+    if not table.is_cuda or table.dtype != torch.float32 or table.dim() != 2 or table.stride(1) != 1:
+        raise TypeError("aaerec: table must be a float32 [vocab, dim] GPU tensor with unit column stride")
+    if csr.shape[1] > table.shape[0]:
+        raise ValueError("aaerec: the sparse matrix has more columns than the table has rows")
+    out = torch.empty(csr.shape[0], table.shape[1], dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _check(load_library().aae_csr_embed(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.values), csr.shape[0],
+                                            _ptr(table), table.shape[0], table.shape[1], table.stride(0), _ptr(out),
+                                            out.stride(0),
+                                            C.c_void_p(torch.cuda.current_stream(table.device).cuda_stream)))
+    return out
 
 
 class DeviceCSR:

@@ -992,6 +992,20 @@ int aae_cat_update(float* table_dev, float* exp_avg_dev, float* exp_avg_sq_dev, 
     return AAE_OK;
 }
 
+int aae_csr_embed(const int64_t* indptr_dev, const int32_t* indices_dev, const float* values_dev, int32_t n_rows,
+                  const float* table_dev, int32_t n_table_rows, int32_t dim, int64_t table_ld, float* out_dev,
+                  int64_t out_ld, void* stream) {
+    if (!indptr_dev || !table_dev || !out_dev) return fail(AAE_EINVAL, "aae_csr_embed: indptr/table/out is NULL");
+    if (n_rows < 0 || n_table_rows < 1 || dim < 1 || table_ld < dim || out_ld < dim)
+        return fail(AAE_EINVAL, "aae_csr_embed: bad shape (need n_table_rows >= 1, dim >= 1, leading dimensions >= dim)");
+    if (n_rows == 0) return AAE_OK;
+    if (!indices_dev || !values_dev) return fail(AAE_EINVAL, "aae_csr_embed: indices/values is NULL");
+    hipLaunchKernelGGL(csr_embed_kernel, dim3(n_rows), dim3(256), 0, S(stream), (const long long*)indptr_dev, indices_dev,
+                       values_dev, table_dev, n_table_rows, dim, (long long)table_ld, out_dev, (long long)out_ld);
+    LAUNCHCHK("csr_embed");
+    return AAE_OK;
+}
+
 int aae_profile_enable(aae_handle h, int on) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     if (on && !h->prof_ev) h->prof_ev = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[AAE_K_N];

@@ -105,4 +105,23 @@ cat_dense_adam_kernel(float* __restrict__ table, float* __restrict__ m, float* _
     table[i] = p; m[i] = mi; v[i] = vi;
 }
 
+// Weighted bag of embedded words (reference ub.py:52-57, `sparse_scores @ self.embedding`): out[r] = sum over the
+// CSR entries e of row r of values[e] * table[indices[e]], entries in CSR order (scipy's order).  One workgroup per
+// document, a thread per column (coalesced 1 KB row segments); the TF-IDF rows of a title hold 5-20 words.
+__global__ void __launch_bounds__(256)
+csr_embed_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices, const float* __restrict__ values,
+                 const float* __restrict__ table, int n_table_rows, int dim, long long ldt, float* __restrict__ out,
+                 long long ldo) {
+    const int r = blockIdx.x;
+    const long long e0 = indptr[r], e1 = indptr[r + 1];
+    for (int col = threadIdx.x; col < dim; col += 256) {
+        float acc = 0.f;
+        for (long long e = e0; e < e1; ++e) {
+            const int j = indices[e];
+            if (j >= 0 && j < n_table_rows) acc += values[e] * table[(size_t)j * ldt + col];
+        }
+        out[(size_t)r * ldo + col] = acc;
+    }
+}
+
 }  // namespace aae

@@ -235,6 +235,13 @@ int aae_cat_encode(const float* table_dev, int32_t vocab, int32_t dim, const int
 int aae_cat_update(float* table_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* grad_scratch_dev, int32_t vocab,
                    int32_t dim, const int32_t* idx_dev, int32_t rows, int32_t width, int32_t reduce,
                    const float* dout_dev, int64_t dout_ld, int32_t optimizer, double lr, int64_t step, void* stream);
+/* PretrainedWordEmbeddingCondition's preprocessing (condition.py:345-369 -> ub.py:52-57, EmbeddedVectorizer.transform:
+ * `sparse_scores @ self.embedding`): out_dev[r][0:dim] = sum over the CSR entries e of row r of
+ * values[e] * table_dev[indices[e]][0:dim], accumulated in CSR order.  indptr int64 [n_rows + 1] (absolute offsets
+ * into indices / values), indices int32, values float32 (the TF-IDF weights); indices outside the table are skipped. */
+int aae_csr_embed(const int64_t* indptr_dev, const int32_t* indices_dev, const float* values_dev, int32_t n_rows,
+                  const float* table_dev, int32_t n_table_rows, int32_t dim, int64_t table_ld, float* out_dev,
+                  int64_t out_ld, void* stream);
 /* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
  * between them) */
 int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);

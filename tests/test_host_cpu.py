@@ -230,3 +230,30 @@ def test_torch_custom_ops_are_registered_and_have_no_cpu_path():
     val = torch.ones(1)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.aaerec.encode(1, ip, idx, val, 0, 1, 1)
+
+
+def test_embedded_vectorizer_host_side_matches_reference_fixture():
+    """aaerec.ub.EmbeddedVectorizer: the TF-IDF half (host, scikit-learn) against the fixture made with the
+    reference's own fit / transform (tools/gen_golden.py vectorizer); the product itself is a GPU kernel and
+    transform() refuses to run without one."""
+    import json
+    from aaerec.ub import EmbeddedVectorizer, GensimEmbeddedVectorizer
+    z = np.load(os.path.join(GOLDEN, "embedded_vectorizer.npz"))
+    words, docs, test = (json.loads(str(z[k])) for k in ("words", "docs", "test"))
+    for tag in ("default", "sublinear"):
+        v = EmbeddedVectorizer(z["embedding"], words, **json.loads(str(z[f"{tag}.kwargs"])))
+        assert v.fit(docs) is v and v.vocabulary_["w7"] == 7 and "oov" not in v.vocabulary_
+        np.testing.assert_allclose(v.tfidf.transform(docs) @ z["embedding"], z[f"{tag}.train"], atol=1e-12)
+        np.testing.assert_allclose(v.tfidf.transform(test) @ z["embedding"], z[f"{tag}.test"], atol=1e-12)
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError, match="no CPU path"):
+                v.transform(docs)
+    with pytest.raises(ValueError):
+        EmbeddedVectorizer(z["embedding"], words[:-1])
+    with pytest.raises(TypeError):
+        EmbeddedVectorizer(z["embedding"], words, vocabulary=words)
+
+    class KV:                      # gensim >= 4 attribute names
+        index_to_key, vectors = words, z["embedding"]
+    g = GensimEmbeddedVectorizer(KV())
+    assert repr(g) == "Gensim Embedded Vectorizer with embedding shape (400, 300)"

@@ -591,3 +591,27 @@ def test_vae_fit_with_reference_rng_and_recommender():
     # and 0.020 / 0.014 / 0.013 after 200 (seeds 1..3, measured with the reference in this repo's container;
     # chance is ~0.003).  Parity with that behaviour is the point, not a good recommender.
     assert 0.006 < np.median(mrr) < 0.1, mrr
+
+
+def test_embedded_vectorizer_product_on_the_gpu_matches_reference_fixture():
+    """EmbeddedVectorizer.transform (TF-IDF on the host, `aae_csr_embed` for the product) against the reference's
+    outputs; then as the vectoriser of a PretrainedWordEmbeddingCondition built from gensim-like vectors."""
+    import json
+    from aaerec import condition as C
+    from aaerec.ub import EmbeddedVectorizer
+    z = np.load(os.path.join(GOLDEN, "embedded_vectorizer.npz"))
+    words, docs, test = (json.loads(str(z[k])) for k in ("words", "docs", "test"))
+    for tag in ("default", "sublinear"):
+        v = EmbeddedVectorizer(z["embedding"], words, **json.loads(str(z[f"{tag}.kwargs"])))
+        got = v.fit_transform(docs)
+        assert got.dtype == np.float32 and got.shape == (len(docs), 300)
+        np.testing.assert_allclose(got, z[f"{tag}.train"], atol=2e-6)
+        np.testing.assert_allclose(v.transform(test), z[f"{tag}.test"], atol=2e-6)
+
+    class KV:                      # gensim < 4 attribute names
+        index2word, vectors = words, z["embedding"]
+    cond = C.PretrainedWordEmbeddingCondition(KV(), use_cuda=True)
+    data = C.ConditionList([("title", cond)]).fit_transform([docs])[0]
+    np.testing.assert_allclose(data, z["default.train"], atol=2e-6)
+    enc = cond.encode(data[:7])
+    assert enc.is_cuda and enc.shape == (7, 300) and cond.size_increment() == 300

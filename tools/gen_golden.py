@@ -160,6 +160,33 @@ def _pad_lists(lists):
     return np.asarray([l + [0] * (L - len(l)) for l in lists], dtype=np.int64)
 
 
+def gen_embedded_vectorizer():
+    """EmbeddedVectorizer.fit / transform of the reference (ub.py:38-68) on a small corpus: TF-IDF over the embedding's
+    vocabulary times the embedding.  Its constructor hands `self` to TfidfVectorizer positionally, which the
+    scikit-learn of this image rejects, so the object is built by calling TfidfVectorizer.__init__ with the same
+    keyword arguments; fit and transform are the reference's own methods."""
+    from sklearn.feature_extraction.text import TfidfVectorizer
+    import aaerec.ub as ref_ub
+    rng = np.random.default_rng(77)
+    words = ["w%d" % i for i in range(400)]
+    emb = rng.standard_normal((400, 300)).astype(np.float32)
+    docs = [" ".join(rng.choice(words + ["unknown", "oov"], size=int(rng.integers(0, 15)))) for _ in range(120)]
+    test = [" ".join(rng.choice(words + ["unseen"], size=int(rng.integers(1, 10)))) for _ in range(40)]
+    out = {"words": np.asarray(json.dumps(words)), "docs": np.asarray(json.dumps(docs)),
+           "test": np.asarray(json.dumps(test)), "embedding": emb}
+    for tag, kw in (("default", {}), ("sublinear", dict(sublinear_tf=True, norm="l1"))):
+        v = ref_ub.EmbeddedVectorizer.__new__(ref_ub.EmbeddedVectorizer)
+        TfidfVectorizer.__init__(v, vocabulary=words, **kw)
+        v.embedding, v.index2word = emb, words            # (get_params reads the constructor arguments back)
+        out[f"{tag}.train"] = np.asarray(ref_ub.EmbeddedVectorizer.fit_transform(v, docs))
+        out[f"{tag}.test"] = np.asarray(ref_ub.EmbeddedVectorizer.transform(v, test))
+        out[f"{tag}.kwargs"] = np.asarray(json.dumps(kw))
+    path = os.path.join(OUT, "embedded_vectorizer.npz")
+    np.savez_compressed(path, **out)
+    print(f"embedded_vectorizer: {os.path.getsize(path) / 1024:.0f} KiB, train {out['default.train'].shape} "
+          f"{out['default.train'].dtype}")
+
+
 ENC_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
 
 
@@ -850,6 +877,8 @@ def main():
         gen_dae()
     if want("vae"):
         gen_vae()
+    if want("vectorizer"):
+        gen_embedded_vectorizer()
     if want("metrics"):
         gen_metric_known_answers()
     if want("e2e"):
