@@ -267,7 +267,7 @@ class AdversarialAutoEncoder:
     def _cond_fn(self, c_batch):
         """z -> (zc, backward) through the condition plugins with torch autograd
         (aae.py:688-690, 699-700, 708-709)."""
-        conditions = self.conditions
+        conditions, dp = self.conditions, self._dp
 
         def fn(z):
             z = z.detach().requires_grad_(True)
@@ -276,6 +276,8 @@ class AdversarialAutoEncoder:
             def back(dzc):
                 conditions.zero_grad()
                 zc.backward(dzc.to(zc.device))
+                if dp is not None:
+                    dp.sync_conditions(conditions)       # data parallel: the plugins' gradients summed over ranks
                 conditions.step()
                 return z.grad
             return zc, back

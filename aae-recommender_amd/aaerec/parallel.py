@@ -42,6 +42,31 @@ class DataParallelAAE:
         lo = start + rank * base + min(rank, extra)
         return lo, lo + base + (1 if rank < extra else 0)
 
+    def sync_conditions(self, conditions):
+        """Sum the parameter gradients of trainable condition plugins (embedding tables with their own optimiser,
+        condition.py:372-508) over the ranks, between their backward and their optimiser step: every rank saw its
+        share of the global batch only, and the loss gradients are already scaled to the global mean.  Row-sparse
+        gradients (nn.Embedding(sparse=True) + SparseAdam) are summed densely and handed back row-sparse, so the
+        optimiser moves the rows the GLOBAL batch named - what the single-process step does."""
+        import torch
+        d = self.dist
+        nccl = str(d.get_backend(self.group)).lower() == "nccl"
+        for cond in conditions.values():
+            opt = getattr(cond, "optimizer", None)
+            if opt is None:
+                continue
+            want_sparse = isinstance(opt, torch.optim.SparseAdam)
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    if not p.requires_grad:
+                        continue
+                    g = p.grad
+                    dense = torch.zeros_like(p.data) if g is None else (g.to_dense() if g.is_sparse else g)
+                    buf = dense.to(self.model.device) if nccl and not dense.is_cuda else dense.contiguous()
+                    d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group)
+                    dense = buf.to(p.device)
+                    p.grad = dense.to_sparse(1) if want_sparse else dense
+
     def _allreduce(self, which, async_op=False):
         return [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
                 for t in self.model.grad_buckets(which)]

@@ -32,7 +32,7 @@ class OracleReplica:
                                                  masks, z_real))
 
     def ae_decode_backward(self, zc):
-        return torch.from_numpy(self.o.ae_decode_backward(zc.numpy()))
+        return torch.from_numpy(self.o.ae_decode_backward(zc.detach().numpy()))
 
     def ae_encoder_backward(self, dz):
         self.o.ae_encoder_backward(dz.numpy())
@@ -187,3 +187,64 @@ def test_two_ranks_with_packed_first_layer_rows_equal_single_process():
     fx = Fixture("step_masks")
     for k, w in fx.expected_params(fx.steps - 1).items():
         np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+
+
+def _worker_cond(rank, world, port, name, ret):
+    """Two ranks, half a batch each, with a trainable CategoricalCondition (real torch plugin, CPU table) behind the
+    autograd bridge: the plugin's gradients have to be summed over the ranks before its optimiser steps."""
+    import types
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.parallel import DataParallelAAE
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec import condition as C
+    fx = Fixture(name)
+    kind = fx.cfg.get("cat", dict(sparse=False, reduce="sum", lr=1e-2))
+    model = OracleReplica(fx.init_params(), **fx.model_kwargs())
+    dp = DataParallelAAE(model, dist)
+    cat = C.CategoricalCondition(8, sparse=kind["sparse"], use_cuda=False, reduce=kind["reduce"], lr=kind["lr"])
+    V = fx.z["init.cond.embedding"].shape[0]
+    cat.vocab = {"a%d" % i: i for i in range(1, V)}
+    cat.embedding = torch.nn.Embedding(V, 8, padding_idx=0, sparse=kind["sparse"])
+    with torch.no_grad():
+        cat.embedding.weight.copy_(torch.from_numpy(fx.z["init.cond.embedding"]))
+    cat.optimizer = (torch.optim.SparseAdam if kind["sparse"] else torch.optim.Adam)(cat.embedding.parameters(), lr=kind["lr"])
+    conds = C.ConditionList([("authors", cat)])
+    host = types.SimpleNamespace(conditions=conds, _dp=dp)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        B = len(ip) - 1
+        lo, hi = dp.shard(0, B)
+        masks = fx.masks(s)
+        if masks is not None:
+            masks = [m[lo:hi] for m in masks]
+        # every rank pads to the GLOBAL batch's width, as the single process does
+        lists = [[int(j) for j in row] for row in fx.cond_inputs(s)[0][lo:hi]]
+        cond_fn = AdversarialAutoEncoder._cond_fn(host, [lists])
+        dp.step((ip, idx, val), lo, hi - lo, global_rows=B, cond_fn=cond_fn, masks=masks,
+                z_real=fx.z[f"step{s}.z_real"][lo:hi])
+    emb = cat.embedding.weight.detach().clone()
+    if rank == 0:
+        ret.update({k: v.copy() for k, v in model.o.p.items()})
+        ret["cond.embedding"] = emb.numpy().copy()
+    other = [torch.empty_like(emb) for _ in range(world)]
+    dist.all_gather(other, emb)
+    assert all(torch.equal(other[0], o) for o in other)          # the replicas' tables stay identical
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["step_cond_categorical", "step_cat_sparse_sum"])
+def test_two_ranks_with_trainable_condition_equal_single_process(name):
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_cond, args=(2, port, name, ret), nprocs=2, join=True)
+        got = dict(ret)
+    fx = Fixture(name)
+    last = fx.steps - 1
+    for k, w in fx.expected_params(last).items():
+        np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+    np.testing.assert_allclose(got["cond.embedding"], fx.z[f"step{last}.cond.embedding"], atol=1e-5)
