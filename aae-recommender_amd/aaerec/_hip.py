@@ -27,7 +27,7 @@ GRAD_FUSED, GRAD_EXPORT = 0, 1
 # tensor ids (aaerec_hip.h)
 T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3 = range(10)
 T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, T_GRAD = 16, 32, 48, 64, 80
-T_ACT_Z, T_ACT_LOSSES, T_ACT_A1, T_ACT_DZC = 96, 97, 98, 99
+T_ACT_Z, T_ACT_LOSSES, T_ACT_A1, T_ACT_DZC, T_ACT_DH2, T_ACT_DA2 = 96, 97, 98, 99, 100, 101
 CAT_SUM, CAT_MEAN = 0, 1
 CAT_SPARSE_ADAM, CAT_ADAM = 0, 1
 O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
@@ -95,6 +95,9 @@ _PROTOS = {
     "aae_w1_packet_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aae_w1_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_set_grad_scale": (C.c_int, [C.c_void_p, C.c_float]),
+    "aae_ae_forward": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_output_layer_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p]),
+    "aae_ae_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_cat_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p]),
     "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -495,6 +498,42 @@ class HipAAE:
             _check(self.lib.aae_step(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
                                      self._stream()))
 
+    # ---- the ae phase cut at the decoder's output layer (vocabulary-sharded data parallelism) -----------
+    def ae_forward(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
+        """Encoder + decoder hidden layers; the last hidden activation stays in tensor(T_ACT_DH2, padded=True)."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        inj = self._inject(masks, z_real)
+        if cond is not None:
+            cond = upload(cond, self.device, torch.float32).contiguous()
+            self._keep.append(cond)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_ae_forward(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
+                                           self._stream()))
+
+    def output_layer_step(self, csr=None, row_start=0, n_rows=0, rows=None):
+        """The decoder's output layer over this handle's items from T_ACT_DH2 -> dL/d(dh2) in T_ACT_DA2; csr = None
+        continues the step ae_forward started on this handle."""
+        b = self._batch(csr, row_start, n_rows, rows) if csr is not None else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_output_layer_step(self.handle, C.byref(b) if b is not None else None, self._stream()))
+
+    def ae_backward(self, da2=None):
+        """Decoder hidden + encoder backward from dL/d(dh2) (None = this handle's T_ACT_DA2)."""
+        if da2 is not None:
+            assert da2.is_cuda and da2.dtype == torch.float32 and da2.stride(1) == 1
+            self._keep.append(da2)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_ae_backward(self.handle, _ptr(da2), da2.stride(0) if da2 is not None else 0,
+                                            self._stream()))
+
+    def dh2_rows(self, n_rows):
+        """[n_rows, ld] view of the decoder's last hidden activation (with its bias-input column and padding)."""
+        return self.tensor(T_ACT_DH2, padded=True)[:n_rows]
+
+    def da2_rows(self, n_rows):
+        """[n_rows, ld] view of dL/d(dh2): written by output_layer_step, read by ae_backward()."""
+        return self.tensor(T_ACT_DA2, padded=True)[:n_rows]
+
     def cond_grad(self, n_rows):
         """dL/d(cond) of the last step's autoencoder phase: [n_rows, cond_inc] view (trainable conditions)."""
         return self.tensor(T_ACT_DZC)[:n_rows, self.c:]
@@ -582,6 +621,8 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_apply_shard(self.handle, tid, row_begin, row_end, C.c_void_p(grad_shard.data_ptr()),
                                             which, self._stream()))
+
+    big_tensor_id = T_DEC_V3      # the decoder's output layer: the one tensor worth sharding across ranks
 
     def big_grad(self):
         """(tensor id, padded gradient view [rows, ld], padded parameter view [rows, ld]) of the one

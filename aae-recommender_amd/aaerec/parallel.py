@@ -166,3 +166,77 @@ class DataParallelAAE:
         m.gen_step()
         self._exchange_encoder(O_GEN)
         self._dec_finish(dec_state)
+
+
+def item_slice(n_items, rank, world):
+    """[lo, hi) of the items whose decoder output rows rank `rank` of `world` owns (contiguous, sizes differ by <= 1)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class VocabParallelAAE(DataParallelAAE):
+    """Documents are sharded over the ranks for everything except the decoder's output layer, which is sharded over
+    the VOCABULARY.
+
+    dec.lin3 holds ~all of the decoder's parameters ([n_items, n_hidden + 1]) and, because the BCE runs over every
+    item, ALL of its rows receive gradient every step: replicated data parallelism has to move that dense gradient
+    (80 MB at 100 k items, reduce-scatter + all-gather of the updated rows) per step.  Here each rank owns the rows
+    of a contiguous slice of the items in a second model (`slice_model`, created with n_items = slice size and the
+    fused optimiser) and the ranks exchange hidden activations instead - [global rows, n_hidden] floats, 0.6 MB at
+    8 x 100 rows:
+
+        model.ae_forward             encoder + decoder hidden layers on this rank's documents        -> dh2
+        all-gather dh2               -> the slice model sees the hidden activations of the GLOBAL batch
+        slice.output_layer_step      logits for its items, BCE against the global batch restricted to them, dV3 + Adam
+                                     on its rows (no exchange: the rows are nobody else's), partial dL/d(dh2)
+        reduce-scatter dL/d(dh2)     summed over the item slices, this rank's documents back
+        model.ae_backward            decoder hidden + encoder backward on this rank's documents
+        ... small decoder layers all-reduced, encoder packets, disc_step, gen_step exactly as DataParallelAAE.
+
+    The global batch must divide evenly over the ranks (callers trim a tail batch).  `slice_csr` is the corpus
+    restricted to this rank's items with ids rebased to the slice; every rank walks the same permutation, so the
+    global batch needs no exchange."""
+
+    def __init__(self, model, slice_model, dist, n_items, group=None):
+        super().__init__(model, dist, group=group, shard_decoder=False)
+        self.slice = slice_model
+        self.n_items = n_items
+        self.item_lo, self.item_hi = item_slice(n_items, dist.get_rank(group), self.world)
+        slice_model.set_grad_scale((self.item_hi - self.item_lo) / float(n_items))
+
+    def step(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None, cond=None,
+             masks=None, z_real=None):
+        """rows / row_start select this rank's documents in `csr`; g_rows / g_row_start the global batch in
+        `slice_csr` (rank-major: rank r's documents are global rows [r * n_rows, (r + 1) * n_rows))."""
+        m, sl, d = self.model, self.slice, self.dist
+        if global_rows != n_rows * self.world:
+            raise ValueError("vocabulary-sharded step: the global batch must divide evenly over the ranks")
+        m.set_grad_scale(n_rows / float(global_rows))
+        m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
+        d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
+        sl.output_layer_step(slice_csr, g_row_start, global_rows, rows=g_rows)
+        d.reduce_scatter_tensor(m.da2_rows(n_rows).view(-1), sl.da2_rows(global_rows).view(-1), op=d.ReduceOp.SUM,
+                                group=self.group)
+        m.ae_backward()
+        work = [d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group, async_op=True) for t in m.grad_buckets("dec_small")]
+        self._exchange_encoder(O_ENC)
+        for w in work:
+            if w is not None:
+                w.wait()
+        m.apply_updates(O_DEC, skip=m.big_tensor_id)
+        m.disc_step()
+        self._allreduce(O_DISC)
+        m.apply_updates(O_DISC)
+        m.gen_step()
+        self._exchange_encoder(O_GEN)
+
+    def recon_loss(self):
+        """Reconstruction loss of the last step over all items: the slices' means weighted by their sizes."""
+        import torch
+        part = torch.tensor([self.slice.losses()[0] * (self.item_hi - self.item_lo) / float(self.n_items)],
+                            dtype=torch.float64)
+        nccl = str(self.dist.get_backend(self.group)).lower() == "nccl"
+        buf = part.to(self.model.device) if nccl else part
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(buf.item())

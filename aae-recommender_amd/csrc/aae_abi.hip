@@ -74,7 +74,8 @@ struct aae_model {
     // gradients (all in export mode, gW1T always)
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
     // activations
-    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave;
+    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
+    bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
     bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
@@ -204,6 +205,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
+    m->da2 = a.mat(R, h + 1, m->ldh);
     if (c.reserved[2] == 3) {
         m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
     }
@@ -657,13 +659,13 @@ int chain_dec_hidden(aae_model* m, bool train, int rows, hipStream_t s) {
 //   dec: sum of the 16 dA2 partial slabs -> act'/dropout -> V2 -> V1 -> gzc
 //   enc: dz (slot or external) -> output activation' -> W3 -> W2 -> ga1
 int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* part_slabs, size_t slab_stride,
-                      const float* gz_ext, int ld_gz, float* dzc_out, int which, hipStream_t s) {
+                      const float* gz_ext, int ld_gz, float* dzc_out, int which, hipStream_t s, int nslab = 16) {
     const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
     if (dec_part) {
         if (part_slabs) {
-            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = nslab; ss.stride = slab_stride;
             cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
             ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1;
             ab.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); cop_out(ab, m->gb0.p, m->ldh);
@@ -1062,6 +1064,8 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
     else if (id >= AAE_T_GRAD && id < AAE_T_GRAD + NP) { t = &h->Gr[id - AAE_T_GRAD]; if (!t->rows) t = nullptr; }
     else if (id == AAE_T_ACT_Z) t = &h->zsave;
     else if (id == AAE_T_ACT_A1) t = &h->a1;
+    else if (id == AAE_T_ACT_DH2) t = &h->dh2;
+    else if (id == AAE_T_ACT_DA2) t = &h->da2;
     else if (id == AAE_T_ACT_DZC) { tmp = h->gzc; tmp.cols = h->cp; t = &tmp; }
     else if (id == AAE_T_ACT_LOSSES) {
         tmp.rows = 1; tmp.cols = 4; tmp.ld = 4; tmp.off = (size_t)((char*)h->losses - h->base); t = &tmp;
@@ -1252,7 +1256,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, B, s));
     const uint8_t* mk2 = m->inj.masks_dev[2];
     const uint8_t* mk3 = m->inj.masks_dev[3];
-    if (m->use_chain) { if (!m->dec_hidden_done) TRY(chain_dec_hidden(m, true, B, s)); }
+    if (m->only_output_layer) { /* ACT_DH2 is the input */ }
+    else if (m->use_chain) { if (!m->dec_hidden_done) TRY(chain_dec_hidden(m, true, B, s)); }
     else TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
@@ -1323,6 +1328,13 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
                            fa.slab_stride, n4, part, fa.slab_stride, m->bce_partials, grid,
                            1.0f / ((float)B * (float)N), m->losses, 0);
+        if (m->only_output_layer) {
+            hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, part, 16,
+                               fa.slab_stride, n4, m->da2.p, (size_t)0, (const float*)nullptr, 0, 0.f, m->losses, 0);
+            LAUNCHCHK("slab_partial -> da2");
+            m->phase = 2;
+            return AAE_OK;
+        }
         if (m->use_chain) {
             chain_part = part; chain_stride = fa.slab_stride;
         } else {
@@ -1358,6 +1370,12 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             (void)launch_gemm<0, 0, 16, 64>(g, e, splits, s);
         }
         LAUNCHCHK("dA2 gemm");
+        if (m->only_output_layer) {
+            const size_t n4 = (size_t)B * m->ldh / 4;
+            hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, m->slabs.p, splits,
+                               e.slab_stride, n4, m->da2.p, (size_t)0, (const float*)nullptr, 0, 0.f, m->losses, 0);
+            LAUNCHCHK("slabs -> da2");
+        } else
         hipLaunchKernelGGL(slab_reduce_actbwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
                            e.slab_stride, B, h, m->ldh, m->dh2.p, m->ldh, m->gb0.p, m->cfg.activation, d2, m->cfg.seed,
                            m->step_ctr);
@@ -1368,6 +1386,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         ProfScope ps(m, AAE_K_DEC_DV3_ADAM, s);
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
     }
+    if (m->only_output_layer) { m->phase = 2; return AAE_OK; }
     }
     if (m->use_chain && m->vae_bwd) {
         TRY(chain_vae_backward(m, chain_part, chain_stride, s));
@@ -1501,6 +1520,74 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
     TRY(encoder_backward(m, gz, ld, m->zsave.p, m->ldz, m->inj.masks_dev[0], m->inj.masks_dev[1], 0, 1, O_ENC, s));
     m->phase = 3;
     return AAE_OK;
+}
+
+// ---- the ae phase cut at the decoder's output layer (vocabulary-sharded data parallelism) -----------------------
+// aae_ae_forward: encoder + the decoder's hidden layers on this rank's documents; dh2 stays in AAE_T_ACT_DH2.
+int aae_ae_forward(aae_handle m, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inj, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (!m->use_chain || m->vae) return fail(AAE_ESTATE, "aae_ae_forward needs the layer-chain kernels (and no VAE mode)");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    hipStream_t s = S(stream);
+    TRY(ae_encode_impl(m, batch, inj, nullptr, true, cond_dev, stream));
+    if (m->cfg.cond_inc > 0) {
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)m->rows * m->cfg.cond_inc)), dim3(256), 0, s, cond_dev,
+                           m->cfg.cond_inc, m->zc.p + m->c, m->ldc, m->rows, m->cfg.cond_inc, 1.0f);
+        LAUNCHCHK("copy cond");
+    }
+    return AAE_OK;
+}
+
+// aae_output_layer_step: the decoder's output layer alone over the handle's items - logits from AAE_T_ACT_DH2, BCE
+// against the batch, dV3 + dec_optim on V3 (or its gradient in export mode), dL/d(dh2) summed into AAE_T_ACT_DA2.
+//   batch != NULL: a step of its own (a handle that owns a shard of the vocabulary: the caller filled ACT_DH2 with
+//                  the hidden activations of batch->n_rows documents, e.g. by an all-gather);
+//   batch == NULL: continues the step aae_ae_forward started on this handle.
+int aae_output_layer_step(aae_handle m, const aae_batch* batch, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->vae) return fail(AAE_ESTATE, "aae_output_layer_step: not in VAE mode");
+    hipStream_t s = S(stream);
+    if (batch) {
+        TRY(set_batch(m, batch));
+        remember_inject(m, nullptr, true);
+        hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                           m->stamp, m->ucount, m->losses);
+        LAUNCHCHK("advance_step");
+        m->enc_bwd_done = false; m->fuse_enc_bwd = false;
+    } else if (m->phase != 1 || !m->dec_hidden_done) {
+        return fail(AAE_ESTATE, "aae_output_layer_step(batch = NULL) without aae_ae_forward");
+    }
+    m->dec_hidden_done = true;
+    m->phase = 1;
+    m->only_output_layer = true;
+    int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream);
+    m->only_output_layer = false;
+    TRY(rc);
+    m->phase = batch ? 0 : 2;
+    return AAE_OK;
+}
+
+// aae_ae_backward: the rest of the ae phase on this rank's documents from dL/d(dh2) (dA2_dev [rows][ld = ACT_DH2's],
+// NULL = AAE_T_ACT_DA2 of this handle): decoder hidden layers backward, encoder backward, their optimiser updates
+// (or exported gradients).  Follows aae_ae_forward.
+int aae_ae_backward(aae_handle m, const float* dA2_dev, int64_t dA2_ld, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (!m->use_chain || m->vae) return fail(AAE_ESTATE, "aae_ae_backward needs the layer-chain kernels (and no VAE mode)");
+    if ((m->phase != 1 && m->phase != 2) || !m->dec_hidden_done) return fail(AAE_ESTATE, "aae_ae_backward without aae_ae_forward");
+    if (dA2_dev && dA2_ld != m->ldh) return fail(AAE_EINVAL, "aae_ae_backward: dA2_ld must equal the leading dimension of AAE_T_ACT_DH2");
+    hipStream_t s = S(stream);
+    const int B = m->rows;
+    TRY(chain_ae_backward(m, true, true, dA2_dev ? dA2_dev : m->da2.p, 0, nullptr, 0, nullptr, O_ENC, s, 1));
+    DwBuilder dw;
+    dw.add(m, m->gb0.p, m->ldh, m->dh1.p, m->ldh, B, P_V2, O_DEC);
+    dw.add(m, m->gb1.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
+    dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
+    dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
+    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+    TRY(dw.launch(s));
+    m->enc_bwd_done = true;
+    m->phase = 2;
+    return aae_ae_encoder_backward(m, nullptr, 0, stream);
 }
 
 // disc_step (aae.py:713-732)

@@ -133,6 +133,8 @@ enum {
     AAE_T_ACT_Z = 96,      /* encoder output of the last encode call [rows][n_code] */
     AAE_T_ACT_LOSSES = 97, /* float[4]: R, D, G of the last step, spare */
     AAE_T_ACT_A1 = 98,     /* first-layer pre-activations of the last encode [rows][n_hidden] */
+    AAE_T_ACT_DH2 = 100,   /* the decoder's last hidden activation [rows][n_hidden + 1] (last column = 1: the bias input) */
+    AAE_T_ACT_DA2 = 101,   /* dL/d(ACT_DH2) written by aae_output_layer_step, same layout */
     AAE_T_ACT_DZC = 99     /* dL/d(decoder input) of the last ae phase [rows][n_code + cond_inc]: columns n_code.. are
                             * the gradient of the condition block handed to aae_step (trainable conditions) */
 };
@@ -214,6 +216,26 @@ int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev,
 int aae_vae_step(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream);
 int aae_vae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev,
                     float* out_dev, int64_t out_ld, void* stream);
+/* The ae phase (aae.py:676-711) cut at the decoder's output layer, for vocabulary-sharded data parallelism: the output
+ * layer holds ~all of the decoder's parameters and every item receives gradient, so instead of exchanging its
+ * [n_items][n_hidden + 1] gradient each rank owns the rows of a slice of the items (a second handle created with
+ * n_items = slice size) and the ranks exchange hidden activations, [global rows][n_hidden], instead:
+ *   aae_ae_forward         encoder + decoder hidden layers on this rank's documents -> AAE_T_ACT_DH2
+ *   [all-gather ACT_DH2 of all ranks into the slice handle's ACT_DH2]
+ *   aae_output_layer_step  on the slice handle, batch = the GLOBAL batch restricted to the slice's items (ids rebased):
+ *                          logits, BCE (scale: aae_set_grad_scale(slice items / all items)), dV3 + dec_optim on the
+ *                          slice's rows, dL/d(dh2) partial -> AAE_T_ACT_DA2; batch = NULL continues the step of
+ *                          aae_ae_forward on the same handle (single device: forward + output_layer_step(NULL) +
+ *                          backward == the ae phase of aae_step)
+ *   [reduce-scatter ACT_DA2 over the ranks -> this rank's rows]
+ *   aae_ae_backward        decoder hidden backward + encoder backward + their updates / exported gradients from
+ *                          dA2_dev (NULL = this handle's ACT_DA2), leading dimension = ACT_DH2's
+ * followed by aae_disc_step / aae_gen_step as in the replicated scheme.  aae_ae_forward / aae_ae_backward: layer-chain models only
+ * (n_hidden, n_code + cond_inc <= 207); the slice handle may be any size. */
+int aae_ae_forward(aae_handle h, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inject, void* stream);
+int aae_output_layer_step(aae_handle h, const aae_batch* batch, void* stream);
+int aae_ae_backward(aae_handle h, const float* dA2_dev, int64_t dA2_ld, void* stream);
+
 /* CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute, reduced over the
  * document's (batch-padded) value list and concatenated to the code.  The table and its optimiser state belong to
  * the caller (plain device arrays [vocab][dim], row-major, dim <= 256); index 0 is the padding / out-of-vocabulary

@@ -583,3 +583,148 @@ def test_categorical_condition_abi_rejects_bad_operands():
     out = torch.empty(4, 8, device=dev)
     _hip.cat_encode(table + 1.0, bad, out)
     assert out.cpu().numpy()[:, 0].tolist() == [0.0, 2.0, 0.0, 1.0]
+
+
+@pytest.mark.parametrize("name", ["step_masks", "step_cond_concat", "step_wide", "step_headline", "step_selu"])
+def test_ae_phase_cut_at_the_output_layer_equals_fused_step(name):
+    """aae_ae_forward + aae_output_layer_step(NULL) + aae_ae_backward(NULL) + disc_gen on one handle reproduce the
+    fixtures of the whole step (the cut vocabulary-sharded data parallelism makes, without any sharding)."""
+    fx = Fixture(name)
+    m = make_model(fx)
+    for s in range(fx.steps):
+        csr = csr_of(fx, m, s)
+        B = csr.shape[0]
+        cond = fx.cond_inputs(s)
+        m.ae_forward(csr, 0, B, cond=torch.as_tensor(cond[0], device=m.device) if cond else None, masks=fx.masks(s),
+                     z_real=fx.z[f"step{s}.z_real"])
+        m.output_layer_step()
+        m.ae_backward()
+        m.disc_gen()
+        np.testing.assert_allclose(m.losses(), fx.z[f"step{s}.losses"], rtol=TOL_LOSS, atol=1e-6)
+        if fx.has_state(s):
+            check_state(fx, m, s, name)
+
+
+class _ThreadDist:
+    """torch.distributed stand-in for `world` ranks living in threads of one process on one GPU: every collective
+    publishes a copy of the rank's operand, meets the others at a barrier and combines the copies in rank order."""
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world):
+        import threading
+        self.world, self.bar, self.slots, self.tls = world, threading.Barrier(world), [None] * world, threading.local()
+
+    def bind(self, rank):
+        self.tls.rank = rank
+
+    def get_rank(self, group=None):
+        return self.tls.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return "threads"
+
+    def _exchange(self, t):
+        torch.cuda.synchronize()
+        self.slots[self.tls.rank] = t.clone()
+        torch.cuda.synchronize()
+        self.bar.wait()
+        parts = list(self.slots)
+        self.bar.wait()
+        return parts
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        parts = self._exchange(t)
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total += p
+        t.copy_(total)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        out.copy_(torch.cat([p.reshape(-1) for p in self._exchange(inp)]))
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        parts = self._exchange(inp)
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total += p
+        out.copy_(total.view(self.world, -1)[self.tls.rank])
+
+
+@pytest.mark.parametrize("name,world", [("step_masks", 2), ("step_cond_concat", 2), ("step_headline", 2), ("step_wide", 4)])
+def test_vocabulary_sharded_ranks_equal_single_process(name, world):
+    """aaerec.parallel.VocabParallelAAE with `world` ranks as threads on one GPU: each rank holds a replica for its
+    share of the documents and a slice model for its share of the items; after every step the replicas' parameters
+    and the concatenated slices of dec.lin3 must be the reference's single-process parameters."""
+    import threading
+    import scipy.sparse as sp
+    from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3
+    from aaerec.parallel import VocabParallelAAE, item_slice
+    fx = Fixture(name)
+    c = fx.cfg
+    N, B = c["N"], c["B"]
+    assert B % world == 0
+    Bl = B // world
+    dist = _ThreadDist(world)
+    kw = fx.model_kwargs()
+    init = fx.init_params()
+    locals_, slices, errors = [None] * world, [None] * world, []
+
+    def rank_main(r):
+        try:
+            dist.bind(r)
+            lo, hi = item_slice(N, r, world)
+            m = HipAAE(N, c["h"], c["c"], cond_inc=c["cond_inc"], max_batch=Bl, rng_mode="inject", grad_mode="export",
+                       dp_world=world, **kw)
+            m.load_params(init)
+            sp_params = dict(init)
+            sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = init["dec.lin3.weight"][lo:hi], init["dec.lin3.bias"][lo:hi]
+            sp_params["enc.lin1.weight"] = init["enc.lin1.weight"][:, lo:hi]
+            sl = HipAAE(hi - lo, c["h"], c["c"], cond_inc=c["cond_inc"], max_batch=B, rng_mode="inject", **kw)
+            sl.load_params(sp_params)
+            locals_[r], slices[r] = m, sl
+            vp = VocabParallelAAE(m, sl, dist, N)
+            assert (vp.item_lo, vp.item_hi) == (lo, hi)
+            for s in range(fx.steps):
+                ip, idx, val = fx.batch(s)
+                if len(ip) - 1 != B:
+                    break                                       # (ragged last batch of a fixture: not divisible)
+                X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+                csr = DeviceCSR(X, m.device)
+                slice_csr = DeviceCSR(X[:, lo:hi], m.device)
+                masks = fx.masks(s)
+                if masks is not None:
+                    masks = [None if k is None else k[r * Bl:(r + 1) * Bl] for k in masks]
+                cond = fx.cond_inputs(s)
+                vp.step(csr, r * Bl, Bl, slice_csr, 0, B,
+                        cond=torch.as_tensor(cond[0][r * Bl:(r + 1) * Bl], device=m.device) if cond else None,
+                        masks=masks, z_real=fx.z[f"step{s}.z_real"][r * Bl:(r + 1) * Bl])
+                loss = vp.recon_loss()
+                if r == 0:
+                    np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        except BaseException as e:              # noqa: B902 - a dead rank must not leave the others at a barrier
+            errors.append((r, e))
+            dist.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    last = fx.steps - 1
+    want = fx.expected_params(last)
+    got0 = locals_[0].state_dict()
+    for k, w in want.items():
+        if k.startswith("dec.lin3"):
+            continue
+        np.testing.assert_allclose(got0[k], w, atol=TOL_PARAM, rtol=0, err_msg=f"{name} {k}")
+        for r in range(1, world):                                # replicas stay identical
+            np.testing.assert_array_equal(locals_[r].state_dict()[k], got0[k], err_msg=f"rank {r} {k}")
+    v3w = np.concatenate([slices[r].state_dict()["dec.lin3.weight"] for r in range(world)])
+    v3b = np.concatenate([slices[r].state_dict()["dec.lin3.bias"] for r in range(world)])
+    np.testing.assert_allclose(v3w, want["dec.lin3.weight"], atol=TOL_PARAM, rtol=0)
+    np.testing.assert_allclose(v3b, want["dec.lin3.bias"], atol=TOL_PARAM, rtol=0)
