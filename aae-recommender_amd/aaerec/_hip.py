@@ -629,29 +629,39 @@ class HipAAE:
         tensor worth sharding across data-parallel ranks: the decoder's output layer."""
         return T_DEC_V3, self.tensor(T_GRAD + T_DEC_V3, padded=True), self.tensor(T_DEC_V3, padded=True)
 
-    def w1_export(self):
-        """Pack this rank's first-layer gradient rows: one flat float32 tensor = int32 header
-        (count, item ids) + rows [cap, n_hidden]."""
+    def _w1_layout(self, cap):
+        """(rows, header words, total floats) of a packet with room for `cap` rows (None = the model's w1_cap)."""
         if self._w1_packet is None:
             hw, tot = C.c_int64(), C.c_int64()
             _check(self.lib.aae_w1_packet_floats(self.handle, self.w1_cap, C.byref(hw), C.byref(tot)))
             assert hw.value == self._w1_hdr
+            self._w1_small = tot.value - hw.value - self.w1_cap * self.h
             self._w1_packet = torch.zeros(tot.value, dtype=torch.float32, device=self.device)
-        pk = self._w1_packet
+        cap = self.w1_cap if cap is None else max(1, min(int(cap), self.w1_cap))
+        hdr = (1 + cap + 3) & ~3
+        return cap, hdr, hdr + cap * self.h + self._w1_small
+
+    def w1_export(self, cap=None):
+        """Pack this rank's first-layer gradient rows: one flat float32 tensor = int32 header (count, item ids) +
+        rows [cap, n_hidden] + the encoder's small-layer gradients.  cap: an upper bound on the distinct items of
+        this exchange that every rank agrees on (e.g. the largest entry count of any rank's share of the batch);
+        the default is the model-wide worst case w1_cap - the packet is what the all-gather moves."""
+        cap, hdr, total = self._w1_layout(cap)
+        pk = self._w1_packet[:total]
         with torch.cuda.device(self.device):
-            _check(self.lib.aae_w1_export(self.handle, C.c_void_p(pk.data_ptr()),
-                                          C.c_void_p(pk.data_ptr() + 4 * self._w1_hdr), self.w1_cap, self._stream()))
+            _check(self.lib.aae_w1_export(self.handle, C.c_void_p(pk.data_ptr()), C.c_void_p(pk.data_ptr() + 4 * hdr), cap,
+                                          self._stream()))
         return pk
 
-    def w1_import(self, packets, n_peers, which):
-        """Sum the peers' packed rows (flat tensor of n_peers packets) and run optimiser `which` on them."""
-        stride = 4 * self._w1_packet.numel()
-        assert packets.numel() * 4 >= n_peers * stride
+    def w1_import(self, packets, n_peers, which, cap=None):
+        """Sum the peers' packed rows (flat tensor of n_peers packets of w1_export(cap)) and run optimiser `which`."""
+        cap, hdr, total = self._w1_layout(cap)
+        assert packets.numel() >= n_peers * total
         self._keep.append(packets)
         with torch.cuda.device(self.device):
             _check(self.lib.aae_w1_import(self.handle, C.c_void_p(packets.data_ptr()),
-                                          C.c_void_p(packets.data_ptr() + 4 * self._w1_hdr), self.w1_cap, n_peers,
-                                          stride, which, self._stream()))
+                                          C.c_void_p(packets.data_ptr() + 4 * hdr), cap, n_peers, 4 * total, which,
+                                          self._stream()))
 
     def set_grad_scale(self, scale):
         _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))

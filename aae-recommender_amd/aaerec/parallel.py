@@ -30,6 +30,9 @@ class DataParallelAAE:
         self.world = dist.get_world_size(group)
         self.global_rows = None
         self._w1_all = None
+        # upper bound on the distinct items of any rank's share of the running batch, agreed by all ranks (e.g. the
+        # largest entry count of a share): sizes the first-layer packets of this step; None = the model-wide worst case
+        self.w1_rows = None
 
     def shard(self, start, stop):
         """Contiguous share [lo, hi) of the global batch [start, stop) for this rank, or
@@ -86,15 +89,20 @@ class DataParallelAAE:
         m = self.model
         if not hasattr(m, "w1_export"):
             return                      # dense stand-in: the gradient is part of grad_buckets()
-        pk = m.w1_export()
+        cap = self.w1_rows
+        pk = m.w1_export() if cap is None else m.w1_export(cap)
         if self.world == 1:
             allp = pk
         else:
-            if self._w1_all is None or self._w1_all.numel() != pk.numel() * self.world:
-                self._w1_all = pk.new_empty(pk.numel() * self.world)
-            self.dist.all_gather_into_tensor(self._w1_all, pk, group=self.group)
-            allp = self._w1_all
-        m.w1_import(allp, self.world, which)
+            need = pk.numel() * self.world
+            if self._w1_all is None or self._w1_all.numel() < need:
+                self._w1_all = pk.new_empty(need)
+            allp = self._w1_all[:need]
+            self.dist.all_gather_into_tensor(allp, pk, group=self.group)
+        if cap is None:
+            m.w1_import(allp, self.world, which)
+        else:
+            m.w1_import(allp, self.world, which, cap)
 
     # ---- decoder output layer: reduce-scatter -> optimiser on this rank's rows -> all-gather ------
     def _dec_start(self):

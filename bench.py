@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shard", action="store_true", help="data parallel: all-reduce + replicated Adam for the decoder output layer")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
+    ap.add_argument("--dp", choices=("vocab", "replicated"), default="vocab",
+                    help="N > 1: 'vocab' shards the decoder's output layer over the vocabulary (ranks exchange hidden "
+                         "activations, aaerec.parallel.VocabParallelAAE); 'replicated' keeps a replica of it on every "
+                         "rank and exchanges its dense gradient (DataParallelAAE)")
     ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
     return ap.parse_args()
 
@@ -112,7 +116,30 @@ def main():
                    grad_mode="export" if use_dp else "fused", device=dev, unfused_decoder=a.unfused_decoder,
                    dp_world=world, w1_cap=w1_cap)
     model.load_params(params)
-    if use_dp:
+    vocab = use_dp and a.dp == "vocab"
+    slice_model = None
+    if vocab:
+        import scipy.sparse as sp
+        from aaerec.parallel import VocabParallelAAE, item_slice
+        lo, hi = item_slice(N, rank, world)
+        # every rank walks the same global batches (in fit(): one shared permutation of one corpus; here: the ranks'
+        # synthetic corpora regenerated from their seeds): rank r's documents are rows [r*B, (r+1)*B) of global batch i
+        Xs = [X if r == rank else throughput_corpus(n_batches * B, N, median_len=a.median_len, seed=1234 + r)
+              for r in range(world)]
+        Xg = sp.vstack([Xs[r][i * B:(i + 1) * B] for i in range(n_batches) for r in range(world)]).tocsr()
+        slice_csr = DeviceCSR(Xg[:, lo:hi], dev)
+        del Xs, Xg
+        sp_params = dict(params)
+        sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
+        sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+        slice_model = HipAAE(hi - lo, h, c, cond_inc=a.cond_inc, max_batch=B * world, rng_mode="device", seed=1 + rank,
+                             device=dev, unfused_decoder=a.unfused_decoder)
+        slice_model.load_params(sp_params)
+        runner = VocabParallelAAE(model, slice_model, dist, N)
+        Bg = B * world
+        step = lambda i: runner.step(csr, (i % n_batches) * B, B, slice_csr, (i % n_batches) * Bg, Bg,   # noqa: E731
+                                     cond=None if cond_all is None else cond_all[(i % n_batches) * B:(i % n_batches + 1) * B])
+    elif use_dp:
         from aaerec.parallel import DataParallelAAE
         runner = DataParallelAAE(model, dist, shard_decoder=False if a.no_shard else ("force" if world == 1 else True))
         step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
@@ -135,7 +162,10 @@ def main():
     # pair costs a few microseconds of stream time, so the other kernels (2 gathers + 2 sparse-Adam launches per
     # step) are timed in a short pass AFTER the timed region; that pass does not enter `value`.
     K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED = range(6)
-    model.profile_enable(True, kernels=(K_BCE, K_DA2, K_DV3, K_FUSED))
+    # (vocabulary-sharded runs: the output-layer kernels run on the slice model, over n_items / world items and the
+    # global batch)
+    out_model = slice_model if vocab else model
+    out_model.profile_enable(True, kernels=(K_BCE, K_DA2, K_DV3, K_FUSED))
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -144,8 +174,10 @@ def main():
         runner.wait_pending()
     barrier()
     dt = time.perf_counter() - t0
-    model.profile_enable(False)
+    out_model.profile_enable(False)
     losses = model.losses()
+    if vocab:
+        losses = (runner.recon_loss(),) + tuple(losses[1:])
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,18 +186,22 @@ def main():
 
     names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
     km = kernel_models(N, h, B, nnz_per_batch)
+    if vocab:       # the output-layer kernels' algorithmic work on this rank: its item slice x the global batch
+        km_out = kernel_models(slice_model.N, h, B * world, nnz_per_batch)
+        for k in ("dec_bce_fwd", "dec_da2", "dec_dv3_adam", "dec_fused"):
+            km[k] = km_out[k]
     kstats = {}
 
-    def collect(kids, steps, wall):
+    def collect(kids, steps, wall, src=None):
         for kid in kids:
-            ms, n = model.profile_read(kid)
+            ms, n = (src or model).profile_read(kid)
             if n:
                 avg_s = ms / n * 1e-3
                 kstats[names[kid]] = dict(launches_per_step=n / steps, avg_us=round(avg_s * 1e6, 2),
                                           step_share=round(ms * 1e-3 / wall, 4),
                                           GBps=round(km[names[kid]]["bytes"] / avg_s / 1e9, 1),
                                           TFLOPs=round(km[names[kid]]["flops"] / avg_s / 1e12, 2))
-    collect((K_BCE, K_DA2, K_DV3, K_FUSED), a.steps, dt)
+    collect((K_BCE, K_DA2, K_DV3, K_FUSED), a.steps, dt, out_model)
     extra = min(a.steps, 40)
     model.profile_enable(True, kernels=(K_GATHER, K_W1))
     for i in range(extra):
@@ -241,7 +277,9 @@ def main():
                                    f"batch={B} docs/GPU/step, full partial_fit (ae+disc+gen, 4 Adam)",
                        "n_items": N, "n_hidden": h, "n_code": c, "batch_per_gpu": B, "global_batch": B * world,
                        "cond_inc": a.cond_inc, "nnz_per_batch": round(nnz_per_batch, 1), "rng": "device",
-                       "parallelism": f"dp{world}"},
+                       "parallelism": (f"dp{world}" if not use_dp else
+                                       f"dp{world}, decoder output layer sharded over the vocabulary" if vocab else
+                                       f"dp{world}, replicated decoder")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
             "losses_last_step": [round(x, 5) for x in losses],
         }

@@ -248,3 +248,150 @@ def test_two_ranks_with_trainable_condition_equal_single_process(name):
     for k, w in fx.expected_params(last).items():
         np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
     np.testing.assert_allclose(got["cond.embedding"], fx.z[f"step{last}.cond.embedding"], atol=1e-5)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# vocabulary-sharded decoder output layer (aaerec.parallel.VocabParallelAAE) over gloo, oracle stand-ins
+# -------------------------------------------------------------------------------------------------------------
+class VocabLocalReplica(OracleReplica):
+    """The document-sharded replica of VocabParallelAAE's interface: ae_forward / dh2_rows / da2_rows / ae_backward
+    (include/aaerec_hip.h: aae_ae_forward, AAE_T_ACT_DH2, AAE_T_ACT_DA2, aae_ae_backward) on the oracle."""
+    big_tensor_id = 6
+
+    def ae_forward(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
+        z = self.ae_encode(csr, row_start, n_rows, masks=masks, z_real=z_real).numpy()
+        o = self.o
+        _, self._dc = o._mlp_fwd("dec", z, (o._mk[2], o._mk[3]))      # (its own output layer result is not used)
+        self._zc = z
+        h = self._dc["h2"].shape[1]
+        self._dh2 = torch.zeros(n_rows, h + 1)
+        self._dh2[:, :h] = torch.from_numpy(self._dc["h2"])
+        self._dh2[:, h] = 1.0
+        self._da2 = torch.zeros(n_rows, h + 1)
+
+    def dh2_rows(self, n):
+        return self._dh2[:n]
+
+    def da2_rows(self, n):
+        return self._da2[:n]
+
+    def ae_backward(self):
+        from oracle.aae_oracle import act_bwd, f32
+        o, dc = self.o, self._dc
+        P = o.p
+        gh2 = self._da2[:, :-1].numpy().astype(f32)
+        ga2 = dc["d2"].bwd(act_bwd(o.act, dc["u2"], dc["h2"], gh2))
+        G = {"dec.lin2.weight": (ga2.T @ dc["h1"]).astype(f32), "dec.lin2.bias": ga2.sum(0).astype(f32)}
+        gh1 = (ga2 @ P["dec.lin2.weight"]).astype(f32)
+        ga1 = dc["d1"].bwd(act_bwd(o.act, dc["u1"], dc["h1"], gh1))
+        G["dec.lin1.bias"] = ga1.sum(0).astype(f32)
+        G["dec.lin1.weight"] = (ga1.T @ self._zc).astype(f32)
+        o.G[1] = G
+        o.ae_encoder_backward((ga1 @ P["dec.lin1.weight"]).astype(f32))
+
+    def grad_buckets(self, which):
+        return super().grad_buckets(1 if which == "dec_small" else which)
+
+    def apply_updates(self, which, skip=-1):
+        self.o.apply_updates(which)          # (O_DEC: G[1] holds the two small layers only)
+
+
+class VocabSliceReplica:
+    """The item-slice model: aae_output_layer_step on rows [lo, hi) of dec.lin3 with its own (fused) Adam."""
+
+    def __init__(self, params, lo, hi, lr):
+        from oracle.aae_oracle import Adam
+        self.p = {"w": params["dec.lin3.weight"][lo:hi].copy(), "b": params["dec.lin3.bias"][lo:hi].copy()}
+        self.lo, self.hi, self.opt, self.scale = lo, hi, Adam(lr), 1.0
+        self._dh2 = self._da2 = None
+        self.loss = 0.0
+
+    def set_grad_scale(self, s):
+        self.scale = float(s)
+
+    def dh2_rows(self, n):
+        if self._dh2 is None or self._dh2.shape[0] != n:
+            h = self.p["w"].shape[1]
+            self._dh2, self._da2 = torch.zeros(n, h + 1), torch.zeros(n, h + 1)
+        return self._dh2
+
+    def da2_rows(self, n):
+        return self._da2
+
+    def output_layer_step(self, slice_csr, g_row_start, global_rows, rows=None):
+        from oracle.aae_oracle import TINY, f32, sigmoid
+        ip, idx, val = slice_csr
+        B, Ns = global_rows, self.hi - self.lo
+        h2 = self._dh2[:, :-1].numpy().astype(f32)
+        xhat = sigmoid((h2 @ self.p["w"].T + self.p["b"]).astype(f32))
+        T = np.zeros((B, Ns), dtype=f32)
+        for b in range(B):
+            r = g_row_start + b
+            T[b, idx[ip[r]:ip[r + 1]]] = val[ip[r]:ip[r + 1]]
+        x, t = xhat + TINY, T + TINY
+        lx, l1x = np.maximum(np.log(x), f32(-100)), np.maximum(np.log1p(-x), f32(-100))
+        self.loss = float((-(t * lx + (f32(1) - t) * l1x)).mean(dtype=np.float64))
+        gx = (x - t) / np.maximum((f32(1) - x) * x, f32(1e-12)) * f32(self.scale / (B * Ns))
+        glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
+        self._da2[:, :-1] = torch.from_numpy((glog @ self.p["w"]).astype(f32))
+        self.opt.step(self.p, {"w": (glog.T @ h2).astype(f32), "b": glog.sum(0).astype(f32)})
+
+    def losses(self):
+        return (self.loss, 0.0, 0.0)
+
+
+def _worker_vocab(rank, world, port, name, ret):
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.parallel import VocabParallelAAE, item_slice
+    fx = Fixture(name)
+    N = fx.cfg["N"]
+    lo, hi = item_slice(N, rank, world)
+    model = VocabLocalReplica(fx.init_params(), **fx.model_kwargs())
+    sl = VocabSliceReplica(fx.init_params(), lo, hi, fx.model_kwargs().get("gen_lr", 1e-3))
+    vp = VocabParallelAAE(model, sl, dist, N)
+    losses = []
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        B = len(ip) - 1
+        Bl = B // world
+        X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+        Xs = X[:, lo:hi].tocsr()
+        masks = fx.masks(s)
+        if masks is not None:
+            masks = [m[rank * Bl:(rank + 1) * Bl] for m in masks]
+        vp.step((ip, idx, val), rank * Bl, Bl, (Xs.indptr, Xs.indices, Xs.data), 0, B, masks=masks,
+                z_real=fx.z[f"step{s}.z_real"][rank * Bl:(rank + 1) * Bl])
+        losses.append(vp.recon_loss())
+    if rank == 0:
+        ret.update({k: v.copy() for k, v in model.o.p.items() if not k.startswith("dec.lin3")})
+        ret["recon_losses"] = losses
+    ret[f"v3w{rank}"], ret[f"v3b{rank}"] = sl.p["w"].copy(), sl.p["b"].copy()
+    flat = torch.from_numpy(np.concatenate([v.ravel() for k, v in model.o.p.items() if not k.startswith("dec.lin3")]))
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(other[0], o) for o in other)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["step_masks", "step_nodrop_gauss"])
+def test_two_ranks_with_vocabulary_sharded_output_layer_equal_single_process(name):
+    """VocabParallelAAE over real gloo collectives: rank r holds half the documents and half the items' output rows;
+    parameters (replicas + the two slices of dec.lin3) and the reconstruction loss equal the reference's."""
+    port = 33500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_vocab, args=(2, port, name, ret), nprocs=2, join=True)
+        got = dict(ret)
+    fx = Fixture(name)
+    want = fx.expected_params(fx.steps - 1)
+    for k, w in want.items():
+        if not k.startswith("dec.lin3"):
+            np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+    np.testing.assert_allclose(np.concatenate([got["v3w0"], got["v3w1"]]), want["dec.lin3.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(np.concatenate([got["v3b0"], got["v3b1"]]), want["dec.lin3.bias"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Per-rank COMPUTE time of one training step at `world` ranks, measured on one GPU: the collectives are replaced by
+local copies of the same shapes (all-gather = this rank's operand repeated, reduce-scatter / all-reduce = identity),
+so what is timed is every kernel a rank launches - the replicated scheme (DataParallelAAE: dense dec.lin3 gradient,
+optimiser on 1/world of its rows) next to the vocabulary-sharded one (VocabParallelAAE: output layer over
+n_items / world items x the global batch).  Communication time is NOT in these numbers; the operand sizes are printed."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+import numpy as np
+import torch
+from aaerec._hip import HipAAE, DeviceCSR
+from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
+from oracle.dense_torch_port import init_params
+from tools.synth import throughput_corpus
+
+N, h, c, B = 100000, 200, 50, 100
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+
+
+class EchoDist:
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world):
+        self.world, self.bytes = world, {}
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return "echo"
+
+    def _count(self, kind, t):
+        self.bytes[kind] = self.bytes.get(kind, 0) + t.numel() * 4
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        self._count("all_reduce", t)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        self._count("all_gather(out)", out)
+        out.reshape(self.world, -1).copy_(inp.reshape(1, -1).expand(self.world, -1))
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        self._count("reduce_scatter(in)", inp)
+        out.view(-1).copy_(inp.reshape(self.world, -1)[0])
+
+
+Bg = B * world
+X = throughput_corpus(64 * Bg, N, seed=1234)
+params = init_params(N, h, c, seed=0)
+dev = torch.device("cuda:0")
+row_nnz = np.sort(X.getnnz(1))[::-1]
+w1_cap = int(min(N, row_nnz[:B].sum()))
+
+
+def timeit(step, steps=200, warm=30):
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+csr = DeviceCSR(X, dev)
+# ---- replicated decoder (the current default for N > 1) -------------------------------------------------------
+m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
+m.load_params(params)
+d1 = EchoDist(world)
+dp = DataParallelAAE(m, d1, shard_decoder=True if N % world == 0 else False)
+t_dp = timeit(lambda i: dp.step(csr, (i % 64) * Bg, B, global_rows=Bg))
+dp.wait_pending()
+per_step = {k: v / 230 for k, v in d1.bytes.items()}
+print(f"world {world}: replicated decoder   {t_dp:.3f} ms/step of compute per rank; exchanged per step: "
+      + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
+del dp, m
+torch.cuda.empty_cache()
+# ---- vocabulary-sharded output layer ---------------------------------------------------------------------------
+lo, hi = item_slice(N, 0, world)
+m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
+m.load_params(params)
+sp = dict(params)
+sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
+sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256)
+sl.load_params(sp)
+slice_csr = DeviceCSR(X[:, lo:hi], dev)
+d2 = EchoDist(world)
+vp = VocabParallelAAE(m, sl, d2, N)
+t_vp = timeit(lambda i: vp.step(csr, (i % 64) * Bg, B, slice_csr, (i % 64) * Bg, Bg))
+per_step = {k: v / 230 for k, v in d2.bytes.items()}
+print(f"world {world}: vocabulary-sharded   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
+      + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
