@@ -90,7 +90,7 @@ class AdversarialAutoEncoder:
     def __init__(self, n_hidden=100, n_code=50, gen_lr=0.001, reg_lr=0.001, prior="gauss", prior_scale=None,
                  batch_size=100, n_epochs=500, optimizer="adam", normalize_inputs=True, activation="ReLU",
                  dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None, data_parallel=None):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab"):
         self.prior = prior.lower()
         self.prior_scale = prior_scale
         self.prior_sampler = PRIOR_SAMPLERS[self.prior]
@@ -108,8 +108,14 @@ class AdversarialAutoEncoder:
         if rng_mode not in ("device", "reference"):
             raise ValueError("rng_mode must be 'device' or 'reference'")
         self.device, self.rng_mode, self.seed, self.data_parallel = device, rng_mode, seed, data_parallel
+        if dp_mode not in ("vocab", "replicated"):
+            raise ValueError("dp_mode must be 'vocab' or 'replicated'")
+        # data_parallel (torch.distributed, one process per GPU): 'vocab' shards the decoder's output layer over the
+        # vocabulary (aaerec.parallel.VocabParallelAAE), 'replicated' keeps it on every rank and exchanges its gradient
+        self.dp_mode = dp_mode
         self.hip = None
         self._dp = None
+        self._slice = self._slice_csr = self._g_rows = None     # dp_mode='vocab': this rank's item slice of dec.lin3
         self.last_losses = None
         self._ae_only = False
 
@@ -145,12 +151,16 @@ class AdversarialAutoEncoder:
 
     # ---- construction: the nets + 4 optimisers of the reference's fit() (aae.py:782-804) ----
     def _build(self, n_items, code_inc, max_row_nnz=None, w1_cap=None):
-        dist_group, dist_world = None, 1
+        dist = dist_group = None
+        dist_world = 1
         if self.data_parallel is not None and self.data_parallel is not False:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                raise RuntimeError("data_parallel needs torch.distributed to be initialised")
-            dist_group = None if self.data_parallel is True else self.data_parallel
+            if hasattr(self.data_parallel, "all_gather_into_tensor"):
+                dist = self.data_parallel                # an object with torch.distributed's collective interface
+            else:
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    raise RuntimeError("data_parallel needs torch.distributed to be initialised")
+                dist_group = None if self.data_parallel is True else self.data_parallel
             dist_world = dist.get_world_size(dist_group)
         seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
             if self.rng_mode == "device" else 0
@@ -160,7 +170,7 @@ class AdversarialAutoEncoder:
             activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
-            grad_mode="export" if self.data_parallel else "fused", device=self.device,
+            grad_mode="export" if dist is not None else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only)
         # nn.Linear default initialisation, drawn from torch's global CPU generator in the
         # reference's construction order (Encoder, Decoder, Discriminator; lin1, lin2, lin3 each),
@@ -184,10 +194,32 @@ class AdversarialAutoEncoder:
         self.enc, self.dec, self.disc = (_NetView(self, n) for n in ("enc", "dec", "disc"))
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")
         self.gen_optim, self.disc_optim = _OptimView(self, "gen"), _OptimView(self, "disc")
-        if self.data_parallel:
-            import torch.distributed as dist
-            from .parallel import DataParallelAAE
-            self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
+        if dist is not None:
+            from .parallel import DataParallelAAE, VocabParallelAAE, item_slice
+            if self._vocab_sharded(code_inc):
+                lo, hi = item_slice(n_items, dist.get_rank(dist_group), dist_world)
+                sl_params = dict(params)
+                sl_params["dec.lin3.weight"] = params["dec.lin3.weight"][lo:hi]
+                sl_params["dec.lin3.bias"] = params["dec.lin3.bias"][lo:hi]
+                sl_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+                self._slice = _hip.HipAAE(
+                    hi - lo, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
+                    max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
+                    activation=self.activation, prior=self.prior, prior_scale=self.prior_scale,
+                    optimizer=self.optimizer, normalize_inputs=self.normalize_inputs, dropout=self.dropout,
+                    gen_lr=self.gen_lr, reg_lr=self.reg_lr, rng_mode="device" if self.rng_mode == "device" else "inject",
+                    seed=seed, device=self.device, ae_only=self._ae_only)
+                self._slice.load_params(sl_params)
+                self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group)
+            else:
+                self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
+
+    def _vocab_sharded(self, code_inc):
+        """dp_mode='vocab' applies when the step has no cut at the condition boundary (no conditions, or constant
+        concatenated blocks only) and the batches are the corpus' own rows (no per-epoch corruption hook)."""
+        if self.dp_mode != "vocab" or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
+            return False
+        return not self.conditions or code_inc == 0 or self._is_constant_concat()
 
     # ---- randomness in the reference's draw order (rng_mode='reference') -------------------
     def _host_randomness(self, B):
@@ -243,7 +275,16 @@ class AdversarialAutoEncoder:
             masks, z_real = self._host_randomness(n_rows)
         hip = self.hip
         use_condition = c_batch is not None
-        if self._dp is not None:
+        if self._dp is not None and self._slice is not None:
+            if self._g_rows is None:
+                raise NotImplementedError("partial_fit on a rank's own batch is not available with dp_mode='vocab' (the "
+                                          "output-layer slices need the global batch): use fit() or dp_mode='replicated'")
+            cond = None
+            if use_condition:
+                cond = torch.cat([_hip.upload(c.encode(x), hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
+            self._dp.step(csr, row_start, n_rows, self._slice_csr, 0, self._dp.global_rows, rows=rows, g_rows=self._g_rows,
+                          cond=cond, masks=masks, z_real=z_real)
+        elif self._dp is not None:
             cond_fn = self._cond_fn(c_batch) if use_condition else None
             self._dp.step(csr, row_start, n_rows, global_rows=getattr(self._dp, "global_rows", None), rows=rows,
                           cond_fn=cond_fn, masks=masks, z_real=z_real)
@@ -319,6 +360,9 @@ class AdversarialAutoEncoder:
         self._build(X.shape[1], code_inc, max_row_nnz=max(int(row_nnz[0]) if X.shape[0] else 1, 4096), w1_cap=w1_cap)
         csr0 = _hip.DeviceCSR(X, self.hip.device)      # the corpus stays resident in HBM
         self._fit_X = X                                 # (host copy; subclasses with host-side randomness use it)
+        row_len = X.getnnz(1)
+        if self._slice is not None:                     # this rank's items of the corpus, ids rebased to the slice
+            self._slice_csr = _hip.DeviceCSR(X[:, self._dp.item_lo:self._dp.item_hi], self.hip.device)
         n_docs = X.shape[0]
         self.train()
         step = 0
@@ -337,10 +381,18 @@ class AdversarialAutoEncoder:
                     # every rank walks the same permutation (same np.random state) and takes its
                     # contiguous share of the global batch; a tail batch with fewer rows than
                     # ranks is skipped on all ranks
+                    if self._slice is not None:
+                        # vocabulary-sharded output layer: equal shares (a tail batch loses < world documents)
+                        stop = start + (stop - start) // self._dp.world * self._dp.world
                     lo, hi = self._dp.shard(start, stop)
                     if lo is None:
                         continue
                     self._dp.global_rows = stop - start
+                    # first-layer packets: no share of this batch names more distinct items than it has entries
+                    shares = np.array_split(row_len[perm[start:stop]], self._dp.world)
+                    self._dp.w1_rows = int(max(sh.sum() for sh in shares)) + 8
+                    if self._slice is not None:
+                        self._g_rows = perm_dev[start:stop]
                     start, stop = lo, hi
                 rows = perm_dev[start:stop]
                 c_batch = None
@@ -349,13 +401,24 @@ class AdversarialAutoEncoder:
                     c_batch = [_take(c, idx) for c in condition_data]
                 self._run_step(csr, 0, int(rows.numel()), rows, c_batch)
                 if self.verbose:
-                    self.last_losses = self.hip.losses()
+                    self.last_losses = self._losses()
                     log_losses(*self.last_losses)
                 step += 1
             if self.verbose:
                 print()
-        self.last_losses = self.hip.losses()
+        self.last_losses = self._losses()
+        self._g_rows = None
+        if self._slice is not None:
+            self._dp.gather_output_layer()              # every replica ends with the whole decoder (predict, state_dict)
         return self
+
+    def _losses(self):
+        """(recon, disc, gen) of the last step; under dp_mode='vocab' the reconstruction loss lives in the item slices
+        (a collective: every rank calls this at the same points)."""
+        losses = self.hip.losses()
+        if self._slice is not None:
+            losses = (self._dp.recon_loss(),) + tuple(losses[1:])
+        return losses
 
     def _epoch_csr(self, csr):
         """The resident corpus as this epoch's batches see it (hook: DenoisingAutoEncoder thins it)."""
@@ -368,6 +431,8 @@ class AdversarialAutoEncoder:
             self.conditions.eval()
         Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         csr = _hip.DeviceCSR(Xs, self.hip.device)
+        if self._slice is not None:
+            self._dp.gather_output_layer()              # (a no-op after fit(); collective otherwise)
         fused = (not use_condition) or self._is_constant_concat()
         native = use_condition and not fused and self._is_device_native()
         pred = _hip.HostRows(Xs.shape[0], Xs.shape[1], self.hip.device)
@@ -397,11 +462,11 @@ class AutoEncoder(AdversarialAutoEncoder):
 
     def __init__(self, n_hidden=100, n_code=50, lr=0.001, batch_size=100, n_epochs=500, optimizer="adam",
                  normalize_inputs=True, activation="ReLU", dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab"):
         super().__init__(n_hidden=n_hidden, n_code=n_code, gen_lr=lr, reg_lr=lr, prior="gauss", batch_size=batch_size,
                          n_epochs=n_epochs, optimizer=optimizer, normalize_inputs=normalize_inputs,
                          activation=activation, dropout=dropout, conditions=conditions, verbose=verbose,
-                         device=device, rng_mode=rng_mode, seed=seed)
+                         device=device, rng_mode=rng_mode, seed=seed, data_parallel=data_parallel, dp_mode=dp_mode)
         self.lr = lr
         self._ae_only = True
 
@@ -428,6 +493,8 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
         raise NotImplementedError("predict_topk supports constant concatenated conditions only")
     Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
     csr = _hip.DeviceCSR(Xs, self.hip.device)
+    if self._slice is not None:
+        self._dp.gather_output_layer()
     ids, vals = [], []
     for start in range(0, Xs.shape[0], self.batch_size):
         n = min(self.batch_size, Xs.shape[0] - start)

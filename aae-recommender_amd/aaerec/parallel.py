@@ -168,11 +168,12 @@ class DataParallelAAE:
         dec_state = self._dec_start()
         m.ae_encoder_backward(dz)
         self._exchange_encoder(O_ENC)
-        m.disc_step()
-        self._allreduce(O_DISC)
-        m.apply_updates(O_DISC)
-        m.gen_step()
-        self._exchange_encoder(O_GEN)
+        if not getattr(m, "ae_only", False):         # the plain AutoEncoder has no disc_step / gen_step (aae.py:221-458)
+            m.disc_step()
+            self._allreduce(O_DISC)
+            m.apply_updates(O_DISC)
+            m.gen_step()
+            self._exchange_encoder(O_GEN)
         self._dec_finish(dec_state)
 
 
@@ -233,11 +234,32 @@ class VocabParallelAAE(DataParallelAAE):
             if w is not None:
                 w.wait()
         m.apply_updates(O_DEC, skip=m.big_tensor_id)
-        m.disc_step()
-        self._allreduce(O_DISC)
-        m.apply_updates(O_DISC)
-        m.gen_step()
-        self._exchange_encoder(O_GEN)
+        if not getattr(m, "ae_only", False):
+            m.disc_step()
+            self._allreduce(O_DISC)
+            m.apply_updates(O_DISC)
+            m.gen_step()
+            self._exchange_encoder(O_GEN)
+        self._gathered = False
+
+    def gather_output_layer(self):
+        """Copy every rank's rows of dec.lin3 into each replica's full copy (predict, state_dict; the optimiser state
+        of those rows stays with their owner).  Collective; a no-op when nothing changed since the last call."""
+        import torch
+        if getattr(self, "_gathered", False):
+            return
+        m, sl, d = self.model, self.slice, self.dist
+        full = m.tensor(m.big_tensor_id, padded=True)
+        mine = sl.tensor(m.big_tensor_id, padded=True)
+        rows = -(-self.n_items // self.world)
+        send = torch.zeros(rows, full.shape[1], dtype=full.dtype, device=full.device)
+        send[:mine.shape[0]] = mine
+        recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
+        d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        for r in range(self.world):
+            lo, hi = item_slice(self.n_items, r, self.world)
+            full[lo:hi] = recv[r * rows:r * rows + (hi - lo)]
+        self._gathered = True
 
     def recon_loss(self):
         """Reconstruction loss of the last step over all items: the slices' means weighted by their sizes."""

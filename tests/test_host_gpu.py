@@ -1,6 +1,7 @@
 """GPU tests of the host-side mirror (aaerec.aae) - through AdversarialAutoEncoder /
 AAERecommender exactly as the reference's drivers call them."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -615,3 +616,100 @@ def test_embedded_vectorizer_product_on_the_gpu_matches_reference_fixture():
     np.testing.assert_allclose(data, z["default.train"], atol=2e-6)
     enc = cond.encode(data[:7])
     assert enc.is_cuda and enc.shape == (7, 300) and cond.size_increment() == 300
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fit() under data parallelism, two processes sharing the one GPU of the test box.  RCCL refuses two ranks on one
+# device, so the ranks talk over gloo with the operands staged through the host; everything else - both models per
+# rank, the kernels, aaerec.parallel - is what runs on a multi-GPU node.
+# ---------------------------------------------------------------------------------------------------------------
+class _HostStagedDist:
+    """torch.distributed's collective interface over a gloo group for GPU tensors."""
+
+    def __init__(self, dist):
+        self.d, self.ReduceOp = dist, dist.ReduceOp
+
+    def get_rank(self, group=None):
+        return self.d.get_rank()
+
+    def get_world_size(self, group=None):
+        return self.d.get_world_size()
+
+    def get_backend(self, group=None):
+        return "gloo"
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        c = torch.empty(out.shape, dtype=out.dtype)
+        self.d.all_gather_into_tensor(c, inp.cpu())
+        out.copy_(c)
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        c = inp.cpu()
+        self.d.all_reduce(c)
+        n = out.numel()
+        out.copy_(c.view(-1)[self.d.get_rank() * n:(self.d.get_rank() + 1) * n].view(out.shape))
+
+
+def _fit_worker(rank, world, port, mode, ret):
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "aae-recommender_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.aae import AutoEncoder
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    m = AutoEncoder(n_hidden=48, n_code=16, lr=0.01, batch_size=40, n_epochs=3, dropout=(0.0, 0.0), verbose=False,
+                    data_parallel=_HostStagedDist(dist), dp_mode=mode)      # batch_size = the GLOBAL batch
+    m.fit(X)
+    pred = m.predict(X[:33])
+    if rank == 0:
+        ret["state"] = m.hip.state_dict()
+        ret["pred"] = pred
+        ret["loss"] = m.last_losses[0]
+        ret["sliced"] = m._slice is not None
+    flat = torch.from_numpy(pred.copy())
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(other[0], o) for o in other)          # every replica predicts the same
+    dist.destroy_process_group()
+
+
+def _dp_corpus():
+    rng = np.random.RandomState(3)
+    protos = [rng.choice(500, size=10, replace=False) for _ in range(12)]
+    rows = [rng.choice(protos[rng.randint(12)], size=rng.randint(3, 9), replace=False) for _ in range(200)]
+    ind0 = [b for b, r in enumerate(rows) for _ in r]
+    return sp.coo_matrix((np.ones(len(ind0), dtype=np.float32), (ind0, np.concatenate(rows))), shape=(200, 500)).tocsr()
+
+
+@pytest.mark.parametrize("mode", ["vocab", "replicated"])
+def test_fit_on_two_ranks_equals_single_process(mode):
+    """AutoEncoder.fit (no dropout, no prior: nothing random but the shared shuffles) on two ranks - batches of 40
+    documents, 20 per rank, in 'vocab' mode each rank owning 250 of the 500 items' output rows - against one process:
+    same parameters, same predictions."""
+    import torch.multiprocessing as mp
+    from aaerec.aae import AutoEncoder
+    port = 35500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fit_worker, args=(2, port, mode, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got["sliced"] == (mode == "vocab")
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    one = AutoEncoder(n_hidden=48, n_code=16, lr=0.01, batch_size=40, n_epochs=3, dropout=(0.0, 0.0), verbose=False)
+    one.fit(X)
+    want = one.hip.state_dict()
+    for k, w in want.items():
+        np.testing.assert_allclose(got["state"][k], w, atol=2e-5, rtol=0, err_msg=f"{mode} {k}")
+    np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=2e-5)
+    if mode == "vocab":          # (the replicated scheme reports each rank's loss over its own share)
+        assert abs(got["loss"] - one.last_losses[0]) < 1e-5
