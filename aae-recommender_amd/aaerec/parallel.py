@@ -270,3 +270,45 @@ class VocabParallelAAE(DataParallelAAE):
         buf = part.to(self.model.device) if nccl else part
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
         return float(buf.item())
+
+
+class HostStagedCollectives:
+    """torch.distributed's collective interface (the subset this module uses) over a gloo group for GPU tensors: every
+    operand is staged through host memory.  Not a production path - RCCL over xGMI is - but it lets several ranks
+    share ONE GPU (RCCL refuses two ranks on a device), which is how the multi-rank logic of fit() and bench.py is
+    exercised on a single-GPU test box (tests/test_host_gpu.py, AAE_BENCH_GLOO_ONE_GPU=1)."""
+
+    def __init__(self, dist):
+        self.d, self.ReduceOp = dist, dist.ReduceOp
+
+    def get_rank(self, group=None):
+        return self.d.get_rank()
+
+    def get_world_size(self, group=None):
+        return self.d.get_world_size()
+
+    def get_backend(self, group=None):
+        return "gloo"
+
+    def barrier(self):
+        self.d.barrier()
+
+    def destroy_process_group(self):
+        self.d.destroy_process_group()
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        import torch
+        c = torch.empty(out.shape, dtype=out.dtype)
+        self.d.all_gather_into_tensor(c, inp.cpu())
+        out.copy_(c)
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        c = inp.cpu()
+        self.d.all_reduce(c)
+        n, r = out.numel(), self.d.get_rank()
+        out.copy_(c.view(-1)[r * n:(r + 1) * n].view(out.shape))

@@ -82,6 +82,11 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AAE step has no CPU fallback")
+    # debugging aid for a single-GPU box: all ranks on device 0, collectives over gloo staged through the host
+    # (aaerec.parallel.HostStagedCollectives) - exercises this file's multi-rank logic; the numbers mean nothing
+    one_gpu = os.environ.get("AAE_BENCH_GLOO_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -90,7 +95,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if one_gpu:
+            from aaerec.parallel import HostStagedCollectives
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = HostStagedCollectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from aaerec._hip import HipAAE, DeviceCSR
     from aaerec import _hip

@@ -623,38 +623,6 @@ def test_embedded_vectorizer_product_on_the_gpu_matches_reference_fixture():
 # device, so the ranks talk over gloo with the operands staged through the host; everything else - both models per
 # rank, the kernels, aaerec.parallel - is what runs on a multi-GPU node.
 # ---------------------------------------------------------------------------------------------------------------
-class _HostStagedDist:
-    """torch.distributed's collective interface over a gloo group for GPU tensors."""
-
-    def __init__(self, dist):
-        self.d, self.ReduceOp = dist, dist.ReduceOp
-
-    def get_rank(self, group=None):
-        return self.d.get_rank()
-
-    def get_world_size(self, group=None):
-        return self.d.get_world_size()
-
-    def get_backend(self, group=None):
-        return "gloo"
-
-    def all_reduce(self, t, op=None, group=None, async_op=False):
-        c = t.cpu()
-        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
-        t.copy_(c)
-
-    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
-        c = torch.empty(out.shape, dtype=out.dtype)
-        self.d.all_gather_into_tensor(c, inp.cpu())
-        out.copy_(c)
-
-    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
-        c = inp.cpu()
-        self.d.all_reduce(c)
-        n = out.numel()
-        out.copy_(c.view(-1)[self.d.get_rank() * n:(self.d.get_rank() + 1) * n].view(out.shape))
-
-
 def _fit_worker(rank, world, port, mode, ret):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
@@ -662,11 +630,12 @@ def _fit_worker(rank, world, port, mode, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from aaerec.aae import AutoEncoder
+    from aaerec.parallel import HostStagedCollectives
     X = _dp_corpus()
     np.random.seed(5)
     torch.manual_seed(5)
     m = AutoEncoder(n_hidden=48, n_code=16, lr=0.01, batch_size=40, n_epochs=3, dropout=(0.0, 0.0), verbose=False,
-                    data_parallel=_HostStagedDist(dist), dp_mode=mode)      # batch_size = the GLOBAL batch
+                    data_parallel=HostStagedCollectives(dist), dp_mode=mode)      # batch_size = the GLOBAL batch
     m.fit(X)
     pred = m.predict(X[:33])
     if rank == 0:

@@ -53,8 +53,7 @@ Bg = B * world
 X = throughput_corpus(64 * Bg, N, seed=1234)
 params = init_params(N, h, c, seed=0)
 dev = torch.device("cuda:0")
-row_nnz = np.sort(X.getnnz(1))[::-1]
-w1_cap = int(min(N, row_nnz[:B].sum()))
+w1_cap = int(X.getnnz(1).reshape(-1, B).sum(1).max()) + 8       # rows of a first-layer packet: the fullest share
 
 
 def timeit(step, steps=200, warm=30):
