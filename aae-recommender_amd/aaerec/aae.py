@@ -115,7 +115,7 @@ class AdversarialAutoEncoder:
         self.dp_mode = dp_mode
         self.hip = None
         self._dp = None
-        self._slice = self._slice_csr = self._g_rows = None     # dp_mode='vocab': this rank's item slice of dec.lin3
+        self._slice = self._slice_csr = self._g_rows = self._g_c_batch = None     # dp_mode='vocab': this rank's item slice of dec.lin3
         self.last_losses = None
         self._ae_only = False
 
@@ -215,11 +215,12 @@ class AdversarialAutoEncoder:
                 self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
 
     def _vocab_sharded(self, code_inc):
-        """dp_mode='vocab' applies when the step has no cut at the condition boundary (no conditions, or constant
-        concatenated blocks only) and the batches are the corpus' own rows (no per-epoch corruption hook)."""
+        """dp_mode='vocab' applies when the step has no cut at the condition boundary (no conditions, constant
+        concatenated blocks, CategoricalConditions the kernels train themselves) and the batches are the corpus' own
+        rows (no per-epoch corruption hook)."""
         if self.dp_mode != "vocab" or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
             return False
-        return not self.conditions or code_inc == 0 or self._is_constant_concat()
+        return not self.conditions or code_inc == 0 or self._is_constant_concat() or self._is_device_native()
 
     # ---- randomness in the reference's draw order (rng_mode='reference') -------------------
     def _host_randomness(self, B):
@@ -243,29 +244,33 @@ class AdversarialAutoEncoder:
         return all(getattr(c, "constant_concat", False) or (hasattr(c, "device_native") and c.device_native(dev))
                    for c in self.conditions.values())
 
-    def _native_cond_block(self, c_batch, n_rows):
+    def _native_cond_block(self, c_batch, n_rows, whole_batch=None):
         """[n_rows, size_increment] block of the encoded conditions, in ConditionList order (encode_impose's
-        concatenation order, condition.py:90-99)."""
+        concatenation order, condition.py:90-99).  whole_batch: the condition inputs of the global batch this is a
+        share of (data parallel) - value lists are padded to ITS width, as the single process would."""
         dev = self.hip.device
         block = torch.empty(n_rows, self.hip.cond_inc, dtype=torch.float32, device=dev)
         off = 0
-        for cond, x in zip(self.conditions.values(), c_batch):
+        for j, (cond, x) in enumerate(zip(self.conditions.values(), c_batch)):
             w = cond.size_increment()
             if getattr(cond, "constant_concat", False):
                 block[:, off:off + w] = _hip.upload(cond.encode(x), dev)
             else:
-                cond.encode_into(block[:, off:off + w], x)
+                cond.encode_into(block[:, off:off + w], x,
+                                 width=None if whole_batch is None else cond.padded_width(whole_batch[j]))
             off += w
         return block
 
-    def _native_cond_update(self, n_rows):
-        """conditions.zero_grad / backward / step (aae.py:699-709) from the step's dL/d(condition block)."""
-        dblock = self.hip.cond_grad(n_rows)
+    def _native_cond_update(self, n_rows, dblock=None, whole_batch=None):
+        """conditions.zero_grad / backward / step (aae.py:699-709) from the step's dL/d(condition block); data
+        parallel: from the gathered gradient of the whole batch and its inputs, identically on every rank."""
+        if dblock is None:
+            dblock = self.hip.cond_grad(n_rows)
         off = 0
-        for cond in self.conditions.values():
+        for j, cond in enumerate(self.conditions.values()):
             w = cond.size_increment()
             if not getattr(cond, "constant_concat", False):
-                cond.update_from(dblock[:, off:off + w])
+                cond.update_from(dblock[:, off:off + w], None if whole_batch is None else whole_batch[j])
             off += w
 
     def _run_step(self, csr, row_start, n_rows, rows, c_batch):
@@ -279,11 +284,15 @@ class AdversarialAutoEncoder:
             if self._g_rows is None:
                 raise NotImplementedError("partial_fit on a rank's own batch is not available with dp_mode='vocab' (the "
                                           "output-layer slices need the global batch): use fit() or dp_mode='replicated'")
-            cond = None
+            cond, trainable = None, False
             if use_condition:
-                cond = torch.cat([_hip.upload(c.encode(x), hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
+                trainable = not self._is_constant_concat()
+                cond = self._native_cond_block(c_batch, n_rows, whole_batch=self._g_c_batch if trainable else None)
             self._dp.step(csr, row_start, n_rows, self._slice_csr, 0, self._dp.global_rows, rows=rows, g_rows=self._g_rows,
                           cond=cond, masks=masks, z_real=z_real)
+            if trainable:
+                # every rank gathers dL/d(condition block) of the whole batch and applies the identical update
+                self._native_cond_update(n_rows, self._dp.gather_rows(hip.cond_grad(n_rows)), self._g_c_batch)
         elif self._dp is not None:
             cond_fn = self._cond_fn(c_batch) if use_condition else None
             self._dp.step(csr, row_start, n_rows, global_rows=getattr(self._dp, "global_rows", None), rows=rows,
@@ -393,6 +402,8 @@ class AdversarialAutoEncoder:
                     self._dp.w1_rows = int(max(sh.sum() for sh in shares)) + 8
                     if self._slice is not None:
                         self._g_rows = perm_dev[start:stop]
+                        if use_condition and not self._is_constant_concat():
+                            self._g_c_batch = [_take(c, perm[start:stop]) for c in condition_data]
                     start, stop = lo, hi
                 rows = perm_dev[start:stop]
                 c_batch = None

@@ -340,28 +340,36 @@ class CategoricalCondition(ConcatenationBasedConditioning):
         return (w is not None and w.is_cuda and w.device == torch.device(device) and self.reduce in (None, "sum", "mean")
                 and not self.embedding_params and self.embedding_dim <= 256)
 
-    def _index_block(self, inputs, device):
+    def _index_block(self, inputs, device, width=None):
         if self.reduce is None:
             arr = np.asarray(inputs, dtype=np.int32).reshape(-1, 1)
         else:
-            width = max(1, max(len(row) for row in inputs))
+            width = max(1, width or 0, max(len(row) for row in inputs))
             arr = np.zeros((len(inputs), width), dtype=np.int32)
             for r, row in enumerate(inputs):
                 arr[r, :len(row)] = row
         from . import _hip
         return _hip.upload(arr, device)
 
-    def encode_into(self, out, inputs):
-        """encode(inputs) written into `out` ([rows, embedding_dim], may be a column slice of a wider block)."""
+    def padded_width(self, inputs):
+        """Width the reference pads a batch of value lists to (its longest list); 'mean' divides by it."""
+        return 1 if self.reduce is None else max(1, max(len(row) for row in inputs))
+
+    def encode_into(self, out, inputs, width=None):
+        """encode(inputs) written into `out` ([rows, embedding_dim], may be a column slice of a wider block).
+        width: pad to at least this many values (a rank's share of a batch uses the whole batch's width)."""
         from . import _hip
         w = self.embedding.weight
-        self._idx = self._index_block(inputs, w.device)
+        self._idx = self._index_block(inputs, w.device, width)
         _hip.cat_encode(w.data, self._idx, out, mean=self.reduce == "mean")
 
-    def update_from(self, dout):
-        """zero_grad + backward + step from dL/d(encoded block) of the rows last handed to encode_into."""
+    def update_from(self, dout, inputs=None):
+        """zero_grad + backward + step from dL/d(encoded block) of the rows last handed to encode_into, or of
+        `inputs` (data parallel: every rank applies the gathered gradient of the whole batch)."""
         from . import _hip
         w = self.embedding.weight
+        if inputs is not None:
+            self._idx = self._index_block(inputs, w.device)
         st = self.optimizer.state[w]
         if "exp_avg" not in st:
             st["step"] = 0 if self.sparse else torch.tensor(0.0)

@@ -242,6 +242,14 @@ class VocabParallelAAE(DataParallelAAE):
             self._exchange_encoder(O_GEN)
         self._gathered = False
 
+    def gather_rows(self, t):
+        """[world * rows, cols] tensor of every rank's [rows, cols] block, in rank (= global batch) order."""
+        import torch
+        t = t.contiguous()
+        out = torch.empty(self.world * t.shape[0], t.shape[1], dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)
+        return out
+
     def gather_output_layer(self):
         """Copy every rank's rows of dec.lin3 into each replica's full copy (predict, state_dict; the optimiser state
         of those rows stays with their owner).  Collective; a no-op when nothing changed since the last call."""

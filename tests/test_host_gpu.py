@@ -623,7 +623,29 @@ def test_embedded_vectorizer_product_on_the_gpu_matches_reference_fixture():
 # device, so the ranks talk over gloo with the operands staged through the host; everything else - both models per
 # rank, the kernels, aaerec.parallel - is what runs on a multi-GPU node.
 # ---------------------------------------------------------------------------------------------------------------
-def _fit_worker(rank, world, port, mode, ret):
+def _dp_conditions(reduce):
+    """A constant 6-wide block + a trainable CategoricalCondition (SparseAdam, table on the GPU) and their data."""
+    from aaerec import condition as C
+
+    class Const(C.ConcatenationBasedConditioning):
+        constant_concat = True
+
+        def size_increment(self):
+            return 6
+
+        def encode(self, inputs):
+            return torch.as_tensor(np.asarray(inputs), dtype=torch.float32)
+
+    rng = np.random.RandomState(11)
+    vec = (rng.standard_normal((200, 6)) * 0.3).astype(np.float32)
+    raw = [["a%d" % a for a in rng.randint(0, 30, size=rng.randint(1, 5))] for _ in range(200)]
+    cat = C.CategoricalCondition(8, use_cuda=True, reduce=reduce, lr=0.01)
+    cat.fit(raw)
+    conds = C.ConditionList([("title", Const()), ("authors", cat)])
+    return conds, [vec, cat.transform(raw)], cat
+
+
+def _fit_worker(rank, world, port, mode, ret, reduce=None):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(os.path.dirname(here), "aae-recommender_amd"))
@@ -634,15 +656,18 @@ def _fit_worker(rank, world, port, mode, ret):
     X = _dp_corpus()
     np.random.seed(5)
     torch.manual_seed(5)
+    conds, cdata, cat = _dp_conditions(reduce) if reduce else (None, None, None)
     m = AutoEncoder(n_hidden=48, n_code=16, lr=0.01, batch_size=40, n_epochs=3, dropout=(0.0, 0.0), verbose=False,
-                    data_parallel=HostStagedCollectives(dist), dp_mode=mode)      # batch_size = the GLOBAL batch
-    m.fit(X)
-    pred = m.predict(X[:33])
+                    conditions=conds, data_parallel=HostStagedCollectives(dist), dp_mode=mode)      # batch_size = the GLOBAL batch
+    m.fit(X, condition_data=cdata)
+    pred = m.predict(X[:33], condition_data=[c[:33] for c in cdata] if cdata else None)
     if rank == 0:
         ret["state"] = m.hip.state_dict()
         ret["pred"] = pred
         ret["loss"] = m.last_losses[0]
         ret["sliced"] = m._slice is not None
+        if cat is not None:
+            ret["embedding"] = cat.embedding.weight.detach().cpu().numpy()
     flat = torch.from_numpy(pred.copy())
     other = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(other, flat)
@@ -682,3 +707,30 @@ def test_fit_on_two_ranks_equals_single_process(mode):
     np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=2e-5)
     if mode == "vocab":          # (the replicated scheme reports each rank's loss over its own share)
         assert abs(got["loss"] - one.last_losses[0]) < 1e-5
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce):
+    """The vocabulary-sharded scheme with a constant block and a device-native CategoricalCondition: every rank
+    gathers dL/d(condition block) of the whole batch and applies the identical SparseAdam update ('mean' pads each
+    share to the whole batch's width, as the single process does)."""
+    import torch.multiprocessing as mp
+    from aaerec.aae import AutoEncoder
+    port = 37500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fit_worker, args=(2, port, "vocab", ret, reduce), nprocs=2, join=True)
+        got = dict(ret)
+    assert got["sliced"]
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    conds, cdata, cat = _dp_conditions(reduce)
+    one = AutoEncoder(n_hidden=48, n_code=16, lr=0.01, batch_size=40, n_epochs=3, dropout=(0.0, 0.0), verbose=False,
+                      conditions=conds)
+    one.fit(X, condition_data=cdata)
+    assert one._is_device_native()
+    for k, w in one.hip.state_dict().items():
+        np.testing.assert_allclose(got["state"][k], w, atol=2e-5, rtol=0, err_msg=k)
+    np.testing.assert_allclose(got["embedding"], cat.embedding.weight.detach().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(got["pred"], one.predict(X[:33], condition_data=[c[:33] for c in cdata]), atol=2e-5)

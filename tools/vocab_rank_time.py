@@ -93,6 +93,18 @@ slice_csr = DeviceCSR(X[:, lo:hi], dev)
 d2 = EchoDist(world)
 vp = VocabParallelAAE(m, sl, d2, N)
 t_vp = timeit(lambda i: vp.step(csr, (i % 64) * Bg, B, slice_csr, (i % 64) * Bg, Bg))
+sl.profile_enable(True)
+for i in range(50):
+    vp.step(csr, (i % 64) * Bg, B, slice_csr, (i % 64) * Bg, Bg)
+torch.cuda.synchronize()
+names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
+parts = []
+for k in range(6):
+    ms, n = sl.profile_read(k)
+    if n:
+        parts.append(f"{names[k]} {1e3 * ms / n:.1f} us")
+sl.profile_enable(False)
+print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
 per_step = {k: v / 230 for k, v in d2.bytes.items()}
 print(f"world {world}: vocabulary-sharded   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
       + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
