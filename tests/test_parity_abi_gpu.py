@@ -728,3 +728,25 @@ def test_vocabulary_sharded_ranks_equal_single_process(name, world):
     v3b = np.concatenate([slices[r].state_dict()["dec.lin3.bias"] for r in range(world)])
     np.testing.assert_allclose(v3w, want["dec.lin3.weight"], atol=TOL_PARAM, rtol=0)
     np.testing.assert_allclose(v3b, want["dec.lin3.bias"], atol=TOL_PARAM, rtol=0)
+
+
+def test_output_layer_cut_rejects_calls_out_of_order():
+    from aaerec._hip import AaeHipError, HipAAE
+    fx = Fixture("step_nodrop_gauss")
+    m = make_model(fx)
+    csr = csr_of(fx, m, 0)
+    with pytest.raises(AaeHipError):
+        m.output_layer_step()                     # continuing a step that aae_ae_forward never started
+    with pytest.raises(AaeHipError):
+        m.ae_backward()
+    m.ae_forward(csr, 0, csr.shape[0], z_real=fx.z["step0.z_real"])
+    with pytest.raises(AaeHipError):              # dL/d(dh2) with a foreign leading dimension
+        m.ae_backward(torch.zeros(csr.shape[0], 7, device=m.device))
+    m.output_layer_step()
+    m.ae_backward()
+    m.disc_gen()
+    np.testing.assert_allclose(m.losses(), fx.z["step0.losses"], rtol=TOL_LOSS, atol=1e-6)
+    # a model too wide for the layer-chain kernels has no cut (its output layer alone still works as a slice handle)
+    wide = HipAAE(300, 256, 16, max_batch=8, rng_mode="inject")
+    with pytest.raises(AaeHipError):
+        wide.ae_forward(csr_of(fx, wide, 0), 0, 8)
