@@ -66,6 +66,7 @@ _PROTOS = {
     "aae_destroy": (C.c_int, [C.c_void_p]),
     "aae_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AaeTensor)]),
     "aae_set_lr": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "aae_params_changed": (C.c_int, [C.c_void_p]),
     "aae_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_load_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aae_store_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -396,6 +397,7 @@ class HipAAE:
             b = torch.as_tensor(np.asarray(params[bk], dtype=np.float32), device=self.device)
             self._put(tid, w, b)
         torch.cuda.synchronize(self.device)
+        _check(self.lib.aae_params_changed(self.handle))     # (written through arena views, not aae_load_linear)
 
     def _put(self, tid, w, b, tid_b1=T_ENC_B1):
         if self._is_w1t(tid):

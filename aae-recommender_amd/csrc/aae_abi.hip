@@ -73,6 +73,10 @@ struct aae_model {
     // parameters, two Adam-state sets (index 0: the owning optimiser, 1: gen_optim for enc),
     // gradients (all in export mode, gW1T always)
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
+    // transposed copies [in][out] of the hidden layers' weights (without the bias column): the layer chains' dX ops
+    // read them with the forward layers' access pattern.  Kept in step by the fused / grouped optimiser kernels;
+    // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
+    Ten PT[NP]; bool pt_ok[NP];
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
@@ -183,6 +187,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+    for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->pt_ok[i] = false; }
+    if (h + 1 <= 208 && cp + 1 <= 208 && c.reserved[2] != 3)          // layer-chain models (not the VAE's programs)
+        for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
+            m->PT[pid] = a.mat(m->P[pid].cols - 1, m->P[pid].rows, r4((int)m->P[pid].rows), 16);
     const int R = m->R, R2 = m->R2;
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
@@ -321,6 +329,7 @@ int linear_dw(aae_model* m, const float* Gd, int ldg, int rows, const float* X, 
     } else {
         const int set = (which == O_GEN) ? 1 : 0;
         EpiAdam e; e.p = W.p; e.m = m->M[set][pid].p; e.v = m->V[set][pid].p; e.ld = (int)W.ld; e.sc = m->sc + which;
+        m->pt_ok[pid] = false;
         if (big) (void)launch_gemm<1, 0, 16, 64>(g, e, 1, s); else (void)launch_gemm<1, 0, 64, 32>(g, e, 1, s);
     }
     LAUNCHCHK("linear_dw");
@@ -519,6 +528,22 @@ ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int e
 }
 void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
 
+// dX of a hidden layer: dst[16][N] = epi(src[16][K] * W[K][0:N]).  With the transposed copy PT[pid] = W[:, 0:N]^T
+// ([N][K], k-contiguous rows) this IS a forward layer - 16-byte weight loads instead of the 4-byte ones of the
+// n-contiguous walk.  The copy is re-derived here if something other than the optimiser kernels wrote the weights.
+ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
+    const Ten& T = m->PT[pid];
+    static const bool off = getenv("AAE_NO_PT") != nullptr;
+    if (!T.p || off) return cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);
+    if (!m->pt_ok[pid]) {
+        const Ten& W = m->P[pid];
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((W.cols - 1 + 31) / 32), (unsigned)((W.rows + 31) / 32)), dim3(256), 0,
+                           s, W.p, (int)W.ld, (int)W.rows, (int)W.cols - 1, T.p, (int)T.ld);
+        m->pt_ok[pid] = true;
+    }
+    return cop_linear(COP_LINEAR, src, dst, T, K, N, epi);
+}
+
 struct ChainBuilder {
     ChainProgram P;
     ChainBuilder(const aae_model* m, int rows) {
@@ -566,6 +591,7 @@ struct DwBuilder {
         J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
         J.p = W.p; J.m = m->M[set][pid].p; J.v = m->V[set][pid].p; J.ld = (int)W.ld; J.sc = m->sc + which;
         J.grad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[pid].p : nullptr;
+        J.pt = m->PT[pid].p; J.ldt = (int)m->PT[pid].ld;      // (fused optimiser: the transposed copy follows p)
         J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
         tiles += ((J.M + 31) / 32) * J.tiles_n;
     }
@@ -673,9 +699,9 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
             cb.add(cop_load(m->gb0.p, m->ldh, 2, h));      // unfused decoder path: gb0 already holds dL/da2
         }
         cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
-        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 2, 4, m->P[P_V2], h, h, CEPI_ACTBWD)); x2.yslot = 3;
+        ChainOp& x2 = cb.add(cop_dx(m, P_V2, 2, 4, h, h, CEPI_ACTBWD, s)); x2.yslot = 3;
         x2.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); cop_out(x2, m->gb1.p, m->ldh);
-        ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 4, 5, m->P[P_V1], h, cp, CEPI_NONE));
+        ChainOp& x1 = cb.add(cop_dx(m, P_V1, 4, 5, h, cp, CEPI_NONE, s));
         cop_out(x1, m->gzc.p, m->ldc);
         if (dzc_out) { x1.out2 = dzc_out; x1.ldo2 = cp; }
     }
@@ -685,11 +711,11 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
         ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
         cop_out(fb, m->ga3.p, m->ldz);
         cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
-        ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 7, 9, m->P[P_W3], c, h, CEPI_ACTBWD)); x3.yslot = 8;
+        ChainOp& x3 = cb.add(cop_dx(m, P_W3, 7, 9, c, h, CEPI_ACTBWD, s)); x3.yslot = 8;
         x3.d = make_drop(m, 1, true, I.masks_dev[which == O_GEN ? 9 : 1], nullptr, B, h, which == O_GEN ? 9 : 1);
         cop_out(x3, m->gb2.p, m->ldh);
         cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
-        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 9, 1, m->P[P_W2], h, h, CEPI_ACTBWD)); x2.yslot = 0;
+        ChainOp& x2 = cb.add(cop_dx(m, P_W2, 9, 1, h, h, CEPI_ACTBWD, s)); x2.yslot = 0;
         x2.d = make_drop(m, 0, true, I.masks_dev[which == O_GEN ? 8 : 0], nullptr, B, h, which == O_GEN ? 8 : 0);
         cop_out(x2, m->gb3.p, m->ldh);
     }
@@ -806,7 +832,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
         cop_out(adv, m->ga3.p, 4);
         ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 4, 5, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
         cop_out(x3, m->gb0.p, m->ldh);
-        ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 5, 6, m->P[P_D2], h, h, CEPI_ACTBWD)); x2.yslot = 1; x2.d = d1.d;
+        ChainOp& x2 = cb.add(cop_dx(m, P_D2, 5, 6, h, h, CEPI_ACTBWD, s)); x2.yslot = 1; x2.d = d1.d;
         cop_out(x2, m->gb1.p, m->ldh);
         TRY(launch_chain(m, cb, s));
     }
@@ -838,13 +864,13 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     cb.add(cop_linear(COP_LINEAR, 5, 6, m->P[P_D3], h + 1, 1, CEPI_SIGMOID));
     ChainOp& adv = cb.add(cop(COP_ADV, 6, 7, 1)); adv.aux = 1; adv.row_split = B; adv.scale = m->grad_scale;
     ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 7, 8, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
-    ChainOp& x2 = cb.add(cop_linear(COP_LINEAR_DX, 8, 9, m->P[P_D2], h, h, CEPI_ACTBWD)); x2.yslot = 4; x2.d = d1.d;
-    cb.add(cop_linear(COP_LINEAR_DX, 9, 0, m->P[P_D1], h, c, CEPI_NONE));                    // dL/dz
+    ChainOp& x2 = cb.add(cop_dx(m, P_D2, 8, 9, h, h, CEPI_ACTBWD, s)); x2.yslot = 4; x2.d = d1.d;
+    cb.add(cop_dx(m, P_D1, 9, 0, h, c, CEPI_NONE, s));                    // dL/dz
     ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;
     cop_out(fb, m->ga3.p, m->ldz);
-    ChainOp& w3 = cb.add(cop_linear(COP_LINEAR_DX, 6, 7, m->P[P_W3], c, h, CEPI_ACTBWD)); w3.yslot = 2; w3.d = e2.d;
+    ChainOp& w3 = cb.add(cop_dx(m, P_W3, 6, 7, c, h, CEPI_ACTBWD, s)); w3.yslot = 2; w3.d = e2.d;
     cop_out(w3, m->gb2.p, m->ldh);
-    ChainOp& w2 = cb.add(cop_linear(COP_LINEAR_DX, 7, 8, m->P[P_W2], h, h, CEPI_ACTBWD)); w2.yslot = 1; w2.d = e1.d;
+    ChainOp& w2 = cb.add(cop_dx(m, P_W2, 7, 8, h, h, CEPI_ACTBWD, s)); w2.yslot = 1; w2.d = e1.d;
     cop_out(w2, m->gb3.p, m->ldh);
     TRY(launch_chain(m, cb, s));
     DwBuilder dw;
@@ -1038,6 +1064,12 @@ int aae_set_grad_scale(aae_handle h, float scale) {
 }
 
 // learning rates are float32 in aae_config; callers that need the exact Python double can set it here
+int aae_params_changed(aae_handle h) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    for (int i = 0; i < NP; ++i) h->pt_ok[i] = false;
+    return AAE_OK;
+}
+
 int aae_set_lr(aae_handle h, double gen_lr, double reg_lr) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     OptScalars hs[4];
@@ -1104,6 +1136,7 @@ static int put_linear(aae_handle h, int pid, const Ten& t, const Ten* tb, const 
         return AAE_OK;
     }
     const int out = (int)t.rows, in = (int)t.cols - 1;
+    h->pt_ok[pid] = false;
     HIPCHK(hipMemcpy(buf.data(), t.p, buf.size() * 4, hipMemcpyDeviceToHost));
     for (int o = 0; o < out; ++o) {
         if (w) memcpy(&buf[(size_t)o * t.ld], &w[(size_t)o * in], sizeof(float) * in);
@@ -1913,12 +1946,14 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
             AdamJob& j = grp.jobs[grp.njobs++];
             j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p; j.g = m->Gr[pid].p;
             j.n4 = (unsigned)n4; j.blk0 = blocks;
+            j.pt = m->PT[pid].p; j.ld = (int)m->P[pid].ld; j.ldt = (int)m->PT[pid].ld; j.nt = (int)m->P[pid].cols - 1;
             blocks += (unsigned)((n4 + 255) / 256);
             continue;
         }
         hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[pid].p, m->M[set][pid].p,
                            m->V[set][pid].p, m->Gr[pid].p, n4, m->sc + which, 0);
         LAUNCHCHK("adam_dense");
+        m->pt_ok[pid] = false;
     }
     if (grp.njobs) {
         hipLaunchKernelGGL(adam_group_kernel, dim3(blocks), dim3(256), 0, s, grp, m->sc + which);

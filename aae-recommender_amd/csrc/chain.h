@@ -400,6 +400,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 } else {
                     for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
                 }
+                // a following forward-pattern layer (dX on a transposed weight copy) reads whole 16-column k-chunks
+                for (int j = op.N + lane; j < kCL; j += 64) o[j] = 0.f;
             }
         } else if (kind == COP_PRIOR) {
             const int lrow = tid >> kRS, grow = r0 + lrow, n = op.N;
@@ -503,6 +505,7 @@ struct DwJob {
     const float* G; int ldg; const float* X; int ldx; int rows;   // K = rows
     int M, N;                                                      // out, in+1
     float* p; float* m; float* v; float* grad; int ld;             // grad != NULL: export
+    float* pt; int ldt;                                            // transposed copy of p[:, 0:N-1] kept in step (or NULL)
     const OptScalars* sc;
     int tile0;                                                     // first linear tile id of this job
     int tiles_n;                                                   // tiles along N
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
             EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
         } else {
             EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
+            e.pt = J.pt; e.ldt = J.ldt; e.nt = J.N - 1;
             EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
         }
     }

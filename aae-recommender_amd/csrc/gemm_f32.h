@@ -299,6 +299,9 @@ struct EpiBce {
 // SURVEY 2.1), or plain store of the gradient (data-parallel export mode).
 struct EpiAdam : EpiNoState {
     float* p; float* m; float* v; int ld; const OptScalars* sc;
+    // optional transposed copy of the weight block kept in step with p (the layer chains' dX ops read it with the
+    // forward layers' access pattern): pt[col][row] for col < nt (the bias column of an augmented matrix has none)
+    float* pt = nullptr; int ldt = 0, nt = 0;
     __device__ void apply(State&, int gm, int gn, int N, float4 g, int) const {
         OptScalars s = *sc;
         size_t off = (size_t)gm * ld + gn;
@@ -310,6 +313,11 @@ struct EpiAdam : EpiNoState {
             adam_update(pp.z, mm.z, vv.z, g.z, s); adam_update(pp.w, mm.w, vv.w, g.w, s);
             *reinterpret_cast<float4*>(p + off) = pp;
             if (!s.is_sgd) { *reinterpret_cast<float4*>(m + off) = mm; *reinterpret_cast<float4*>(v + off) = vv; }
+            if (pt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (gn + i < nt) pt[(size_t)(gn + i) * ldt + gm] = (&pp.x)[i];
+            }
             return;
         }
         for (int i = 0; i < 4 && gn + i < N; ++i) {
@@ -317,6 +325,7 @@ struct EpiAdam : EpiNoState {
             adam_update(pp, mm, vv, (&g.x)[i], s);
             p[off + i] = pp;
             if (!s.is_sgd) { m[off + i] = mm; v[off + i] = vv; }
+            if (pt && gn + i < nt) pt[(size_t)(gn + i) * ldt + gm] = pp;
         }
     }
 };

@@ -159,6 +159,10 @@ int aae_tensor_info(aae_handle h, int tensor_id, aae_tensor* out);
  * is pending, after which the arena views of ENC_W1T / ADAM_ENC / ADAM_GEN hold the values an
  * eager implementation would.  aae_load_* / aae_store_* call it themselves. */
 int aae_sync(aae_handle h, void* stream);
+/* Call after writing PARAMETER tensors through the arena views of aae_tensor_info (instead of aae_load_linear): the
+ * library keeps derived copies of the hidden layers' weights (transposed, for the backward layer chains) and
+ * re-derives them before their next use. */
+int aae_params_changed(aae_handle h);
 /* gen_lr / reg_lr as the exact Python doubles (aae_config carries them as float32) */
 int aae_set_lr(aae_handle h, double gen_lr, double reg_lr);
 
