@@ -133,6 +133,11 @@ struct Arena {
     }
 };
 
+// layer widths the fused decoder output-layer kernel (dec_fused.h) is instantiated for
+inline bool fused_width_ok(int h, int ldh) {
+    return (h + 1 + 15) / 16 <= 13 && ldh <= 256 && (ldh % 4) == 0 && ldh <= kSD - 2;
+}
+
 int validate(const aae_config* c) {
     if (!c) return fail(AAE_EINVAL, "cfg is NULL");
     if (c->abi_version != AAE_ABI_VERSION) return fail(AAE_EINVAL, "abi_version mismatch");
@@ -200,10 +205,11 @@ size_t layout(aae_model* m, char* base, bool dry) {
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
         m->max_slabs = std::max(1, std::min(128, 2048 / tiles));
-        // the fused decoder kernel writes one dA2 slab per workgroup (<= 304 CUs assumed for sizing)
-        int nslab = m->max_slabs;
-        if (R <= 16 * kMB && dec_fused_lds_bytes(R, h) <= 160 * 1024) nslab = std::max(nslab, 304 + 16);
-        m->slabs = a.mat((int64_t)nslab * R, h, m->ldh);
+        // the fused decoder kernel writes one dA2 slab per workgroup (<= 304 CUs assumed for sizing) of at most
+        // 16 * kMB rows: a model with a larger max_batch still takes it for its short (tail) batches
+        int64_t slab_rows = (int64_t)m->max_slabs * R;
+        if (fused_width_ok(h, m->ldh)) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * std::min(R, 16 * kMB));
+        m->slabs = a.mat(slab_rows, h, m->ldh);
     }
     m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
     m->gb2 = a.mat(R2, h + 1, m->ldh); m->gb3 = a.mat(R2, h + 1, m->ldh);
@@ -920,7 +926,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->n_cu = std::min(cus, 304);
         const int nb = (m->h + 1 + 15) / 16;
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
-        m->fused_ok = m->fused_nb != 0 && m->ldh <= 256 && (m->ldh % 4) == 0 && m->ldh <= kSD - 2;
+        m->fused_ok = m->fused_nb != 0 && fused_width_ok(m->h, m->ldh);       // (the arena's slab area is sized by the same test)
         m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= 208) && getenv("AAE_NO_CHAIN") == nullptr;
         if (m->use_chain && hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1322,7 +1328,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.gradV3 = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_V3].p : nullptr;
         fa.N = N; fa.B = B; fa.h = h; fa.gscale = gscale;
         fa.te.start = m->tstart; fa.te.eb = m->teb; fa.te.en = m->ten; fa.te.ev = m->tev;
-        fa.slabs = m->slabs.p; fa.slab_stride = (size_t)m->R * m->ldh; fa.ld_slab = m->ldh;
+        fa.slabs = m->slabs.p; fa.slab_stride = (size_t)std::min(m->R, 16 * kMB) * m->ldh; fa.ld_slab = m->ldh;
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
         { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
         static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile

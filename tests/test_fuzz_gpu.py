@@ -8,7 +8,12 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-N_SEEDS = int(os.environ.get("AAE_FUZZ_SEEDS", "28"))       # (a wider hunt: AAE_FUZZ_SEEDS=400 pytest tests/test_fuzz_gpu.py)
+N_SEEDS = int(os.environ.get("AAE_FUZZ_SEEDS", "28"))       # (a wider hunt: AAE_FUZZ_SEEDS=1000 pytest tests/test_fuzz_gpu.py)
+# configurations the wide hunts turned up, kept as regressions:
+#   228  max_batch 113 with a 103-row last batch - the short batch qualifies for the fused output-layer kernel on a
+#        model whose arena was sized for the three-kernel path only (out-of-bounds slab writes before the fix)
+#   347  a decoder pre-activation 2e-8 from the LeakyReLU kink (see the tolerance note below)
+SEEDS = sorted(set(range(N_SEEDS)) | {228, 347})
 
 ACTS = ["ReLU", "SELU", "Tanh", "Sigmoid", "ELU", "LeakyReLU"]
 
@@ -21,10 +26,13 @@ def _config(seed):
                opt=str(r.choice(["adam", "adam", "sgd"])), drop=bool(r.integers(0, 2)), norm=bool(r.integers(0, 4)),
                scale=float(r.choice([0.0, 0.0, 2.0])), cut=bool(r.integers(0, 2)))
     cfg["inc"] = min(cfg["inc"], 206 - cfg["c"])
+    if r.random() < 0.2:                      # batches past the fused output-layer kernel's 104 rows: the three-kernel path
+        cfg["B"] = int(r.integers(105, 260))
+        cfg["N"] = min(cfg["N"], 1200)
     return cfg, r
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_configuration_matches_oracle(seed):
     import torch
     from aaerec._hip import HipAAE, DeviceCSR

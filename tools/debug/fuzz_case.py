@@ -41,7 +41,14 @@ for s in range(3):
     masks = [(r.random((Bs, h)) > (p[j % 2])).astype(np.uint8) for j in range(12)] if cfg["drop"] else None
     zr = r.standard_normal((Bs, c)).astype(np.float32) if cfg["prior"] == "gauss" else (np.eye(c, dtype=np.float32)[r.integers(0, c, size=Bs)] if cfg["prior"] == "categorical" else np.zeros((Bs, c), dtype=np.float32))
     cond = (r.standard_normal((Bs, inc)) * 0.4).astype(np.float32) if inc else None
-    dev.step(DeviceCSR.from_arrays(ip, idx, val, N, dev.device), 0, Bs, cond=torch.as_tensor(cond, device=dev.device) if inc else None, masks=masks, z_real=zr)
+    csr_ = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+    cdev_ = torch.as_tensor(cond, device=dev.device) if inc else None
+    if cfg["cut"]:
+        for name, fn in (("ae_forward", lambda: dev.ae_forward(csr_, 0, Bs, cond=cdev_, masks=masks, z_real=zr)),
+                         ("output_layer_step", dev.output_layer_step), ("ae_backward", dev.ae_backward), ("disc_gen", dev.disc_gen)):
+            fn(); torch.cuda.synchronize(); print("   ok", name, flush=True)
+    else:
+        dev.step(csr_, 0, Bs, cond=cdev_, masks=masks, z_real=zr)
     want = ora.partial_fit(ip, idx, val, zr, masks, [cond] if inc else None)
     print(f"step {s}: losses dev {dev.losses()} oracle {want}")
     got = dev.state_dict()
