@@ -88,3 +88,182 @@ def test_random_configuration_matches_oracle(seed):
         d = np.abs(got[k] - w)
         assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 3 * max(lr), \
             f"{cfg} {k}: {(d > 5e-5).sum()} of {d.size} off, max {d.max():.2e}"
+
+
+def _batch(r, N, Bs, B, max_len=12):
+    rows = [np.sort(r.choice(N, size=int(r.integers(0 if B > 2 else 1, min(N, max_len))), replace=False)) for _ in range(Bs)]
+    if not any(len(x) for x in rows):
+        rows[0] = np.array([int(r.integers(0, N))])
+    ip = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    idx = np.concatenate(rows).astype(np.int32)
+    return ip, idx, np.ones(len(idx), dtype=np.float32)
+
+
+class _Solo:
+    """torch.distributed stand-in for one rank."""
+    class ReduceOp:
+        SUM = 0
+
+    def get_world_size(self, group=None):
+        return 1
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_backend(self, group=None):
+        return "solo"
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        return None
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        out.copy_(inp.reshape(out.shape))
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        out.copy_(inp.reshape(out.shape))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "16"))))
+def test_random_long_run_and_execution_paths_match_oracle(seed):
+    """25-40 steps on a SMALL vocabulary, so items come and go with irregular gaps (the deferred Adam on enc.lin1
+    replays the steps a row missed), through a randomly chosen execution path: the fused step, the gradient-export
+    path of the two data-parallel drivers on one rank, or hidden widths beyond the layer-chain kernels (per-layer
+    GEMM path); then eval-mode predict and the on-device top-k against the oracle."""
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from aaerec.parallel import DataParallelAAE, VocabParallelAAE
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    r = np.random.default_rng(5000 + seed)
+    path = str(r.choice(["fused", "replicated", "vocab", "wide"]))
+    N = int(r.integers(40, 400))
+    h = int(r.integers(208, 300)) if path == "wide" else int(r.integers(8, 120))
+    c = int(r.integers(2, 40))
+    B = int(r.integers(2, 60))
+    steps = int(r.integers(25, 41))
+    act = str(r.choice(["ReLU", "Tanh", "ELU"]))
+    params = init_params(N, h, c, seed=seed)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.0, 0.0), activation=act)
+    ora = O.OracleAAE(params, **kw)
+    if path in ("fused", "wide"):
+        dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+        dev.load_params(params)
+        run = lambda csr, Bs, zr: dev.step(csr, 0, Bs, z_real=zr)                                   # noqa: E731
+        losses = dev.losses
+    else:
+        dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", grad_mode="export", dp_world=1, w1_cap=min(N, B * 12), **kw)
+        dev.load_params(params)
+        if path == "replicated":
+            dp = DataParallelAAE(dev, _Solo(), shard_decoder=bool(r.integers(0, 2)) and "force")
+            run = lambda csr, Bs, zr: (dp.step(csr, 0, Bs, global_rows=Bs, z_real=zr), dp.wait_pending())   # noqa: E731
+            losses = dev.losses
+        else:
+            sl = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+            sl.load_params(params)
+            dp = VocabParallelAAE(dev, sl, _Solo(), N)
+            run = lambda csr, Bs, zr: dp.step(csr, 0, Bs, csr, 0, Bs, z_real=zr)                   # noqa: E731
+            losses = lambda: (dp.recon_loss(),) + tuple(dev.losses()[1:])                          # noqa: E731
+    for s in range(steps):
+        Bs = B if r.random() < 0.8 else int(r.integers(1, B + 1))
+        ip, idx, val = _batch(r, N, Bs, B, max_len=6)
+        zr = r.standard_normal((Bs, c)).astype(np.float32)
+        run(DeviceCSR.from_arrays(ip, idx, val, N, dev.device), Bs, zr)
+        want = ora.partial_fit(ip, idx, val, zr)
+        if s % 8 == 0 or s == steps - 1:
+            np.testing.assert_allclose(losses(), want, rtol=2e-4, atol=5e-6, err_msg=f"{path} N={N} h={h} c={c} B={B} step {s}")
+    if path == "vocab":
+        dp.gather_output_layer()
+    got = dev.state_dict()
+    for k, w in ora.p.items():
+        d = np.abs(got[k] - w)
+        # (fp32 rounding differences compound over the run; single elements may take an activation kink differently)
+        assert (d > 2e-4).sum() <= max(8, 0.01 * d.size) and d.max() <= 0.02, \
+            f"{path} N={N} h={h} c={c} B={B} {k}: {(d > 2e-4).sum()} of {d.size} off, max {d.max():.2e}"
+    # eval-mode reconstruction and the on-device ranking of it
+    ip, idx, val = _batch(r, N, B, B, max_len=6)
+    csr = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+    pred = dev.predict(csr, 0, B).cpu().numpy()
+    want = ora.predict(ip, idx, val)
+    np.testing.assert_allclose(pred, want, atol=5e-4)
+    k = int(min(10, N - 6))
+    ids, _ = dev.predict_topk(csr, 0, B, k)
+    ids = ids.cpu().numpy()
+    for b in range(B):
+        known = set(idx[ip[b]:ip[b + 1]].tolist())
+        assert not (set(ids[b].tolist()) & known)                              # items of the input row are excluded
+        score = pred[b].copy()
+        score[list(known)] = -1.0
+        kth = np.sort(score)[-k]
+        assert (score[ids[b]] >= kth - 1e-4).all(), f"{path} row {b}: not the top {k}"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "12"))))
+def test_random_decoder_and_vae_steps_match_oracle(seed):
+    """The sibling models' entry points over random shapes: aae_decoder_step (DecodingRecommender: decoder only, input
+    block from the conditions, dL/d(input) returned) and aae_vae_step / aae_vae_predict (VAE)."""
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    r = np.random.default_rng(9000 + seed)
+    N, h, B = int(r.integers(17, 1500)), int(r.integers(3, 208)), int(r.integers(1, 150))
+    act = str(r.choice(["ReLU", "Tanh", "SELU", "ELU"]))
+    if seed % 2 == 0:
+        # ---- decoder only: the input block is what the condition plugins produced (width n_code here) ----
+        c = int(r.integers(2, 200))
+        params = init_params(N, h, c, seed=seed)
+        p = (0.2, 0.2) if r.integers(0, 2) else (0.0, 0.0)
+        dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", gen_lr=2e-3, reg_lr=2e-3, dropout=p, activation=act)
+        dev.load_params(params)
+        ora = O.OracleDecoder(params, lr=2e-3, dropout=p, activation=act, conditions=[O.ConcatConst(c)])
+        for s in range(3):
+            ip, idx, val = _batch(r, N, B, B)
+            zin = (r.standard_normal((B, c)) * 0.5).astype(np.float32)
+            masks = [(r.random((B, h)) > 0.2).astype(np.uint8) for _ in range(2)] if p[0] else None
+            dz = dev.decoder_step(DeviceCSR.from_arrays(ip, idx, val, N, dev.device), 0, B,
+                                  torch.as_tensor(zin, device=dev.device), masks=masks)
+            want = ora.partial_fit([zin], ip, idx, val, masks)
+            np.testing.assert_allclose(dev.losses()[0], want, rtol=5e-5, atol=2e-6)
+            np.testing.assert_allclose(dz.cpu().numpy(), ora.last_dzin, rtol=5e-4, atol=5e-9)
+        got = dev.state_dict()
+        for k, w in ora.p.items():
+            d = np.abs(got[k] - w)
+            assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"decoder N={N} h={h} c={c} B={B} {k}: max {d.max():.2e}"
+        zp = (r.standard_normal((B, c)) * 0.5).astype(np.float32)
+        np.testing.assert_allclose(dev.decode(torch.as_tensor(zp, device=dev.device)).cpu().numpy(), ora.predict([zp]), atol=2e-5)
+        return
+    # ---- VAE ----
+    c, inc = int(r.integers(2, 100)), int(r.choice([0, 0, 9, 40]))
+    inc = min(inc, 206 - c)
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(o, i):
+        k = 1.0 / np.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1) * k).numpy(), ((torch.rand(o, generator=g) * 2 - 1) * k).numpy()
+    vp = {}
+    for name, (o, i) in (("fc1", (h, N)), ("fc21", (c, h)), ("fc22", (c, h)), ("fc3", (h, c + inc)), ("fc4", (N, h))):
+        vp[name + ".weight"], vp[name + ".bias"] = lin(o, i)
+    dev = HipAAE(N, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", gen_lr=2e-3, reg_lr=2e-3, dropout=(0.0, 0.0),
+                 activation=act, vae=True)
+    dev.load_params({"enc.lin1.weight": vp["fc1.weight"], "enc.lin1.bias": vp["fc1.bias"],
+                     "enc.lin3.weight": np.vstack([vp["fc21.weight"], vp["fc22.weight"]]),
+                     "enc.lin3.bias": np.concatenate([vp["fc21.bias"], vp["fc22.bias"]]),
+                     "dec.lin1.weight": vp["fc3.weight"], "dec.lin1.bias": vp["fc3.bias"],
+                     "dec.lin3.weight": vp["fc4.weight"], "dec.lin3.bias": vp["fc4.bias"]})
+    ora = O.OracleVAE(vp, lr=2e-3, activation=act, conditions=[O.ConcatConst(inc)] if inc else [])
+    for s in range(3):
+        Bs = B if s < 2 else max(1, B - int(r.integers(0, min(B, 9))))
+        ip, idx, val = _batch(r, N, Bs, B)
+        eps = r.standard_normal((Bs, c)).astype(np.float32)
+        cond = (r.standard_normal((Bs, inc)) * 0.4).astype(np.float32) if inc else None
+        dev.vae_step(DeviceCSR.from_arrays(ip, idx, val, N, dev.device), 0, Bs,
+                     cond=torch.as_tensor(cond, device=dev.device) if inc else None, eps=eps)
+        want = ora.partial_fit(ip, idx, val, eps, [cond] if inc else None)
+        l = dev.losses()
+        np.testing.assert_allclose((l[0] + l[1]) / Bs, want, rtol=5e-5)
+    got = dev.state_dict()
+    want = {"enc.lin1.weight": ora.p["fc1.weight"], "enc.lin3.weight": np.vstack([ora.p["fc21.weight"], ora.p["fc22.weight"]]),
+            "dec.lin1.weight": ora.p["fc3.weight"], "dec.lin3.weight": ora.p["fc4.weight"], "dec.lin3.bias": ora.p["fc4.bias"]}
+    for k, w in want.items():
+        d = np.abs(got[k] - w)
+        assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"vae N={N} h={h} c={c} inc={inc} B={B} {k}: max {d.max():.2e}"
