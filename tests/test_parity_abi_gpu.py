@@ -750,3 +750,38 @@ def test_output_layer_cut_rejects_calls_out_of_order():
     wide = HipAAE(300, 256, 16, max_batch=8, rng_mode="inject")
     with pytest.raises(AaeHipError):
         wide.ae_forward(csr_of(fx, wide, 0), 0, 8)
+
+
+@pytest.mark.parametrize("cut", [False, True])
+def test_short_batch_on_a_model_sized_for_long_ones(cut):
+    """max_batch = 130 (past the fused output-layer kernel's 112 rows) followed by a 90-row batch: the short batch
+    qualifies for the fused kernel, whose per-workgroup dA2 slabs the arena must have room for (regression: it was
+    sized for the three-kernel path only and the fused kernel wrote out of bounds)."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    N, h, c = 1500, 64, 20
+    rng = np.random.default_rng(4)
+    params = init_params(N, h, c, seed=4)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.0, 0.0))
+    dev = HipAAE(N, h, c, max_batch=130, rng_mode="inject", **kw)
+    dev.load_params(params)
+    ora = O.OracleAAE(params, **kw)
+    for B in (130, 90, 130, 7):
+        rows = [np.sort(rng.choice(N, size=int(rng.integers(1, 10)), replace=False)) for _ in range(B)]
+        ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        idx = np.concatenate(rows).astype(np.int32)
+        val = np.ones(len(idx), dtype=np.float32)
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        csr = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+        if cut:
+            dev.ae_forward(csr, 0, B, z_real=zr)
+            dev.output_layer_step()
+            dev.ae_backward()
+            dev.disc_gen()
+        else:
+            dev.step(csr, 0, B, z_real=zr)
+        np.testing.assert_allclose(dev.losses(), ora.partial_fit(ip, idx, val, zr), rtol=2e-5, atol=1e-6, err_msg=f"B={B}")
+    got = dev.state_dict()
+    for k, w in ora.p.items():
+        np.testing.assert_allclose(got[k], w, atol=2e-5, rtol=0, err_msg=k)
