@@ -278,3 +278,98 @@ def test_random_decoder_and_vae_steps_match_oracle(seed):
     for k, w in want.items():
         d = np.abs(got[k] - w)
         assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"vae N={N} h={h} c={c} inc={inc} B={B} {k}: max {d.max():.2e}"
+
+
+@pytest.mark.parametrize("scheme", ["vocab", "replicated"])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "6"))))
+def test_random_multi_rank_runs_match_oracle(seed, scheme):
+    """Both data-parallel drivers with 2-4 ranks as threads on this GPU over random shapes: vocabularies that do not
+    divide by the world size (uneven item slices / the un-sharded fallback), global batches on both sides of the fused
+    output-layer kernel's row limit, dropout masks and a condition block sliced per rank - against the oracle's
+    single-process step."""
+    import threading
+    import scipy.sparse as sp
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    from test_parity_abi_gpu import _ThreadDist
+    r = np.random.default_rng(12000 + seed)
+    world = int(r.integers(2, 5))
+    Bl = int(r.integers(1, 50))
+    B = Bl * world
+    N, h, c = int(r.integers(world + 20, 1200)), int(r.integers(4, 150)), int(r.integers(2, 60))
+    inc = int(r.choice([0, 0, 11]))
+    drop = bool(r.integers(0, 2))
+    p = (0.2, 0.2) if drop else (0.0, 0.0)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=p, activation=str(r.choice(["ReLU", "Tanh", "ELU"])))
+    params = init_params(N, h, c, cond_inc=inc, seed=seed)
+    ora = O.OracleAAE(params, conditions=[O.ConcatConst(inc)] if inc else [], **kw)
+    steps = []
+    for s in range(3):
+        ip, idx, val = _batch(r, N, B, B)
+        masks = [(r.random((B, h)) > 0.2).astype(np.uint8) for _ in range(12)] if drop else None
+        zr = r.standard_normal((B, c)).astype(np.float32)
+        cond = (r.standard_normal((B, inc)) * 0.4).astype(np.float32) if inc else None
+        steps.append((ip, idx, val, masks, zr, cond, ora.partial_fit(ip, idx, val, zr, masks, [cond] if inc else None)))
+    dist = _ThreadDist(world)
+    locals_, slices, errors = [None] * world, [None] * world, []
+
+    def rank_main(rk):
+        try:
+            dist.bind(rk)
+            lo, hi = item_slice(N, rk, world)
+            m = HipAAE(N, h, c, cond_inc=inc, max_batch=Bl, rng_mode="inject", grad_mode="export", dp_world=world, **kw)
+            m.load_params(params)
+            sp_params = dict(params)
+            sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
+            sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+            locals_[rk] = m
+            if scheme == "replicated":
+                dp = DataParallelAAE(m, dist, shard_decoder=True)
+                for ip, idx, val, masks, zr, cond, want in steps:
+                    X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+                    mk = None if masks is None else [k[rk * Bl:(rk + 1) * Bl] for k in masks]
+                    cond_fn = None
+                    if inc:
+                        ct = torch.as_tensor(cond[rk * Bl:(rk + 1) * Bl], device=m.device)
+                        cond_fn = lambda z, ct=ct: (torch.cat([z, ct], 1), lambda dzc: dzc[:, :c].contiguous())   # noqa: E731
+                    dp.step(DeviceCSR(X, m.device), rk * Bl, Bl, global_rows=B, cond_fn=cond_fn, masks=mk,
+                            z_real=zr[rk * Bl:(rk + 1) * Bl])
+                    dp.wait_pending()
+                return
+            sl = HipAAE(hi - lo, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", **kw)
+            sl.load_params(sp_params)
+            slices[rk] = sl
+            vp = VocabParallelAAE(m, sl, dist, N)
+            for ip, idx, val, masks, zr, cond, want in steps:
+                X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+                mk = None if masks is None else [k[rk * Bl:(rk + 1) * Bl] for k in masks]
+                vp.step(DeviceCSR(X, m.device), rk * Bl, Bl, DeviceCSR(X[:, lo:hi], m.device), 0, B,
+                        cond=torch.as_tensor(cond[rk * Bl:(rk + 1) * Bl], device=m.device) if inc else None, masks=mk,
+                        z_real=zr[rk * Bl:(rk + 1) * Bl])
+                loss = vp.recon_loss()
+                if rk == 0:
+                    np.testing.assert_allclose(loss, want[0], rtol=5e-5)
+        except BaseException as e:              # noqa: B902 - a dead rank must not leave the others at a barrier
+            errors.append((rk, e))
+            dist.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(rk,)) for rk in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    got0 = locals_[0].state_dict()
+    tag = f"{scheme} world={world} N={N} h={h} c={c} B={B} inc={inc}"
+    for k, w in ora.p.items():
+        if k.startswith("dec.lin3") and scheme == "vocab":
+            got = np.concatenate([slices[rk].state_dict()[k] for rk in range(world)])
+        else:
+            got = got0[k]
+            for rk in range(1, world):
+                np.testing.assert_array_equal(locals_[rk].state_dict()[k], got, err_msg=f"{tag} rank {rk} {k}")
+        d = np.abs(got - w)
+        assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"{tag} {k}: {(d > 5e-5).sum()} off, max {d.max():.2e}"

@@ -644,14 +644,14 @@ class _ThreadDist:
         t.copy_(total)
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
-        out.copy_(torch.cat([p.reshape(-1) for p in self._exchange(inp)]))
+        out.copy_(torch.cat([p.reshape(-1) for p in self._exchange(inp)]).view(out.shape))
 
     def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
         parts = self._exchange(inp)
         total = parts[0].clone()
         for p in parts[1:]:
             total += p
-        out.copy_(total.view(self.world, -1)[self.tls.rank])
+        out.copy_(total.reshape(self.world, -1)[self.tls.rank].view(out.shape))
 
 
 @pytest.mark.parametrize("name,world", [("step_masks", 2), ("step_cond_concat", 2), ("step_headline", 2), ("step_wide", 4)])
