@@ -196,16 +196,19 @@ def test_random_long_run_and_execution_paths_match_oracle(seed):
     pred = dev.predict(csr, 0, B).cpu().numpy()
     want = ora.predict(ip, idx, val)
     np.testing.assert_allclose(pred, want, atol=5e-4)
-    k = int(min(10, N - 6))
-    ids, _ = dev.predict_topk(csr, 0, B, k)
-    ids = ids.cpu().numpy()
+    k = int(min(r.integers(1, 33), N - 6))
+    excl = bool(r.integers(0, 2))
+    ids, vals = dev.predict_topk(csr, 0, B, k, exclude_known=excl)
+    ids, vals = ids.cpu().numpy(), vals.cpu().numpy()
     for b in range(B):
         known = set(idx[ip[b]:ip[b + 1]].tolist())
-        assert not (set(ids[b].tolist()) & known)                              # items of the input row are excluded
+        assert len(set(ids[b].tolist())) == k and (np.diff(vals[b]) <= 1e-6).all()      # k distinct items, best first
         score = pred[b].copy()
-        score[list(known)] = -1.0
+        if excl:
+            assert not (set(ids[b].tolist()) & known)                          # items of the input row are excluded
+            score[list(known)] = -1.0
         kth = np.sort(score)[-k]
-        assert (score[ids[b]] >= kth - 1e-4).all(), f"{path} row {b}: not the top {k}"
+        assert (score[ids[b]] >= kth - 1e-4).all(), f"{path} row {b}: not the top {k} (exclude_known={excl})"
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "12"))))
