@@ -376,3 +376,41 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
                 np.testing.assert_array_equal(locals_[rk].state_dict()[k], got, err_msg=f"{tag} rank {rk} {k}")
         d = np.abs(got - w)
         assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"{tag} {k}: {(d > 5e-5).sum()} off, max {d.max():.2e}"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "4"))))
+def test_random_large_vocabulary_matches_oracle(seed):
+    """Vocabularies of 9-60 k items: more 32-item tiles than compute units, so every workgroup of the fused output-layer
+    kernel walks several tiles (its cross-tile software pipeline: prefetched entries, moments and parameter stores of
+    the previous tile in flight) - against the oracle, plus the three-kernel path on the same batches."""
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    r = np.random.default_rng(15000 + seed)
+    N, h, c, B = int(r.integers(9000, 60000)), int(r.integers(20, 208)), int(r.integers(4, 60)), int(r.integers(3, 105))
+    drop = bool(r.integers(0, 2))
+    p = (0.2, 0.2) if drop else (0.0, 0.0)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=p, activation=str(r.choice(["ReLU", "Tanh"])))
+    params = init_params(N, h, c, seed=seed)
+    fused = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+    plain = HipAAE(N, h, c, max_batch=B, rng_mode="inject", unfused_decoder=True, **kw)
+    fused.load_params(params)
+    plain.load_params(params)
+    ora = O.OracleAAE(params, **kw)
+    for s in range(3):
+        ip, idx, val = _batch(r, N, B, B, max_len=40)
+        masks = [(r.random((B, h)) > 0.2).astype(np.uint8) for _ in range(12)] if drop else None
+        zr = r.standard_normal((B, c)).astype(np.float32)
+        csr = DeviceCSR.from_arrays(ip, idx, val, N, fused.device)
+        fused.step(csr, 0, B, masks=masks, z_real=zr)
+        plain.step(csr, 0, B, masks=masks, z_real=zr)
+        want = ora.partial_fit(ip, idx, val, zr, masks)
+        np.testing.assert_allclose(fused.losses(), want, rtol=5e-5, atol=2e-6, err_msg=f"N={N} h={h} c={c} B={B} step {s}")
+        np.testing.assert_allclose(plain.losses(), want, rtol=5e-5, atol=2e-6)
+    gf, gp = fused.state_dict(), plain.state_dict()
+    for k, w in ora.p.items():
+        for name, got in (("fused", gf[k]), ("three-kernel", gp[k])):
+            d = np.abs(got - w)
+            assert (d > 5e-5).sum() <= max(8, 0.001 * d.size) and d.max() <= 6e-3, \
+                f"{name} N={N} h={h} c={c} B={B} {k}: {(d > 5e-5).sum()} of {d.size} off, max {d.max():.2e}"
