@@ -414,3 +414,45 @@ def test_random_large_vocabulary_matches_oracle(seed):
             d = np.abs(got - w)
             assert (d > 5e-5).sum() <= max(8, 0.001 * d.size) and d.max() <= 6e-3, \
                 f"{name} N={N} h={h} c={c} B={B} {k}: {(d > 5e-5).sum()} of {d.size} off, max {d.max():.2e}"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "10"))))
+def test_random_categorical_condition_kernels_match_oracle(seed):
+    """aae_cat_encode / aae_cat_update (+ aae_csr_embed) over random shapes: table widths 1..256, list widths 1..80,
+    vocabularies smaller than a batch (every row shared by many slots), sum / mean, SparseAdam / dense Adam."""
+    import scipy.sparse as sp
+    import torch
+    from aaerec import _hip
+    from oracle import aae_oracle as O
+    r = np.random.default_rng(20000 + seed)
+    rows, width = int(r.integers(1, 200)), int(r.choice([1, 1, 2, 5, 17, 80]))
+    vocab, dim = int(r.integers(2, 400)), int(r.choice([1, 3, 32, 64, 65, 200, 256]))
+    mean, sparse = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+    dev = torch.device("cuda:0")
+    table0 = (r.standard_normal((vocab, dim)) * 0.1).astype(np.float32)
+    table0[0] = 0
+    ora = O.CategoricalEmbedding(table0, lr=5e-3, reduce="mean" if mean else "sum", sparse=sparse)
+    table = torch.from_numpy(table0.copy()).to(dev)
+    m, v = torch.zeros_like(table), torch.zeros_like(table)
+    scratch = None if sparse else torch.zeros_like(table)
+    for step in range(1, 5):
+        idx = r.integers(0, vocab, size=(rows, width))
+        idx[r.random((rows, width)) < 0.25] = 0
+        d = (r.standard_normal((rows, dim)) * 0.05).astype(np.float32)
+        idx_dev = torch.from_numpy(idx.astype(np.int32)).to(dev)
+        out = torch.empty(rows, dim, device=dev)
+        _hip.cat_encode(table, idx_dev, out, mean=mean)
+        np.testing.assert_allclose(out.cpu().numpy(), ora.encode(idx), atol=2e-6, rtol=1e-5)
+        _hip.cat_update(table, m, v, idx_dev, torch.from_numpy(d).to(dev), 5e-3, step, mean=mean, grad_scratch=scratch)
+        ora._c = 0
+        ora.bwd(d)
+        ora.step()
+        tag = f"rows={rows} width={width} vocab={vocab} dim={dim} mean={mean} sparse={sparse} step {step}"
+        np.testing.assert_allclose(table.cpu().numpy(), ora.params["w"], atol=5e-6, rtol=0, err_msg=tag)
+        om, ov = (ora.opt.m, ora.opt.v) if sparse else (ora.opt.m["w"], ora.opt.v["w"])
+        np.testing.assert_allclose(m.cpu().numpy(), om, atol=1e-8, rtol=1e-4, err_msg=tag)
+        np.testing.assert_allclose(v.cpu().numpy(), ov, atol=1e-12, rtol=1e-4, err_msg=tag)
+    # the TF-IDF x embedding product on the same table: a random sparse weight matrix times the table
+    S = sp.random(rows, vocab, density=min(1.0, 6.0 / vocab), format="csr", random_state=int(seed), dtype=np.float32)
+    got = _hip.csr_embed(_hip.DeviceCSR(S, dev), table).cpu().numpy()
+    np.testing.assert_allclose(got, S @ table.cpu().numpy(), atol=1e-5)
