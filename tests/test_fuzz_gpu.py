@@ -17,15 +17,18 @@ SEEDS = list(range(N_SEEDS))
 ACTS = ["ReLU", "SELU", "Tanh", "Sigmoid", "ELU", "LeakyReLU"]
 
 
-def _config(seed):
-    r = np.random.default_rng(1000 + seed)
-    cfg = dict(N=int(r.integers(17, 2500)), h=int(r.integers(3, 208)), c=int(r.integers(2, 100)),
-               B=int(r.integers(1, 105)), inc=int(r.choice([0, 0, 5, 30, 64])), act=str(r.choice(ACTS)),
+def _config(seed, tiny=False):
+    r = np.random.default_rng((3000 if tiny else 1000) + seed)
+    dims = dict(N=int(r.integers(2, 40)), h=int(r.integers(1, 9)), c=int(r.integers(1, 7)), B=int(r.integers(1, 6)),
+                inc=int(r.choice([0, 0, 1, 3]))) if tiny else \
+        dict(N=int(r.integers(17, 2500)), h=int(r.integers(3, 208)), c=int(r.integers(2, 100)),
+             B=int(r.integers(1, 105)), inc=int(r.choice([0, 0, 5, 30, 64])))
+    cfg = dict(**dims, act=str(r.choice(ACTS)),
                prior=str(r.choice(["gauss", "gauss", "categorical", "bernoulli"])),
                opt=str(r.choice(["adam", "adam", "sgd"])), drop=bool(r.integers(0, 2)), norm=bool(r.integers(0, 4)),
                scale=float(r.choice([0.0, 0.0, 2.0])), cut=bool(r.integers(0, 2)))
-    cfg["inc"] = min(cfg["inc"], 206 - cfg["c"])
-    if r.random() < 0.2:                      # batches past the fused output-layer kernel's 104 rows: the three-kernel path
+    cfg["inc"] = max(0, min(cfg["inc"], 206 - cfg["c"]))
+    if not tiny and r.random() < 0.2:         # batches past the fused output-layer kernel's 104 rows: the three-kernel path
         cfg["B"] = int(r.integers(105, 260))
         cfg["N"] = min(cfg["N"], 1200)
     cfg["long_rows"] = bool(r.random() < 0.15)       # documents with hundreds of items (per-row chunking, >1024 entries per tile)
@@ -33,13 +36,14 @@ def _config(seed):
     return cfg, r
 
 
+@pytest.mark.parametrize("tiny", [False, True])
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_configuration_matches_oracle(seed):
+def test_random_configuration_matches_oracle(seed, tiny):
     import torch
     from aaerec._hip import HipAAE, DeviceCSR
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
-    cfg, r = _config(seed)
+    cfg, r = _config(seed, tiny)           # tiny: degenerate sizes (one hidden unit, a code of one, two items, one document)
     N, h, c, B, inc = cfg["N"], cfg["h"], cfg["c"], cfg["B"], cfg["inc"]
     params = init_params(N, h, c, cond_inc=inc, seed=seed)
     p = (0.2, 0.3) if cfg["drop"] else (0.0, 0.0)
@@ -51,7 +55,7 @@ def test_random_configuration_matches_oracle(seed):
     ora = O.OracleAAE(params, conditions=[O.ConcatConst(inc)] if inc else [], **kw)
     for s in range(3):
         Bs = B if s < 2 else max(1, B - int(r.integers(0, min(B, 17))))          # a shorter last batch
-        max_len = int(min(N, 600)) if cfg["long_rows"] else 12
+        max_len = int(min(N, 600)) if cfg["long_rows"] else int(min(N + 1, 12))
         n_docs = 3 * Bs if cfg["window"] else Bs
         rows = [np.sort(r.choice(N, size=int(r.integers(0 if B > 2 else 1, max_len)), replace=False)) for _ in range(n_docs)]
         if not any(len(x) for x in rows):
