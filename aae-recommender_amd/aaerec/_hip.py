@@ -67,6 +67,7 @@ _PROTOS = {
     "aae_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AaeTensor)]),
     "aae_set_lr": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "aae_params_changed": (C.c_int, [C.c_void_p]),
+    "aae_set_rng_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "aae_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_load_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aae_store_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -664,6 +665,11 @@ class HipAAE:
             _check(self.lib.aae_w1_import(self.handle, C.c_void_p(packets.data_ptr()),
                                           C.c_void_p(packets.data_ptr() + 4 * hdr), cap, n_peers, 4 * total, which,
                                           self._stream()))
+
+    def set_rng_rows(self, row_offset, global_rows):
+        """Device RNG under data parallelism: this rank's rows are [row_offset, row_offset + n_rows) of a global batch
+        of global_rows; with one seed on every rank the ranks draw what a single process draws for the whole batch."""
+        _check(self.lib.aae_set_rng_rows(self.handle, int(row_offset), int(global_rows)))
 
     def set_grad_scale(self, scale):
         _check(self.lib.aae_set_grad_scale(self.handle, float(scale)))

@@ -70,6 +70,14 @@ class DataParallelAAE:
                     dense = buf.to(p.device)
                     p.grad = dense.to_sparse(1) if want_sparse else dense
 
+    def _set_rng_rows(self, n_rows, global_rows):
+        """Tell the model which rows of the global batch it holds (contiguous shares in rank order, as shard() deals
+        them): its device RNG then draws what a single process draws for those rows."""
+        if hasattr(self.model, "set_rng_rows"):
+            rank = self.dist.get_rank(self.group)
+            base, extra = divmod(int(global_rows), self.world)
+            self.model.set_rng_rows(rank * base + min(rank, extra), global_rows)
+
     def _allreduce(self, which, async_op=False):
         return [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
                 for t in self.model.grad_buckets(which)]
@@ -156,6 +164,7 @@ class DataParallelAAE:
         if global_rows is None:
             global_rows = n_rows * self.world
         m.set_grad_scale(n_rows / float(global_rows))
+        self._set_rng_rows(n_rows, global_rows)
         z = m.ae_encode(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
         self.wait_pending()
         if cond_fn is None:
@@ -222,6 +231,7 @@ class VocabParallelAAE(DataParallelAAE):
         if global_rows != n_rows * self.world:
             raise ValueError("vocabulary-sharded step: the global batch must divide evenly over the ranks")
         m.set_grad_scale(n_rows / float(global_rows))
+        self._set_rng_rows(n_rows, global_rows)
         m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
         d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
         sl.output_layer_step(slice_csr, g_row_start, global_rows, rows=g_rows)

@@ -70,6 +70,7 @@ struct aae_model {
     int ldh, ldw1, ldc, ldz, ldn;
     bool alpha_mode;
     float grad_scale;
+    int rng_row0, rng_global;   // device rng: this rank's rows are [rng_row0, rng_row0 + rows) of a global batch of rng_global (0: local)
     // parameters, two Adam-state sets (index 0: the owning optimiser, 1: gen_optim for enc),
     // gradients (all in export mode, gW1T always)
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
@@ -282,6 +283,8 @@ DropSpec make_drop(const aae_model* m, int layer, bool train, const uint8_t* ma,
     if (!d.enabled) return d;
     d.mask_a = ma; d.mask_b = mb; d.split_row = split; d.width = width;
     d.device_rng = m->cfg.rng_mode == AAE_RNG_DEVICE;
+    d.goff_a = m->rng_row0;
+    d.goff_b = m->rng_row0 + (m->rng_global > 0 ? m->rng_global - split : 0);
     d.keep_threshold = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
     d.stream_id = stream_id;
     if (m->alpha_mode) {
@@ -827,6 +830,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
         ChainOp& l = cb.add(cop(COP_PRIOR, 0, 0, c)); l.one_col = c;
         l.W = m->zin.p; l.ldw = m->ldz; l.row_split = B; l.aux = m->cfg.prior;
         l.scale = m->cfg.has_prior_scale ? m->cfg.prior_scale : 1.0f;
+        l.grow0 = m->rng_row0;
         l.aux_ptr = m->cfg.rng_mode == AAE_RNG_DEVICE ? nullptr : const_cast<float*>(I.z_real_dev); l.aux_ld = c;
         cop_out(l, m->zin.p, m->ldz);                      // the weight-gradient GEMM of D1 reads all 2B rows
         ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_D1], c + 1, h, CEPI_DROPACT));
@@ -943,6 +947,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         }
     }
     m->grad_scale = 1.f;
+    m->rng_row0 = 0; m->rng_global = 0;
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
     if (e != hipSuccess) { delete m; return fail(AAE_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
@@ -1070,6 +1075,14 @@ int aae_set_grad_scale(aae_handle h, float scale) {
 }
 
 // learning rates are float32 in aae_config; callers that need the exact Python double can set it here
+int aae_set_rng_rows(aae_handle h, int64_t row_offset, int64_t global_rows) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    if (row_offset < 0 || global_rows < 0 || row_offset > (1 << 30) || global_rows > (1 << 30))
+        return fail(AAE_EINVAL, "aae_set_rng_rows: bad offset / global_rows");
+    h->rng_row0 = (int)row_offset; h->rng_global = (int)global_rows;
+    return AAE_OK;
+}
+
 int aae_params_changed(aae_handle h) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     for (int i = 0; i < NP; ++i) h->pt_ok[i] = false;
@@ -1644,7 +1657,7 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
     if (!m->use_chain) {                 // (the layer-chain program draws / copies z_real itself: COP_PRIOR)
         if (m->cfg.rng_mode == AAE_RNG_DEVICE) {
             hipLaunchKernelGGL(prior_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, m->zin.p, m->ldz, B, cc,
-                               m->cfg.prior, pscale, m->cfg.seed, m->step_ctr);
+                               m->cfg.prior, pscale, m->cfg.seed, m->step_ctr, m->rng_row0);
         } else {
             hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cc)), dim3(256), 0, s, I.z_real_dev, cc, m->zin.p,
                                m->ldz, B, cc, pscale);

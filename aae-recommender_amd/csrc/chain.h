@@ -61,6 +61,7 @@ struct ChainOp {
     int row_split;                      // COP_ADV mode 0: rows >= row_split are "fake"
     int dst_col0;                       // COP_LOAD: first destination column (appending a condition block)
     float* aux_ptr; int aux_ld;         // COP_REPARAM*: the eps buffer [rows][aux_ld] in global memory
+    int grow0;                          // COP_PRIOR: global-batch row of this rank's row 0 (the prior draw is keyed by global row)
 };
 
 struct ChainProgram {
@@ -85,7 +86,7 @@ __device__ __forceinline__ void chain_barrier() { asm volatile("s_waitcnt lgkmcn
 template <class T> __device__ __forceinline__ T chain_pin(T v) { asm volatile("" : "+s"(v)); return v; }
 
 struct EpiCtx {
-    int epi, act, den, drng, split, width;
+    int epi, act, den, drng, split, width, goa, gob;
     uint32_t thr;
     uint64_t dkey;
     float mk, ak, ad;
@@ -99,6 +100,7 @@ __device__ __forceinline__ EpiCtx chain_epi_ctx(int epi, const ChainOp& op, cons
     c.epi = chain_pin(epi); c.act = chain_pin(P.act);
     c.den = chain_pin(op.d.enabled); c.drng = chain_pin(op.d.device_rng);
     c.split = chain_pin(op.d.split_row); c.width = chain_pin(op.d.width);
+    c.goa = chain_pin(op.d.goff_a); c.gob = chain_pin(op.d.goff_b);
     c.thr = chain_pin(op.d.keep_threshold);
     c.dkey = chain_pin(key ^ ((uint64_t)op.d.stream_id * 0xA0761D6478BD642Full));
     c.mk = chain_pin(op.d.mul_keep); c.ak = chain_pin(op.d.add_keep); c.ad = chain_pin(op.d.add_drop);
@@ -108,7 +110,7 @@ __device__ __forceinline__ EpiCtx chain_epi_ctx(int epi, const ChainOp& op, cons
 }
 
 __device__ __forceinline__ int chain_keep(const EpiCtx& c, int row, int col) {      // drop_keep() on the pinned copy
-    if (c.drng) return hash_cell(c.dkey, (uint32_t)row, (uint32_t)col) >= c.thr;
+    if (c.drng) return hash_cell(c.dkey, (uint32_t)(row + (row < c.split ? c.goa : c.gob)), (uint32_t)col) >= c.thr;
     // (the pinned copies lost their address space: say "global" again, or these become flat loads)
     typedef const __attribute__((address_space(1))) uint8_t* gmask_t;
     gmask_t m = (gmask_t)(row < c.split ? c.ma : c.mb);
@@ -412,13 +414,13 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     if (grow >= op.row_split) v = op.W[(size_t)grow * op.ldw + col];
                     else if (op.aux_ptr) v = op.aux_ptr[(size_t)grow * op.aux_ld + col] * op.scale;
                     else if (op.aux == 0) {          // gauss: Box-Muller on two words of the counter generator
-                        const uint32_t u1 = hash_cell(k, (uint32_t)grow, (uint32_t)(2 * col));
-                        const uint32_t u2 = hash_cell(k, (uint32_t)grow, (uint32_t)(2 * col + 1));
+                        const uint32_t u1 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * col));
+                        const uint32_t u2 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * col + 1));
                         const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
                         const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
                         v = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2) * op.scale;
                     } else if (op.aux == 1) {        // categorical: one-hot of a uniform class per row
-                        const uint32_t u = hash_cell(k, (uint32_t)grow, 0xFFFFFFFFu);
+                        const uint32_t u = hash_cell(k, (uint32_t)(grow + op.grow0), 0xFFFFFFFFu);
                         v = ((int)(u % (uint32_t)n) == col) ? op.scale : 0.f;
                     }                                // bernoulli: the reference's randint(0, 1) is always 0 (aae.py:86-88)
                 }

@@ -61,6 +61,10 @@ struct DropSpec {
     float mul_keep;          // 1/(1-p)            | a
     float add_keep;          // 0                  | alpha*a*p
     float add_drop;          // 0                  | -alpha*a + alpha*a*p
+    // device rng: the generator is keyed by the row of the GLOBAL batch, so a data-parallel rank that holds rows
+    // [o, o + B_l) of B_g draws what a single process draws for those rows: global row = row + goff_a for rows below
+    // split_row, row + goff_b for the rest (the discriminator's stacked [z_real; z_fake] rows)
+    int goff_a, goff_b;
 };
 
 __device__ __forceinline__ uint32_t hash_u32(uint64_t key, uint64_t ctr) {
@@ -91,7 +95,8 @@ __device__ __forceinline__ uint32_t hash_cell(uint64_t key, uint32_t row, uint32
 // returns keep in {0,1}
 __device__ __forceinline__ int drop_keep(const DropSpec& d, uint64_t key, int row, int col) {
     if (d.device_rng)
-        return hash_cell(key ^ ((uint64_t)d.stream_id * 0xA0761D6478BD642Full), (uint32_t)row, (uint32_t)col) >= d.keep_threshold;
+        return hash_cell(key ^ ((uint64_t)d.stream_id * 0xA0761D6478BD642Full),
+                         (uint32_t)(row + (row < d.split_row ? d.goff_a : d.goff_b)), (uint32_t)col) >= d.keep_threshold;
     const uint8_t* m = row < d.split_row ? d.mask_a : d.mask_b;
     if (!m) return 1;
     int r = row < d.split_row ? row : row - d.split_row;

@@ -384,19 +384,20 @@ __global__ void fill_col_kernel(float* dst, int ld, int rows, int col, float v) 
 
 // z_real ~ prior (PRIOR_SAMPLERS, aae.py:78-94) from the counter generator, times prior_scale
 __global__ void prior_kernel(float* __restrict__ z, int ld, int rows, int c, int prior, float scale, uint64_t seed,
-                             const long long* step_ctr) {
+                             const long long* step_ctr, int grow0) {
     const uint64_t key = rng_key(seed, (uint64_t)*step_ctr, 100);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * c; i += gridDim.x * blockDim.x) {
         int r = i / c, j = i - r * c;
+        const uint64_t gr = (uint64_t)(r + grow0);       // keyed by the row of the global batch
         float v = 0.f;
         if (prior == 0) {   // gauss: Box-Muller
-            uint32_t u1 = hash_u32(key, ((uint64_t)r << 32) | (uint32_t)(2 * j));
-            uint32_t u2 = hash_u32(key, ((uint64_t)r << 32) | (uint32_t)(2 * j + 1));
+            uint32_t u1 = hash_u32(key, (gr << 32) | (uint32_t)(2 * j));
+            uint32_t u2 = hash_u32(key, (gr << 32) | (uint32_t)(2 * j + 1));
             float f1 = ((float)u1 + 1.f) * 2.3283064365386963e-10f;   // (0,1]
             float f2 = (float)u2 * 2.3283064365386963e-10f;
             v = sqrtf(-2.f * logf(f1)) * cosf(6.283185307179586f * f2);
         } else if (prior == 1) {   // categorical: one-hot of a uniform class per row
-            uint32_t u = hash_u32(key, ((uint64_t)r << 32) | 0xFFFFFFFFu);
+            uint32_t u = hash_u32(key, (gr << 32) | 0xFFFFFFFFu);
             v = ((int)(u % (uint32_t)c) == j) ? 1.f : 0.f;
         }                     // bernoulli: the reference's randint(0,1) is always 0 (aae.py:86-88)
         z[(size_t)r * ld + j] = v * scale;

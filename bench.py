@@ -122,7 +122,9 @@ def main():
         capt = torch.tensor([w1_cap], dtype=torch.int64, device=dev)
         dist.all_reduce(capt, op=dist.ReduceOp.MAX)
         w1_cap = int(capt.item())
-    model = HipAAE(N, h, c, cond_inc=a.cond_inc, max_batch=B, rng_mode="device", seed=1 + rank,
+    # one seed on every rank: the device generator is keyed by the row of the global batch (aae_set_rng_rows), so the
+    # ranks together draw what one process would for the whole batch
+    model = HipAAE(N, h, c, cond_inc=a.cond_inc, max_batch=B, rng_mode="device", seed=1,
                    grad_mode="export" if use_dp else "fused", device=dev, unfused_decoder=a.unfused_decoder,
                    dp_world=world, w1_cap=w1_cap)
     model.load_params(params)
@@ -142,7 +144,7 @@ def main():
         sp_params = dict(params)
         sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
         sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
-        slice_model = HipAAE(hi - lo, h, c, cond_inc=a.cond_inc, max_batch=B * world, rng_mode="device", seed=1 + rank,
+        slice_model = HipAAE(hi - lo, h, c, cond_inc=a.cond_inc, max_batch=B * world, rng_mode="device", seed=1,
                              device=dev, unfused_decoder=a.unfused_decoder)
         slice_model.load_params(sp_params)
         runner = VocabParallelAAE(model, slice_model, dist, N)

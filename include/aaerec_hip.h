@@ -159,6 +159,12 @@ int aae_tensor_info(aae_handle h, int tensor_id, aae_tensor* out);
  * is pending, after which the arena views of ENC_W1T / ADAM_ENC / ADAM_GEN hold the values an
  * eager implementation would.  aae_load_* / aae_store_* call it themselves. */
 int aae_sync(aae_handle h, void* stream);
+/* Device RNG (AAE_RNG_DEVICE) under data parallelism: dropout masks and the prior sample are drawn from a counter
+ * generator keyed by (seed, step, stream, ROW, column).  With the ranks' handles created with the SAME seed and each
+ * told which rows of the global batch it holds - rows [row_offset, row_offset + n_rows) of global_rows - the ranks
+ * together draw exactly what one process draws for the whole batch, so 1-GPU and N-GPU runs of a seed are comparable
+ * (SURVEY 8e).  (0, 0) = a batch of its own (the default). */
+int aae_set_rng_rows(aae_handle h, int64_t row_offset, int64_t global_rows);
 /* Call after writing PARAMETER tensors through the arena views of aae_tensor_info (instead of aae_load_linear): the
  * library keeps derived copies of the hidden layers' weights (transposed, for the backward layer chains) and
  * re-derives them before their next use. */

@@ -785,3 +785,79 @@ def test_short_batch_on_a_model_sized_for_long_ones(cut):
     got = dev.state_dict()
     for k, w in ora.p.items():
         np.testing.assert_allclose(got[k], w, atol=2e-5, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("scheme,world", [("vocab", 2), ("replicated", 3), ("vocab", 4)])
+def test_device_rng_draws_by_global_row_so_ranks_reproduce_the_single_process_run(scheme, world):
+    """rng_mode='device' (the production generator): dropout masks and the prior sample are keyed by the row of the
+    GLOBAL batch (aae_set_rng_rows), so `world` ranks with one seed, each holding a share of the batch, reproduce the
+    single-process run of that seed up to fp32 summation order (1-GPU and N-GPU runs comparable)."""
+    import threading
+    import scipy.sparse as sp
+    from aaerec._hip import HipAAE, DeviceCSR
+    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
+    from oracle.dense_torch_port import init_params
+    N, h, c, Bl = 700, 48, 12, 12
+    B = Bl * world
+    rng = np.random.default_rng(world)
+    params = init_params(N, h, c, seed=9)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.2, 0.3), rng_mode="device", seed=1234)
+    batches = []
+    for s in range(4):
+        rows = [np.sort(rng.choice(N, size=int(rng.integers(1, 10)), replace=False)) for _ in range(B)]
+        ip = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+        idx = np.concatenate(rows).astype(np.int32)
+        batches.append(sp.csr_matrix((np.ones(len(idx), dtype=np.float32), idx, ip), shape=(B, N)))
+    one = HipAAE(N, h, c, max_batch=B, **kw)
+    one.load_params(params)
+    for X in batches:
+        one.step(DeviceCSR(X, one.device), 0, B)
+    want = one.state_dict()
+    dist = _ThreadDist(world)
+    locals_, slices, errors = [None] * world, [None] * world, []
+
+    def rank_main(rk):
+        try:
+            dist.bind(rk)
+            m = HipAAE(N, h, c, max_batch=Bl, grad_mode="export", dp_world=world, **kw)
+            m.load_params(params)
+            locals_[rk] = m
+            if scheme == "vocab":
+                lo, hi = item_slice(N, rk, world)
+                sp_params = dict(params)
+                sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
+                sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+                sl = HipAAE(hi - lo, h, c, max_batch=B, **kw)
+                sl.load_params(sp_params)
+                slices[rk] = sl
+                dp = VocabParallelAAE(m, sl, dist, N)
+                for X in batches:
+                    dp.step(DeviceCSR(X, m.device), rk * Bl, Bl, DeviceCSR(X[:, lo:hi], m.device), 0, B)
+            else:
+                dp = DataParallelAAE(m, dist, shard_decoder=True)
+                for X in batches:
+                    dp.step(DeviceCSR(X, m.device), rk * Bl, Bl, global_rows=B)
+                    dp.wait_pending()
+        except BaseException as e:              # noqa: B902
+            errors.append((rk, e))
+            dist.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(rk,)) for rk in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    got0 = locals_[0].state_dict()
+    for k, w in want.items():
+        got = got0[k]
+        if k.startswith("dec.lin3") and scheme == "vocab":
+            got = np.concatenate([slices[rk].state_dict()[k] for rk in range(world)])
+        d = np.abs(got - w)
+        assert (d > 5e-5).sum() <= max(8, 0.01 * d.size) and d.max() <= 6e-3, f"{scheme} x{world} {k}: {(d > 5e-5).sum()} off, max {d.max():.2e}"
+    # and a different seed does give a different run (the comparison above is not vacuous)
+    other = HipAAE(N, h, c, max_batch=B, **dict(kw, seed=99))
+    other.load_params(params)
+    for X in batches:
+        other.step(DeviceCSR(X, other.device), 0, B)
+    assert np.abs(other.state_dict()["enc.lin2.weight"] - want["enc.lin2.weight"]).max() > 1e-3
