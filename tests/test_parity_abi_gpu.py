@@ -787,7 +787,7 @@ def test_short_batch_on_a_model_sized_for_long_ones(cut):
         np.testing.assert_allclose(got[k], w, atol=2e-5, rtol=0, err_msg=k)
 
 
-@pytest.mark.parametrize("scheme,world", [("vocab", 2), ("replicated", 3), ("vocab", 4)])
+@pytest.mark.parametrize("scheme,world", [("vocab", 2), ("replicated", 3), ("vocab", 4), ("vocab", 8), ("replicated", 8)])
 def test_device_rng_draws_by_global_row_so_ranks_reproduce_the_single_process_run(scheme, world):
     """rng_mode='device' (the production generator): dropout masks and the prior sample are keyed by the row of the
     GLOBAL batch (aae_set_rng_rows), so `world` ranks with one seed, each holding a share of the batch, reproduce the
