@@ -14,8 +14,10 @@ from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
 from oracle.dense_torch_port import init_params
 from tools.synth import throughput_corpus
 
-N, h, c, B = 100000, 200, 50, 100
+N, h, c, B = int(os.environ.get("VR_N", 100000)), 200, 50, int(os.environ.get("VR_B", 100))     # B = docs per rank
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+NB = int(os.environ.get("VR_BATCHES", 64))
+MEDIAN_LEN = int(os.environ.get("VR_MEDIAN_LEN", 20))
 
 
 class EchoDist:
@@ -50,13 +52,13 @@ class EchoDist:
 
 
 Bg = B * world
-X = throughput_corpus(64 * Bg, N, seed=1234)
+X = throughput_corpus(NB * Bg, N, median_len=MEDIAN_LEN, seed=1234)
 params = init_params(N, h, c, seed=0)
 dev = torch.device("cuda:0")
 w1_cap = int(X.getnnz(1).reshape(-1, B).sum(1).max()) + 8       # rows of a first-layer packet: the fullest share
 
 
-def timeit(step, steps=200, warm=30):
+def timeit(step, steps=int(os.environ.get('VR_STEPS', 200)), warm=int(os.environ.get('VR_WARM', 30))):
     for i in range(warm):
         step(i)
     torch.cuda.synchronize()
@@ -73,9 +75,9 @@ m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=w
 m.load_params(params)
 d1 = EchoDist(world)
 dp = DataParallelAAE(m, d1, shard_decoder=True if N % world == 0 else False)
-t_dp = timeit(lambda i: dp.step(csr, (i % 64) * Bg, B, global_rows=Bg))
+t_dp = timeit(lambda i: dp.step(csr, (i % NB) * Bg, B, global_rows=Bg))
 dp.wait_pending()
-per_step = {k: v / 230 for k, v in d1.bytes.items()}
+per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d1.bytes.items()}
 print(f"world {world}: replicated decoder   {t_dp:.3f} ms/step of compute per rank; exchanged per step: "
       + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
 del dp, m
@@ -92,10 +94,10 @@ sl.load_params(sp)
 slice_csr = DeviceCSR(X[:, lo:hi], dev)
 d2 = EchoDist(world)
 vp = VocabParallelAAE(m, sl, d2, N)
-t_vp = timeit(lambda i: vp.step(csr, (i % 64) * Bg, B, slice_csr, (i % 64) * Bg, Bg))
+t_vp = timeit(lambda i: vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg))
 sl.profile_enable(True)
 for i in range(50):
-    vp.step(csr, (i % 64) * Bg, B, slice_csr, (i % 64) * Bg, Bg)
+    vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)
 torch.cuda.synchronize()
 names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
 parts = []
@@ -105,6 +107,6 @@ for k in range(6):
         parts.append(f"{names[k]} {1e3 * ms / n:.1f} us")
 sl.profile_enable(False)
 print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
-per_step = {k: v / 230 for k, v in d2.bytes.items()}
+per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d2.bytes.items()}
 print(f"world {world}: vocabulary-sharded   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
       + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
