@@ -579,7 +579,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         unsigned long long h[32];
         hipStreamSynchronize(s);
         hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "PRIOR"};
+        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "DISC_HEAD", "PRIOR"};
         fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
         for (int i = 0; i < cb.P.nops; ++i)
             fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
@@ -837,10 +837,9 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
         d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
         ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_D2], h + 1, h, CEPI_DROPACT));
         d2.d = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5); d2.one_col = h; cop_out(d2, m->xh2.p, m->ldh);
-        cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_D3], h + 1, 1, CEPI_SIGMOID));
-        ChainOp& adv = cb.add(cop(COP_ADV, 3, 4, 1)); adv.aux = 0; adv.row_split = B; adv.scale = m->grad_scale;
-        cop_out(adv, m->ga3.p, 4);
-        ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 4, 5, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
+        // D3 (h -> 1) + sigmoid + adversarial loss + its dX in one op
+        ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 2, 5, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
+        x3.aux = 0; x3.row_split = B; x3.scale = m->grad_scale; x3.aux_ptr = m->ga3.p; x3.aux_ld = 4;
         cop_out(x3, m->gb0.p, m->ldh);
         ChainOp& x2 = cb.add(cop_dx(m, P_D2, 5, 6, h, h, CEPI_ACTBWD, s)); x2.yslot = 1; x2.d = d1.d;
         cop_out(x2, m->gb1.p, m->ldh);
@@ -871,9 +870,8 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     d1.d = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10); d1.one_col = h;
     ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 4, 5, m->P[P_D2], h + 1, h, CEPI_DROPACT));
     d2.d = make_drop(m, 1, true, I.masks_dev[11], nullptr, B, h, 11); d2.one_col = h;
-    cb.add(cop_linear(COP_LINEAR, 5, 6, m->P[P_D3], h + 1, 1, CEPI_SIGMOID));
-    ChainOp& adv = cb.add(cop(COP_ADV, 6, 7, 1)); adv.aux = 1; adv.row_split = B; adv.scale = m->grad_scale;
-    ChainOp& x3 = cb.add(cop_linear(COP_LINEAR_DX, 7, 8, m->P[P_D3], 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
+    ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 5, 8, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
+    x3.aux = 1; x3.row_split = B; x3.scale = m->grad_scale;
     ChainOp& x2 = cb.add(cop_dx(m, P_D2, 8, 9, h, h, CEPI_ACTBWD, s)); x2.yslot = 4; x2.d = d1.d;
     cb.add(cop_dx(m, P_D1, 9, 0, h, c, CEPI_NONE, s));                    // dL/dz
     ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;

@@ -41,6 +41,9 @@ enum { COP_LOAD = 0,        // dst <- global src [rows][lds_] cols [0, N)       
        COP_REPARAM,         // VAE (vae.py:115-118): src = [mu | logvar] (2N cols) -> dst[:, 0:N) = mu + eps * exp(logvar / 2);
                             //   eps: W (global [rows][ldw], injected) or the counter generator; always written to aux_ptr
        COP_REPARAM_BWD,
+       COP_DISC_HEAD,       // the discriminator's 1-unit output layer in one op: logit = src[:, 0:K) . W[0:K) (K-1 = bias input), D = sigmoid,
+                            //   adversarial loss + dL/dlogit as COP_ADV (aux, row_split, scale; dL/dlogit also -> aux_ptr[row * aux_ld]),
+                            //   dst[:, 0:N) = dL/dlogit * W[0:N) through the ACTBWD epilogue (yslot, d)
        COP_PRIOR };         // disc_step input rows: r < row_split: z_real = prior sample (aux = kind; aux_ptr = injected draws
                             //   [row_split][aux_ld] instead) * scale (aae.py:716-718); r >= row_split: W[r] (z_fake)   // src = dL/dz (N/2 cols), yslot = [mu | logvar], eps from aux_ptr -> dst = [dL/dmu | dL/dlogvar] (N cols)
                             //   incl. the KL term's own gradient (vae.py:141-145), whose value goes to the loss slot
@@ -470,6 +473,40 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             }
             kl = wave_sum(kl);
             if (lane == 0 && kl != 0.f) atomicAdd(P.loss_out + P.loss_slot, kl);
+        } else if (kind == COP_DISC_HEAD) {
+            // one wave per row of the block (tid >> 6 == local row): three ops' worth of weight round trips and
+            // barriers for a layer whose arithmetic is 16 dot products and 16 scaled copies of one weight row
+            static_assert(kCT == 1024 && kTPR == 64, "COP_DISC_HEAD maps one wavefront to one row");
+            const EpiCtx ec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
+            const int lrow = tid >> kRS, grow = r0 + lrow, t = tid & (kTPR - 1);
+            const int Kk = chain_pin(op.K), Nn = chain_pin(op.N);
+            float wv[4], part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = t + 64 * j;
+                wv[j] = op.W[min(k, Kk - 1)];
+                if (k < Kk) part += src[lrow * kCL + k] * wv[j];
+            }
+            const float logit = wave_sum(part);
+            float gv = 0.f;
+            if (lrow < nrows) {
+                const float dv = sigmoidf_(logit);
+                const int Bsplit = op.row_split;
+                const float invB = 1.f / (float)Bsplit;
+                float l, gg;
+                if (op.aux == 0 && grow >= Bsplit) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
+                else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
+                gv = gg * dv * (1.f - dv) * op.scale;
+                if (t == 0) {
+                    atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                    if (op.aux_ptr) op.aux_ptr[(size_t)grow * op.aux_ld] = gv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = t + 64 * j;
+                if (k < kCL) dst[lrow * kCL + k] = (lrow < nrows && k < Nn) ? chain_epi(ec, grow, lrow, k, gv * wv[j]) : 0.f;
+            }
         } else if (kind == COP_ADV) {
             // src col 0 = D(x) of each row.  mode 0: rows < row_split real, others fake; mode 1: all fake(gen)
             if (tid < kCR) {
