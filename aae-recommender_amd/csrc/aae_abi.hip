@@ -659,7 +659,10 @@ int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* 
     ChainBuilder cb(m, B);
     piggyback_buckets(m, cb);
     chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p);
-    ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final;
+    // the encoder's output activation; the identity (gauss prior, aae.py:97-101) is no op of its own: its stores and
+    // bias-input column ride on the last linear layer
+    ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
+    f.aux = m->cfg.enc_final;
     cop_out(f, m->zc.p, m->ldc); f.out2 = m->zsave.p; f.ldo2 = m->ldz;
     if (z_out) { ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, z_out, c); }
     if (with_dec) {
@@ -716,7 +719,7 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
     }
     if (enc_part) {
         if (!dec_part || gz_ext) cb.add(cop_load(gz_ext ? gz_ext : m->gzc.p, gz_ext ? ld_gz : m->ldc, 5, c));
-        cb.add(cop_load(m->zsave.p, m->ldz, 6, c));
+        if (m->cfg.enc_final != AAE_FINAL_LINEAR) cb.add(cop_load(m->zsave.p, m->ldz, 6, c));   // z: only the derivative of a softmax / sigmoid output needs it
         ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
         cop_out(fb, m->ga3.p, m->ldz);
         cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
@@ -820,7 +823,8 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
         ChainBuilder cb(m, B);
         chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr);
-        ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final; cop_out(f, m->zin.p, m->ldz, B);
+        ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
+        f.aux = m->cfg.enc_final; cop_out(f, m->zin.p, m->ldz, B);
         TRY(launch_chain(m, cb, s));
     }
     {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
@@ -864,8 +868,9 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     e1.d = make_drop(m, 0, true, I.masks_dev[8], nullptr, B, h, 8); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
     ChainOp& e2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W2], h + 1, h, CEPI_DROPACT));
     e2.d = make_drop(m, 1, true, I.masks_dev[9], nullptr, B, h, 9); e2.one_col = h; cop_out(e2, m->eh2.p, m->ldh);
-    cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_W3], h + 1, c, CEPI_NONE));
-    ChainOp& f = cb.add(cop(COP_FINAL_FWD, 3, 3, c)); f.aux = m->cfg.enc_final; f.one_col = c;
+    ChainOp& l3 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_W3], h + 1, c, CEPI_NONE));
+    ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? l3 : cb.add(cop(COP_FINAL_FWD, 3, 3, c));
+    f.aux = m->cfg.enc_final; f.one_col = c;
     ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 3, 4, m->P[P_D1], c + 1, h, CEPI_DROPACT));
     d1.d = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10); d1.one_col = h;
     ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 4, 5, m->P[P_D2], h + 1, h, CEPI_DROPACT));
