@@ -703,10 +703,10 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
     ChainBuilder cb(m, B);
     if (dec_part) {
         if (part_slabs) {
-            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = nslab; ss.stride = slab_stride;
-            cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
-            ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1;
-            ab.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); cop_out(ab, m->gb0.p, m->ldh);
+            // sum of the dA2 partial slabs times act'(dh2) and the dropout scale in one op (dh2 read from global)
+            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 2, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = nslab; ss.stride = slab_stride;
+            ss.epi = CEPI_ACTBWD; ss.aux_ptr = m->dh2.p; ss.aux_ld = m->ldh;
+            ss.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); cop_out(ss, m->gb0.p, m->ldh);
         } else {
             cb.add(cop_load(m->gb0.p, m->ldh, 2, h));      // unfused decoder path: gb0 already holds dL/da2
         }

@@ -359,6 +359,17 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
 #pragma unroll
                 for (int z = 0; z < 16; ++z)
                     if (z < op.aux) { acc4.x += v[z].x; acc4.y += v[z].y; acc4.z += v[z].z; acc4.w += v[z].w; }
+                if (op.epi == CEPI_ACTBWD) {
+                    // fused: times act'(y) and the dropout scale; y = the forward activation straight from global memory
+                    // (aux_ptr [rows][aux_ld]), instead of a LOAD op and an ACTBWD op behind this one
+                    const EpiCtx sec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
+                    const float4 y4 = *reinterpret_cast<const float4*>(op.aux_ptr + (size_t)(r0 + rowc) * op.aux_ld + c4c * 4);
+                    const int gr = r0 + lrow;
+                    acc4.x *= act_grad_from_y(sec.act, y4.x) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 0)) ? 0.f : (sec.den ? sec.mk : 1.f));
+                    acc4.y *= act_grad_from_y(sec.act, y4.y) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 1)) ? 0.f : (sec.den ? sec.mk : 1.f));
+                    acc4.z *= act_grad_from_y(sec.act, y4.z) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 2)) ? 0.f : (sec.den ? sec.mk : 1.f));
+                    acc4.w *= act_grad_from_y(sec.act, y4.w) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 3)) ? 0.f : (sec.den ? sec.mk : 1.f));
+                }
                 const bool ok = lrow < nrows;
                 if (!ok || c4 * 4 + 0 >= op.N) acc4.x = 0.f;
                 if (!ok || c4 * 4 + 1 >= op.N) acc4.y = 0.f;
