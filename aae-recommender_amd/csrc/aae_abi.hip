@@ -719,11 +719,19 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
     }
     if (enc_part) {
         if (!dec_part || gz_ext) cb.add(cop_load(gz_ext ? gz_ext : m->gzc.p, gz_ext ? ld_gz : m->ldc, 5, c));
-        if (m->cfg.enc_final != AAE_FINAL_LINEAR) cb.add(cop_load(m->zsave.p, m->ldz, 6, c));   // z: only the derivative of a softmax / sigmoid output needs it
-        ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
-        cop_out(fb, m->ga3.p, m->ldz);
+        // the encoder's output activation backward; for the identity (gauss prior) with nothing concatenated the dX op
+        // that produced dL/dz stores it as the W3 weight-gradient operand itself and no op is needed
+        int sg = 7;
+        ChainOp* prod = (dec_part && !gz_ext && cb.P.nops) ? &cb.P.ops[cb.P.nops - 1] : nullptr;
+        if (m->cfg.enc_final == AAE_FINAL_LINEAR && prod && cp == c && !prod->out2) {
+            prod->out2 = m->ga3.p; prod->ldo2 = m->ldz; sg = 5;
+        } else {
+            if (m->cfg.enc_final != AAE_FINAL_LINEAR) cb.add(cop_load(m->zsave.p, m->ldz, 6, c));   // z: only the derivative of a softmax / sigmoid output needs it
+            ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
+            cop_out(fb, m->ga3.p, m->ldz);
+        }
         cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
-        ChainOp& x3 = cb.add(cop_dx(m, P_W3, 7, 9, c, h, CEPI_ACTBWD, s)); x3.yslot = 8;
+        ChainOp& x3 = cb.add(cop_dx(m, P_W3, sg, 9, c, h, CEPI_ACTBWD, s)); x3.yslot = 8;
         x3.d = make_drop(m, 1, true, I.masks_dev[which == O_GEN ? 9 : 1], nullptr, B, h, which == O_GEN ? 9 : 1);
         cop_out(x3, m->gb2.p, m->ldh);
         cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
@@ -878,10 +886,15 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 5, 8, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
     x3.aux = 1; x3.row_split = B; x3.scale = m->grad_scale;
     ChainOp& x2 = cb.add(cop_dx(m, P_D2, 8, 9, h, h, CEPI_ACTBWD, s)); x2.yslot = 4; x2.d = d1.d;
-    cb.add(cop_dx(m, P_D1, 9, 0, h, c, CEPI_NONE, s));                    // dL/dz
-    ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;
-    cop_out(fb, m->ga3.p, m->ldz);
-    ChainOp& w3 = cb.add(cop_dx(m, P_W3, 6, 7, c, h, CEPI_ACTBWD, s)); w3.yslot = 2; w3.d = e2.d;
+    ChainOp& dz = cb.add(cop_dx(m, P_D1, 9, 0, h, c, CEPI_NONE, s));    // dL/dz
+    int sg = 6;
+    if (m->cfg.enc_final == AAE_FINAL_LINEAR) {        // identity output activation: dL/dz is dL/da3 already
+        cop_out(dz, m->ga3.p, m->ldz); sg = 0;
+    } else {
+        ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;
+        cop_out(fb, m->ga3.p, m->ldz);
+    }
+    ChainOp& w3 = cb.add(cop_dx(m, P_W3, sg, 7, c, h, CEPI_ACTBWD, s)); w3.yslot = 2; w3.d = e2.d;
     cop_out(w3, m->gb2.p, m->ldh);
     ChainOp& w2 = cb.add(cop_dx(m, P_W2, 7, 8, h, h, CEPI_ACTBWD, s)); w2.yslot = 1; w2.d = e1.d;
     cop_out(w2, m->gb3.p, m->ldh);
