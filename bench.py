@@ -104,8 +104,7 @@ def main():
 
     from aaerec._hip import HipAAE, DeviceCSR
     from aaerec import _hip
-    from oracle.dense_torch_port import init_params, DenseTorchAAE
-    from tools.synth import throughput_corpus
+    from tools.synth import init_params, throughput_corpus
 
     N, h, c, B = a.items, a.hidden, a.code, a.batch
     n_batches = 64
@@ -248,6 +247,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         host_cores = os.cpu_count() or 1
+        from oracle.dense_torch_port import DenseTorchAAE      # the checker's dense port, timed here as the CPU baseline only
         ref = DenseTorchAAE(params)
         Xc = X[:B * 8]
         # intra-op thread count: the dense step's ATen ops stop scaling (and collapse) well below the

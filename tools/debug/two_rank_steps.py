@@ -6,7 +6,7 @@ import numpy as np, scipy.sparse as sp, torch
 from aaerec._hip import HipAAE, DeviceCSR
 from aaerec.parallel import DataParallelAAE
 from test_parity_abi_gpu import _ThreadDist
-from oracle.dense_torch_port import init_params
+from tools.synth import init_params
 rng = np.random.RandomState(3)
 N, h, c, B, W = 500, 48, 16, 40, 2
 protos = [rng.choice(N, size=10, replace=False) for _ in range(12)]

@@ -10,7 +10,7 @@ from tools.synth import throughput_corpus
 N, h, c, B = 100000, 200, 50, 100
 X = throughput_corpus(64 * B, N, seed=1234)
 m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256)
-from oracle.dense_torch_port import init_params
+from tools.synth import init_params
 m.load_params(init_params(N, h, c, seed=0))
 csr = DeviceCSR(X, m.device)
 for i in range(20):

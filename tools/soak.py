@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "aae-recommender
 import numpy as np, torch
 from aaerec._hip import HipAAE, DeviceCSR
 from tools.synth import throughput_corpus
-from oracle.dense_torch_port import init_params
+from tools.synth import init_params
 N, h, c, B, steps = 100000, 200, 50, 100, int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"       # fused | vocab | replicated (one rank, gradient-export path)
 X = throughput_corpus(256 * B, N, seed=7)

@@ -53,3 +53,22 @@ def docs_to_csr(docs, n_items):
         indptr[i + 1] = indptr[i] + len(d)
     indices = np.concatenate(docs).astype(np.int32) if docs else np.zeros(0, np.int32)
     return sp.csr_matrix((np.ones(indices.size, dtype=np.float32), indices, indptr), shape=(len(docs), n_items))
+
+
+def init_params(n_items, n_hidden, n_code, cond_inc=0, seed=0):
+    """nn.Linear default initialisation (U(+-1/sqrt(fan_in)) for weight and bias) of the three nets, keyed like the
+    reference's state_dicts ("enc.lin1.weight" ...): random-init weights for benchmarks and tools."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f):
+        k = 1.0 / np.sqrt(in_f)
+        return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * k).numpy(), ((torch.rand(out_f, generator=g) * 2 - 1) * k).numpy()
+    shapes = {"enc.lin1": (n_hidden, n_items), "enc.lin2": (n_hidden, n_hidden), "enc.lin3": (n_code, n_hidden),
+              "dec.lin1": (n_hidden, n_code + cond_inc), "dec.lin2": (n_hidden, n_hidden),
+              "dec.lin3": (n_items, n_hidden), "disc.lin1": (n_hidden, n_code),
+              "disc.lin2": (n_hidden, n_hidden), "disc.lin3": (1, n_hidden)}
+    p = {}
+    for name, (o, i) in shapes.items():
+        p[name + ".weight"], p[name + ".bias"] = lin(o, i)
+    return p

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from aaerec._hip import HipAAE, DeviceCSR
 from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
-from oracle.dense_torch_port import init_params
+from tools.synth import init_params
 from tools.synth import throughput_corpus
 
 N, h, c, B = int(os.environ.get("VR_N", 100000)), 200, 50, int(os.environ.get("VR_B", 100))     # B = docs per rank
