@@ -262,8 +262,10 @@ class DeviceCSR:
         self.shape = X.shape
         self.nnz_per_row_max = int(np.diff(X.indptr).max()) if X.shape[0] else 0
         self.indptr = upload(X.indptr.astype(np.int64), device)
-        self.indices = upload(X.indices.astype(np.int32), device)
-        self.values = upload(X.data.astype(np.float32), device)
+        # (a matrix without entries - e.g. an item slice none of the batch's documents touches - still hands the
+        # library valid pointers: one unused element)
+        self.indices = upload(X.indices.astype(np.int32) if X.nnz else np.zeros(1, dtype=np.int32), device)
+        self.values = upload(X.data.astype(np.float32) if X.nnz else np.zeros(1, dtype=np.float32), device)
 
     @classmethod
     def from_arrays(cls, indptr, indices, values, n_cols, device):
@@ -271,8 +273,8 @@ class DeviceCSR:
         self.shape = (len(indptr) - 1, n_cols)
         self.nnz_per_row_max = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
         self.indptr = upload(np.asarray(indptr, dtype=np.int64), device)
-        self.indices = upload(np.asarray(indices, dtype=np.int32), device)
-        self.values = upload(np.asarray(values, dtype=np.float32), device)
+        self.indices = upload(np.asarray(indices, dtype=np.int32) if len(indices) else np.zeros(1, dtype=np.int32), device)
+        self.values = upload(np.asarray(values, dtype=np.float32) if len(values) else np.zeros(1, dtype=np.float32), device)
         return self
 
 

@@ -365,10 +365,15 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     const EpiCtx sec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
                     const float4 y4 = *reinterpret_cast<const float4*>(op.aux_ptr + (size_t)(r0 + rowc) * op.aux_ld + c4c * 4);
                     const int gr = r0 + lrow;
-                    acc4.x *= act_grad_from_y(sec.act, y4.x) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 0)) ? 0.f : (sec.den ? sec.mk : 1.f));
-                    acc4.y *= act_grad_from_y(sec.act, y4.y) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 1)) ? 0.f : (sec.den ? sec.mk : 1.f));
-                    acc4.z *= act_grad_from_y(sec.act, y4.z) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 2)) ? 0.f : (sec.den ? sec.mk : 1.f));
-                    acc4.w *= act_grad_from_y(sec.act, y4.w) * ((sec.den && !chain_keep(sec, gr, c4 * 4 + 3)) ? 0.f : (sec.den ? sec.mk : 1.f));
+                    // (the mask / generator lookup only for cells of the block that exist: an injected mask tensor
+                    // ends with the batch's last row)
+                    const bool den = sec.den && lrow < nrows;
+                    const float k0 = (den && c4 * 4 + 0 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 0) ? sec.mk : 0.f) : 1.f;
+                    const float k1 = (den && c4 * 4 + 1 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 1) ? sec.mk : 0.f) : 1.f;
+                    const float k2 = (den && c4 * 4 + 2 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 2) ? sec.mk : 0.f) : 1.f;
+                    const float k3 = (den && c4 * 4 + 3 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 3) ? sec.mk : 0.f) : 1.f;
+                    acc4.x *= act_grad_from_y(sec.act, y4.x) * k0; acc4.y *= act_grad_from_y(sec.act, y4.y) * k1;
+                    acc4.z *= act_grad_from_y(sec.act, y4.z) * k2; acc4.w *= act_grad_from_y(sec.act, y4.w) * k3;
                 }
                 const bool ok = lrow < nrows;
                 if (!ok || c4 * 4 + 0 >= op.N) acc4.x = 0.f;

@@ -248,7 +248,7 @@ def test_random_decoder_and_vae_steps_match_oracle(seed):
                                   torch.as_tensor(zin, device=dev.device), masks=masks)
             want = ora.partial_fit([zin], ip, idx, val, masks)
             np.testing.assert_allclose(dev.losses()[0], want, rtol=5e-5, atol=2e-6)
-            np.testing.assert_allclose(dz.cpu().numpy(), ora.last_dzin, rtol=5e-4, atol=5e-9)
+            np.testing.assert_allclose(dz.cpu().numpy(), ora.last_dzin, rtol=5e-4, atol=1e-7)     # (entries are sums with cancellation, ~1e-4 in size)
         got = dev.state_dict()
         for k, w in ora.p.items():
             _close_enough(got[k], w, 5e-5, 6e-3, f"decoder N={N} h={h} c={c} B={B} {k}")
