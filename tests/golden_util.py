@@ -82,3 +82,11 @@ class Fixture:
                     out[(tag, f"{net}.{k}")] = (self.z[key], self.z[f"step{s}.{tag}.{i}.v"],
                                                 float(self.z[f"step{s}.{tag}.{i}.t"]))
         return out
+
+
+def free_port():
+    """A TCP port nothing listens on right now (for the rendezvous of a spawned process group): bind to 0, read it back."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]

@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from golden_util import CAT_CASES, Fixture
+from golden_util import free_port, CAT_CASES, Fixture
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -701,7 +701,7 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
     adversarial model with dropout + prior drawn by the device generator (keyed by global row, one seed)."""
     import torch.multiprocessing as mp
     import aaerec.aae                               # noqa: F401  (seeds torch at import: import before seeding below)
-    port = 35500 + (os.getpid() % 2000) + (7 if adversarial else 0)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_fit_worker, args=(2, port, mode, ret, None, adversarial), nprocs=2, join=True)
@@ -729,7 +729,7 @@ def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce):
     share to the whole batch's width, as the single process does)."""
     import torch.multiprocessing as mp
     from aaerec.aae import AutoEncoder
-    port = 37500 + (os.getpid() % 2000)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_fit_worker, args=(2, port, "vocab", ret, reduce), nprocs=2, join=True)

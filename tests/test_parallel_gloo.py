@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from golden_util import Fixture
+from golden_util import free_port, Fixture
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,7 +81,7 @@ def _worker(rank, world, port, name, ret):
 
 @pytest.mark.parametrize("name", ["step_masks", "step_masks_uneven", "step_ragged"])
 def test_two_ranks_equal_single_process(name):
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker, args=(2, port, name, ret), nprocs=2, join=True)
@@ -179,7 +179,7 @@ def _worker_sparse(rank, world, port, name, ret):
 
 
 def test_two_ranks_with_packed_first_layer_rows_equal_single_process():
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker_sparse, args=(2, port, "step_masks", ret), nprocs=2, join=True)
@@ -238,7 +238,7 @@ def _worker_cond(rank, world, port, name, ret):
 
 @pytest.mark.parametrize("name", ["step_cond_categorical", "step_cat_sparse_sum"])
 def test_two_ranks_with_trainable_condition_equal_single_process(name):
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker_cond, args=(2, port, name, ret), nprocs=2, join=True)
@@ -382,7 +382,7 @@ def _worker_vocab(rank, world, port, name, ret):
 def test_two_ranks_with_vocabulary_sharded_output_layer_equal_single_process(name):
     """VocabParallelAAE over real gloo collectives: rank r holds half the documents and half the items' output rows;
     parameters (replicas + the two slices of dec.lin3) and the reconstruction loss equal the reference's."""
-    port = 33500 + (os.getpid() % 2000)
+    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker_vocab, args=(2, port, name, ret), nprocs=2, join=True)
