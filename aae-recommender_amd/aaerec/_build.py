@@ -7,7 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 OUT = os.path.join(_HERE, "libaaerec_hip.so")
 SOURCES = ["aae_abi.hip"]
-HEADERS = ["device_common.h", "gemm_f32.h", "kernels.h", os.path.join("..", "..", "include", "aaerec_hip.h")]
+
+
+def _headers():
+    """Every header the library is compiled from: csrc/*.h and the public C-ABI header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "aaerec_hip.h")]
 
 
 def hipcc():
@@ -18,7 +23,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, f) for f in SOURCES] + _headers())
 
 
 def build(force=False, verbose=True):

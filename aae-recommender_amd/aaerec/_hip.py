@@ -292,7 +292,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False, vae=False):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32"):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -321,6 +321,10 @@ class HipAAE:
         cfg.reserved[0] = 1 if unfused_decoder else 0
         cfg.reserved[1] = int(dp_world) if grad_mode == "export" else 0
         cfg.reserved[2] = 3 if vae else 1 if ae_only else 0
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        cfg.reserved[3] = 1 if dtype == "bf16" else 0
+        self.dtype = dtype
         self.ae_only, self.vae = bool(ae_only or vae), bool(vae)
         self.dp_world = int(dp_world)
         # rows of the packed first-layer gradient one rank may send per exchange
@@ -470,6 +474,9 @@ class HipAAE:
         return b
 
     def _inject(self, masks, z_real):
+        # every step-opening entry point passes through here: the buffers kept alive for the PREVIOUS step (condition
+        # blocks, injected masks, packets handed to the library by pointer) are released now, whatever the rng mode
+        self._keep = []
         if masks is None and z_real is None:
             return None
         inj = AaeRngInject()
@@ -569,7 +576,7 @@ class HipAAE:
         zin = zin.detach().to(self.device, torch.float32).contiguous()
         assert zin.shape == (n_rows, self.c + self.cond_inc), "decoder input width mismatch"
         dz = torch.empty_like(zin) if want_grad else None
-        self._keep = getattr(self, "_keep", []) + [zin]
+        self._keep.append(zin)
         with torch.cuda.device(self.device):
             _check(self.lib.aae_decoder_step(self.handle, C.byref(b), _ptr(zin), zin.shape[1],
                                              C.byref(inj) if inj else None, _ptr(dz), self._stream()))

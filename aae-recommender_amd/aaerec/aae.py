@@ -17,6 +17,8 @@ Build-only keyword arguments (all optional, defaults keep the reference behaviou
     seed        seed of the device generator (default: drawn from torch's global generator)
     data_parallel  torch.distributed process group (or True for the default group): shard every
                 batch over the ranks and all-reduce gradients over RCCL
+    dtype       'f32' (default: the reference's arithmetic) or 'bf16': the GEMM-shaped products take bf16 matrix-core
+                inputs with fp32 accumulation; master weights, optimiser state, losses stay fp32 (BASELINE config C2)
 """
 import numpy as np
 import scipy.sparse as sp
@@ -68,6 +70,7 @@ class _NetView:
         return None      # gradients never outlive the fused kernels
 
     def state_dict(self):
+        self._owner._dp_settle()
         sd = self._owner.hip.state_dict()
         pre = self._name + "."
         return {k[len(pre):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items() if k.startswith(pre)}
@@ -81,6 +84,7 @@ class _OptimView:
         self._owner, self._name = owner, name
 
     def state_dict(self):
+        self._owner._dp_settle()
         return self._owner.hip.adam_state(self._name)
 
 
@@ -90,7 +94,7 @@ class AdversarialAutoEncoder:
     def __init__(self, n_hidden=100, n_code=50, gen_lr=0.001, reg_lr=0.001, prior="gauss", prior_scale=None,
                  batch_size=100, n_epochs=500, optimizer="adam", normalize_inputs=True, activation="ReLU",
                  dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab"):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab", dtype="f32"):
         self.prior = prior.lower()
         self.prior_scale = prior_scale
         self.prior_sampler = PRIOR_SAMPLERS[self.prior]
@@ -113,6 +117,11 @@ class AdversarialAutoEncoder:
         # data_parallel (torch.distributed, one process per GPU): 'vocab' shards the decoder's output layer over the
         # vocabulary (aaerec.parallel.VocabParallelAAE), 'replicated' keeps it on every rank and exchanges its gradient
         self.dp_mode = dp_mode
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core inputs, fp32 "
+                             "accumulation, fp32 master weights and optimiser state)")
+        self.dtype = dtype
+        self._unfused_decoder = False                  # A/B switch of bench.py: keep the three-kernel output layer
         self.hip = None
         self._dp = None
         self._slice = self._slice_csr = self._g_rows = self._g_c_batch = None     # dp_mode='vocab': this rank's item slice of dec.lin3
@@ -149,6 +158,12 @@ class AdversarialAutoEncoder:
     def zero_grad(self):
         return None
 
+    def _dp_settle(self):
+        """Data parallel: block until a still-travelling exchange of updated parameters (the asynchronous all-gather
+        of dec.lin3 rows in dp_mode='replicated') has landed, before anything outside the step reads them."""
+        if self._dp is not None and hasattr(self._dp, "wait_pending"):
+            self._dp.wait_pending()
+
     # ---- construction: the nets + 4 optimisers of the reference's fit() (aae.py:782-804) ----
     def _build(self, n_items, code_inc, max_row_nnz=None, w1_cap=None):
         dist = dist_group = None
@@ -162,19 +177,9 @@ class AdversarialAutoEncoder:
                     raise RuntimeError("data_parallel needs torch.distributed to be initialised")
                 dist_group = None if self.data_parallel is True else self.data_parallel
             dist_world = dist.get_world_size(dist_group)
-        seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
-            if self.rng_mode == "device" else 0
-        self.hip = _hip.HipAAE(
-            n_items, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
-            max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
-            activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
-            normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
-            rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
-            grad_mode="export" if dist is not None else "fused", device=self.device,
-            dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only)
         # nn.Linear default initialisation, drawn from torch's global CPU generator in the
         # reference's construction order (Encoder, Decoder, Discriminator; lin1, lin2, lin3 each),
-        # so equal seeds give equal initial weights
+        # so equal seeds give equal initial weights (the device generator's seed is drawn AFTER them)
         params = {}
         shapes = [("enc", (n_items, self.n_hidden, self.n_code)),
                   ("dec", (self.n_code + code_inc, self.n_hidden, n_items)),
@@ -190,6 +195,31 @@ class AdversarialAutoEncoder:
                     lin = torch.nn.Linear(i, o)
                 params["{}.lin{}.weight".format(net, layer)] = lin.weight.detach().numpy()
                 params["{}.lin{}.bias".format(net, layer)] = lin.bias.detach().numpy()
+        seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
+            if self.rng_mode == "device" else 0
+        if dist is not None and dist_world > 1 and hasattr(dist, "broadcast"):
+            # rank 0 is authoritative for everything the replicas must agree on: initial weights and the device
+            # generator's seed (each process seeds torch's generator by itself; nothing else guarantees equality)
+            from .parallel import broadcast_array
+            dev = self.device if self.device is not None else "cuda:{}".format(torch.cuda.current_device())
+            keys = sorted(params)
+            flat = np.concatenate([params[k].ravel() for k in keys] + [np.array([seed], dtype=np.float64).view(np.float32)])
+            flat = broadcast_array(dist, dist_group, flat.astype(np.float32, copy=False), dev)
+            off = 0
+            for k in keys:
+                n = params[k].size
+                params[k] = flat[off:off + n].reshape(params[k].shape).copy()
+                off += n
+            seed = int(flat[off:off + 2].view(np.float64)[0])
+        self.hip = _hip.HipAAE(
+            n_items, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
+            max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
+            activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
+            normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
+            rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
+            grad_mode="export" if dist is not None else "fused", device=self.device,
+            dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
+            unfused_decoder=self._unfused_decoder)
         self.hip.load_params(params)
         self.enc, self.dec, self.disc = (_NetView(self, n) for n in ("enc", "dec", "disc"))
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")
@@ -208,7 +238,8 @@ class AdversarialAutoEncoder:
                     activation=self.activation, prior=self.prior, prior_scale=self.prior_scale,
                     optimizer=self.optimizer, normalize_inputs=self.normalize_inputs, dropout=self.dropout,
                     gen_lr=self.gen_lr, reg_lr=self.reg_lr, rng_mode="device" if self.rng_mode == "device" else "inject",
-                    seed=seed, device=self.device, ae_only=self._ae_only)
+                    seed=seed, device=self.device, ae_only=self._ae_only, dtype=self.dtype,
+                    unfused_decoder=self._unfused_decoder)
                 self._slice.load_params(sl_params)
                 self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group)
             else:
@@ -342,6 +373,7 @@ class AdversarialAutoEncoder:
         Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         if self.hip is None:
             self._build(Xs.shape[1], self.conditions.size_increment() if use_condition else 0)
+        Xs.sum_duplicates()                             # a non-canonical CSR hides a target of 2.0 in two entries
         _validate_targets(Xs)
         if Xs.shape[0] > self.hip.max_batch:
             raise ValueError("batch of {} rows exceeds batch_size={}".format(Xs.shape[0], self.hip.max_batch))
@@ -356,11 +388,22 @@ class AdversarialAutoEncoder:
     def fit(self, X, y=None, condition_data=None):
         if y is not None:
             raise NotImplementedError("(Semi-)supervised usage not supported")
+        for _step in self.fit_steps(X, condition_data=condition_data):
+            pass
+        return self
+
+    def fit_steps(self, X, condition_data=None, n_epochs=None):
+        """fit() as a generator: builds the model, uploads the corpus and yields after every partial_fit of the epoch
+        loop (reference aae.py:808-831), so a caller can meter the loop (bench.py times exactly K of its steps, host
+        batch assembly included).  Exhausting it is fit()."""
         use_condition = _check_conditions(self.conditions, condition_data)
         code_inc = self.conditions.size_increment() if use_condition else 0
         print(("Using condition, code size:" if use_condition else "Not using condition, code size:"),
               self.n_code + code_inc)
         X = X.tocsr()
+        if not X.has_canonical_format:
+            X = X.copy()
+            X.sum_duplicates()
         _validate_targets(X)
         row_nnz = np.sort(X.getnnz(1))[::-1]
         # most distinct items any batch can touch: the batch_size longest rows (bounds the packed
@@ -368,6 +411,7 @@ class AdversarialAutoEncoder:
         w1_cap = int(min(X.shape[1], max(1, row_nnz[:self.batch_size].sum())))
         self._build(X.shape[1], code_inc, max_row_nnz=max(int(row_nnz[0]) if X.shape[0] else 1, 4096), w1_cap=w1_cap)
         csr0 = _hip.DeviceCSR(X, self.hip.device)      # the corpus stays resident in HBM
+        self._fit_csr = csr0
         self._fit_X = X                                 # (host copy; subclasses with host-side randomness use it)
         row_len = X.getnnz(1)
         if self._slice is not None:                     # this rank's items of the corpus, ids rebased to the slice
@@ -375,13 +419,19 @@ class AdversarialAutoEncoder:
         n_docs = X.shape[0]
         self.train()
         step = 0
-        for epoch in range(self.n_epochs):
+        for epoch in range(self.n_epochs if n_epochs is None else n_epochs):
             if self.verbose:
                 print("Epoch", epoch + 1)
             # sklearn.utils.shuffle(X, *condition_data) == one permutation from np.random's
             # global state applied to every array (aae.py:813-817); only the permutation moves
             perm = np.arange(n_docs)
             np.random.shuffle(perm)
+            if self._dp is not None and self._dp.world > 1 and hasattr(self._dp.dist, "broadcast"):
+                # every rank walks rank 0's permutation (np.random's global state is per process and nothing else
+                # makes the ranks' draws agree; in dp_mode='vocab' a rank pairs OTHER ranks' hidden activations with
+                # targets taken from this order)
+                from .parallel import broadcast_array
+                perm = broadcast_array(self._dp.dist, self._dp.group, perm.astype(np.int64), self.hip.device)
             perm_dev = torch.as_tensor(perm.astype(np.int32), device=self.hip.device)
             csr = self._epoch_csr(csr0)
             for start in range(0, n_docs, self.batch_size):
@@ -415,13 +465,18 @@ class AdversarialAutoEncoder:
                     self.last_losses = self._losses()
                     log_losses(*self.last_losses)
                 step += 1
+                yield step
             if self.verbose:
                 print()
+        self._fit_finish()
+
+    def _fit_finish(self):
+        """What fit() does after its last step (also for a caller that stops fit_steps() early)."""
+        self._dp_settle()                               # replicated scheme: the last step's parameter all-gather
         self.last_losses = self._losses()
         self._g_rows = None
         if self._slice is not None:
             self._dp.gather_output_layer()              # every replica ends with the whole decoder (predict, state_dict)
-        return self
 
     def _losses(self):
         """(recon, disc, gen) of the last step; under dp_mode='vocab' the reconstruction loss lives in the item slices
@@ -442,6 +497,7 @@ class AdversarialAutoEncoder:
             self.conditions.eval()
         Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         csr = _hip.DeviceCSR(Xs, self.hip.device)
+        self._dp_settle()
         if self._slice is not None:
             self._dp.gather_output_layer()              # (a no-op after fit(); collective otherwise)
         fused = (not use_condition) or self._is_constant_concat()
@@ -504,6 +560,7 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
         raise NotImplementedError("predict_topk supports constant concatenated conditions only")
     Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
     csr = _hip.DeviceCSR(Xs, self.hip.device)
+    self._dp_settle()
     if self._slice is not None:
         self._dp.gather_output_layer()
     ids, vals = [], []
@@ -573,6 +630,14 @@ class DecodingRecommender(Recommender):
     # ---- internals ---------------------------------------------------------------------------
     def _build(self, n_items, max_row_nnz=None):
         n_in = int(self.conditions.size_increment())
+        # Decoder(size_increment, n_hidden, n_items): nn.Linear default init in construction order (aae.py:521-524);
+        # the device generator's seed is drawn after them, so equal torch seeds give the reference's initial weights
+        params = {}
+        for layer, (i, o) in enumerate(((n_in, self.n_hidden), (self.n_hidden, self.n_hidden),
+                                        (self.n_hidden, n_items)), start=1):
+            lin = torch.nn.Linear(i, o)
+            params["dec.lin{}.weight".format(layer)] = lin.weight.detach().numpy()
+            params["dec.lin{}.bias".format(layer)] = lin.bias.detach().numpy()
         seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
             if self.rng_mode == "device" else 0
         self.hip = _hip.HipAAE(
@@ -581,15 +646,11 @@ class DecodingRecommender(Recommender):
             activation=self.activation, optimizer=self.optimizer, dropout=self.dropout, gen_lr=self.lr,
             reg_lr=self.lr, rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
             device=self.device)
-        # Decoder(size_increment, n_hidden, n_items): nn.Linear default init in construction order (aae.py:521-524)
-        params = {}
-        for layer, (i, o) in enumerate(((n_in, self.n_hidden), (self.n_hidden, self.n_hidden),
-                                        (self.n_hidden, n_items)), start=1):
-            lin = torch.nn.Linear(i, o)
-            params["dec.lin{}.weight".format(layer)] = lin.weight.detach().numpy()
-            params["dec.lin{}.bias".format(layer)] = lin.bias.detach().numpy()
         self.hip.load_params(params)
         self.mlp, self.mlp_optim = _NetView(self, "dec"), _OptimView(self, "dec")
+
+    def _dp_settle(self):
+        return None      # single device: nothing travels
 
     def _inputs(self, condition_data):
         """ Encode ALL condition data with the respective condition, start with the first encoded condition

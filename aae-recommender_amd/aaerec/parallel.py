@@ -186,6 +186,17 @@ class DataParallelAAE:
         self._dec_finish(dec_state)
 
 
+def broadcast_array(dist, group, arr, device=None, src=0):
+    """numpy array of rank `src` on every rank (same shape / dtype everywhere).  RCCL moves device tensors only."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    nccl = str(dist.get_backend(group)).lower() == "nccl"
+    buf = t.to(device) if nccl else t.clone()
+    dist.broadcast(buf, src, group=group)
+    return buf.cpu().numpy()
+
+
 def item_slice(n_items, rank, world):
     """[lo, hi) of the items whose decoder output rows rank `rank` of `world` owns (contiguous, sizes differ by <= 1)."""
     base, extra = divmod(n_items, world)
@@ -317,6 +328,11 @@ class HostStagedCollectives:
     def all_reduce(self, t, op=None, group=None, async_op=False):
         c = t.cpu()
         self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def broadcast(self, t, src=0, group=None, async_op=False):
+        c = t.cpu()
+        self.d.broadcast(c, src)
         t.copy_(c)
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):

@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: AAE training docs/sec at |items|=100k, hidden=200 (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--items N] [--hidden H]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--items N] [--hidden H] [--dtype f32|bf16]
 
-A "step" is one AdversarialAutoEncoder.partial_fit (ae_step + disc_step + gen_step with all
-four optimiser updates, reference aaerec/aae.py:745-766) over one batch of B synthetic docs per
-GPU, inputs (the CSR corpus) already resident in HBM.  For N > 1 launch with
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
-GPU, RCCL); every rank processes its own B docs per step (weak scaling) and the gradients are
-summed across ranks before the optimisers run.
+A "step" is one AdversarialAutoEncoder.partial_fit (ae_step + disc_step + gen_step with all four optimiser
+updates, reference aaerec/aae.py:745-766) over one batch of B synthetic docs per GPU, driven by the epoch loop of
+AdversarialAutoEncoder.fit (reference aae.py:808-831: per-epoch permutation, batches = windows of it) over a corpus
+that is resident in HBM - SURVEY section 8d's "docs/s over fit epochs incl. host batch assembly".  `value` is that.
+`raw_step` (N = 1) is the same step called directly on contiguous row windows (no fit loop around it).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the kernel that takes the most time in the
-step, from hipEvent pairs recorded around its launches inside the timed region;
-`cpu_baseline` is the PyTorch-CPU dense port of the reference step (oracle/dense_torch_port.py)
-timed on this box's host cores over a bounded sample of the same workload (N=1 only).
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), or `python bench.py --gpus N` spawns
+them itself (before anything touches the GPU) and relays rank 0's line.  Every rank processes B docs per step (weak
+scaling): the global batch of N * B rows is sharded over the ranks by AdversarialAutoEncoder(data_parallel=...).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel that takes the most time in the step, from hipEvent
+pairs recorded around its launches inside the timed region; `cpu_baseline` is the PyTorch-CPU dense port of the
+reference step (oracle/dense_torch_port.py) timed on this box's host cores over a bounded sample of the same
+workload (N = 1 only); `extra.b512` is the MFMA-bound batch-512 variant of the same configuration (N = 1, f32).
 """
 import argparse
+import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +37,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -38,27 +46,61 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=100, help="docs per GPU per step (reference default 100, aae.py:599)")
-    ap.add_argument("--items", type=int, default=100000)
-    ap.add_argument("--hidden", type=int, default=200)
+    ap.add_argument("--items", type=int, default=None, help="default: 100000 (config C3), 47000 with --dtype bf16 (config C2)")
+    ap.add_argument("--hidden", type=int, default=None, help="default: 200 (C3), 100 with --dtype bf16 (C2)")
     ap.add_argument("--code", type=int, default=50)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="arithmetic of the GEMM-shaped products: f32 (reference precision, config C3) or bf16 MFMA inputs "
+                         "with fp32 accumulation, fp32 master weights and fp32 Adam (config C2)")
     ap.add_argument("--cond-inc", type=int, default=0, help="width of a constant concatenated condition block (config C4: 300)")
     ap.add_argument("--median-len", type=int, default=20, help="median items per synthetic doc")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps, the median is reported (0 = auto: 5 when "
+                                                           "K steps take well under a second, else 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-shard", action="store_true", help="data parallel: all-reduce + replicated Adam for the decoder output layer")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batch-512 extra line")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
     ap.add_argument("--dp", choices=("vocab", "replicated"), default="vocab",
                     help="N > 1: 'vocab' shards the decoder's output layer over the vocabulary (ranks exchange hidden "
                          "activations, aaerec.parallel.VocabParallelAAE); 'replicated' keeps a replica of it on every "
                          "rank and exchanges its dense gradient (DataParallelAAE)")
     ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.items is None:
+        a.items = 47000 if a.dtype == "bf16" else 100000
+    if a.hidden is None:
+        a.hidden = 100 if a.dtype == "bf16" else 200
+    return a
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU (this process has not touched the GPU and
+    never will), wait for them, relay rank 0's JSON line.  Children get the torch.distributed.run environment."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode(errors="replace")
+    rcs = [p.wait() for p in procs]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    rc = max((abs(r) for r in rcs), default=0)
+    sys.exit(rc if rc or lines else 1)
 
 
 def kernel_models(N, h, B, nnz_per_batch):
     """ALGORITHMIC bytes / flops per launch of the instrumented kernels."""
     P3 = N * (h + 1)      # decoder output layer, augmented with its bias column
-    P1 = N * h            # encoder first layer
     return {
         "enc_gather":  dict(bytes=nnz_per_batch * h * 4, flops=2 * nnz_per_batch * h),
         "dec_bce_fwd": dict(bytes=4 * P3 + 4 * B * N, flops=2 * B * P3),
@@ -72,14 +114,54 @@ def kernel_models(N, h, B, nnz_per_batch):
     }
 
 
+NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
+K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED = range(6)
+
+
+class _ConstVectors:
+    """Stand-in for the fitted TF-IDF x word2vec vectoriser behind PretrainedWordEmbeddingCondition (config C4): the
+    document vectors are precomputed once per dataset (condition.py:345-369), here they are synthetic N(0, 0.1)."""
+
+    def __init__(self, dim):
+        self.embedding = np.zeros((1, dim), dtype=np.float32)
+
+    def fit(self, x):
+        return self
+
+    def transform(self, x):
+        return x
+
+
+def make_model(a, B_global, dist, dtype=None, conditions=None):
+    from aaerec.aae import AdversarialAutoEncoder
+    kw = {}
+    if (dtype or a.dtype) != "f32":
+        kw["dtype"] = dtype or a.dtype
+    m = AdversarialAutoEncoder(n_hidden=a.hidden, n_code=a.code, batch_size=B_global, n_epochs=1 << 30, verbose=False,
+                               rng_mode="device", seed=1, data_parallel=dist, dp_mode=a.dp, conditions=conditions, **kw)
+    if a.unfused_decoder:
+        m._unfused_decoder = True
+    return m
+
+
+def timed_steps(it, k, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        next(it)
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)          # does not return
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AAE step has no CPU fallback")
     # debugging aid for a single-GPU box: all ranks on device 0, collectives over gloo staged through the host
@@ -102,153 +184,161 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    from aaerec._hip import HipAAE, DeviceCSR
     from aaerec import _hip
+    from aaerec.condition import ConditionList, PretrainedWordEmbeddingCondition
     from tools.synth import init_params, throughput_corpus
 
     N, h, c, B = a.items, a.hidden, a.code, a.batch
+    Bg = B * world
     n_batches = 64
-    X = throughput_corpus(n_batches * B, N, median_len=a.median_len, seed=1234 + rank)
-    nnz_per_batch = X.nnz / n_batches
-    csr = DeviceCSR(X, dev)
-    params = init_params(N, h, c, cond_inc=a.cond_inc, seed=0)
-    cond_all = None
+    # one corpus, the same on every rank (as in fit(): every rank holds the corpus and walks rank 0's permutation)
+    X = throughput_corpus(n_batches * Bg, N, median_len=a.median_len, seed=1234)
+    nnz_per_batch = X.nnz / n_batches / world            # per rank and step
+    conditions = cond_data = None
     if a.cond_inc:
-        cond_all = (torch.randn(n_batches * B, a.cond_inc, device=dev) * 0.1)
-    # rows of the packed first-layer gradient per exchange: must be the same on every rank
-    w1_cap = int(X.getnnz(1).reshape(n_batches, B).sum(1).max()) + 8
-    if use_dp and world > 1:
-        capt = torch.tensor([w1_cap], dtype=torch.int64, device=dev)
-        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
-        w1_cap = int(capt.item())
-    # one seed on every rank: the device generator is keyed by the row of the global batch (aae_set_rng_rows), so the
-    # ranks together draw what one process would for the whole batch
-    model = HipAAE(N, h, c, cond_inc=a.cond_inc, max_batch=B, rng_mode="device", seed=1,
-                   grad_mode="export" if use_dp else "fused", device=dev, unfused_decoder=a.unfused_decoder,
-                   dp_world=world, w1_cap=w1_cap)
-    model.load_params(params)
-    vocab = use_dp and a.dp == "vocab"
-    slice_model = None
-    if vocab:
-        import scipy.sparse as sp
-        from aaerec.parallel import VocabParallelAAE, item_slice
-        lo, hi = item_slice(N, rank, world)
-        # every rank walks the same global batches (in fit(): one shared permutation of one corpus; here: the ranks'
-        # synthetic corpora regenerated from their seeds): rank r's documents are rows [r*B, (r+1)*B) of global batch i
-        Xs = [X if r == rank else throughput_corpus(n_batches * B, N, median_len=a.median_len, seed=1234 + r)
-              for r in range(world)]
-        Xg = sp.vstack([Xs[r][i * B:(i + 1) * B] for i in range(n_batches) for r in range(world)]).tocsr()
-        slice_csr = DeviceCSR(Xg[:, lo:hi], dev)
-        del Xs, Xg
-        sp_params = dict(params)
-        sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
-        sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
-        slice_model = HipAAE(hi - lo, h, c, cond_inc=a.cond_inc, max_batch=B * world, rng_mode="device", seed=1,
-                             device=dev, unfused_decoder=a.unfused_decoder)
-        slice_model.load_params(sp_params)
-        runner = VocabParallelAAE(model, slice_model, dist, N)
-        Bg = B * world
-        step = lambda i: runner.step(csr, (i % n_batches) * B, B, slice_csr, (i % n_batches) * Bg, Bg,   # noqa: E731
-                                     cond=None if cond_all is None else cond_all[(i % n_batches) * B:(i % n_batches + 1) * B])
-    elif use_dp:
-        from aaerec.parallel import DataParallelAAE
-        runner = DataParallelAAE(model, dist, shard_decoder=False if a.no_shard else ("force" if world == 1 else True))
-        step = lambda i: runner.step(csr, (i % n_batches) * B, B, global_rows=B * world)   # noqa: E731
-    else:
-        if cond_all is not None:
-            step = lambda i: model.step(csr, (i % n_batches) * B, B,   # noqa: E731
-                                        cond=cond_all[(i % n_batches) * B:(i % n_batches + 1) * B])
-        else:
-            step = lambda i: model.step(csr, (i % n_batches) * B, B)   # noqa: E731
+        conditions = ConditionList([("title", PretrainedWordEmbeddingCondition(_ConstVectors(a.cond_inc), use_cuda=True))])
+        cond_data = [torch.randn(n_batches * Bg, a.cond_inc, device=dev) * 0.1]
+    model = make_model(a, Bg, dist if use_dp else None, conditions=conditions)
+    with contextlib.redirect_stdout(sys.stderr):
+        it = model.fit_steps(X, condition_data=cond_data)
+        next(it)                                          # construction + corpus upload + first step
+    vocab = model._slice is not None
+    out_model = model._slice if vocab else model.hip     # the handle that runs the decoder's output layer
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        step(i)
+    for _ in range(a.warmup):
+        next(it)
     # Live HIP-event timing inside the timed region, on the launch stream (C ABI: aae_profile_*), of the decoder
     # output-layer kernels only - the candidates for the dominant kernel the roofline block reports.  An event
     # pair costs a few microseconds of stream time, so the other kernels (2 gathers + 2 sparse-Adam launches per
     # step) are timed in a short pass AFTER the timed region; that pass does not enter `value`.
-    K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED = range(6)
-    # (vocabulary-sharded runs: the output-layer kernels run on the slice model, over n_items / world items and the
-    # global batch)
-    out_model = slice_model if vocab else model
     out_model.profile_enable(True, kernels=(K_BCE, K_DA2, K_DV3, K_FUSED))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    if use_dp:
-        runner.wait_pending()
-    barrier()
-    dt = time.perf_counter() - t0
+    dts = [timed_steps(it, a.steps, barrier)]
+    repeats = a.repeats or (5 if dts[0] < 0.25 else 1)
+    for _ in range(repeats - 1):
+        dts.append(timed_steps(it, a.steps, barrier))
     out_model.profile_enable(False)
-    losses = model.losses()
-    if vocab:
-        losses = (runner.recon_loss(),) + tuple(losses[1:])
+    dt = float(np.median(dts))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    docs_per_s = a.steps * B * world / dt
+    losses = model._losses()
+    docs_per_s = a.steps * Bg / dt
 
-    names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
     km = kernel_models(N, h, B, nnz_per_batch)
     if vocab:       # the output-layer kernels' algorithmic work on this rank: its item slice x the global batch
-        km_out = kernel_models(slice_model.N, h, B * world, nnz_per_batch)
+        km_out = kernel_models(out_model.N, h, Bg, nnz_per_batch)
         for k in ("dec_bce_fwd", "dec_da2", "dec_dv3_adam", "dec_fused"):
             km[k] = km_out[k]
     kstats = {}
 
-    def collect(kids, steps, wall, src=None):
+    def collect(kids, steps, wall, src, models=km):
         for kid in kids:
-            ms, n = (src or model).profile_read(kid)
+            ms, n = src.profile_read(kid)
             if n:
                 avg_s = ms / n * 1e-3
-                kstats[names[kid]] = dict(launches_per_step=n / steps, avg_us=round(avg_s * 1e6, 2),
+                kstats[NAMES[kid]] = dict(launches_per_step=round(n / steps, 3), avg_us=round(avg_s * 1e6, 2),
                                           step_share=round(ms * 1e-3 / wall, 4),
-                                          GBps=round(km[names[kid]]["bytes"] / avg_s / 1e9, 1),
-                                          TFLOPs=round(km[names[kid]]["flops"] / avg_s / 1e12, 2))
-    collect((K_BCE, K_DA2, K_DV3, K_FUSED), a.steps, dt, out_model)
-    extra = min(a.steps, 40)
-    model.profile_enable(True, kernels=(K_GATHER, K_W1))
-    for i in range(extra):
-        step(a.warmup + a.steps + i)
-    if use_dp:
-        runner.wait_pending()
+                                          GBps=round(models[NAMES[kid]]["bytes"] / avg_s / 1e9, 1),
+                                          TFLOPs=round(models[NAMES[kid]]["flops"] / avg_s / 1e12, 2))
+    collect((K_BCE, K_DA2, K_DV3, K_FUSED), a.steps * len(dts), sum(dts), out_model)
+    extra_steps = min(a.steps, 40)
+    model.hip.profile_enable(True, kernels=(K_GATHER, K_W1))
+    t0 = time.perf_counter()
+    for _ in range(extra_steps):
+        next(it)
     barrier()
-    model.profile_enable(False)
-    collect((K_GATHER, K_W1), extra, dt * extra / a.steps)
+    model.hip.profile_enable(False)
+    collect((K_GATHER, K_W1), extra_steps, time.perf_counter() - t0, model.hip)
+
+    peak_tf = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
     roofline = None
     if kstats:
         dom = max(kstats, key=lambda k: kstats[k]["step_share"])
         ks = kstats[dom]
         hbm_frac = ks["GBps"] / HBM_PEAK_GBS
-        mfma_frac = ks["TFLOPs"] / MFMA_F32_PEAK_TF
+        mfma_frac = ks["TFLOPs"] / peak_tf
         if hbm_frac >= mfma_frac:
             roofline = dict(kernel=dom, bound="hbm", achieved=ks["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(hbm_frac, 4), traffic=None)
         else:
-            roofline = dict(kernel=dom, bound="mfma", achieved=ks["TFLOPs"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+            roofline = dict(kernel=dom, bound="mfma", achieved=ks["TFLOPs"], peak=peak_tf, unit="TFLOP/s",
                             frac=round(mfma_frac, 4), traffic=None)
         roofline["avg_us"] = ks["avg_us"]
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-        # MI355X_MICROARCH.md prescribes), collected separately and committed under profiles/
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pmc["config"] == {"n_items": N, "n_hidden": h, "batch": B} and dom in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][dom]["traffic_bytes"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # MI355X_MICROARCH.md prescribes) of this same command, collected in separate runs and committed under
+        # profiles/ (a counter pass cannot share a run with the timed region); null when no pass matches the config
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if not name.endswith("_pmc_traffic.json"):
+                continue
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                want = {"n_items": N, "n_hidden": h, "batch": B}
+                if a.dtype != "f32":
+                    want["dtype"] = a.dtype
+                if pmc["config"] == want and dom in pmc["kernels"] and world == 1:
+                    roofline["traffic"] = pmc["kernels"][dom]["traffic_bytes"]
+                    roofline["traffic_source"] = "profiles/" + name
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+
+    raw = None
+    extra = {}
+    if world == 1 and not use_dp:
+        # the same step called directly on contiguous row windows of the resident corpus (r1's headline figure)
+        csr = model._fit_csr
+        hip = model.hip
+        cond_all = cond_data[0] if cond_data else None
+
+        def raw_step(i):
+            s0 = (i % n_batches) * B
+            hip.step(csr, s0, B, cond=None if cond_all is None else cond_all[s0:s0 + B])
+        for i in range(5):
+            raw_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            raw_step(i)
+        barrier()
+        rdt = time.perf_counter() - t0
+        raw = dict(docs_per_s=round(a.steps * B / rdt, 1), ms_per_step=round(rdt / a.steps * 1e3, 4))
+        if not a.no_extra and a.dtype == "f32" and B != 512 and not a.cond_inc:
+            # SURVEY 8d asks for the MFMA-bound batch (512) next to the reference's default batch
+            a2 = argparse.Namespace(**vars(a))
+            m2 = make_model(a2, 512, None)
+            X2 = throughput_corpus(16 * 512, N, median_len=a.median_len, seed=4321)
+            with contextlib.redirect_stdout(sys.stderr):
+                it2 = m2.fit_steps(X2)
+                next(it2)
+            for _ in range(5):
+                next(it2)
+            k2 = max(10, min(a.steps, 50))
+            m2.hip.profile_enable(True, kernels=(K_BCE, K_DA2, K_DV3, K_FUSED))
+            d2 = timed_steps(it2, k2, barrier)
+            m2.hip.profile_enable(False)
+            km2 = kernel_models(N, h, 512, X2.nnz / 16)
+            ks2 = {}
+            for kid in (K_BCE, K_DA2, K_DV3, K_FUSED):
+                ms, n = m2.hip.profile_read(kid)
+                if n:
+                    avg_s = ms / n * 1e-3
+                    ks2[NAMES[kid]] = dict(avg_us=round(avg_s * 1e6, 2), TFLOPs=round(km2[NAMES[kid]]["flops"] / avg_s / 1e12, 2),
+                                           frac_mfma=round(km2[NAMES[kid]]["flops"] / avg_s / 1e12 / MFMA_F32_PEAK_TF, 4))
+            extra["b512"] = dict(docs_per_s=round(k2 * 512 / d2, 1), ms_per_step=round(d2 / k2 * 1e3, 4), steps=k2,
+                                 kernels=ks2)
+            del m2, it2
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         host_cores = os.cpu_count() or 1
         from oracle.dense_torch_port import DenseTorchAAE      # the checker's dense port, timed here as the CPU baseline only
-        ref = DenseTorchAAE(params)
+        ref = DenseTorchAAE(init_params(N, h, c, cond_inc=0, seed=0))
         Xc = X[:B * 8]
         # intra-op thread count: the dense step's ATen ops stop scaling (and collapse) well below the
         # core count of a 100+-core host, so time one step at a few counts and keep the fastest
@@ -276,25 +366,36 @@ def main():
             if (el > a.cpu_seconds and done >= 3) or done >= 200:
                 break
         cpu = dict(value=round(done * B / el, 1), unit="docs/s", cores=cores, kind="port",
-                   sample=f"{done} partial_fit steps of batch {B} (toarray + dense PyTorch-CPU step), "
+                   sample=f"{done} partial_fit steps of batch {B} (toarray + dense fp32 PyTorch-CPU step, no conditions), "
                           f"{el:.1f} s, {cores} intra-op threads (fastest of {cands} on a {host_cores}-core host)")
 
     if rank == 0:
+        cfg_name = ("C2 RCV1-scale" if a.dtype == "bf16" else "C4 EconBiz-scale + 300-d title condition" if a.cond_inc
+                    else "C3 PubMed-scale")
         out = {
             "metric": "train docs/sec at |items|=100k h=200",
             "value": round(docs_per_s, 1), "unit": "docs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3 PubMed-scale synthetic Bags: |items|={N}, hidden={h}, code={c}, fp32, "
-                                   f"batch={B} docs/GPU/step, full partial_fit (ae+disc+gen, 4 Adam)",
-                       "n_items": N, "n_hidden": h, "n_code": c, "batch_per_gpu": B, "global_batch": B * world,
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{cfg_name} synthetic Bags: |items|={N}, hidden={h}, code={c}, "
+                                   f"{'fp32' if a.dtype == 'f32' else 'bf16 MFMA inputs / fp32 accumulate, master weights and Adam'}, "
+                                   f"batch={B} docs/GPU/step, full partial_fit (ae+disc+gen, 4 Adam) inside the "
+                                   f"AdversarialAutoEncoder.fit epoch loop (permutation batches of a corpus resident in HBM)",
+                       "n_items": N, "n_hidden": h, "n_code": c, "batch_per_gpu": B, "global_batch": Bg,
                        "cond_inc": a.cond_inc, "nnz_per_batch": round(nnz_per_batch, 1), "rng": "device",
+                       "timed_repeats": len(dts), "repeat_ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts],
                        "parallelism": (f"dp{world}" if not use_dp else
                                        f"dp{world}, decoder output layer sharded over the vocabulary" if vocab else
                                        f"dp{world}, replicated decoder")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
-            "losses_last_step": [round(x, 5) for x in losses],
+            "losses_last_step": [round(float(x), 5) for x in losses],
         }
+        if raw:
+            out["raw_step"] = raw
+        if extra:
+            out["extra"] = extra
+        if use_dp and hasattr(model._dp, "comm_stats"):
+            out["collectives_per_step"] = model._dp.comm_stats()
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(docs_per_s / cpu["value"], 1)
         result_line = json.dumps(out)

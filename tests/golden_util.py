@@ -11,7 +11,7 @@ STEP_CASES = [
     "step_nodrop_gauss", "step_masks", "step_masks_uneven", "step_cond_concat",
     "step_cond_categorical", "step_cond_concat_bias", "step_selu", "step_categorical_prior",
     "step_bernoulli_prior", "step_prior_scale", "step_sgd", "step_nonorm", "step_ragged",
-    "step_tanh", "step_lrs", "step_wide", "step_headline",
+    "step_tanh", "step_lrs", "step_wide", "step_headline", "step_c4",
 ]
 
 # trainable CategoricalCondition variants (SparseAdam / mean / single index / behind a constant block)

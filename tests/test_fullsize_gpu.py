@@ -1,0 +1,104 @@
+"""GPU parity at BASELINE.json's full sizes (the small fixtures pin every code path; these pin the SHAPES the benchmark
+runs: 3 125 item tiles, 12.2 tile rounds per workgroup, 64-bit offsets into 80 MB tensors).
+
+C3 (|items| = 100 000, hidden 200, code 50, batch 100): three full partial_fit steps with injected dropout masks and
+prior draws on (a) the fused output-layer kernel, (b) the three-kernel output layer, (c) the NumPy oracle over the WHOLE
+vocabulary (it finishes a step at this size in a few seconds, so nothing is sampled): losses and every parameter.
+
+C5, one rank's share (the decoder's output layer over a slice of 275 000 of the 2.2 M items x the global batch of 512
+rows, what a rank of the vocabulary-sharded scheme runs per step - aae_output_layer_step): against the NumPy
+restatement of the slice (tests/test_parallel_gloo.py::VocabSliceReplica, itself checked against the oracle there).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(rng, B, h, p=(0.2, 0.2)):
+    return [(rng.random((B, h)) >= p[i % 2]).astype(np.uint8) for i in range(12)]
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def test_c3_full_size_step_fused_equals_three_kernel_path_equals_oracle():
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from tools.synth import init_params, throughput_corpus
+    N, h, c, B, steps = 100000, 200, 50, 100, 3
+    params = init_params(N, h, c, seed=3)
+    X = throughput_corpus(steps * B, N, median_len=20, seed=77)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3)
+    fused = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+    plain = HipAAE(N, h, c, max_batch=B, rng_mode="inject", unfused_decoder=True, **kw)
+    for m in (fused, plain):
+        m.load_params(params)
+    ora = O.OracleAAE({k: v.copy() for k, v in params.items()}, **kw)
+    csr = DeviceCSR(X, fused.device)
+    rng = np.random.default_rng(5)
+    for s in range(steps):
+        masks, z_real = _masks(rng, B, h), rng.standard_normal((B, c)).astype(np.float32)
+        for m in (fused, plain):
+            m.step(csr, s * B, B, masks=masks, z_real=z_real)
+        Xb = X[s * B:(s + 1) * B]
+        want = ora.partial_fit(Xb.indptr.astype(np.int64), Xb.indices, Xb.data.astype(np.float32), z_real, masks)
+        lf, lp = fused.losses(), plain.losses()
+        np.testing.assert_allclose(lf, want, rtol=1e-5, atol=1e-6, err_msg=f"fused losses, step {s}")
+        np.testing.assert_allclose(lp, want, rtol=1e-5, atol=1e-6, err_msg=f"three-kernel losses, step {s}")
+    sf, sp_ = fused.state_dict(), plain.state_dict()
+    worst = {}
+    for k, w in ora.p.items():
+        worst[k] = (_maxdiff(sf[k], sp_[k]), _maxdiff(sf[k], w), _maxdiff(sp_[k], w))
+    print("max |fused - three-kernel|, |fused - oracle|, |three-kernel - oracle| per tensor:", worst)
+    for k, (d_fp, d_fo, d_po) in worst.items():
+        # the two device paths differ by fp32 summation order only (same kernels elsewhere)
+        assert d_fp <= 2e-6, (k, d_fp)
+        # against the oracle: the tolerance of the fixture tests (1e-5 absolute on parameters)
+        assert d_fo <= 1e-5 and d_po <= 1e-5, (k, d_fo, d_po)
+    # and the predictions of the trained weights, over the whole vocabulary (north star: 1e-4)
+    Xp = X[:B]
+    want = ora.predict(Xp.indptr.astype(np.int64), Xp.indices, Xp.data.astype(np.float32))
+    got = fused.predict(csr, 0, B).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+def test_c5_share_output_layer_of_one_rank():
+    """Config C5 (|items| = 2.2 M, batch 512, 8 ranks): the item slice one rank owns, 275 000 rows of dec.lin3, against
+    the global batch of 512 rows - two consecutive steps (the second one starts from the first one's Adam state)."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from test_parallel_gloo import VocabSliceReplica
+    from tools.synth import throughput_corpus
+    Ns, h, c, B, world = 275000, 200, 50, 512, 8
+    rng = np.random.default_rng(11)
+    k = 1.0 / np.sqrt(h)
+    params = {"dec.lin3.weight": ((rng.random((Ns, h)) * 2 - 1) * k).astype(np.float32),
+              "dec.lin3.bias": ((rng.random(Ns) * 2 - 1) * k).astype(np.float32)}
+    X = throughput_corpus(2 * B, Ns, median_len=8, seed=9)           # the slice's share of a playlist's ~60 tracks
+    sl = HipAAE(Ns, h, c, max_batch=B, rng_mode="inject", dropout=(0.2, 0.2))
+    full = {"dec.lin3.weight": params["dec.lin3.weight"], "dec.lin3.bias": params["dec.lin3.bias"]}
+    sl.load_params(full)
+    sl.set_grad_scale(1.0 / world)                                     # slice items / all items
+    ref = VocabSliceReplica(params, 0, Ns, 1e-3)
+    ref.set_grad_scale(1.0 / world)
+    csr = DeviceCSR(X, sl.device)
+    for s in range(2):
+        dh2 = np.abs(rng.standard_normal((B, h + 1))).astype(np.float32) * 0.5
+        dh2[rng.random((B, h + 1)) < 0.4] = 0.0                       # post-ReLU + dropout sparsity
+        dh2[:, h] = 1.0                                                # the bias input column
+        sl.dh2_rows(B)[:, :h + 1].copy_(torch.from_numpy(dh2))
+        sl.output_layer_step(csr, s * B, B)
+        ref.dh2_rows(B)[:] = torch.from_numpy(dh2)
+        ref.output_layer_step((X.indptr.astype(np.int64), X.indices, X.data.astype(np.float32)), s * B, B)
+        np.testing.assert_allclose(sl.losses()[0], ref.loss, rtol=1e-5)
+        got = sl.da2_rows(B)[:, :h].cpu().numpy()
+        want = ref.da2_rows(B)[:, :h].numpy()
+        # dL/d(dh2): sums over 275 000 items of terms ~1e-9 each: absolute differences of fp32 summation order
+        scale = float(np.abs(want).max())
+        assert _maxdiff(got, want) <= 2e-5 * scale + 1e-12, (_maxdiff(got, want), scale)
+    sd = sl.state_dict()
+    dw, db = _maxdiff(sd["dec.lin3.weight"], ref.p["w"]), _maxdiff(sd["dec.lin3.bias"], ref.p["b"])
+    print("C5 share: max |dW|", dw, "max |db|", db)
+    assert dw <= 1e-5 and db <= 1e-5

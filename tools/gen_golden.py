@@ -199,15 +199,16 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
     conditions = None
     cond_inc = 0
     cond_batches = None
-    if cond == "concat30":
+    concat_w = int(cond[6:]) if cond and cond.startswith("concat") and cond[6:].isdigit() else 0
+    if concat_w:            # a constant concatenated block: "concat30", "concat300" (config C4's 300-d title vectors)
         class ConstConcat(ref_cond.ConcatenationBasedConditioning):
             def size_increment(self):
-                return 30
+                return concat_w
 
             def encode(self, inputs):
                 return torch.as_tensor(inputs, dtype=torch.float32)
         conditions = ref_cond.ConditionList([("title", ConstConcat())])
-        cond_inc = 30
+        cond_inc = concat_w
     elif cond in CAT_KINDS:
         kind = CAT_KINDS[cond]
         cc = ref_cond.CategoricalCondition(8, sparse=kind["sparse"], use_cuda=False, reduce=kind["reduce"], lr=1e-2)
@@ -310,8 +311,8 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
         out[f"step{s}.indices"] = X.indices.astype(np.int32)
         out[f"step{s}.values"] = X.data.astype(np.float32)
         cbatch = None
-        if cond in ("concat30",):
-            cv = (rng.standard_normal((Bs, 30)) * 0.5).astype(np.float32)
+        if concat_w:
+            cv = (rng.standard_normal((Bs, concat_w)) * (0.5 if concat_w <= 30 else 0.1)).astype(np.float32)
             out[f"step{s}.cond0"] = cv
             cbatch = [cv]
         elif cond == "concat30+bias":
@@ -365,8 +366,8 @@ def run_case(ref_aae, ref_cond, name, N=300, h=20, c=10, B=16, steps=3, seed=0,
     out["predict.indices"] = Xp.indices.astype(np.int32)
     out["predict.values"] = Xp.data.astype(np.float32)
     pc = None
-    if cond == "concat30":
-        pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
+    if concat_w:
+        pcv = (rng.standard_normal((B, concat_w)) * (0.5 if concat_w <= 30 else 0.1)).astype(np.float32)
         out["predict.cond0"] = pcv
         pc = [pcv]
     elif cond == "concat30+bias":
@@ -860,6 +861,12 @@ def main():
         # the headline layer widths (h=200, c=50, batch 100: 13 column blocks in the layer chains and in the fused
         # decoder output layer, 7 row blocks) on a small vocabulary, straight from the reference
         run_case(ref_aae, ref_cond, "step_headline", seed=16, N=330, h=200, c=50, B=100, steps=2,
+                 dropout=(0.2, 0.2), batch_kw=dict(max_len=24), capture_acts=False, states='last')
+    if want("c4"):
+        # config C4's widths: a 300-d constant title block concatenated to the 50-d code (condition.py:345-369,
+        # aae.py:688-690) -> dec.lin1 is [350 -> 200], beyond the layer-chain kernels; batch > 104 rows (the reference's
+        # EconBiz driver uses 1000, eval/econis.py:45): the three-kernel output layer
+        run_case(ref_aae, ref_cond, "step_c4", seed=17, N=460, h=200, c=50, B=128, steps=2, cond="concat300",
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=24), capture_acts=False, states='last')
     if want("catcond"):
         # trainable CategoricalCondition variants: SparseAdam (the reference's default), mean / no reduction, and
