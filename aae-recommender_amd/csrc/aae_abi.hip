@@ -28,6 +28,7 @@
 #include "gemm_f32.h"
 #include "kernels.h"
 #include "dec_fused.h"
+#include "dec_fused_bf16.h"
 #include "chain.h"
 #include "cond_embed.h"
 
@@ -83,6 +84,7 @@ struct aae_model {
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
+    bool bf16;               // cfg.reserved[3] = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
     bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
     Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
@@ -154,7 +156,9 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 3; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 4; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[3] != 0 && c->reserved[3] != 1) return fail(AAE_EINVAL, "reserved[3] must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
+    if (c->reserved[3] == 1 && c->reserved[2] == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
     if (c->reserved[2] < 0 || c->reserved[2] > 3 || c->reserved[2] == 2)
         return fail(AAE_EINVAL, "reserved[2] must be 0 (AAE), 1 (plain autoencoder) or 3 (VAE)");
     if (c->reserved[2] == 3 && (c->n_hidden + 1 > 208 || c->n_code + c->cond_inc + 1 > 208 || 2 * c->n_code > 208))
@@ -178,13 +182,13 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
     m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 16);
     m->P[P_V2] = a.mat(h, h + 1, m->ldh, 16);
-    m->P[P_V3] = a.mat(N, h + 1, m->ldh);
+    m->P[P_V3] = a.mat(N, h + 1, m->ldh, kTI);      // (+ one tile of zero rows: dec_fused_bf16.h reads whole tiles unclamped)
     m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 16);
     m->P[P_D2] = a.mat(h, h + 1, m->ldh, 16);
     m->P[P_D3] = a.mat(1, h + 1, m->ldh, 16);
     for (int i = 0; i < NP; ++i) {
-        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
-        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? kTI : 0);
+        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? kTI : 0);
     }
     for (int i = P_W1T; i <= P_W3; ++i) {
         m->M[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
@@ -639,7 +643,8 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 // The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
 // as one extra workgroup (chain.h), off the critical path.
 static bool fused_decoder_applies(const aae_model* m) {
-    return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB && dec_fused_lds_bytes(m->rows, m->h) <= 160 * 1024;
+    return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB &&
+           (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes(m->rows, m->h)) <= 160 * 1024;
 }
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const int ntiles = (m->N + kTI - 1) / kTI;
@@ -935,6 +940,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
     m->vae = cfg->reserved[2] == 3; m->vae_bwd = false;
+    m->bf16 = cfg->reserved[3] == 1;
     m->ae_only = cfg->reserved[2] == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
@@ -960,6 +966,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 2048);
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) m->fused_ok = false;
+            if (m->bf16 &&
+                (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess ||
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess ||
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess))
+                m->fused_ok = false;
         }
     }
     m->grad_scale = 1.f;
@@ -1330,7 +1341,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
-    const size_t fused_lds = dec_fused_lds_bytes(B, h);
+    const size_t fused_lds = m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(B, h);
     const float* chain_part = nullptr; size_t chain_stride = 0;
     if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
@@ -1370,7 +1381,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         const int grid = std::min(ntiles, m->n_cu);
         {
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
-            switch (m->fused_nb) {
+            if (m->bf16) switch (m->fused_nb) {
+                case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+            } else switch (m->fused_nb) {
                 case 4: hipLaunchKernelGGL(dec_fused_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
                 case 7: hipLaunchKernelGGL(dec_fused_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
                 default: hipLaunchKernelGGL(dec_fused_kernel<13>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;

@@ -281,14 +281,29 @@ def _lin(x, W, b):
     return (x @ W.T + b).astype(f32)
 
 
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: what v_cvt_pk_bf16_f32 does to a matrix-core
+    operand in the build's bf16 mode (BASELINE config C2; the reference has no bf16 path, SURVEY section 7 defines it
+    as bf16 MFMA inputs, fp32 accumulate, fp32 master parameters and optimiser)."""
+    u = np.ascontiguousarray(x, dtype=f32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(f32)
+
+
 class OracleAAE:
     """State = torch-layout parameters ([out,in]) + four optimiser states."""
+    bf16 = False        # (subclasses with constructors of their own run in the reference's fp32)
 
     def __init__(self, params, gen_lr=1e-3, reg_lr=1e-3, prior="gauss", prior_scale=None,
                  optimizer="adam", normalize_inputs=True, activation="ReLU",
-                 dropout=(0.2, 0.2), conditions=None):
+                 dropout=(0.2, 0.2), conditions=None, bf16=False):
         # params: dict "enc.lin1.weight" -> ndarray (copied)
         self.p = {k: np.array(v, dtype=f32) for k, v in params.items()}
+        # bf16 mode of the build (not of the reference): every dense product that runs on the matrix cores takes its
+        # two operands rounded to bf16 and accumulates in fp32 - the Linear layers' forward (bias included: it is a
+        # column of the augmented weight matrix) and dX products, and all three products of the decoder's output
+        # layer; the sparse first encoder layer, the hidden layers' weight gradients, losses, optimisers stay fp32
+        self.bf16 = bool(bf16)
         self.N = self.p["enc.lin1.weight"].shape[1]
         self.c = self.p["enc.lin3.weight"].shape[0]
         self.prior, self.prior_scale = prior, prior_scale
@@ -321,32 +336,44 @@ class OracleAAE:
             a1[b] = W[:, indices[lo:hi]] @ xn + b1
         return a1
 
+    def _R(self, x):
+        return bf16_round(x) if self.bf16 else x
+
+    def _linear(self, x, W, b):
+        return _lin(self._R(x), self._R(W), self._R(b))
+
     def _mlp_fwd(self, net, x0, masks, first_pre=None):
         """3-layer stack; returns (output_pre_final, cache). masks: (keep1, keep2) or None."""
         P = self.p
         k1, k2 = masks if masks is not None else (None, None)
         d1, d2 = Drop(self.dropout[0], k1, self.alpha_mode), Drop(self.dropout[1], k2, self.alpha_mode)
-        a1 = first_pre if first_pre is not None else _lin(x0, P[net + ".lin1.weight"], P[net + ".lin1.bias"])
+        a1 = first_pre if first_pre is not None else self._linear(x0, P[net + ".lin1.weight"], P[net + ".lin1.bias"])
         u1 = d1.fwd(a1)
         h1 = act_fwd(self.act, u1)
-        a2 = _lin(h1, P[net + ".lin2.weight"], P[net + ".lin2.bias"])
+        a2 = self._linear(h1, P[net + ".lin2.weight"], P[net + ".lin2.bias"])
         u2 = d2.fwd(a2)
         h2 = act_fwd(self.act, u2)
-        a3 = _lin(h2, P[net + ".lin3.weight"], P[net + ".lin3.bias"])
+        if net == "disc":     # the discriminator's 1-unit output layer is a dot product on the vector units: fp32 in every mode
+            a3 = _lin(h2, P[net + ".lin3.weight"], P[net + ".lin3.bias"])
+        else:
+            a3 = self._linear(h2, P[net + ".lin3.weight"], P[net + ".lin3.bias"])
         return a3, dict(x0=x0, d1=d1, d2=d2, u1=u1, h1=h1, u2=u2, h2=h2)
 
     def _mlp_bwd(self, net, g3, cache, need_dx=True):
         """Given dL/da3 -> grads of lin3/lin2/lin1 (lin1 weight grad returned as da1), dL/dx0."""
-        P = self.p
-        G = {net + ".lin3.weight": (g3.T @ cache["h2"]).astype(f32), net + ".lin3.bias": g3.sum(0).astype(f32)}
-        gh2 = (g3 @ P[net + ".lin3.weight"]).astype(f32)
+        P, R = self.p, self._R
+        if net == "dec" and self.bf16:       # the decoder's output layer: its weight gradient is a matrix-core product too
+            G = {net + ".lin3.weight": (R(g3).T @ R(cache["h2"])).astype(f32), net + ".lin3.bias": R(g3).sum(0).astype(f32)}
+        else:
+            G = {net + ".lin3.weight": (g3.T @ cache["h2"]).astype(f32), net + ".lin3.bias": g3.sum(0).astype(f32)}
+        gh2 = (g3 @ P[net + ".lin3.weight"]).astype(f32) if net == "disc" else (R(g3) @ R(P[net + ".lin3.weight"])).astype(f32)
         ga2 = cache["d2"].bwd(act_bwd(self.act, cache["u2"], cache["h2"], gh2))
         G[net + ".lin2.weight"] = (ga2.T @ cache["h1"]).astype(f32)
         G[net + ".lin2.bias"] = ga2.sum(0).astype(f32)
-        gh1 = (ga2 @ P[net + ".lin2.weight"]).astype(f32)
+        gh1 = (R(ga2) @ R(P[net + ".lin2.weight"])).astype(f32)
         ga1 = cache["d1"].bwd(act_bwd(self.act, cache["u1"], cache["h1"], gh1))
         G[net + ".lin1.bias"] = ga1.sum(0).astype(f32)
-        gx = (ga1 @ P[net + ".lin1.weight"]).astype(f32) if need_dx else None
+        gx = (R(ga1) @ R(P[net + ".lin1.weight"])).astype(f32) if need_dx else None
         return G, ga1, gx
 
     def _enc_final_fwd(self, a3):

@@ -16,8 +16,8 @@ TOL_PARAM = 5e-6
 def build_oracle(fx):
     conds = []
     cond = fx.cfg["cond"]
-    if cond.startswith("concat") and cond.split("+")[0][6:].isdigit():     # "concat30", "concat300", "concat30+bias"
-        conds.append(O.ConcatConst(int(cond.split("+")[0][6:])))
+    if cond.startswith("concat") and cond.split("+")[0][6:].isdigit() and "cat" not in fx.cfg:
+        conds.append(O.ConcatConst(int(cond.split("+")[0][6:])))               # "concat30", "concat300", "concat30+bias"
     if cond == "concat30+bias":
         conds.append(O.BiasConst())
     if cond == "categorical":
