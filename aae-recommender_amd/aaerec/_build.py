@@ -30,7 +30,8 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + \
-          [os.path.join(CSRC, f) for f in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"]
+          [os.path.join(CSRC, f) for f in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"] + \
+          os.environ.get("AAE_HIPCC_FLAGS", "").split()        # (experiments: extra -D switches)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -182,13 +182,13 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
     m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 16);
     m->P[P_V2] = a.mat(h, h + 1, m->ldh, 16);
-    m->P[P_V3] = a.mat(N, h + 1, m->ldh, kTI);      // (+ one tile of zero rows: dec_fused_bf16.h reads whole tiles unclamped)
+    m->P[P_V3] = a.mat(N, h + 1, m->ldh, 2 * kTI);  // (+ two tiles of padding rows: dec_fused_bf16.h reads whole tiles unclamped and parks the stores of lanes without a cell there)
     m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 16);
     m->P[P_D2] = a.mat(h, h + 1, m->ldh, 16);
     m->P[P_D3] = a.mat(1, h + 1, m->ldh, 16);
     for (int i = 0; i < NP; ++i) {
-        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? kTI : 0);
-        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? kTI : 0);
+        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
+        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     }
     for (int i = P_W1T; i <= P_W3; ++i) {
         m->M[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
@@ -196,7 +196,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     }
     m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
     if (c.grad_mode == AAE_GRAD_EXPORT)
-        for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+        for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->pt_ok[i] = false; }
     if (h + 1 <= 208 && cp + 1 <= 208 && c.reserved[2] != 3)          // layer-chain models (not the VAE's programs)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
@@ -644,6 +644,7 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 // as one extra workgroup (chain.h), off the critical path.
 static bool fused_decoder_applies(const aae_model* m) {
     return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB &&
+           (!m->bf16 || ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31)) &&
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes(m->rows, m->h)) <= 160 * 1024;
 }
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
@@ -1343,7 +1344,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
     const size_t fused_lds = m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(B, h);
     const float* chain_part = nullptr; size_t chain_stride = 0;
-    if (m->fused_ok && !m->force_unfused && B <= 16 * kMB && fused_lds <= 160 * 1024) {
+    if (fused_decoder_applies(m)) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
         const int ntiles = (N + kTI - 1) / kTI;
         if (m->buckets_valid) {
@@ -1375,16 +1376,16 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         static unsigned long long* ts_dev = nullptr;
         fa.ts = nullptr;
         if (want_ts) {
-            if (!ts_dev && hipMalloc(&ts_dev, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
+            if (!ts_dev && hipMalloc(&ts_dev, 128 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
             fa.ts = ts_dev;
         }
         const int grid = std::min(ntiles, m->n_cu);
         {
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
             if (m->bf16) switch (m->fused_nb) {
-                case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
-                case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
-                default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
+                case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
+                default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
             } else switch (m->fused_nb) {
                 case 4: hipLaunchKernelGGL(dec_fused_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
                 case 7: hipLaunchKernelGGL(dec_fused_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
@@ -1393,13 +1394,20 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         }
         LAUNCHCHK("dec_fused");
         if (want_ts) {
-            unsigned long long t[16];
+            unsigned long long t[128];
             hipStreamSynchronize(s);
             hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+            if (m->bf16)
+                for (int k = 0; k < 5; ++k) {
+                    fprintf(stderr, "[dec_fused_bf16 arrivals at barrier %d, us after the unit's start]", k);
+                    for (int w = 0; w < 16; ++w) fprintf(stderr, " %.2f", ((double)t[16 + 16 * k + w] - (double)t[0]) * 0.01);
+                    fprintf(stderr, "\n");
+                }
             fprintf(stderr, "[dec_fused tile 5] S0=%.2f GEMM1+BCE0=%.2f entries=%.2f GEMM2+GEMM3=%.2f S5=%.2f | tile=%.2f us, %.0f shader clocks -> %.2f GHz\n",
                     (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
                     (t[6] - t[4]) * 0.01, (t[6] - t[0]) * 0.01, (double)(t[9] - t[8]),
                     (double)(t[9] - t[8]) / ((t[6] - t[0]) * 10.0));
+            if (m->bf16) fprintf(stderr, "[dec_fused_bf16 S0] barrier A=%.2f work=%.2f barrier B=%.2f us\n", (t[14] - t[0]) * 0.01, (t[15] - t[14]) * 0.01, (t[1] - t[15]) * 0.01);
             fprintf(stderr, "[dec_fused wg 0] prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
                     (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
                     (t[12] - t[7]) * 0.01);

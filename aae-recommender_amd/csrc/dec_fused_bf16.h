@@ -15,15 +15,20 @@
 //   every image is "k-contiguous": a lane's 8 k-values of a 16x16x32 fragment are two 8-byte LDS reads; row strides
 //   are 4 * odd dwords, which puts the 32 lanes of a ds_read_b64 half-wave on 32 distinct bank pairs.
 //
-//   per tile, one persistent 512-thread workgroup per CU (8 waves, 2 per SIMD: the 256-register budget holds the
-//   wave's share of dh2^T, of the dA2 accumulators and three tiles' worth of parameter / moment stream in flight
-//   without spilling - a scratch reload would wait for every older global load), 4 LDS-only barriers:
-//     S0     this tile's V3a (registers, requested one tile ahead) -> v3K, v3T; request V3a(t+1), m(t), v(t)
+//   per unit of 16 items (half a 32-item tile of the entry buckets), one persistent 1024-thread workgroup per CU, 4
+//   LDS-only barriers.  16-item units keep a wave's share of the parameter / moment stream at ONE float4 slot per
+//   stream (16 waves x 128 registers: with 32-item units the kernel spilled, and a scratch reload waits for every
+//   older global load; 8 waves x 256 registers ran at half the issue rate: the phases are instruction-issue bound):
+//     S0     this unit's V3a (registers, requested one unit ahead) -> v3K, v3T; request V3a(u+1), m(u), v(u)
 //     GEMM1  logits[b][n] = dhA * v3K^T; epilogue: zero-target BCE -> gK, gT (bf16), raw logits (fp32), loss
 //     S2     the tile's CSR entries (non-zero targets) patch their cells
-//     GEMM2  dV3a^T[c][n] = dhT * gT^T: the accumulator layout (4 consecutive c of one item per lane) is the layout
-//            the wave loaded p / m / v in, so dec_optim (Adam) runs on the accumulators and stores float4 - no
-//            staging tile, no barrier;   GEMM3  dA2[b][c] += gK * v3T^T (fp32 accumulators across the tiles)
+//     GEMM2  dV3a^T[c][n] = dhT * gT^T -> fp32 staging tile os [n][c] (one 16-byte LDS write per lane);
+//            GEMM3  dA2[b][c] += gK * v3T^T (fp32 accumulators across the units)
+//     S5     dec_optim (Adam) on the unit in the tensors' own row-major order: thread t owns the t-th float4 of the
+//            unit's contiguous 13 KB span of V3a / m / v - every global load and store of the kernel is a fully
+//            coalesced 1 KB wave access.  (Loading the stream in GEMM2's accumulator layout instead - no staging tile,
+//            one barrier less - made every 16-lane group of a load touch 16 different cache lines: the vector-memory
+//            unit then needed ~2 us per unit just to take the loads, 4x the coalesced cost.)
 #pragma once
 #include "dec_fused.h"
 
@@ -41,6 +46,13 @@ __device__ __forceinline__ unsigned bf16_pack(float a, float b) {
 }
 __device__ __forceinline__ unsigned short bf16_bits(float a) { return (unsigned short)(bf16_pack(a, 0.f) & 0xFFFFu); }
 
+// adam_update() without the per-element optimiser test
+__device__ __forceinline__ void adam_only(float& p, float& m, float& v, float g, const OptScalars& s) {
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f + (0.001f * g) * g;
+    p = p + (s.neg_step_size * m) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * s.inv_bc2_sqrt + 1e-8f);
+}
+
 // row stride (dwords) of a k-contiguous bf16 image with kc 32-wide k-steps: 16 * kc + 4 (= 4 * odd)
 __host__ __device__ constexpr int bf_stride(int kc) { return 16 * kc + 4; }
 
@@ -54,49 +66,53 @@ __device__ __forceinline__ bf16x8 bf_frag(const unsigned* img, int row, int S, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
-constexpr int kBfSR = 33;      // row stride (floats) of the raw-logit tile [b][n]
-
-// LDS bytes for (B, NB)
-inline size_t dec_fused_bf16_lds_bytes(int NB) {
-    const int KC1 = (NB + 1) / 2, S1 = bf_stride(KC1), S2 = bf_stride(4), S3 = bf_stride(1);
-    return sizeof(float) * ((size_t)kGR * S1 + (size_t)kTI * S1 + (size_t)16 * NB * S3 + (size_t)kGR * S3 +
-                            (size_t)kTI * S2 + (size_t)kGR * kBfSR + 64);
-}
-
-constexpr int kBT = 512;       // threads per workgroup
+constexpr int kBfSR = 17;      // row stride (floats) of the raw-logit tile [b][n]
+// The transposed V3a image v3T [c][n] (k = item) is WRITTEN by threads that hold 4 consecutive columns c of one item:
+// consecutive lanes are 4 image rows apart, and with plain rows any even stride puts all 64 lanes of a 16-bit write on
+// two banks (4 * 20 dwords = 16 mod 32).  Rows therefore go in blocks of four with a block stride of 66 dwords
+// (2 mod 32): the lanes of a write walk the banks in steps of 2.
+__host__ __device__ constexpr int vt_off(int c) { return (c >> 2) * 66 + (c & 3) * 16; }   // dword offset of row c (32 halfword slots)
+constexpr int kBU = 16;        // items per unit
+constexpr int kBT = 1024;      // threads per workgroup
 constexpr int kBW = kBT / 64;  // waves
 
-template <int NB>   // NB = ceil((h + 1) / 16) column blocks
+// LDS bytes for NB column blocks
+inline size_t dec_fused_bf16_lds_bytes(int NB) {
+    const int KC1 = (NB + 1) / 2, S1 = bf_stride(KC1), S2 = bf_stride(4), S3 = bf_stride(1);
+    return sizeof(float) * ((size_t)kGR * S1 + (size_t)kBU * S1 + (size_t)vt_off(16 * NB) + (size_t)kGR * S3 +
+                            (size_t)kBU * S2 + (size_t)2 * kGR * kBfSR + (size_t)kBU * kSO + 64);
+}
+
+template <int NB>   // NB = ceil((h + 1) / 16) column blocks (<= 16)
 __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
     constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
     constexpr int KR = 4;                       // 32-wide k-steps over the (<= 112 -> 128) batch rows
     constexpr int S1 = bf_stride(KC1), S2 = bf_stride(KR), S3 = bf_stride(1);
-    // Ownership.  GEMM1: wave w < row blocks owns row block w (both item halves).  Everything that touches the
-    // parameter stream - the V3a / m / v loads, the LDS images of the tile, GEMM2 + optimiser, GEMM3 - is owned by
-    // column block: wave w owns column blocks w, w + 8 (QC of them), each as 2 float4 slots per lane (item n = 16 ib +
-    // fr, columns 16 cb + 4 fk ..+3): exactly the accumulator layout of GEMM2 (rows = columns c, cols = items).
-    constexpr int QC = (NB + kBW - 1) / kBW;
-    constexpr int NS = 2 * QC;                  // float4 slots per lane and stream
+    static_assert(NB <= kBW, "one column block per wave");
+    // Ownership.  GEMM1: wave w < row blocks owns row block w.  GEMM2 / GEMM3: wave w < NB owns column block w.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned* dhA = reinterpret_cast<unsigned*>(lds);          // [kGR][S1]   dh2, k = hidden column
-    unsigned* v3K = dhA + kGR * S1;                             // [32][S1]    V3a tile, k = hidden column
-    unsigned* v3T = v3K + kTI * S1;                             // [16 NB][S3] V3a tile transposed, k = item
-    unsigned* gK = v3T + 16 * NB * S3;                          // [kGR][S3]   G, k = item
-    unsigned* gT = gK + kGR * S3;                               // [32][S2]    G transposed, k = batch row
-    float* raw = reinterpret_cast<float*>(gT + kTI * S2);       // [kGR][kBfSR] raw logits (fp32) for the entry patch
-    float* red = raw + kGR * kBfSR;                             // [64]
+    unsigned* v3K = dhA + kGR * S1;                             // [16][S1]    V3a unit, k = hidden column
+    unsigned* v3T = v3K + kBU * S1;                             // [16 NB] rows at vt_off(c): V3a unit transposed, k = item (16 of 32 used)
+    unsigned* gK = v3T + vt_off(16 * NB);                          // [kGR][S3]   G, k = item (16 of 32 used)
+    unsigned* gT = gK + kGR * S3;                               // [16][S2]    G transposed, k = batch row
+    float* raw = reinterpret_cast<float*>(gT + kBU * S2);       // [2][kGR][kBfSR] raw logits (fp32): the two k-halves of GEMM1
+    float* os = raw + 2 * kGR * kBfSR;                          // [16][kSO]   dV3a of the unit (fp32), row-major like the tensor
+    float* red = os + kBU * kSO;                                // [64]
 
     const int tid = threadIdx.x, lane = tid & 63;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     const int B = a.B, ldv = a.ldv, N = a.N;
     const int nmb = (B + 15) >> 4;
-    const int ntiles = (N + kTI - 1) / kTI;
+    const int ntiles = (N + kTI - 1) / kTI;     // 32-item tiles of the entry buckets
+    const int nunits = (N + kBU - 1) / kBU;
     const OptScalars sc = *a.sc;
     const bool do_adam = a.gradV3 == nullptr;
 
     // ---- once per workgroup: LDS images of dh2 (zero padded), zeroed G images, zero k-padding of the V3a images
-    for (int i = tid; i < kGR * S1 + kTI * S1 + 16 * NB * S3 + kGR * S3 + kTI * S2; i += kBT) dhA[i] = 0u;
+    for (int i = tid; i < kGR * S1 + kBU * S1 + vt_off(16 * NB) + kGR * S3 + kBU * S2; i += kBT) dhA[i] = 0u;
     __syncthreads();
     {
         const int f4 = a.ldh >> 2;
@@ -107,213 +123,269 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
         }
     }
     __syncthreads();
-    // dh2 transposed, in registers: for each owned column block the fragment rows c = 16 cb + fr, k = batch row,
-    // picked out of the (zero padded, already rounded) dhA image: no masks, no second pass over global memory
-    bf16x8 dhT[QC][KR];
+    const bool own = wave < NB;                 // this wave owns a column block
+    const int cb = min(wave, NB - 1);
+    // dh2 transposed, in registers: fragment rows c = 16 cb + fr, k = batch row, picked out of the (zero padded,
+    // already rounded) dhA image: no masks, no second pass over global memory
+    bf16x8 dhT[KR];
     {
         const unsigned short* a16 = reinterpret_cast<const unsigned short*>(dhA);
+        const int c = 16 * cb + fr;
 #pragma unroll
-        for (int j = 0; j < QC; ++j) {
-            const int c = 16 * min(wave + kBW * j, NB - 1) + fr;
+        for (int kc = 0; kc < KR; ++kc) {
+            unsigned h[8];
 #pragma unroll
-            for (int kc = 0; kc < KR; ++kc) {
-                unsigned h[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int b = 32 * kc + 4 * fk + (e & 3) + ((e >> 2) << 4);          // < kGR unless kc == 3 && e >= 4
-                    h[e] = (32 * kc + ((e >> 2) << 4) + 15 < kGR) ? (unsigned)a16[b * (2 * S1) + c] : 0u;
-                }
-                const u32x4_t v = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-                dhT[j][kc] = __builtin_bit_cast(bf16x8, v);
+            for (int e = 0; e < 8; ++e) {
+                const int b = 32 * kc + 4 * fk + (e & 3) + ((e >> 2) << 4);          // < kGR unless kc == 3 && e >= 4
+                h[e] = (32 * kc + ((e >> 2) << 4) + 15 < kGR) ? (unsigned)a16[b * (2 * S1) + c] : 0u;
             }
+            const u32x4_t v = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            dhT[kc] = __builtin_bit_cast(bf16x8, v);
         }
     }
-    f32x4 acc3[QC][kMB];
+    f32x4 acc3[kMB];
 #pragma unroll
-    for (int j = 0; j < QC; ++j)
-#pragma unroll
-        for (int q = 0; q < kMB; ++q) acc3[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < kMB; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float loss = 0.f;
 
-    // slot s = 2 j + ib: column block cb = wave + 8 j, item half ib.  Addressing: a wave-uniform base (scalar registers:
-    // tensor + tile + slot) plus ONE per-lane byte offset shared by every load and store of the kernel.  Nothing is
-    // clamped: the arena keeps kTI zero rows behind V3a and its moments (layout(): pad_rows), so the tail tile's rows
-    // >= N and the float4 behind a row's last column are readable (and never stored, never used).
-    const unsigned lane_off = (unsigned)(fr * ldv + 4 * fk) * 4u;
-    auto slot_c0 = [&](int s) { return 16 * (wave + kBW * (s >> 1)) + 4 * fk; };
-    auto slot_ok = [&](int s) { return wave + kBW * (s >> 1) < NB && slot_c0(s) < ldv; };   // (ldv % 4 == 0)
-    auto slot_ptr = [&](float* P, int tile, int s) -> char* {          // wave-uniform part of a slot's address
-        return reinterpret_cast<char*>(P + ((size_t)tile * kTI + 16 * (s & 1)) * ldv + 16 * (wave + kBW * (s >> 1)));
+    // The parameter stream: thread t owns the t-th float4 of a unit's contiguous span (16 rows x ldv floats) of V3a, m
+    // and v.  Addressing: tensor base in a buffer resource descriptor (scalar registers), the unit's byte offset in a
+    // scalar register, t * 16 in ONE vector register for every access of the kernel.  Nothing is clamped: the arena
+    // keeps 2 * kTI padding rows behind V3a, its moments and its gradient (layout(): pad_rows), so the last unit's
+    // rows >= N are readable (never used).  A store without a cell (threads beyond the span, rows beyond the
+    // vocabulary, the moments in SGD / export mode) gets a vector offset beyond the descriptor's range and is dropped
+    // by the buffer unit's bounds check (raw buffer: offset >= num_records; tensors are kept below 2 GB by the
+    // dispatcher): no branch around any load or store, so the compiler's wait counters stay exact and a wait for an
+    // older load never has to cover younger stores.
+    const int f4_row = ldv >> 2, nf4 = kBU * f4_row;       // float4 per row / per unit (<= 1024: ldv <= 256)
+    const int tq = min(tid, nf4 - 1);
+    const int t_n = tq / f4_row, t_c0 = 4 * (tq - t_n * f4_row);   // this thread's item (row of the unit) and first column
+    const bool t_ok = tid < nf4;
+    const unsigned lane_off = (unsigned)tq * 16u;
+    constexpr unsigned kOob = 0x80000000u;
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, ((size_t)N + 2 * kTI) * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
+    auto unit_so = [&](int u) -> unsigned {               // byte offset of unit u (uniform)
+        if (a.dbg_skip & 128) u = blockIdx.x;             // timing-only ablation: L2-resident units
+        return (unsigned)((size_t)u * kBU * ldv) * 4u;
     };
-    auto ld4 = [&](float* P, int tile, int s) { return *reinterpret_cast<const float4*>(slot_ptr(P, tile, s) + lane_off); };
-    auto st4 = [&](float* P, int tile, int s, float4 v) { *reinterpret_cast<float4*>(slot_ptr(P, tile, s) + lane_off) = v; };
-    float4 p_cur[NS], p_nxt[NS], mreg[NS], sreg[NS];
-    int tile = blockIdx.x;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int u) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, unit_so(u), 0));
+    };
+    float4 p_cur, p_nxt, mreg, sreg;
+    int unit = blockIdx.x;
     const int stride = gridDim.x;
     const int last_e = max(a.te.start[ntiles] - 1, 0);
-    auto load_range = [&](int t, int& lo, int& hi) {
-        const int tc = min(t, ntiles - 1);
+    // (VECTOR loads through an index the compiler cannot prove uniform: a scalar load would sit in lgkmcnt, and the
+    // LDS-only barriers - s_waitcnt lgkmcnt(0) - would wait out its L2 round trip once per unit)
+    int oz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    auto load_range = [&](int u, int& lo, int& hi) {
+        const int tc = min(u >> 1, ntiles - 1) + oz;
         lo = a.te.start[tc]; hi = a.te.start[tc + 1];
-        if (t >= ntiles) hi = lo;
+        if (u >= nunits) hi = lo;
     };
+    // The entry lists: ONE wave prefetches ranges (two units ahead) and the first 64 entries of the next unit's
+    // tile (64 covers all but degenerate vocabularies: C3 has < 1 entry per tile) - as per-thread work of all 16 waves
+    // these five small loads per wave were 80 of the 128 vector-memory instructions of a unit.  The range of the
+    // running unit reaches the other waves through LDS (red[32..33]); entries beyond the first 64 are read in place.
+    const int ewave = (a.dbg_skip & 64) ? kBW - 1 : 0;      // (A/B: 120-128 us with wave 0, 128-140 with the last wave)
     int ce0 = 0, ce1 = 0, ne0 = 0, ne1 = 0, fe0 = 0, fe1 = 0;
     int ent_b = 0, ent_n = 0; float ent_v = 0.f;
     auto load_entry = [&](int lo) {
-        const int e = min(lo + tid, last_e);
+        const int e = min(lo + lane, last_e);
         ent_b = a.te.eb[e]; ent_n = a.te.en[e]; ent_v = a.te.ev[e];
     };
-    if (tile < ntiles) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) p_nxt[s] = ld4(a.V3a, tile, s);
-        load_range(tile, ne0, ne1);
-        load_range(tile + stride, fe0, fe1);
-        load_entry(ne0);
+    if (unit < nunits) {
+        p_nxt = ld4(rP, unit);
+        if (wave == ewave) {
+            load_range(unit, ne0, ne1);
+            load_range(unit + stride, fe0, fe1);
+            load_entry(ne0);
+        }
     }
     __syncthreads();
+    // debug (AAE_DEC_TS): 100 MHz phase timestamps of workgroup 0, its eleventh unit
+    int iter = 0;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[11] = wall_clock64();
+    // (debug) arrival of every wave at barrier k of that unit: ts[16 + 16 k + wave]
+    auto wstamp = [&](int k) { if (a.ts && blockIdx.x == 0 && lane == 0 && iter == 10) a.ts[16 + 16 * k + wave] = wall_clock64(); };
+    auto stamp = [&](int k) { if (a.ts && blockIdx.x == 0 && tid == 0 && iter == 10) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
 
-    for (; tile < ntiles; tile += stride) {
-        const int i0 = tile * kTI;
-        lds_barrier();                                  // the previous tile's readers of v3K / v3T / gK / gT are done
-        // ---- S0: this tile's V3a (fp32 registers) -> bf16 LDS images; rotate the pipeline, request the next stage
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            p_cur[s] = p_nxt[s];
-            if (slot_ok(s)) {
-                const int n = 16 * (s & 1) + fr, c0 = slot_c0(s);
-                float4 p = p_cur[s];
-                if (i0 + n >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<uint2*>(v3K + n * S1 + (c0 >> 1)) = make_uint2(bf16_pack(p.x, p.y), bf16_pack(p.z, p.w));
-                unsigned short* t16 = reinterpret_cast<unsigned short*>(v3T);
-                t16[(c0 + 0) * (2 * S3) + n] = bf16_bits(p.x);
-                t16[(c0 + 1) * (2 * S3) + n] = bf16_bits(p.y);
-                t16[(c0 + 2) * (2 * S3) + n] = bf16_bits(p.z);
-                t16[(c0 + 3) * (2 * S3) + n] = bf16_bits(p.w);
-            }
+    for (; unit < nunits; unit += stride, ++iter) {
+        const int i0 = unit * kBU, half = unit & 1;
+        const int par = iter & 1;                         // which k-half of gK / v3T this unit fills (GEMM3 runs on every second unit)
+        stamp(0);
+        lds_barrier();                                  // the previous unit's readers of v3K / v3T / gK / gT are done
+        stamp(14);
+        // ---- S0: rotate the pipeline and request the next stage FIRST (the vector-memory unit takes ~0.5 us to accept
+        // the 48 KB burst of a unit's loads: the image building below runs beside that), then this unit's V3a (fp32
+        // registers) -> bf16 LDS images
+        int my_b = 0, my_n = 0; float my_v = 0.f;
+        if (wave == ewave) {
+            ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
+            my_b = ent_b; my_n = ent_n; my_v = ent_v;
+            if (lane == 0) { reinterpret_cast<int*>(red)[32] = ce0; reinterpret_cast<int*>(red)[33] = ce1; }
+            load_range(unit + 2 * stride, fe0, fe1);
+            load_entry(ne0);
         }
-        ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
-        const int my_b = ent_b, my_n = ent_n; const float my_v = ent_v;
-        {
-            const int tn = min(tile + stride, ntiles - 1);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                // (all three unconditional - the moment tensors exist in every mode: a load under a condition is waited
-                // for on the spot and its result is carried in duplicate registers down both paths)
-                p_nxt[s] = ld4(a.V3a, tn, s);
-                mreg[s] = ld4(a.M, tile, s);
-                sreg[s] = ld4(a.V, tile, s);
-            }
+        p_cur = p_nxt;
+        // (all three unconditional - the moment tensors exist in every mode: a load under a condition is waited for on
+        // the spot and its result is carried in duplicate registers down both paths)
+        p_nxt = ld4(rP, min(unit + stride, nunits - 1));
+        mreg = ld4(rM, unit);
+        sreg = ld4(rV, unit);
+        if (t_ok) {
+            float4 p = p_cur;
+            if (i0 + t_n >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<uint2*>(v3K + t_n * S1 + (t_c0 >> 1)) = make_uint2(bf16_pack(p.x, p.y), bf16_pack(p.z, p.w));
+            unsigned short* t16 = reinterpret_cast<unsigned short*>(v3T) + 2 * vt_off(t_c0) + 16 * par + t_n;   // (t_c0 % 4 == 0: one block)
+            t16[0] = bf16_bits(p.x);
+            t16[32] = bf16_bits(p.y);
+            t16[64] = bf16_bits(p.z);
+            t16[96] = bf16_bits(p.w);
         }
-        load_range(tile + 2 * stride, fe0, fe1);
-        load_entry(ne0);
+        wstamp(4);
+        stamp(15);
+        wstamp(1);
         lds_barrier();
+        stamp(1);
 
-        // ---- GEMM1: logits[b][n] for the wave's row block, both item halves; epilogue = BCE against a zero target
-        if (wave < nmb) {
-            const int mb = wave;
-            f32x4 c[2];
-            c[0] = c[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- GEMM1: logits[b][n]: wave w < 14 takes row block w >> 1 and every second k-step (w & 1) -> its half's raw
+        // tile (fp32; the BCE phase adds the halves).  C map: row = 4 fk + r -> batch row, col = fr -> item
+        if (wave < 2 * kMB) {
+            const int mb = wave >> 1, kh = wave & 1;
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const unsigned* pa = dhA + (16 * mb + fr) * S1 + 2 * fk + 16 * kh;
+            const unsigned* pb = v3K + fr * S1 + 2 * fk + 16 * kh;
 #pragma unroll
-            for (int kc = 0; kc < KC1; ++kc) {
-                const bf16x8 x = bf_frag(dhA, 16 * mb + fr, S1, kc, fk);
-                c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bf_frag(v3K, fr, S1, kc, fk), c[0], 0, 0, 0);
-                c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bf_frag(v3K, 16 + fr, S1, kc, fk), c[1], 0, 0, 0);
-                // (two k-steps of fragment reads in flight at a time: left alone the scheduler hoists all 21 fragments
-                // of the phase above its first MFMA - 84 registers on top of ~150 persistent ones - and spills)
-                if (kc & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            // C map: row = 4 fk + r -> batch row, col = fr -> item
-            const int rb = 16 * mb + 4 * fk;
-            unsigned short* k16 = reinterpret_cast<unsigned short*>(gK);
+            for (int j = 0; j < (KC1 + 1) / 2; ++j)
+                if (2 * j + kh < KC1)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_frag(pa, 0, 0, 2 * j, 0), bf_frag(pb, 0, 0, 2 * j, 0), c, 0, 0, 0);
+            float* rw = raw + kh * (kGR * kBfSR) + (16 * mb + 4 * fk) * kBfSR + fr;
 #pragma unroll
-            for (int nb2 = 0; nb2 < 2; ++nb2) {
-                const int n = 16 * nb2 + fr;
-                const bool item_ok = i0 + n < N;
-                float g[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float l = 0.f;
-                    g[r] = 0.f;
-                    if (rb + r < B) {
-                        if (item_ok) bce_elem_t0(c[nb2][r], a.gscale, g[r], l);
-                        raw[(rb + r) * kBfSR + n] = c[nb2][r];
-                        k16[(rb + r) * (2 * S3) + n] = bf16_bits(g[r]);
-                        loss += l;
-                    }
-                }
-                *reinterpret_cast<uint2*>(gT + n * S2 + (rb >> 1)) = make_uint2(bf16_pack(g[0], g[1]), bf16_pack(g[2], g[3]));
-            }
+            for (int r = 0; r < 4; ++r) rw[r * kBfSR] = c[r];
         }
+        wstamp(2);
         lds_barrier();
-
-        // ---- S2: the CSR entries of the tile (non-zero targets) replace their cell's gradient and loss term
+        stamp(2);
+        // ---- BCE against a zero target, every thread: cell id = tid + 1024 j -> (b = id >> 4, n = id & 15); dL/dlogit
+        // -> gK, gT (bf16), loss.  (As GEMM1's epilogue the 7 waves that own a row block did this alone.)
         {
             unsigned short* k16 = reinterpret_cast<unsigned short*>(gK);
             unsigned short* t16 = reinterpret_cast<unsigned short*>(gT);
-            auto patch = [&](int b, int n, float v) {
-                const float lg = raw[b * kBfSR + n];
+#pragma unroll
+            for (int j = 0; j < (kGR * kBU + kBT - 1) / kBT; ++j) {
+                const int id = tid + kBT * j, b = id >> 4, n = id & 15;
+                if (b < B) {
+                    float g, l;
+                    bce_elem_t0(raw[b * kBfSR + n] + raw[kGR * kBfSR + b * kBfSR + n], a.gscale, g, l);
+                    const bool ok = i0 + n < N;
+                    g = ok ? g : 0.f;
+                    loss += ok ? l : 0.f;
+                    const unsigned short hb = bf16_bits(g);
+                    k16[b * (2 * S3) + 16 * par + n] = hb;
+                    t16[n * (2 * S2) + b] = hb;
+                }
+            }
+        }
+        wstamp(3);
+        lds_barrier();
+
+        // ---- S2: the CSR entries of this half of the 32-item tile (non-zero targets) replace their cell's gradient
+        // and loss term
+        {
+            unsigned short* k16 = reinterpret_cast<unsigned short*>(gK);
+            unsigned short* t16 = reinterpret_cast<unsigned short*>(gT);
+            auto patch = [&](int b, int n32, float v) {
+                if ((n32 >> 4) != half) return;
+                const int n = n32 & 15;
+                const float lg = raw[b * kBfSR + n] + raw[kGR * kBfSR + b * kBfSR + n];
                 float g0, l0, g1, l1;
                 bce_elem_t0(lg, a.gscale, g0, l0);
                 bce_elem(lg, v, a.gscale, g1, l1);
                 loss += l1 - l0;
                 const unsigned short h = bf16_bits(g1);
-                k16[b * (2 * S3) + n] = h;
+                k16[b * (2 * S3) + 16 * par + n] = h;
                 t16[n * (2 * S2) + b] = h;
             };
-            if (tid < ce1 - ce0) patch(my_b, my_n, my_v);
-            for (int e = ce0 + kBT + tid; e < ce1; e += kBT) patch(a.te.eb[e], a.te.en[e], a.te.ev[e]);
+            if (wave == ewave && lane < ce1 - ce0) patch(my_b, my_n, my_v);
+            const int r0 = reinterpret_cast<const int*>(red)[32], r1 = reinterpret_cast<const int*>(red)[33];
+            for (int e = r0 + 64 + tid; e < r1; e += kBT) patch(a.te.eb[e], a.te.en[e], a.te.ev[e]);
         }
         lds_barrier();
+        stamp(3);
 
-        // ---- GEMM2 + optimiser: dV3a^T[c][n] = sum_b dh2[b][c] G[b][n]; lane holds columns c0..c0+3 of item n
+        // ---- GEMM2: dV3a^T[c][n] = sum_b dh2[b][c] G[b][n]; lane holds columns 16 cb + 4 fk ..+3 of item fr -> os
+        if (own) {
+            f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (wave + kBW * (s >> 1) < NB) {           // (wave-uniform)
-                const int ib = s & 1;
-                f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kc = 0; kc < KR; ++kc)
-                    g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dhT[s >> 1][kc], bf_frag(gT, 16 * ib + fr, S2, kc, fk), g, 0, 0, 0);
-                if (slot_c0(s) < ldv && i0 + 16 * ib + fr < N) {
-                    if (!do_adam) {
-                        st4(a.gradV3, tile, s, make_float4(g[0], g[1], g[2], g[3]));
-                    } else {
-                        float4 p = p_cur[s], mm = mreg[s], vv = sreg[s];
-                        adam_update(p.x, mm.x, vv.x, g[0], sc); adam_update(p.y, mm.y, vv.y, g[1], sc);
-                        adam_update(p.z, mm.z, vv.z, g[2], sc); adam_update(p.w, mm.w, vv.w, g[3], sc);
-                        st4(a.V3a, tile, s, p);
-                        if (!sc.is_sgd) {
-                            st4(a.M, tile, s, mm);
-                            st4(a.V, tile, s, vv);
-                        }
-                    }
-                }
-            }
+            for (int kc = 0; kc < KR; ++kc)
+                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dhT[kc], bf_frag(gT, fr, S2, kc, fk), g, 0, 0, 0);
+            if (16 * cb + 4 * fk < kSO)
+                *reinterpret_cast<float4*>(os + fr * kSO + 16 * cb + 4 * fk) = make_float4(g[0], g[1], g[2], g[3]);
         }
-        // ---- GEMM3: dA2[b][c] += sum_n G[b][n] V3a[n][c] for the wave's column blocks, every row block
+        stamp(4);
+        // ---- GEMM3: dA2[b][c] += sum_n G[b][n] V3a[n][c] for the wave's column block, every row block, on every second
+        // unit: two units fill the two halves of the 32-wide k-step of gK / v3T (which items share a k-step is free)
+        auto gemm3 = [&]() {
+            const bf16x8 vt = bf_frag(v3T + vt_off(16 * cb + fr), 0, 0, 0, fk);
+            const unsigned* pg = gK + fr * S3 + 2 * fk;
 #pragma unroll
-        for (int j = 0; j < QC; ++j) {
-            if (wave + kBW * j < NB) {
-                const bf16x8 vt = bf_frag(v3T, 16 * (wave + kBW * j) + fr, S3, 0, fk);
-#pragma unroll
-                for (int q = 0; q < kMB; ++q)
-                    if (q < nmb)
-                        acc3[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_frag(gK, 16 * q + fr, S3, 0, fk), vt, acc3[j][q], 0, 0, 0);
+            for (int q = 0; q < kMB; ++q)       // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
+                acc3[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_frag(pg, 0, 0, 0, 0) , vt, acc3[q], 0, 0, 0), pg += 16 * S3;
+        };
+        if (own && par) gemm3();
+        wstamp(0);
+        lds_barrier();                                   // os complete
+        // ---- S5: optimiser on the unit in row-major order.  The three stores are issued on every path (see above).
+        {
+            const float4 g = *reinterpret_cast<const float4*>(os + t_n * kSO + t_c0);
+            const unsigned so = unit_so(unit);
+            const bool valid = t_ok && i0 + t_n < N;
+            float4 p = p_cur, mm = mreg, vv = sreg;
+            if (sc.is_sgd) {                              // (wave-uniform; arithmetic only)
+                p.x += sc.neg_step_size * g.x; p.y += sc.neg_step_size * g.y;
+                p.z += sc.neg_step_size * g.z; p.w += sc.neg_step_size * g.w;
+            } else {
+                adam_only(p.x, mm.x, vv.x, g.x, sc); adam_only(p.y, mm.y, vv.y, g.y, sc);
+                adam_only(p.z, mm.z, vv.z, g.z, sc); adam_only(p.w, mm.w, vv.w, g.w, sc);
             }
+            const float4 out = do_adam ? p : g;
+            const unsigned vo = valid ? lane_off : kOob;
+            const unsigned vo2 = (valid && do_adam && !sc.is_sgd) ? lane_off : kOob;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, out), do_adam ? rP : rG, vo, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, mm), rM, vo2, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv), rV, vo2, so, 0);
+        }
+        stamp(6);
+    }
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
+    if (iter & 1) {                                     // an odd number of units: the last one's half is still to be added
+        lds_barrier();
+        for (int i = tid; i < kGR * 8; i += kBT) gK[(i >> 3) * S3 + 8 + (i & 7)] = 0u;      // k-half 1 of gK <- 0
+        lds_barrier();
+        if (own) {
+            const bf16x8 vt = bf_frag(v3T + vt_off(16 * cb + fr), 0, 0, 0, fk);
+            const unsigned* pg = gK + fr * S3 + 2 * fk;
+#pragma unroll
+            for (int q = 0; q < kMB; ++q)
+                acc3[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_frag(pg, 0, 0, 0, 0) , vt, acc3[q], 0, 0, 0), pg += 16 * S3;
         }
     }
 
     // ---- dA2 partial of this workgroup -> its slab; loss partial
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    if (own) {
 #pragma unroll
-    for (int j = 0; j < QC; ++j) {
-        if (wave + kBW * j < NB) {
+        for (int q = 0; q < kMB; ++q) {
+            const int rb = q * 16 + fk * 4, cc = cb * 16 + fr;
 #pragma unroll
-            for (int q = 0; q < kMB; ++q) {
-                const int rb = q * 16 + fk * 4, cc = (wave + kBW * j) * 16 + fr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rb + r < B && cc < a.ld_slab) slab[(size_t)(rb + r) * a.ld_slab + cc] = acc3[j][q][r];
-            }
+            for (int r = 0; r < 4; ++r)
+                if (rb + r < B && cc < a.ld_slab) slab[(size_t)(rb + r) * a.ld_slab + cc] = acc3[q][r];
         }
     }
     loss = wave_sum(loss);
@@ -324,6 +396,7 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
         float s = 0.f;
         for (int w = 0; w < kBW; ++w) s += red[w];
         a.partials[blockIdx.x] = s;
+        if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
     }
 }
 

@@ -73,7 +73,7 @@ def test_bf16_fused_output_layer_matches_the_rounded_restatement(N, h, B):
         loss, da2 = emu.step(dh2, X[s * B:(s + 1) * B])
         np.testing.assert_allclose(sl.losses()[0], loss, rtol=1e-5)
         got = sl.da2_rows(B)[:, :h].cpu().numpy()
-        assert _maxdiff(got, da2) <= 5e-5 * float(np.abs(da2).max()) + 1e-12, (s, _maxdiff(got, da2), float(np.abs(da2).max()))
+        assert _maxdiff(got, da2) <= 2e-4 * float(np.abs(da2).max()) + 1e-12, (s, _maxdiff(got, da2), float(np.abs(da2).max()))
     sd = sl.state_dict()
     assert _maxdiff(sd["dec.lin3.weight"], emu.p["w"]) <= 1e-5
     assert _maxdiff(sd["dec.lin3.bias"], emu.p["b"]) <= 1e-5
