@@ -311,21 +311,22 @@ inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n +
 // GEMM wrappers (see gemm_f32.h for operand forms)
 // ------------------------------------------------------------------------------------------
 // Y[rows][out] = epi( X[rows][in+1] * Wa[out][in+1]^T )
+// bf: bf16 matrix-core inputs (cfg.reserved[3]); every forward and dX product of a Linear layer takes them
 template <class Epi>
-int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s) {
+int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s, bool bf = false) {
     GemmShape g{X, Wa.p, rows, (int)Wa.rows, (int)Wa.cols, ldx, (int)Wa.ld, r4((int)Wa.cols) + 16};
     g.k_per_split = ((int)Wa.cols + 63) / 64 * 64;
-    if (Wa.rows > 4096) (void)launch_gemm<0, 1, 16, 64>(g, epi, 1, s);   // vocabulary-wide: streaming regime
-    else (void)launch_gemm<0, 1, 64, 32>(g, epi, 1, s);
+    if (Wa.rows > 4096) (void)launch_gemm_mode<0, 1, true>(bf, g, epi, 1, s);   // vocabulary-wide: streaming regime
+    else (void)launch_gemm_mode<0, 1, false>(bf, g, epi, 1, s);
     LAUNCHCHK("linear_fwd");
     return AAE_OK;
 }
 // dX[rows][n_in] = epi( Gd[rows][out] * Wa[out][0:n_in] )
 template <class Epi>
-int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s) {
+int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s, bool bf = false) {
     GemmShape g{Gd, Wa.p, rows, n_in, (int)Wa.rows, ldg, (int)Wa.ld, 0};
     g.k_per_split = ((int)Wa.rows + 63) / 64 * 64;
-    (void)launch_gemm<0, 0, 64, 32>(g, epi, 1, s);
+    (void)launch_gemm_mode<0, 0, false>(bf, g, epi, 1, s);
     LAUNCHCHK("linear_dx");
     return AAE_OK;
 }
@@ -336,14 +337,17 @@ int linear_dw(aae_model* m, const float* Gd, int ldg, int rows, const float* X, 
     GemmShape g{Gd, X, (int)W.rows, (int)W.cols, rows, ldg, ldx, 0};
     g.k_per_split = (rows + 63) / 64 * 64;
     const bool big = W.rows > 4096;
+    // bf16 mode: of the weight gradients only the decoder output layer's is a bf16 product (the hidden layers' and the
+    // sparse first layer's stay fp32: they are launch-latency, not matrix-pipe, bound)
+    const bool bf = m->bf16 && pid == P_V3;
     if (m->cfg.grad_mode == AAE_GRAD_EXPORT) {
         EpiStore e; e.out = m->Gr[pid].p; e.ld = (int)W.ld;
-        if (big) (void)launch_gemm<1, 0, 16, 64>(g, e, 1, s); else (void)launch_gemm<1, 0, 64, 32>(g, e, 1, s);
+        if (big) (void)launch_gemm_mode<1, 0, true>(bf, g, e, 1, s); else (void)launch_gemm_mode<1, 0, false>(bf, g, e, 1, s);
     } else {
         const int set = (which == O_GEN) ? 1 : 0;
         EpiAdam e; e.p = W.p; e.m = m->M[set][pid].p; e.v = m->V[set][pid].p; e.ld = (int)W.ld; e.sc = m->sc + which;
         m->pt_ok[pid] = false;
-        if (big) (void)launch_gemm<1, 0, 16, 64>(g, e, 1, s); else (void)launch_gemm<1, 0, 64, 32>(g, e, 1, s);
+        if (big) (void)launch_gemm_mode<1, 0, true>(bf, g, e, 1, s); else (void)launch_gemm_mode<1, 0, false>(bf, g, e, 1, s);
     }
     LAUNCHCHK("linear_dw");
     return AAE_OK;
@@ -412,9 +416,9 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
     }
     EpiDropAct e2; e2.out = m->eh2.p; e2.ld = m->ldh; e2.act = m->cfg.activation; e2.d = d2; e2.seed = m->cfg.seed;
     e2.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->eh1.p, m->ldh, B, m->P[P_W2], e2, s));
+    TRY(linear_fwd(m->eh1.p, m->ldh, B, m->P[P_W2], e2, s, m->bf16));
     EpiStore e3; e3.out = z_dst; e3.ld = ldz_dst;
-    TRY(linear_fwd(m->eh2.p, m->ldh, B, m->P[P_W3], e3, s));
+    TRY(linear_fwd(m->eh2.p, m->ldh, B, m->P[P_W3], e3, s, m->bf16));
     if (m->cfg.enc_final != AAE_FINAL_LINEAR) {
         hipLaunchKernelGGL(final_act_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, z_dst, B, m->c, ldz_dst,
                            m->cfg.enc_final, (float*)nullptr, 0);
@@ -440,12 +444,12 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     // lin3: dX first (needs the old weights), then dW + update
     EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->eh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
     b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
-    TRY(linear_dx(ga3, ldga3, B, m->P[P_W3], h, b2, s));
+    TRY(linear_dx(ga3, ldga3, B, m->P[P_W3], h, b2, s, m->bf16));
     TRY(linear_dw(m, ga3, ldga3, B, m->eh2.p, m->ldh, P_W3, which, s));
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->eh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
-    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s));
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s, m->bf16));
     TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->eh1.p, m->ldh, P_W2, which, s));
     // lin1: sparse scatter into gW1T, bias column sum
     const int set = (which == O_GEN) ? 1 : 0;
@@ -486,9 +490,9 @@ int disc_forward(aae_model* m, int rows, const uint8_t* m1a, const uint8_t* m1b,
     DropSpec d2 = make_drop(m, 1, true, m2a, m2b, split, h, sid2);
     EpiDropAct e1; e1.out = m->xh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
     e1.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->zin.p, m->ldz, rows, m->P[P_D1], e1, s));
+    TRY(linear_fwd(m->zin.p, m->ldz, rows, m->P[P_D1], e1, s, m->bf16));
     EpiDropAct e2 = e1; e2.out = m->xh2.p; e2.d = d2;
-    TRY(linear_fwd(m->xh1.p, m->ldh, rows, m->P[P_D2], e2, s));
+    TRY(linear_fwd(m->xh1.p, m->ldh, rows, m->P[P_D2], e2, s, m->bf16));
     EpiSigmoid e3; e3.out = m->dout.p; e3.ld = 4;
     TRY(linear_fwd(m->xh2.p, m->ldh, rows, m->P[P_D3], e3, s));
     return AAE_OK;
@@ -509,9 +513,9 @@ int decoder_hidden_forward(aae_model* m, bool train, const uint8_t* mk1, const u
     DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, rows, m->h, 3);
     EpiDropAct e1; e1.out = m->dh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
     e1.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->zc.p, m->ldc, rows, m->P[P_V1], e1, s));
+    TRY(linear_fwd(m->zc.p, m->ldc, rows, m->P[P_V1], e1, s, m->bf16));
     EpiDropAct e2 = e1; e2.out = m->dh2.p; e2.d = d2;
-    TRY(linear_fwd(m->dh1.p, m->ldh, rows, m->P[P_V2], e2, s));
+    TRY(linear_fwd(m->dh1.p, m->ldh, rows, m->P[P_V2], e2, s, m->bf16));
     return AAE_OK;
 }
 
@@ -577,7 +581,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
         cb.P.ts = ts_dev;
     }
-    hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     LAUNCHCHK("chain_kernel");
     if (want_ts) {
         unsigned long long h[32];
@@ -955,9 +960,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
         m->fused_ok = m->fused_nb != 0 && fused_width_ok(m->h, m->ldh);       // (the arena's slab area is sized by the same test)
         m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= 208) && getenv("AAE_NO_CHAIN") == nullptr;
-        if (m->use_chain && hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess)
+        if (m->use_chain && (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess ||
+                             hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess))
             m->use_chain = false;
         m->force_unfused = cfg->reserved[0] == 1;   // debugging / A-B switch: reserved[0] = 1 keeps the 3-kernel path
         if (m->fused_ok) {
@@ -1440,7 +1448,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         EpiBce e; e.G = m->G.p; e.ldg = m->ldn; e.gscale = gscale; e.partials = m->bce_partials;
         {
             ProfScope ps(m, AAE_K_DEC_BCE_FWD, s);
-            TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s));
+            TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s, m->bf16));
         }
         hipLaunchKernelGGL(bce_fixup_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
                            h + 1, m->G.p, m->ldn, gscale, m->fix_partials);
@@ -1458,7 +1466,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
         {
             ProfScope ps(m, AAE_K_DEC_DA2, s);
-            (void)launch_gemm<0, 0, 16, 64>(g, e, splits, s);
+            (void)launch_gemm_mode<0, 0, true>(m->bf16, g, e, splits, s);
         }
         LAUNCHCHK("dA2 gemm");
         if (m->only_output_layer) {
@@ -1510,11 +1518,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
-    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_V2], h, b1, s));
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_V2], h, b1, s, m->bf16));
     TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->dh1.p, m->ldh, P_V2, O_DEC, s));
     // lin1
     EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
-    TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_V1], cp, ez, s));
+    TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_V1], cp, ez, s, m->bf16));
     TRY(linear_dw(m, m->gb1.p, m->ldh, B, m->zc.p, m->ldc, P_V1, O_DEC, s));
     if (dzc_out) {
         hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cp)), dim3(256), 0, s, m->gzc.p, m->ldc, dzc_out, cp,
@@ -1584,7 +1592,7 @@ int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev,
     TRY(gather_first_layer(m, false, nullptr, 0, s));
     TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
-    TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s));
+    TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s, m->bf16));
     m->phase = 0;
     return AAE_OK;
 }
@@ -1721,7 +1729,7 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
         TRY(linear_dx(m->ga3.p, 4, 2 * B, m->P[P_D3], h, b2, s));
         TRY(linear_dw(m, m->ga3.p, 4, 2 * B, m->xh2.p, m->ldh, P_D3, O_DISC, s));
         EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
-        TRY(linear_dx(m->gb0.p, m->ldh, 2 * B, m->P[P_D2], h, b1, s));
+        TRY(linear_dx(m->gb0.p, m->ldh, 2 * B, m->P[P_D2], h, b1, s, m->bf16));
         TRY(linear_dw(m, m->gb0.p, m->ldh, 2 * B, m->xh1.p, m->ldh, P_D2, O_DISC, s));
         TRY(linear_dw(m, m->gb1.p, m->ldh, 2 * B, m->zin.p, m->ldz, P_D1, O_DISC, s));
     }
@@ -1757,9 +1765,9 @@ int aae_gen_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
         b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
         TRY(linear_dx(m->ga3.p, 4, B, m->P[P_D3], h, b2, s));
         EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
-        TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_D2], h, b1, s));
+        TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_D2], h, b1, s, m->bf16));
         EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
-        TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_D1], cc, ez, s));
+        TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_D1], cc, ez, s, m->bf16));
     }
     TRY(encoder_backward(m, m->gzc.p, m->ldc, m->zsave.p, m->ldz, I.masks_dev[8], I.masks_dev[9], 8, 9, O_GEN, s));
     m->phase = 0;
@@ -1836,7 +1844,7 @@ int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
     if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
     else TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
-    TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s));
+    TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s, m->bf16));
     return AAE_OK;
 }
 

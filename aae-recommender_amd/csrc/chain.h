@@ -279,6 +279,44 @@ __device__ __forceinline__ void chain_linear_dx(const ChainOp& op, const float* 
     }
 }
 
+// bf16 mode of the build (BASELINE config C2): the forward-pattern layer on v_mfma_f32_16x16x32_bf16.  Same operands
+// (fp32 activations in the LDS slot, fp32 weights streamed from L2), rounded to bf16 on the way into the matrix core
+// (v_cvt_pk_bf16_f32, ties to even), fp32 accumulation: 7 MFMAs of 16 cycles instead of 52 of 32 for a 201-wide layer.
+// Lane (fr, fk) takes k = 32c + 4 fk + {0..3} and 32c + 16 + 4 fk + {0..3} of chunk c for both operands (two float4
+// each).  The last chunk may run past the weight row (the arena keeps 16 zero rows behind every matrix: readable) and
+// past the slot row (masked: the slot's columns beyond the layer's K are zero, but the next row's are not).
+typedef __bf16 chain_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ chain_bf16x8 chain_pack8(const float4& lo, const float4& hi) {
+    const gemm_u32x4 v = {gemm_pack_bf16(lo.x, lo.y), gemm_pack_bf16(lo.z, lo.w), gemm_pack_bf16(hi.x, hi.y), gemm_pack_bf16(hi.z, hi.w)};
+    return __builtin_bit_cast(chain_bf16x8, v);
+}
+template <int MC>
+__device__ __forceinline__ void chain_linear_fwd_bf16(const ChainOp& op, const float* src, int b0, int fr, int fk, f32x4& acc) {
+    const int ldw = op.ldw, N = op.N;
+    const int kch = (op.K + 31) >> 5;
+    const uint32_t o0 = (uint32_t)(min(b0 * 16 + fr, N - 1) * ldw + 4 * fk) * 4u;
+    const float* a = src + fr * kCL;
+    float4 w0[MC], w1[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        const char* base = reinterpret_cast<const char*>(op.W + min(c, kch - 1) * 32);     // uniform
+        w0[c] = *reinterpret_cast<const float4*>(base + o0);
+        w1[c] = *reinterpret_cast<const float4*>(base + o0 + 64);
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        if (c < kch) {
+            const int k0 = 32 * c + 4 * fk, k1 = k0 + 16;
+            float4 x0 = *reinterpret_cast<const float4*>(a + min(k0, kCL - 4));
+            float4 x1 = *reinterpret_cast<const float4*>(a + min(k1, kCL - 4));
+            if (k0 > kCL - 4) x0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k1 > kCL - 4) x1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(chain_pack8(x0, x1), chain_pack8(w0[c], w1[c]), acc, 0, 0, 0);
+        }
+    }
+}
+
+template <bool BF>
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
@@ -312,7 +350,11 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 // Load volume follows the layer: short-K layers (K <= 64) take the 4-chunk /
                 // chunk variant and layers of <= 128 columns skip the second block - the weight stream of a
                 // layer is bound by the CU's 64 B/clk vector-memory path, so unneeded (clamped) loads cost time.
-                if (kind == COP_LINEAR) {
+                if (kind == COP_LINEAR && BF) {
+                    static_assert(kCQ == 1, "one block per wave");
+                    if (((op.K + 31) >> 5) <= 2) chain_linear_fwd_bf16<2>(op, src, b0, fr, fk, acc[0]);
+                    else chain_linear_fwd_bf16<7>(op, src, b0, fr, fk, acc[0]);
+                } else if (kind == COP_LINEAR) {
                     const int kch = (op.K + 15) >> 4;
                     if (kch <= 4) { if (two) chain_linear_fwd<4, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<4, false>(op, src, b0, b1, fr, fk, acc); }
                     else          { if (two) chain_linear_fwd<13, true>(op, src, b0, b1, fr, fk, acc); else chain_linear_fwd<13, false>(op, src, b0, b1, fr, fk, acc); }

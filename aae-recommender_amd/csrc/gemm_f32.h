@@ -30,8 +30,22 @@ struct GemmShape {
 //   workgroups, 4x shorter chains).
 // BK = k-depth of one staged slab: 16 for the streaming GEMMs (small LDS footprint, 8 workgroups
 //   per CU hide the load latency), 64 for the tiny ones (4x fewer load->barrier round trips).
-template <int AT, int BT, int BK, int TS, class Epi>
+// BF = true (bf16 mode of the build, BASELINE config C2): the same staging, fp32 LDS images and epilogues, but the
+// products run on v_mfma_f32_16x16x32_bf16 - a lane gathers its 8 k-values of a 32-deep step from the fp32 image (the
+// same conflict-free ds_read_b32 walk, k = kk + fk + 4 j) and rounds them to bf16 (v_cvt_pk_bf16_f32, ties to even) on
+// the way into the matrix core; accumulation stays fp32.  One MFMA then does the work of eight.
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gemm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gemm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gemm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned gemm_pack_bf16(float a, float b) {
+    gemm_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, gemm_bf16x2));
+}
+
+template <int AT, int BT, int BK, int TS, class Epi, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
+    static_assert(!BF || BK % 32 == 0, "bf16 products take 32-deep k-steps");
     constexpr int LDT = TS + 16;                    // operand image row stride (floats): the two k-rows a
                                                     // ds_read_b32 half-wave touches land on disjoint banks
     constexpr int LDC = TS + 4;                     // accumulator image row stride
@@ -121,6 +135,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
             __syncthreads();
             if (k0 + BK < kend) load_tiles(k0 + BK);
             const int fr = lane & 15, fk = lane >> 4;
+            if constexpr (BF) {
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 32) {
+                    gemm_bf16x8 a[MI], b[MI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        float x[8], y[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            x[e] = As[(kk + fk + 4 * e) * LDT + wm + i * 16 + fr];
+                            y[e] = Bs[(kk + fk + 4 * e) * LDT + wn + i * 16 + fr];
+                        }
+                        const gemm_u32x4 xa = {gemm_pack_bf16(x[0], x[1]), gemm_pack_bf16(x[2], x[3]), gemm_pack_bf16(x[4], x[5]), gemm_pack_bf16(x[6], x[7])};
+                        const gemm_u32x4 yb = {gemm_pack_bf16(y[0], y[1]), gemm_pack_bf16(y[2], y[3]), gemm_pack_bf16(y[4], y[5]), gemm_pack_bf16(y[6], y[7])};
+                        a[i] = __builtin_bit_cast(gemm_bf16x8, xa);
+                        b[i] = __builtin_bit_cast(gemm_bf16x8, yb);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
                 float a[MI], b[MI];
@@ -134,6 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 #pragma unroll
                     for (int j = 0; j < MI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
             }
             __syncthreads();
         }
@@ -330,11 +369,17 @@ struct EpiAdam : EpiNoState {
     }
 };
 
-template <int AT, int BT, int BK, int TS, class Epi>
+template <int AT, int BT, int BK, int TS, class Epi, bool BF = false>
 inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
     dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS, splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, BK, TS, Epi>), grid, dim3(256), 0, s, g, epi);
+    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, BK, TS, Epi, BF>), grid, dim3(256), 0, s, g, epi);
     return hipGetLastError();
+}
+// the streaming (vocabulary-wide) / small-layer variants in either arithmetic: bf16 = true takes 32-deep slabs
+template <int AT, int BT, bool BIG, class Epi>
+inline hipError_t launch_gemm_mode(bool bf16, const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
+    if (BIG) return bf16 ? launch_gemm<AT, BT, 32, 64, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 16, 64, Epi>(g, epi, splits, s);
+    return bf16 ? launch_gemm<AT, BT, 64, 32, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 64, 32, Epi>(g, epi, splits, s);
 }
 
 }  // namespace aae
