@@ -106,6 +106,8 @@ _PROTOS = {
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_void_p]),
     "aae_csr_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_dense_to_csr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.POINTER(C.c_int32 * 4), C.c_void_p]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -266,6 +268,39 @@ class DeviceCSR:
         # library valid pointers: one unused element)
         self.indices = upload(X.indices.astype(np.int32) if X.nnz else np.zeros(1, dtype=np.int32), device)
         self.values = upload(X.data.astype(np.float32) if X.nnz else np.zeros(1, dtype=np.float32), device)
+
+    @classmethod
+    def from_dense(cls, X, device, capacity):
+        """The reference's call form (aae.py:745-754): a dense [rows, n_cols] float32 / float64 batch.  The matrix is
+        uploaded as it is (one pass of host memory: no host-side scan, no float64 -> float32 copy) and compacted on the
+        device (aae_dense_to_csr); raises like the reference's BCE for values outside [0, 1]."""
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float32)
+        if X.ndim != 2:
+            raise ValueError("expected a 2-D batch")
+        dev = torch.device(device)
+        rows, n_cols = X.shape
+        dense = upload(X, dev)
+        self = cls.__new__(cls)
+        self.shape = (rows, n_cols)
+        cap = int(max(1, min(int(capacity), rows * n_cols)))
+        self.indptr = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+        self.indices = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.values = torch.empty(cap, dtype=torch.float32, device=dev)
+        scratch = torch.empty(rows + 8, dtype=torch.int32, device=dev)
+        stats = (C.c_int32 * 4)()
+        with torch.cuda.device(dev):
+            _check(load_library().aae_dense_to_csr(_ptr(dense), X.dtype.itemsize, n_cols, rows, n_cols, _ptr(self.indptr),
+                                                   _ptr(self.indices), _ptr(self.values), cap, _ptr(scratch), C.byref(stats),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if stats[2]:
+            raise RuntimeError("all elements of target should be between 0 and 1")
+        if stats[3]:
+            raise ValueError(f"the batch holds {stats[1]} entries, more than the model's capacity of {cap} (max_nnz)")
+        self.nnz_per_row_max = int(stats[0])
+        self.nnz = int(stats[1])
+        return self
 
     @classmethod
     def from_arrays(cls, indptr, indices, values, n_cols, device):
@@ -665,14 +700,16 @@ class HipAAE:
                                           self._stream()))
         return pk
 
-    def w1_import(self, packets, n_peers, which, cap=None):
-        """Sum the peers' packed rows (flat tensor of n_peers packets of w1_export(cap)) and run optimiser `which`."""
+    def w1_import(self, packets, n_peers, which, cap=None, stride_floats=None):
+        """Sum the peers' packed rows (flat tensor of n_peers packets of w1_export(cap)) and run optimiser `which`.
+        stride_floats: distance between consecutive peers' packets when they carry riders behind them."""
         cap, hdr, total = self._w1_layout(cap)
-        assert packets.numel() >= n_peers * total
+        stride = total if stride_floats is None else int(stride_floats)
+        assert stride >= total and packets.numel() >= (n_peers - 1) * stride + total
         self._keep.append(packets)
         with torch.cuda.device(self.device):
             _check(self.lib.aae_w1_import(self.handle, C.c_void_p(packets.data_ptr()),
-                                          C.c_void_p(packets.data_ptr() + 4 * hdr), cap, n_peers, 4 * total, which,
+                                          C.c_void_p(packets.data_ptr() + 4 * hdr), cap, n_peers, 4 * stride, which,
                                           self._stream()))
 
     def set_rng_rows(self, row_offset, global_rows):

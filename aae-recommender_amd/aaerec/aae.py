@@ -370,16 +370,21 @@ class AdversarialAutoEncoder:
         if y is not None:
             raise NotImplementedError("(Semi-)supervised usage not supported")
         use_condition = _check_conditions(self.conditions, condition_data)
-        Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
         if self.hip is None:
-            self._build(Xs.shape[1], self.conditions.size_increment() if use_condition else 0)
-        Xs.sum_duplicates()                             # a non-canonical CSR hides a target of 2.0 in two entries
-        _validate_targets(Xs)
-        if Xs.shape[0] > self.hip.max_batch:
-            raise ValueError("batch of {} rows exceeds batch_size={}".format(Xs.shape[0], self.hip.max_batch))
-        csr = _hip.DeviceCSR(Xs, self.hip.device)
+            self._build(X.shape[1], self.conditions.size_increment() if use_condition else 0)
+        if X.shape[0] > self.hip.max_batch:
+            raise ValueError("batch of {} rows exceeds batch_size={}".format(X.shape[0], self.hip.max_batch))
+        if sp.issparse(X):
+            Xs = X.tocsr()
+            Xs.sum_duplicates()                         # a non-canonical CSR hides a target of 2.0 in two entries
+            _validate_targets(Xs)
+            csr = _hip.DeviceCSR(Xs, self.hip.device)
+        else:
+            # the reference's call form: the dense batch of X_shuf[start:end].toarray() (aae.py:823).  It crosses PCIe as
+            # it is and becomes CSR on the device (target validation included)
+            csr = _hip.DeviceCSR.from_dense(np.asarray(X), self.hip.device, self.hip.cfg.max_nnz)
         self.train()
-        self._run_step(csr, 0, Xs.shape[0], None, condition_data if use_condition else None)
+        self._run_step(csr, 0, X.shape[0], None, condition_data if use_condition else None)
         if self.verbose:
             self.last_losses = self.hip.losses()
             log_losses(*self.last_losses)
@@ -495,8 +500,12 @@ class AdversarialAutoEncoder:
         use_condition = _check_conditions(self.conditions, condition_data)
         if self.conditions:
             self.conditions.eval()
-        Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
-        csr = _hip.DeviceCSR(Xs, self.hip.device)
+        if sp.issparse(X):
+            Xs = X.tocsr()
+            csr = _hip.DeviceCSR(Xs, self.hip.device)
+        else:                                           # dense test matrix: compacted on the device, batch-size rows at a time
+            Xs = np.asarray(X)
+            csr = None
         self._dp_settle()
         if self._slice is not None:
             self._dp.gather_output_layer()              # (a no-op after fit(); collective otherwise)
@@ -507,16 +516,20 @@ class AdversarialAutoEncoder:
             for start in range(0, Xs.shape[0], self.batch_size):
                 n = min(self.batch_size, Xs.shape[0] - start)
                 c_batch = [_take(c, slice(start, start + n)) for c in condition_data] if use_condition else None
+                if not sp.issparse(X):
+                    dcsr, dstart = _hip.DeviceCSR.from_dense(Xs[start:start + n], self.hip.device, self.hip.cfg.max_nnz), 0
+                else:
+                    dcsr, dstart = csr, start
                 if fused:
                     cond = None
                     if use_condition:
                         cond = torch.cat([_hip.upload(c.encode(x), self.hip.device)
                                           for c, x in zip(self.conditions.values(), c_batch)], 1)
-                    out = self.hip.predict(csr, start, n, cond=cond)
+                    out = self.hip.predict(dcsr, dstart, n, cond=cond)
                 elif native:
-                    out = self.hip.predict(csr, start, n, cond=self._native_cond_block(c_batch, n))
+                    out = self.hip.predict(dcsr, dstart, n, cond=self._native_cond_block(c_batch, n))
                 else:
-                    z = self.hip.encode(csr, start, n)
+                    z = self.hip.encode(dcsr, dstart, n)
                     out = self.hip.decode(self.conditions.encode_impose(z, c_batch))
                 pred.put(start, out)
         return pred.numpy()

@@ -29,7 +29,9 @@ class DataParallelAAE:
         self._shard_grad = self._shard_p = self._pending = None
         self.world = dist.get_world_size(group)
         self.global_rows = None
-        self._w1_all = None
+        self._w1_all = self._w1_ext = None
+        self._coll = [0, 0]          # collectives / payload bytes (this rank's send side) of the running step
+        self._coll_last = (0, 0)
         # upper bound on the distinct items of any rank's share of the running batch, agreed by all ranks (e.g. the
         # largest entry count of a share): sizes the first-layer packets of this step; None = the model-wide worst case
         self.w1_rows = None
@@ -78,20 +80,42 @@ class DataParallelAAE:
             base, extra = divmod(int(global_rows), self.world)
             self.model.set_rng_rows(rank * base + min(rank, extra), global_rows)
 
-    def _allreduce(self, which, async_op=False):
-        return [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-                for t in self.model.grad_buckets(which)]
+    def _count(self, t):
+        self._coll[0] += 1
+        self._coll[1] += t.numel() * t.element_size()
 
-    def _exchange_encoder(self, which):
+    def comm_stats(self):
+        """{'collectives': n, 'bytes': b} of the last completed step: how many collectives this rank took part in and the
+        payload it contributed to them (bench.py reports it)."""
+        return {"collectives": self._coll_last[0], "bytes": self._coll_last[1]}
+
+    def _allreduce(self, which, async_op=False):
+        out = []
+        for t in self.model.grad_buckets(which):
+            self._count(t)
+            out.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return out
+
+    def _exchange_encoder(self, which, ride=None):
         """All encoder gradients of one optimiser step (enc_optim after the ae phases, gen_optim after
         gen_step).  GPU model: one all-gather of packets (packed first-layer rows + the small layers).
-        Stand-ins without the packed path: all-reduce of dense buckets."""
-        if not hasattr(self.model, "w1_export") or getattr(self.model, "packet_has_small", True) is False:
+        Stand-ins without the packed path: all-reduce of dense buckets.
+        ride: (gradient views, then()) - other small gradients that are due at the same point of the step travel in the
+        same packets (one collective instead of two: at ~20-40 us of latency each on a ~0.5 ms step the count matters
+        more than the bytes); then() runs once they are summed."""
+        packed = hasattr(self.model, "w1_export")
+        if not packed or getattr(self.model, "packet_has_small", True) is False:
             self._allreduce(which)
             self.model.apply_updates(which)
-        self._exchange_w1(which)
+        if ride is not None and not packed:
+            for t in ride[0]:
+                self._count(t)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            ride[1]()
+            ride = None
+        self._exchange_w1(which, ride)
 
-    def _exchange_w1(self, which):
+    def _exchange_w1(self, which, ride=None):
         """First encoder layer: only the rows of the items in the global batch carry gradient, so the
         ranks all-gather their packed rows (a few MB) instead of all-reducing the dense [N, h] tensor."""
         m = self.model
@@ -99,6 +123,19 @@ class DataParallelAAE:
             return                      # dense stand-in: the gradient is part of grad_buckets()
         cap = self.w1_rows
         pk = m.w1_export() if cap is None else m.w1_export(cap)
+        total = pk.numel()
+        extra = [t.reshape(-1) for t in ride[0]] if ride is not None else []
+        if extra:                       # the riders sit behind the packet proper
+            n_ext = total + sum(t.numel() for t in extra)
+            if self._w1_ext is None or self._w1_ext.numel() < n_ext:
+                self._w1_ext = pk.new_empty(n_ext)
+            ext = self._w1_ext[:n_ext]
+            ext[:total].copy_(pk)
+            off = total
+            for t in extra:
+                ext[off:off + t.numel()].copy_(t)
+                off += t.numel()
+            pk = ext
         if self.world == 1:
             allp = pk
         else:
@@ -106,8 +143,19 @@ class DataParallelAAE:
             if self._w1_all is None or self._w1_all.numel() < need:
                 self._w1_all = pk.new_empty(need)
             allp = self._w1_all[:need]
+            self._count(pk)
             self.dist.all_gather_into_tensor(allp, pk, group=self.group)
-        if cap is None:
+        if extra:
+            # summed over the peers in one fixed order on identical inputs: bitwise the same on every rank
+            peers = allp.view(self.world, pk.numel())
+            off = total
+            for t in extra:
+                t.copy_(peers[:, off:off + t.numel()].sum(0))
+                off += t.numel()
+            ride[1]()
+        if extra:
+            m.w1_import(allp, self.world, which, cap, stride_floats=pk.numel())
+        elif cap is None:
             m.w1_import(allp, self.world, which)
         else:
             m.w1_import(allp, self.world, which, cap)
@@ -161,6 +209,7 @@ class DataParallelAAE:
     def step(self, csr, row_start, n_rows, global_rows=None, rows=None, cond_fn=None, masks=None, z_real=None):
         """cond_fn(z) -> (zc, backward(dzc) -> dz) for condition plugins; None = no condition."""
         m = self.model
+        self._coll = [0, 0]
         if global_rows is None:
             global_rows = n_rows * self.world
         m.set_grad_scale(n_rows / float(global_rows))
@@ -184,6 +233,7 @@ class DataParallelAAE:
             m.gen_step()
             self._exchange_encoder(O_GEN)
         self._dec_finish(dec_state)
+        self._coll_last = tuple(self._coll)
 
 
 def broadcast_array(dist, group, arr, device=None, src=0):
@@ -241,20 +291,21 @@ class VocabParallelAAE(DataParallelAAE):
         m, sl, d = self.model, self.slice, self.dist
         if global_rows != n_rows * self.world:
             raise ValueError("vocabulary-sharded step: the global batch must divide evenly over the ranks")
+        self._coll = [0, 0]
         m.set_grad_scale(n_rows / float(global_rows))
         self._set_rng_rows(n_rows, global_rows)
         m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
+        self._count(m.dh2_rows(n_rows))
         d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
         sl.output_layer_step(slice_csr, g_row_start, global_rows, rows=g_rows)
+        self._count(sl.da2_rows(global_rows))
         d.reduce_scatter_tensor(m.da2_rows(n_rows).view(-1), sl.da2_rows(global_rows).view(-1), op=d.ReduceOp.SUM,
                                 group=self.group)
         m.ae_backward()
-        work = [d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group, async_op=True) for t in m.grad_buckets("dec_small")]
-        self._exchange_encoder(O_ENC)
-        for w in work:
-            if w is not None:
-                w.wait()
-        m.apply_updates(O_DEC, skip=m.big_tensor_id)
+        # the decoder's hidden-layer gradients ride in the encoder's packets: 5 collectives per step, each on the
+        # critical path of the next phase (dh2 -> dA2 -> encoder + decoder-hidden -> discriminator -> encoder again)
+        self._exchange_encoder(O_ENC, ride=(m.grad_buckets("dec_small"),
+                                            lambda: m.apply_updates(O_DEC, skip=m.big_tensor_id)))
         if not getattr(m, "ae_only", False):
             m.disc_step()
             self._allreduce(O_DISC)
@@ -262,6 +313,7 @@ class VocabParallelAAE(DataParallelAAE):
             m.gen_step()
             self._exchange_encoder(O_GEN)
         self._gathered = False
+        self._coll_last = tuple(self._coll)
 
     def gather_rows(self, t):
         """[world * rows, cols] tensor of every rank's [rows, cols] block, in rank (= global batch) order."""

@@ -1081,6 +1081,28 @@ int aae_csr_embed(const int64_t* indptr_dev, const int32_t* indices_dev, const f
     return AAE_OK;
 }
 
+int aae_dense_to_csr(const void* dense_dev, int32_t elem_bytes, int64_t ld, int32_t rows, int32_t n_cols,
+                     int64_t* indptr_dev, int32_t* indices_dev, float* values_dev, int64_t capacity,
+                     int32_t* scratch_dev, int32_t* stats_out_host, void* stream) {
+    if (!dense_dev || !indptr_dev || !indices_dev || !values_dev || !scratch_dev || !stats_out_host)
+        return fail(AAE_EINVAL, "aae_dense_to_csr: NULL argument");
+    if (rows < 1 || n_cols < 1 || ld < n_cols || capacity < 1) return fail(AAE_EINVAL, "aae_dense_to_csr: bad shape");
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(AAE_EINVAL, "aae_dense_to_csr: elem_bytes must be 4 (float32) or 8 (float64)");
+    hipStream_t s = S(stream);
+    int* stats = scratch_dev;                 // [0..3] statistics, [8..] row counts
+    int* rowcnt = scratch_dev + 8;
+    HIPCHK(hipMemsetAsync(stats, 0, 8 * sizeof(int), s));
+    if (elem_bytes == 4) hipLaunchKernelGGL(dense_count_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)dense_dev, (long long)ld, n_cols, rowcnt, stats);
+    else hipLaunchKernelGGL(dense_count_kernel<double>, dim3(rows), dim3(256), 0, s, (const double*)dense_dev, (long long)ld, n_cols, rowcnt, stats);
+    hipLaunchKernelGGL(dense_scan_kernel, dim3(1), dim3(1024), 0, s, rowcnt, rows, (long long)capacity, (long long*)indptr_dev, stats);
+    if (elem_bytes == 4) hipLaunchKernelGGL(dense_fill_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)dense_dev, (long long)ld, n_cols, (const long long*)indptr_dev, stats, indices_dev, values_dev);
+    else hipLaunchKernelGGL(dense_fill_kernel<double>, dim3(rows), dim3(256), 0, s, (const double*)dense_dev, (long long)ld, n_cols, (const long long*)indptr_dev, stats, indices_dev, values_dev);
+    LAUNCHCHK("dense_to_csr");
+    HIPCHK(hipMemcpyAsync(stats_out_host, stats, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AAE_OK;
+}
+
 int aae_profile_enable(aae_handle h, int on) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     if (on && !h->prof_ev) h->prof_ev = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[AAE_K_N];

@@ -725,6 +725,83 @@ __global__ void accumulate_peers_kernel(float* __restrict__ dst, const char* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense batch -> CSR on the device (the reference's call form: partial_fit / predict take the dense [B, N] matrix that
+// X[start:end].toarray() produced, aae.py:745-754, 823).  The matrix crosses PCIe once, as it is (float32 or float64);
+// three small launches compact it: per-row counts (+ the [0, 1] target check of F.binary_cross_entropy), a one-block
+// scan -> indptr, an ordered fill (ascending columns per row, as scipy's tocsr()).  stats: [0] longest row, [1] total
+// entries, [2] != 0: a value outside [0, 1], [3] != 0: more entries than `capacity`.
+// ---------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void dense_count_kernel(const T* __restrict__ X, long long ld, int n_cols,
+                                                          int* __restrict__ rowcnt, int* __restrict__ stats) {
+    __shared__ int red[4];
+    const T* x = X + (size_t)blockIdx.x * ld;
+    int cnt = 0, bad = 0;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        const float v = (float)x[c];
+        cnt += v != 0.f;
+        bad |= !(v >= 0.f && v <= 1.f);
+    }
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); bad |= __shfl_xor(bad, o, 64); }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    if (bad && (threadIdx.x & 63) == 0) atomicOr(&stats[2], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) rowcnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void dense_scan_kernel(const int* __restrict__ rowcnt, int rows, long long capacity,
+                                                          long long* __restrict__ indptr, int* __restrict__ stats) {
+    __shared__ long long part[1024];
+    __shared__ int mx[1024];
+    const int t = threadIdx.x, per = (rows + 1023) / 1024;
+    const int lo = min(t * per, rows), hi = min(rows, lo + per);
+    long long s = 0; int m = 0;
+    for (int i = lo; i < hi; ++i) { s += rowcnt[i]; m = max(m, rowcnt[i]); }
+    part[t] = s; mx[t] = m;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const long long v = t >= o ? part[t - o] : 0;
+        const int w = t >= o ? mx[t - o] : 0;
+        __syncthreads();
+        part[t] += v; mx[t] = max(mx[t], w);
+        __syncthreads();
+    }
+    long long run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { indptr[i] = run; run += rowcnt[i]; }
+    if (t == 1023) {
+        indptr[rows] = part[1023];
+        stats[0] = mx[1023];
+        stats[1] = (int)min(part[1023], (long long)0x7FFFFFFF);
+        if (part[1023] > capacity) stats[3] = 1;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dense_fill_kernel(const T* __restrict__ X, long long ld, int n_cols,
+                                                         const long long* __restrict__ indptr, const int* __restrict__ stats,
+                                                         int* __restrict__ indices, float* __restrict__ values) {
+    __shared__ int wsum[4];
+    if (stats[3]) return;                                  // over capacity: nothing is written, the host raises
+    const T* x = X + (size_t)blockIdx.x * ld;
+    long long base = indptr[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < n_cols; c0 += 256) {             // 256 consecutive columns per pass: positions stay ordered
+        const int c = c0 + threadIdx.x;
+        const float v = c < n_cols ? (float)x[c] : 0.f;
+        const unsigned long long m = __ballot(v != 0.f);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (v != 0.f) { indices[base + off + before] = c; values[base + off + before] = v; }
+        base += total;
+        __syncthreads();
+    }
+}
+
 // predict-time prologue of the unique-row pass: new stamp, empty list
 __global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucount = 0; }
 

@@ -274,6 +274,16 @@ int aae_cat_update(float* table_dev, float* exp_avg_dev, float* exp_avg_sq_dev, 
 int aae_csr_embed(const int64_t* indptr_dev, const int32_t* indices_dev, const float* values_dev, int32_t n_rows,
                   const float* table_dev, int32_t n_table_rows, int32_t dim, int64_t table_ld, float* out_dev,
                   int64_t out_ld, void* stream);
+/* The reference's call form: partial_fit(X) / predict(X) take the DENSE [rows][n_cols] batch that
+ * X_shuf[start:end].toarray() produced (aae.py:745-754, 823, 848-853) and upload it whole.  aae_dense_to_csr compacts
+ * such a matrix, already on the device as float32 (elem_bytes = 4) or float64 (8), into the CSR form aae_batch takes:
+ * indptr_dev int64 [rows + 1], indices_dev int32 / values_dev float32 [capacity], columns ascending within a row.
+ * scratch_dev: int32 [rows + 8].  stats_out_host (int32[4], after a stream synchronisation): longest row, total
+ * entries, != 0 if a value lies outside [0, 1] (the reference's F.binary_cross_entropy raises on such targets),
+ * != 0 if the matrix has more than `capacity` entries (nothing was written). */
+int aae_dense_to_csr(const void* dense_dev, int32_t elem_bytes, int64_t ld, int32_t rows, int32_t n_cols,
+                     int64_t* indptr_dev, int32_t* indices_dev, float* values_dev, int64_t capacity,
+                     int32_t* scratch_dev, int32_t* stats_out_host, void* stream);
 /* the two halves of aae_disc_gen (data parallel needs the discriminator update applied
  * between them) */
 int aae_disc_step(aae_handle h, const aae_rng_inject* inject, void* stream);

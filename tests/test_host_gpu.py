@@ -780,3 +780,65 @@ def test_conditioned_recommender_through_bags_attributes():
     assert rec.model._is_device_native() and cat.embedding.weight.is_cuda
     assert float(cat.optimizer.state[cat.embedding.weight]["step"]) > 100          # trained by aae_cat_update
     assert mrr_cond > 0.3 and mrr_cond > mrr_plain + 0.05, (mrr_cond, mrr_plain)
+
+
+@pytest.mark.parametrize("dp", ["vocab", "replicated"])
+def test_bench_spawns_its_own_ranks(dp):
+    """`python bench.py --gpus 2` the way the driver starts it - no launcher: bench.py spawns one process per rank before
+    touching the GPU and relays rank 0's single JSON line.  On this one-GPU box the ranks share device 0 and their
+    collectives go over gloo staged through the host (AAE_BENCH_GLOO_ONE_GPU=1): the numbers mean nothing, the protocol
+    (rendezvous, rank-0 broadcast of weights / seed / permutation, both exchange schemes, one JSON line, exit code 0) does."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AAE_BENCH_GLOO_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--items", "6000", "--hidden", "64", "--dp", dp], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["global_batch"] == 200 and out["value"] > 0
+    assert np.all(np.isfinite(out["losses_last_step"]))
+
+
+def test_dense_batches_are_compacted_on_the_device():
+    """partial_fit / predict on the DENSE batch the reference passes (X_shuf[start:end].toarray(), aae.py:823, 848-853),
+    float64 as toarray() gives it and float32: same step as the CSR call, bit for bit (the device-side compaction gives
+    scipy's CSR: ascending columns, float32 values); targets outside [0, 1] raise as the reference's BCE does."""
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec._hip import DeviceCSR
+    rng = np.random.default_rng(3)
+    N, B = 700, 37
+    X = sp.random(3 * B, N, density=0.02, random_state=5, format="csr", dtype=np.float32)
+    X.data[:] = 1.0
+    X.data[::5] = 0.25
+    # the compaction itself, against scipy
+    d = DeviceCSR.from_dense(X[:B].toarray().astype(np.float64), "cuda", 10000)
+    ref = X[:B].tocsr()
+    assert d.nnz == ref.nnz and d.nnz_per_row_max == int(np.diff(ref.indptr).max())
+    np.testing.assert_array_equal(d.indptr.cpu().numpy(), ref.indptr)
+    np.testing.assert_array_equal(d.indices[:ref.nnz].cpu().numpy(), ref.indices)
+    np.testing.assert_array_equal(d.values[:ref.nnz].cpu().numpy(), ref.data)
+    models = []
+    for form in ("csr", "dense64", "dense32"):
+        torch.manual_seed(11)
+        m = AdversarialAutoEncoder(n_hidden=40, n_code=12, batch_size=B, verbose=False, rng_mode="device", seed=5)
+        for s in range(3):
+            Xb = X[s * B:(s + 1) * B]
+            m.partial_fit(Xb if form == "csr" else Xb.toarray().astype(np.float64 if form == "dense64" else np.float32))
+        models.append(m)
+    sd0 = models[0].hip.state_dict()
+    for m in models[1:]:
+        for k, v in m.hip.state_dict().items():
+            np.testing.assert_array_equal(v, sd0[k], err_msg=k)
+    p0 = models[0].predict(X[:50])
+    np.testing.assert_array_equal(models[1].predict(X[:50].toarray()), p0)
+    bad = X[:B].toarray()
+    bad[3, 5] = 2.0
+    with pytest.raises(RuntimeError, match="between 0 and 1"):
+        models[0].partial_fit(bad)

@@ -21,3 +21,17 @@ for _ in range(10):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"partial_fit(scipy batch) loop: {10 * DOCS / dt:.0f} docs/s ({1e3 * dt / (10 * len(batches)):.3f} ms/step)")
+# the reference's own call form: the dense batch of X_shuf[start:end].toarray() (float64), aae.py:823 - PCIe-inclusive
+for dt_name, conv in (("float64 (as toarray() gives it)", lambda b: b.toarray()), ("float32", lambda b: b.toarray().astype("float32"))):
+    dense = [conv(b) for b in batches[:16]]
+    for d in dense[:4]:
+        m.partial_fit(d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for d in dense:
+            m.partial_fit(d)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"partial_fit(dense {dt_name} ndarray) loop: {3 * len(dense) * B / dt:.0f} docs/s ({1e3 * dt / (3 * len(dense)):.3f} ms/step, "
+          f"{dense[0].nbytes / 1e6:.0f} MB over PCIe per step)")
