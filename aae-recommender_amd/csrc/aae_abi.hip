@@ -649,7 +649,7 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 // as one extra workgroup (chain.h), off the critical path.
 static bool fused_decoder_applies(const aae_model* m) {
     return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB &&
-           (!m->bf16 || ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31)) &&
+           ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes(m->rows, m->h)) <= 160 * 1024;
 }
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {

@@ -152,11 +152,21 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     //   V3a(t+1), the CSR entries of tile t+1 and the entry range of tile t+2 are requested in S0(t),
     //   m/v(t) before GEMM2(t); parameter stores of S5(t) retire behind GEMM3(t).
     float4 vreg[NV], mreg[NV], sreg[NV];
+    typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
     int tile = blockIdx.x;
     const int stride = gridDim.x;
     const int last_e = max(a.te.start[ntiles] - 1, 0);        // clamp for the unconditional entry loads
+    // (VECTOR loads through an index the compiler cannot prove uniform: as scalar loads they sit in lgkmcnt, and the
+    // LDS-only barrier of the phase that issues them - s_waitcnt lgkmcnt(0) - waits out their L2 round trip once per tile)
+    int ozr;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(ozr));
     auto load_range = [&](int t, int& lo, int& hi) {
-        const int tc = min(t, ntiles - 1);
+        const int tc = min(t, ntiles - 1) + ozr;
         lo = a.te.start[tc]; hi = a.te.start[tc + 1];
         if (t >= ntiles) hi = lo;
     };
@@ -279,7 +289,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
 
         stamp(3);
         // the optimiser moments of this tile travel while GEMM2 and GEMM3 run
-        if (do_adam && !sc.is_sgd) { load_span(a.M, tile, mreg); load_span(a.V, tile, sreg); }
+        // (unconditional: the moment tensors exist in every mode, and a load under a condition is waited for on the spot)
+        load_span(a.M, tile, mreg); load_span(a.V, tile, sreg);
         // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib, a wave owns the ids
         // wave + 16q: they share the item half ib (one G read serves them all) and differ in the column block.
         // k runs over the batch rows in groups of 16: k-step (g, j) multiplies rows 16g + j + 4*fk.  Rows 4
@@ -380,32 +391,31 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         lds_barrier();                               // os complete
         stamp(4);
 
-        // ---- S5: optimiser on the tile (or gradient export), whole rows, float4 per lane
+        // ---- S5: optimiser on the tile (or gradient export), whole rows, float4 per lane.  The stores are issued on
+        // every path with the same count (no branch around them): a lane without a cell (beyond the tile span, rows past
+        // the vocabulary, the moments in SGD / export mode) gets a buffer offset beyond the descriptor's range and the
+        // bounds check drops it.  With stores under lane- or mode-dependent branches the compiler's wait counters lose
+        // track of how many are in flight, and the next tile's first use of its prefetched V3a waited for all of them.
         if (!(a.dbg_skip & 16))
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            if (tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < a.N) {
-                const float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
-                // the tile span is contiguous: element offset = i0 * ldv + 4 * slot
-                const size_t off = (size_t)((a.dbg_skip & 128) ? (int)blockIdx.x * kTI : i0) * ldv + (size_t)(tid + kNT * j) * 4;
-                if (!do_adam) {
-                    *reinterpret_cast<float4*>(a.gradV3 + off) = g;
-                } else {
-                    const float* ps = v3s + slot_v3(j);
-                    float4 p = make_float4(ps[0], ps[1], ps[2], ps[3]);
-                    float4 mm = mreg[j], vv = sreg[j];
-                    if (!(a.dbg_skip & 64)) {
-                    adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
-                    adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
-                    }
-                    if (a.dbg_skip & 32) { if (p.x + mm.x + vv.x == 123.f) a.partials[1] = 1.f; continue; }
-                    *reinterpret_cast<float4*>(a.V3a + off) = p;
-                    if (!sc.is_sgd) {
-                        *reinterpret_cast<float4*>(a.M + off) = mm;
-                        *reinterpret_cast<float4*>(a.V + off) = vv;
-                    }
-                }
+            const bool valid = tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < a.N && !(a.dbg_skip & 32);
+            const float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
+            // the tile span is contiguous: byte offset = (i0 * ldv + 4 * slot) * 4
+            const unsigned so = (unsigned)((size_t)((a.dbg_skip & 128) ? (int)blockIdx.x * kTI : i0) * ldv) * 4u;
+            const unsigned vo = valid ? (unsigned)(tid + kNT * j) * 16u : 0x80000000u;
+            const float* ps = v3s + slot_v3(j);
+            float4 p = make_float4(ps[0], ps[1], ps[2], ps[3]);
+            float4 mm = mreg[j], vv = sreg[j];
+            if (!(a.dbg_skip & 64)) {
+                adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
+                adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
             }
+            const float4 out = do_adam ? p : g;
+            const unsigned vo2 = (do_adam && !sc.is_sgd) ? vo : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, out), do_adam ? rP : rG, vo, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, 0);
         }
 
         stamp(5);

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"partial_fit(scipy batch) loop: {10 * DOCS / dt:.0f} docs/s ({1e3 * dt / (10 * len(batches)):.3f} ms/step)")
 # the reference's own call form: the dense batch of X_shuf[start:end].toarray() (float64), aae.py:823 - PCIe-inclusive
-for dt_name, conv in (("float64 (as toarray() gives it)", lambda b: b.toarray()), ("float32", lambda b: b.toarray().astype("float32"))):
+for dt_name, conv in (("float64 (as toarray() gives it)", lambda b: b.toarray().astype("float64")), ("float32", lambda b: b.toarray().astype("float32"))):
     dense = [conv(b) for b in batches[:16]]
     for d in dense[:4]:
         m.partial_fit(d)
