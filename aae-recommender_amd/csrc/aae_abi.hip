@@ -30,6 +30,7 @@
 #include "dec_fused.h"
 #include "dec_fused_bf16.h"
 #include "chain.h"
+#include "chain4.h"
 #include "cond_embed.h"
 
 using namespace aae;
@@ -75,8 +76,8 @@ struct aae_model {
     // parameters, two Adam-state sets (index 0: the owning optimiser, 1: gen_optim for enc),
     // gradients (all in export mode, gW1T always)
     Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
-    // transposed copies [in][out] of the hidden layers' weights (without the bias column): the layer chains' dX ops
-    // read them with the forward layers' access pattern.  Kept in step by the fused / grouped optimiser kernels;
+    // transposed copies [in + 1][out] of the hidden layers' augmented weights: chain.h's dX ops read rows [0, in) with
+    // the forward layers' access pattern, chain4.h's forward layers read all of it (n contiguous).  Kept in step by the fused / grouped optimiser kernels;
     // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
     Ten PT[NP]; bool pt_ok[NP];
     // activations
@@ -88,6 +89,7 @@ struct aae_model {
     bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
     Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
+    bool use_chain4;         // ... with 4 rows per workgroup (chain4.h) where a program allows it
     bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
     bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
     bool enc_bwd_done;
@@ -200,7 +202,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->pt_ok[i] = false; }
     if (h + 1 <= 208 && cp + 1 <= 208 && c.reserved[2] != 3)          // layer-chain models (not the VAE's programs)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
-            m->PT[pid] = a.mat(m->P[pid].cols - 1, m->P[pid].rows, r4((int)m->P[pid].rows), 16);
+            m->PT[pid] = a.mat(m->P[pid].cols, m->P[pid].rows, r4((int)m->P[pid].rows), 16);     // [in + 1][out]: the bias is its last row
     const int R = m->R, R2 = m->R2;
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
@@ -541,24 +543,40 @@ ChainOp cop_load(const float* g, int ld, int dst, int N, int row0 = 0) {
     ChainOp o = cop(COP_LOAD, 0, dst, N); o.W = g; o.ldw = ld; o.out_row0 = row0; return o;
 }
 ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int epi) {
-    ChainOp o = cop(kind, src, dst, N); o.W = W.p; o.ldw = (int)W.ld; o.K = K; o.epi = epi; return o;
+    ChainOp o = cop(kind, src, dst, N); o.W = W.p; o.ldw = (int)W.ld; o.K = K; o.epi = epi;
+    if (kind == COP_LINEAR_DX) { o.Wkn = W.p; o.ldkn = (int)W.ld; }      // already k-major
+    return o;
 }
 void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
 
-// dX of a hidden layer: dst[16][N] = epi(src[16][K] * W[K][0:N]).  With the transposed copy PT[pid] = W[:, 0:N]^T
-// ([N][K], k-contiguous rows) this IS a forward layer - 16-byte weight loads instead of the 4-byte ones of the
-// n-contiguous walk.  The copy is re-derived here if something other than the optimiser kernels wrote the weights.
+// (re-)derive the transposed copy of a hidden layer after something other than the optimiser kernels wrote the weights
+void ensure_pt(aae_model* m, int pid, hipStream_t s) {
+    const Ten& T = m->PT[pid];
+    if (!T.p || m->pt_ok[pid]) return;
+    const Ten& W = m->P[pid];
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((W.cols + 31) / 32), (unsigned)((W.rows + 31) / 32)), dim3(256), 0,
+                       s, W.p, (int)W.ld, (int)W.rows, (int)W.cols, T.p, (int)T.ld);
+    m->pt_ok[pid] = true;
+}
+
+// forward layer: dst[rows][N] = epi(src[rows][K] * W[N][K]^T), K = in + 1 (the bias input is the last column)
+ChainOp cop_fwd(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
+    ChainOp o = cop_linear(COP_LINEAR, src, dst, m->P[pid], K, N, epi);
+    if (m->PT[pid].p) { ensure_pt(m, pid, s); o.Wkn = m->PT[pid].p; o.ldkn = (int)m->PT[pid].ld; }
+    return o;
+}
+
+// dX of a hidden layer: dst[rows][N] = epi(src[rows][K] * W[K][0:N]).  chain.h: with the transposed copy PT[pid] (rows
+// [0, N): W[:, 0:N]^T, k-contiguous) this IS a forward layer - 16-byte weight loads instead of the 4-byte ones of the
+// n-contiguous walk; chain4.h reads the matrix itself (k-major for this product).
 ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
     const Ten& T = m->PT[pid];
     static const bool off = getenv("AAE_NO_PT") != nullptr;
     if (!T.p || off) return cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);
-    if (!m->pt_ok[pid]) {
-        const Ten& W = m->P[pid];
-        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((W.cols - 1 + 31) / 32), (unsigned)((W.rows + 31) / 32)), dim3(256), 0,
-                           s, W.p, (int)W.ld, (int)W.rows, (int)W.cols - 1, T.p, (int)T.ld);
-        m->pt_ok[pid] = true;
-    }
-    return cop_linear(COP_LINEAR, src, dst, T, K, N, epi);
+    ensure_pt(m, pid, s);
+    ChainOp o = cop_linear(COP_LINEAR, src, dst, T, K, N, epi);
+    o.Wkn = m->P[pid].p; o.ldkn = (int)m->P[pid].ld;
+    return o;
 }
 
 struct ChainBuilder {
@@ -581,7 +599,17 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
         cb.P.ts = ts_dev;
     }
-    if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    // 4-row workgroups (chain4.h) whenever every linear op of the program has its k-major matrix (all but the VAE's)
+    bool four = m->use_chain4;
+    for (int i = 0; i < cb.P.nops && four; ++i)
+        if ((cb.P.ops[i].kind == COP_LINEAR || cb.P.ops[i].kind == COP_LINEAR_DX) && !cb.P.ops[i].Wkn) four = false;
+    for (int i = 0; i < cb.P.nops && four; ++i)
+        if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
+    if (four) {
+        const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
+        if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+        else hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    } else if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     LAUNCHCHK("chain_kernel");
     if (want_ts) {
@@ -636,13 +664,13 @@ struct DwBuilder {
 // Encoder hidden stack from the gathered first layer (eh1 in global): lin2, lin3, output activation.
 // ops appended to `cb`; z ends in slot 2.
 void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_t* mk2, uint32_t sid2, int rows,
-                        float* eh2_out) {
+                        float* eh2_out, hipStream_t s) {
     const int h = m->h;
     ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
-    ChainOp& a = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_W2], h + 1, h, CEPI_DROPACT));
+    ChainOp& a = cb.add(cop_fwd(m, P_W2, 0, 1, h + 1, h, CEPI_DROPACT, s));
     a.d = make_drop(m, 1, train, mk2, nullptr, rows, h, sid2); a.one_col = h;
     if (eh2_out) cop_out(a, eh2_out, m->ldh);
-    cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W3], h + 1, m->c, CEPI_NONE));
+    cb.add(cop_fwd(m, P_W3, 1, 2, h + 1, m->c, CEPI_NONE, s));
 }
 
 // The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
@@ -669,7 +697,7 @@ int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* 
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
     piggyback_buckets(m, cb);
-    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p);
+    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p, s);
     // the encoder's output activation; the identity (gauss prior, aae.py:97-101) is no op of its own: its stores and
     // bias-input column ride on the last linear layer
     ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
@@ -682,9 +710,9 @@ int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* 
         } else {
             f.one_col = cp;
         }
-        ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+        ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
         v1.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
-        ChainOp& v2 = cb.add(cop_linear(COP_LINEAR, 3, 4, m->P[P_V2], h + 1, h, CEPI_DROPACT));
+        ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 3, 4, h + 1, h, CEPI_DROPACT, s));
         v2.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
     }
     m->dec_hidden_done = with_dec;
@@ -697,9 +725,9 @@ int chain_dec_hidden(aae_model* m, bool train, int rows, hipStream_t s) {
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, rows);
     ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 0, cp)); l.one_col = cp;
-    ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 0, 1, cp + 1, h, CEPI_DROPACT, s));
     v1.d = make_drop(m, 0, train, I.masks_dev[2], nullptr, rows, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
-    ChainOp& v2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_V2], h + 1, h, CEPI_DROPACT));
+    ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 1, 2, h + 1, h, CEPI_DROPACT, s));
     v2.d = make_drop(m, 1, train, I.masks_dev[3], nullptr, rows, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
     return launch_chain(m, cb, s);
 }
@@ -797,7 +825,7 @@ int chain_vae_forward(aae_model* m, const float* cond_dev, const float* eps_dev,
     const int h = m->h, c = m->c, cp = m->cp;
     ChainBuilder cb(m, rows);
     ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
-    ChainOp& ml = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_W3], h + 1, 2 * c, CEPI_NONE));
+    ChainOp& ml = cb.add(cop_fwd(m, P_W3, 0, 1, h + 1, 2 * c, CEPI_NONE, s));
     cop_out(ml, m->mulv.p, (int)m->mulv.ld);
     ChainOp& rp = cb.add(cop(COP_REPARAM, 1, 2, c));
     rp.W = eps_dev; rp.ldw = c; rp.aux = 12; rp.aux_ptr = m->veps.p; rp.aux_ld = (int)m->veps.ld;
@@ -807,7 +835,7 @@ int chain_vae_forward(aae_model* m, const float* cond_dev, const float* eps_dev,
         rp.one_col = cp;
     }
     ChainOp& st = cb.add(cop(COP_STORE, 2, 2, cp)); cop_out(st, m->zc.p, m->ldc);
-    ChainOp& v1 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_V1], cp + 1, h, CEPI_DROPACT));
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
     v1.one_col = h; cop_out(v1, m->dh2.p, m->ldh);        // no dropout in the VAE: DropSpec stays disabled
     return launch_chain(m, cb, s);
 }
@@ -841,7 +869,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     TRY(gather_first_layer(m, false, nullptr, 0, s));
     {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
         ChainBuilder cb(m, B);
-        chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr);
+        chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
         ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
         f.aux = m->cfg.enc_final; cop_out(f, m->zin.p, m->ldz, B);
         TRY(launch_chain(m, cb, s));
@@ -856,9 +884,9 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
         l.grow0 = m->rng_row0;
         l.aux_ptr = m->cfg.rng_mode == AAE_RNG_DEVICE ? nullptr : const_cast<float*>(I.z_real_dev); l.aux_ld = c;
         cop_out(l, m->zin.p, m->ldz);                      // the weight-gradient GEMM of D1 reads all 2B rows
-        ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 0, 1, m->P[P_D1], c + 1, h, CEPI_DROPACT));
+        ChainOp& d1 = cb.add(cop_fwd(m, P_D1, 0, 1, c + 1, h, CEPI_DROPACT, s));
         d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
-        ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_D2], h + 1, h, CEPI_DROPACT));
+        ChainOp& d2 = cb.add(cop_fwd(m, P_D2, 1, 2, h + 1, h, CEPI_DROPACT, s));
         d2.d = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5); d2.one_col = h; cop_out(d2, m->xh2.p, m->ldh);
         // D3 (h -> 1) + sigmoid + adversarial loss + its dX in one op
         ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 2, 5, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
@@ -885,14 +913,14 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     cb.add(cop_load(m->a1.p, m->ldh, 0, h));
     ChainOp& e1 = cb.add(cop(COP_DROPACT, 0, 1, h));
     e1.d = make_drop(m, 0, true, I.masks_dev[8], nullptr, B, h, 8); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
-    ChainOp& e2 = cb.add(cop_linear(COP_LINEAR, 1, 2, m->P[P_W2], h + 1, h, CEPI_DROPACT));
+    ChainOp& e2 = cb.add(cop_fwd(m, P_W2, 1, 2, h + 1, h, CEPI_DROPACT, s));
     e2.d = make_drop(m, 1, true, I.masks_dev[9], nullptr, B, h, 9); e2.one_col = h; cop_out(e2, m->eh2.p, m->ldh);
-    ChainOp& l3 = cb.add(cop_linear(COP_LINEAR, 2, 3, m->P[P_W3], h + 1, c, CEPI_NONE));
+    ChainOp& l3 = cb.add(cop_fwd(m, P_W3, 2, 3, h + 1, c, CEPI_NONE, s));
     ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? l3 : cb.add(cop(COP_FINAL_FWD, 3, 3, c));
     f.aux = m->cfg.enc_final; f.one_col = c;
-    ChainOp& d1 = cb.add(cop_linear(COP_LINEAR, 3, 4, m->P[P_D1], c + 1, h, CEPI_DROPACT));
+    ChainOp& d1 = cb.add(cop_fwd(m, P_D1, 3, 4, c + 1, h, CEPI_DROPACT, s));
     d1.d = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10); d1.one_col = h;
-    ChainOp& d2 = cb.add(cop_linear(COP_LINEAR, 4, 5, m->P[P_D2], h + 1, h, CEPI_DROPACT));
+    ChainOp& d2 = cb.add(cop_fwd(m, P_D2, 4, 5, h + 1, h, CEPI_DROPACT, s));
     d2.d = make_drop(m, 1, true, I.masks_dev[11], nullptr, B, h, 11); d2.one_col = h;
     ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 5, 8, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
     x3.aux = 1; x3.row_split = B; x3.scale = m->grad_scale;
@@ -967,6 +995,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess))
             m->use_chain = false;
+        m->use_chain4 = m->use_chain && getenv("AAE_CHAIN16") == nullptr &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         m->force_unfused = cfg->reserved[0] == 1;   // debugging / A-B switch: reserved[0] = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;
@@ -1838,7 +1871,7 @@ int aae_encode(aae_handle m, const aae_batch* batch, float* z_out, void* stream)
     if (m->use_chain) {
         TRY(gather_first_layer(m, false, nullptr, 0, s));
         ChainBuilder cb(m, m->rows);
-        chain_encoder_tail(m, cb, false, nullptr, 0, m->rows, nullptr);
+        chain_encoder_tail(m, cb, false, nullptr, 0, m->rows, nullptr, s);
         ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, m->c)); f.aux = m->cfg.enc_final; cop_out(f, m->zc.p, m->ldc);
         if (z_out) { f.out2 = z_out; f.ldo2 = m->c; }
         TRY(launch_chain(m, cb, s));
@@ -2034,7 +2067,7 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
             AdamJob& j = grp.jobs[grp.njobs++];
             j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p; j.g = m->Gr[pid].p;
             j.n4 = (unsigned)n4; j.blk0 = blocks;
-            j.pt = m->PT[pid].p; j.ld = (int)m->P[pid].ld; j.ldt = (int)m->PT[pid].ld; j.nt = (int)m->P[pid].cols - 1;
+            j.pt = m->PT[pid].p; j.ld = (int)m->P[pid].ld; j.ldt = (int)m->PT[pid].ld; j.nt = (int)m->P[pid].cols;
             blocks += (unsigned)((n4 + 255) / 256);
             continue;
         }

@@ -53,6 +53,7 @@ enum { CEPI_NONE = 0, CEPI_DROPACT = 1, CEPI_ACTBWD = 2, CEPI_SIGMOID = 3 };
 struct ChainOp {
     int kind, src, dst, K, N;
     const float* W; int ldw;            // weights / global source (COP_LOAD, COP_SLABSUM)
+    const float* Wkn; int ldkn;         // the same layer's matrix in k-major form [K][N] (n contiguous) for chain4.h
     int epi, yslot;                     // epilogue; slot holding y for ACTBWD / FINAL_BWD
     DropSpec d;
     float* out; int ldo; int out_row0;  // optional global store of dst[:, 0:N] at rows out_row0 + r
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
             EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
         } else {
             EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
-            e.pt = J.pt; e.ldt = J.ldt; e.nt = J.N - 1;
+            e.pt = J.pt; e.ldt = J.ldt; e.nt = J.N;        // (the transposed copy includes the bias row)
             EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
         }
     }

@@ -1,0 +1,275 @@
+// Row-blocked layer chains, 4 rows per workgroup (the r2 form of chain.h's programs; same ChainProgram, same ops).
+//
+// chain.h gives a 1024-thread workgroup 16 rows of the batch: a batch of 100 is 7 workgroups on a 256-CU chip, and on
+// the one CU that owns them a 201 -> 200 layer costs its weight stream (~1.5 us through the CU's 64 B/clk vector-memory
+// path) PLUS 3 us of matrix pipe (13 blocks x 52 v_mfma_f32_16x16x4_f32 on 4 SIMDs) plus epilogue - 6-7 us, 46 layer
+// ops per step.  Here a workgroup takes 4 rows (25 workgroups at batch 100, 50 for the discriminator's stacked batch)
+// and the layer runs on v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4x4 with K = 1 per instruction - 4 rows x 64 columns
+// per wave and k-step at the same 64 flop/clk/SIMD, i.e. a quarter of the matrix time (0.75 us) and a quarter of the
+// epilogue per workgroup; every workgroup still streams the whole weight matrix (L2 serves 25 readers of 160 KB).
+//
+//   operands:  A = x[row = lane % 4][k]  from the LDS slot (one 16-byte read = 4 k-steps; 4 distinct addresses per
+//                  wave-instruction, each broadcast to 16 lanes);
+//              B = Wkn[k][64 cg + lane]: the weight matrix in its "k-major" form (n contiguous) - the transposed
+//                  copy PT of a forward layer (now including the bias row), the matrix itself for a dX layer - one
+//                  coalesced 256-byte row segment per wave-instruction;
+//              D = 4 registers: rows 0..3 of column 64 cg + lane.
+//   waves:     16 = (column group of 64) x (k split): a 200-wide layer has 4 column groups x 4 k-quarters, a 50-wide
+//              one 1 x 16.  Partial sums of the k-split meet in LDS ([k-slice][row][column]), the epilogue (dropout +
+//              activation, activation' x dropout, ...) runs one output cell per thread.
+//   bf16 mode: both operands are rounded to bf16 values on the way in (v_cvt_pk_bf16_f32, ties to even) and multiplied
+//              as fp32: the products of bf16 values are exact in fp32, so this IS bf16-input / fp32-accumulate
+//              arithmetic (the layer is bound by its weight stream, not by the matrix pipe).
+#pragma once
+#include "chain.h"
+
+namespace aae {
+
+constexpr int kR4 = 4;          // rows per workgroup
+constexpr int kC4T = 1024;      // threads
+constexpr int kC4Part = 4096;   // floats of the k-split partial-sum scratch: [16 / cgp][4][64 cgp]
+
+__device__ __forceinline__ float chain4_rb(float x) {       // nearest bf16 value, as fp32
+    return __builtin_bit_cast(float, gemm_pack_bf16(x, 0.f) << 16);
+}
+
+// One layer's matrix work for this wave: MK = k-steps per wave (compile-time bound of the register arrays).
+template <int MK, bool BF>
+__device__ __forceinline__ void chain4_linear(const ChainOp& op, const float* src, float* part, int wave, int lane,
+                                              int cgp, int kper) {
+    const int N = op.N, K = op.K, ld = op.ldkn;
+    const int cg = wave & (cgp - 1), ks = wave / cgp;
+    const int k0 = ks * kper;
+    const int n = min(64 * cg + lane, N - 1);
+    // all weight loads of the layer in flight before the first MFMA; row index clamped (the A operand is zero beyond K)
+    float w[MK];
+    const float* wp = op.Wkn + n;
+#pragma unroll
+    for (int i = 0; i < MK; ++i) w[i] = wp[(size_t)min(k0 + i, K - 1) * ld];
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const float* a = src + (lane & 3) * kCL;
+#pragma unroll
+    for (int j = 0; j < MK / 4; ++j) {
+        const int kk = k0 + 4 * j;
+        float4 x = *reinterpret_cast<const float4*>(a + min(kk, kCL - 4));
+        if (kk > kCL - 4 || 4 * j >= kper) x = make_float4(0.f, 0.f, 0.f, 0.f);    // beyond the slot row / this wave's k-slice
+        if (kk + 0 >= K) x.x = 0.f;
+        if (kk + 1 >= K) x.y = 0.f;
+        if (kk + 2 >= K) x.z = 0.f;
+        if (kk + 3 >= K) x.w = 0.f;
+        float w0 = w[4 * j], w1 = w[4 * j + 1], w2 = w[4 * j + 2], w3 = w[4 * j + 3];
+        if (BF) {
+            x.x = chain4_rb(x.x); x.y = chain4_rb(x.y); x.z = chain4_rb(x.z); x.w = chain4_rb(x.w);
+            w0 = chain4_rb(w0); w1 = chain4_rb(w1); w2 = chain4_rb(w2); w3 = chain4_rb(w3);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, w1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, w2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, w3, acc1, 0, 0, 0);
+    }
+    acc0 += acc1;
+    // partial sums: part[ks][row][64 cg + lane], row stride 64 cgp
+    float* pp = part + (size_t)ks * (4 * 64 * cgp) + 64 * cg + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pp[r * 64 * cgp] = acc0[r];
+}
+
+template <bool BF>
+__global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
+    extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][4][kCL], then the partial-sum scratch
+    if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
+        tile_bucket_body(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
+        return;
+    }
+    float* part = slots + kCSlots * kR4 * kCL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int erow = tid >> 8, ecol = tid & 255;       // element-wise work: one cell per thread
+    const int r0 = blockIdx.x * kR4;
+    const int nrows = min(kR4, P.rows - r0);
+    const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
+
+    for (int oi = 0; oi < P.nops; ++oi) {
+        const ChainOp& op = P.ops[oi];
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[oi] = wall_clock64();
+        float* dst = slots + op.dst * kR4 * kCL;
+        const float* src = slots + op.src * kR4 * kCL;
+        const int kind = op.kind;
+
+        if (kind == COP_LINEAR || kind == COP_LINEAR_DX) {
+            const int N = op.N, K = op.K;
+            const int CG = (N + 63) >> 6;
+            const int cgp = CG <= 1 ? 1 : CG <= 2 ? 2 : 4;                 // column groups, rounded to a power of two
+            const int KS = 16 / cgp;                                        // waves per column group: the k-split
+            const int kper = ((K + KS - 1) / KS + 3) & ~3;                  // k-steps per wave, a multiple of 4
+            if ((wave & (cgp - 1)) < CG) {
+                if (kper <= 16) chain4_linear<16, BF>(op, src, part, wave, lane, cgp, kper);
+                else if (kper <= 28) chain4_linear<28, BF>(op, src, part, wave, lane, cgp, kper);
+                else chain4_linear<52, BF>(op, src, part, wave, lane, cgp, kper);
+            }
+            chain_barrier();
+            const EpiCtx ec = chain_epi_ctx(op.epi, op, P, key, slots);
+            if (ecol < kCL) {
+                float v = 0.f;
+                if (ecol < N && erow < nrows) {
+                    const float* pp = part + erow * 64 * cgp + ecol;
+                    for (int ks = 0; ks < KS; ++ks) v += pp[(size_t)ks * (4 * 64 * cgp)];
+                    // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
+                    if (ec.epi == CEPI_ACTBWD) {
+                        v *= act_grad_from_y(ec.act, (slots + op.yslot * kR4 * kCL)[erow * kCL + ecol]);
+                        if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
+                    } else {
+                        v = chain_epi(ec, r0 + erow, erow, ecol, v);
+                    }
+                }
+                dst[erow * kCL + ecol] = v;                                 // columns >= N read as zero for the next layer
+            }
+        } else if (kind == COP_LOAD) {
+            if (ecol + op.dst_col0 < kCL)
+                dst[erow * kCL + op.dst_col0 + ecol] =
+                    (erow < nrows && ecol < op.N) ? op.W[(size_t)(op.out_row0 + r0 + erow) * op.ldw + ecol] * op.scale : 0.f;
+        } else if (kind == COP_SLABSUM) {
+            // sum of op.aux (<= 16) partial slabs: every slab load of a thread is in flight at once
+            if (ecol < kCL) {
+                const int rowc = min(erow, max(nrows, 1) - 1), cc = min(ecol, op.N - 1);
+                float v[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z)
+                    v[z] = op.W[(size_t)min(z, op.aux - 1) * op.stride + (size_t)(r0 + rowc) * op.ldw + cc];
+                float acc = 0.f;
+#pragma unroll
+                for (int z = 0; z < 16; ++z)
+                    if (z < op.aux) acc += v[z];
+                if (op.epi == CEPI_ACTBWD) {
+                    const EpiCtx sec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
+                    const float y = op.aux_ptr[(size_t)(r0 + rowc) * op.aux_ld + cc];
+                    const bool cell = erow < nrows && ecol < op.N;
+                    const float kp = (sec.den && cell) ? (chain_keep(sec, r0 + erow, ecol) ? sec.mk : 0.f) : 1.f;
+                    acc *= act_grad_from_y(sec.act, y) * kp;
+                }
+                dst[erow * kCL + ecol] = (erow < nrows && ecol < op.N) ? acc : 0.f;
+            }
+        } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
+            const EpiCtx ec = chain_epi_ctx(kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD, op, P, key, slots);
+            if (ecol < kCL) {
+                float v = 0.f;
+                if (erow < nrows && ecol < op.N) {
+                    v = src[erow * kCL + ecol];
+                    if (kind == COP_DROPACT) v = chain_epi(ec, r0 + erow, erow, ecol, v);
+                    else {
+                        v *= act_grad_from_y(ec.act, (slots + op.yslot * kR4 * kCL)[erow * kCL + ecol]);
+                        if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
+                    }
+                }
+                dst[erow * kCL + ecol] = v;
+            }
+        } else if (kind == COP_FINAL_FWD) {
+            if (wave < kR4) {                           // one wave per row; softmax / sigmoid / identity, in place on dst
+                float* zr = dst + wave * kCL;
+                if (op.aux == 1) {
+                    float mx = -INFINITY;
+                    for (int j = lane; j < op.N; j += 64) mx = fmaxf(mx, zr[j]);
+                    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    float sum = 0.f;
+                    for (int j = lane; j < op.N; j += 64) sum += expf(zr[j] - mx);
+                    sum = wave_sum(sum);
+                    for (int j = lane; j < op.N; j += 64) zr[j] = expf(zr[j] - mx) / sum;
+                } else if (op.aux == 2) {
+                    for (int j = lane; j < op.N; j += 64) zr[j] = sigmoidf_(zr[j]);
+                }
+            }
+        } else if (kind == COP_FINAL_BWD) {
+            if (wave < kR4) {
+                const float* zr = slots + op.yslot * kR4 * kCL + wave * kCL;
+                const float* gr = src + wave * kCL;
+                float* o = dst + wave * kCL;
+                if (op.aux == 1) {
+                    float dot = 0.f;
+                    for (int j = lane; j < op.N; j += 64) dot += gr[j] * zr[j];
+                    dot = wave_sum(dot);
+                    for (int j = lane; j < op.N; j += 64) o[j] = zr[j] * (gr[j] - dot);
+                } else if (op.aux == 2) {
+                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j] * zr[j] * (1.f - zr[j]);
+                } else {
+                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
+                }
+                for (int j = op.N + lane; j < kCL; j += 64) o[j] = 0.f;
+            }
+        } else if (kind == COP_PRIOR) {
+            if (ecol < kCL) {
+                const int grow = r0 + erow, n = op.N;
+                const uint64_t k = key ^ (100ull * 0xA0761D6478BD642Full);
+                float v = 0.f;
+                if (erow < nrows && ecol < n) {
+                    if (grow >= op.row_split) v = op.W[(size_t)grow * op.ldw + ecol];
+                    else if (op.aux_ptr) v = op.aux_ptr[(size_t)grow * op.aux_ld + ecol] * op.scale;
+                    else if (op.aux == 0) {          // gauss: Box-Muller on two words of the counter generator
+                        const uint32_t u1 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * ecol));
+                        const uint32_t u2 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * ecol + 1));
+                        const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+                        const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
+                        v = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2) * op.scale;
+                    } else if (op.aux == 1) {        // categorical: one-hot of a uniform class per row
+                        const uint32_t u = hash_cell(k, (uint32_t)(grow + op.grow0), 0xFFFFFFFFu);
+                        v = ((int)(u % (uint32_t)n) == ecol) ? op.scale : 0.f;
+                    }                                // bernoulli: the reference's randint(0, 1) is always 0 (aae.py:86-88)
+                }
+                dst[erow * kCL + ecol] = v;
+            }
+        } else if (kind == COP_DISC_HEAD) {
+            // one wave per row: the discriminator's 1-unit output layer, its loss and its dX (see chain.h)
+            if (wave < kR4) {
+                const EpiCtx ec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
+                const int lrow = wave, grow = r0 + lrow;
+                const int Kk = op.K, Nn = op.N;
+                float wv[4], dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    wv[j] = op.W[min(k, Kk - 1)];
+                    if (k < Kk) dot += src[lrow * kCL + k] * wv[j];
+                }
+                const float logit = wave_sum(dot);
+                float gv = 0.f;
+                if (lrow < nrows) {
+                    const float dv = sigmoidf_(logit);
+                    const int Bsplit = op.row_split;
+                    const float invB = 1.f / (float)Bsplit;
+                    float l, gg;
+                    if (op.aux == 0 && grow >= Bsplit) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
+                    else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
+                    gv = gg * dv * (1.f - dv) * op.scale;
+                    if (lane == 0) {
+                        atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                        if (op.aux_ptr) op.aux_ptr[(size_t)grow * op.aux_ld] = gv;
+                    }
+                }
+                const float* ys = slots + op.yslot * kR4 * kCL;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < kCL) {
+                        float v = 0.f;
+                        if (lrow < nrows && k < Nn) {
+                            v = gv * wv[j] * act_grad_from_y(ec.act, ys[lrow * kCL + k]);
+                            if (ec.den) v *= chain_keep(ec, grow, k) ? ec.mk : 0.f;
+                        }
+                        dst[lrow * kCL + k] = v;
+                    }
+                }
+            }
+        }   // COP_STORE: only the stores below.  (COP_ADV / COP_REPARAM*: VAE programs stay on chain.h's kernel)
+        chain_barrier();
+        if (op.one_col >= 0) {
+            if (tid < kR4) dst[tid * kCL + op.one_col] = tid < nrows ? 1.f : 0.f;
+            chain_barrier();
+        }
+        if (erow < nrows && ecol < op.N) {
+            if (op.out) op.out[(size_t)(op.out_row0 + r0 + erow) * op.ldo + ecol] = dst[erow * kCL + ecol];
+            if (op.out2) op.out2[(size_t)(r0 + erow) * op.ldo2 + ecol] = dst[erow * kCL + ecol];
+        }
+    }
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[P.nops] = wall_clock64();
+}
+
+}  // namespace aae
