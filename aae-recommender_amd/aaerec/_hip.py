@@ -14,7 +14,7 @@ import numpy as np
 import torch  # must be imported before the library so both share one HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaaerec_hip.so")
+LIB_PATH = os.environ.get("AAE_HIP_LIB") or os.path.join(_HERE, "libaaerec_hip.so")     # (AAE_HIP_LIB: A/B builds of the library)
 
 ABI_VERSION = 1
 ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5}
