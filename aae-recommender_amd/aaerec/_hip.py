@@ -111,7 +111,7 @@ _PROTOS = {
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
-K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED = range(6)
+K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN = range(7)
 
 _lib = None
 

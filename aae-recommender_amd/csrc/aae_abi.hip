@@ -599,6 +599,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
         cb.P.ts = ts_dev;
     }
+    ProfScope ps(m, AAE_K_CHAIN, s);
     // 4-row workgroups (chain4.h) whenever every linear op of the program has its k-major matrix (all but the VAE's)
     bool four = m->use_chain4;
     for (int i = 0; i < cb.P.nops && four; ++i)

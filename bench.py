@@ -98,7 +98,7 @@ def spawn_ranks(n):
     sys.exit(rc if rc or lines else 1)
 
 
-def kernel_models(N, h, B, nnz_per_batch):
+def kernel_models(N, h, B, nnz_per_batch, c=50):
     """ALGORITHMIC bytes / flops per launch of the instrumented kernels."""
     P3 = N * (h + 1)      # decoder output layer, augmented with its bias column
     return {
@@ -111,11 +111,16 @@ def kernel_models(N, h, B, nnz_per_batch):
         # fused decoder output layer: V3a read once (4 B) + m, v read (8 B) + p, m, v written (12 B) per
         # parameter; logits/dL/dlogits never leave the chip; three GEMMs of 2*B*N*(h+1) flop each
         "dec_fused": dict(bytes=24 * P3, flops=6 * B * P3),
+        # a layer-chain program (5 per step: the hidden stacks of ae forward, ae backward, the discriminator's encoder
+        # pass, the discriminator step, gen_step).  Per step: 13 passes of B rows through an h x (h+1) layer and 11 through
+        # an (h or c)-wide x (c or h)+1 one, forward and dX; the weights are the algorithmic bytes (each program reads its
+        # matrices once).  Latency-, not roofline-bound: the figure is reported, not a target.
+        "chain": dict(bytes=4 * (13 * h * (h + 1) + 11 * c * (h + 1)) / 5.0, flops=2.0 * B * (13 * h * (h + 1) + 11 * c * (h + 1)) / 5.0),
     }
 
 
-NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
-K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED = range(6)
+NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain"]
+K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED, K_CHAIN = range(7)
 
 
 class _ConstVectors:
@@ -230,9 +235,9 @@ def main():
     losses = model._losses()
     docs_per_s = a.steps * Bg / dt
 
-    km = kernel_models(N, h, B, nnz_per_batch)
+    km = kernel_models(N, h, B, nnz_per_batch, c)
     if vocab:       # the output-layer kernels' algorithmic work on this rank: its item slice x the global batch
-        km_out = kernel_models(out_model.N, h, Bg, nnz_per_batch)
+        km_out = kernel_models(out_model.N, h, Bg, nnz_per_batch, c)
         for k in ("dec_bce_fwd", "dec_da2", "dec_dv3_adam", "dec_fused"):
             km[k] = km_out[k]
     kstats = {}
@@ -248,13 +253,13 @@ def main():
                                           TFLOPs=round(models[NAMES[kid]]["flops"] / avg_s / 1e12, 2))
     collect((K_BCE, K_DA2, K_DV3, K_FUSED), a.steps * len(dts), sum(dts), out_model)
     extra_steps = min(a.steps, 40)
-    model.hip.profile_enable(True, kernels=(K_GATHER, K_W1))
+    model.hip.profile_enable(True, kernels=(K_GATHER, K_W1, K_CHAIN))
     t0 = time.perf_counter()
     for _ in range(extra_steps):
         next(it)
     barrier()
     model.hip.profile_enable(False)
-    collect((K_GATHER, K_W1), extra_steps, time.perf_counter() - t0, model.hip)
+    collect((K_GATHER, K_W1, K_CHAIN), extra_steps, time.perf_counter() - t0, model.hip)
 
     peak_tf = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
     roofline = None
@@ -322,7 +327,7 @@ def main():
             m2.hip.profile_enable(True, kernels=(K_BCE, K_DA2, K_DV3, K_FUSED))
             d2 = timed_steps(it2, k2, barrier)
             m2.hip.profile_enable(False)
-            km2 = kernel_models(N, h, 512, X2.nnz / 16)
+            km2 = kernel_models(N, h, 512, X2.nnz / 16, c)
             ks2 = {}
             for kid in (K_BCE, K_DA2, K_DV3, K_FUSED):
                 ms, n = m2.hip.profile_read(kid)

@@ -345,6 +345,7 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_DEC_DV3_ADAM,     /* dV3 GEMM + fused Adam on V3 */
        AAE_K_ENC_W1_ADAM,      /* Adam over the touched rows of the encoder's first layer */
        AAE_K_DEC_FUSED,        /* fused decoder output layer: logits + BCE + dV3/Adam + dA2 (B <= ~104) */
+       AAE_K_CHAIN,            /* a layer-chain program: the hidden stacks of one phase (5 launches per step) */
        AAE_K_N };
 /* on = 0: off; 1: every kernel id above; otherwise a selection: bit (k + 1) of `on` times kernel id k
  * (an event pair costs a few microseconds of stream time, so a timed run selects only what it reports) */
