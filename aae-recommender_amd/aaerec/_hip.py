@@ -110,8 +110,10 @@ _PROTOS = {
                                    C.c_int64, C.c_void_p, C.POINTER(C.c_int32 * 4), C.c_void_p]),
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "aae_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
 }
-K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN = range(7)
+K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN, K_DEC_CRIT, K_DEC_OPT = range(9)
 
 _lib = None
 
@@ -394,7 +396,9 @@ class HipAAE:
 
     # ---- views into the arena ---------------------------------------------------------
     def tensor(self, tid, padded=False):
-        """float32 view [rows, cols] (strided by ld) of a tensor of the model."""
+        """float32 view [rows, cols] (strided by ld) of a tensor of the model.  (The current stream first waits for the
+        deferred optimiser launch of the last step, if one is pending: a view is about to read or write what it touches.)"""
+        self.join()
         info = AaeTensor()
         _check(self.lib.aae_tensor_info(self.handle, tid, C.byref(info)))
         flat = self.arena[info.byte_offset: info.byte_offset + info.rows * info.ld * 4].view(torch.float32)
@@ -404,6 +408,7 @@ class HipAAE:
     def _span(self, tid_lo, tid_hi):
         """One flat float32 view from the start of tensor tid_lo to the end of tid_hi (they are
         adjacent in the arena; the 256-byte alignment gaps in between are never written)."""
+        self.join()
         a, b = AaeTensor(), AaeTensor()
         _check(self.lib.aae_tensor_info(self.handle, tid_lo, C.byref(a)))
         _check(self.lib.aae_tensor_info(self.handle, tid_hi, C.byref(b)))
@@ -420,6 +425,16 @@ class HipAAE:
         if which == "dec_small":
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2)]
         return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
+
+    def join(self):
+        """Make the current stream wait for the last step's deferred dec_optim launch (aae_join; no-op when none)."""
+        _check(self.lib.aae_join(self.handle, self._stream()))
+
+    def set_split(self, workgroups):
+        """0: the fused output layer as one launch on the caller's stream; n > 0: split form, n workgroups for the
+        deferred dec_optim launch (aae_set_split)."""
+        self.sync()
+        _check(self.lib.aae_set_split(self.handle, int(workgroups)))
 
     # ---- state_dict in the reference layout ------------------------------------------
     def sync(self):

@@ -15,6 +15,7 @@
 // The step is a fixed sequence of kernel launches on one stream (no host sync, no allocation),
 // so a caller may capture it into a hipGraph.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -116,7 +117,13 @@ struct aae_model {
     // optional per-kernel timing (hipEvent pairs on the launch stream)
     bool prof_on; unsigned prof_mask;   // bit k: time kernel id k
     std::vector<std::pair<hipEvent_t, hipEvent_t>>* prof_ev;   // [AAE_K_N]
-    size_t prof_used[8];
+    size_t prof_used[AAE_K_N];
+    // split form of the fused decoder output layer (dec_fused.h, kDecCrit / kDecOpt): the optimiser launch of a step
+    // runs on `side` behind the rest of the step; ev_crit = the critical launch is done (the side stream waits for it),
+    // ev_opt = the optimiser launch is done (join_deferred() makes a caller's stream wait for it)
+    bool split_ok; int split_wgs; bool opt_pending;
+    hipStream_t side; hipEvent_t ev_crit, ev_opt;
+    float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
 };
 
 namespace {
@@ -207,7 +214,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
     m->dh1 = a.mat(R, h + 1, m->ldh); m->dh2 = a.mat(R, h + 1, m->ldh);
-    m->G = a.mat(R, N, m->ldn);
+    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1);   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
     // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
@@ -280,6 +287,37 @@ struct ProfScope {
         m->prof_used[k]++;
     }
 };
+
+// A timing pair for a launch through hipExtLaunchKernelGGL (the events ride on the kernel's own start / completion
+// signals: no marker packets on the stream); false when kernel id k is not being timed
+bool prof_pair(aae_model* m, int k, hipEvent_t* a, hipEvent_t* b) {
+    if (!(m->prof_on && ((m->prof_mask >> k) & 1))) return false;
+    auto& v = m->prof_ev[k];
+    if (m->prof_used[k] == v.size()) {
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        v.emplace_back(x, y);
+    }
+    *a = v[m->prof_used[k]].first; *b = v[m->prof_used[k]].second;
+    m->prof_used[k]++;
+    return true;
+}
+
+// The previous step's deferred optimiser launch (dec_fused.h kDecOpt on m->side) writes DEC_V3 and its moments and
+// reads dh2 / the G scratch / the decoder's step scalars: everything that touches those waits for it here.
+int join_deferred(aae_model* m, hipStream_t s) {
+    if (!m->opt_pending) return AAE_OK;
+    HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
+    m->opt_pending = false;
+    return AAE_OK;
+}
+// ... for the entry points without a stream (host-synchronous state import / export)
+int join_host(aae_model* m) {
+    if (!m->opt_pending) return AAE_OK;
+    HIPCHK(hipStreamSynchronize(m->side));
+    m->opt_pending = false;
+    return AAE_OK;
+}
 
 DropSpec make_drop(const aae_model* m, int layer, bool train, const uint8_t* ma, const uint8_t* mb, int split,
                    int width, uint32_t stream_id) {
@@ -1018,6 +1056,29 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     }
     m->grad_scale = 1.f;
     m->rng_row0 = 0; m->rng_global = 0;
+    m->Gt = m->G.p;
+    m->split_ok = false; m->opt_pending = false; m->side = nullptr; m->ev_crit = m->ev_opt = nullptr;
+    m->split_wgs = std::max(1, m->n_cu / 2);
+    { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
+    if (m->fused_ok && !m->bf16 && cfg->grad_mode == AAE_GRAD_FUSED && m->split_wgs > 0 &&
+        (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
+        int lo = 0, hi = 0;
+        // both events order work of this device only: no system-scope release (an L2 write-back) at the record
+        unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
+        { const char* e = getenv("AAE_SPLIT_EVFLAGS"); if (e) evflags = (unsigned)strtoul(e, nullptr, 0); }
+        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+                  hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_crit, evflags) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_opt, evflags) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        m->split_ok = ok;
+        (void)hipGetLastError();
+    }
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
     if (e != hipSuccess) { delete m; return fail(AAE_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
@@ -1042,6 +1103,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
 
 int aae_destroy(aae_handle h) {
     if (!h) return AAE_OK;
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);     // the arena is the caller's: nothing of ours may still write it
+        (void)hipStreamDestroy(h->side);
+    }
+    if (h->ev_crit) (void)hipEventDestroy(h->ev_crit);
+    if (h->ev_opt) (void)hipEventDestroy(h->ev_opt);
     if (h->prof_ev) {
         for (int k = 0; k < AAE_K_N; ++k)
             for (auto& pr : h->prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1161,6 +1228,19 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
     return AAE_OK;
 }
 
+int aae_join(aae_handle h, void* stream) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    return join_deferred(h, S(stream));
+}
+
+int aae_set_split(aae_handle h, int32_t workgroups) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    if (workgroups < 0) return fail(AAE_EINVAL, "workgroups must be >= 0");
+    if (h->opt_pending) return fail(AAE_ESTATE, "aae_set_split with a deferred launch pending: call aae_join / aae_sync first");
+    h->split_wgs = workgroups;
+    return AAE_OK;
+}
+
 int aae_set_grad_scale(aae_handle h, float scale) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     h->grad_scale = scale; return AAE_OK;
@@ -1183,6 +1263,7 @@ int aae_params_changed(aae_handle h) {
 
 int aae_set_lr(aae_handle h, double gen_lr, double reg_lr) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    TRY(join_host(h));
     OptScalars hs[4];
     HIPCHK(hipMemcpy(hs, h->sc, sizeof(hs), hipMemcpyDeviceToHost));
     hs[O_ENC].lr = gen_lr; hs[O_DEC].lr = gen_lr; hs[O_GEN].lr = reg_lr; hs[O_DISC].lr = reg_lr;
@@ -1222,6 +1303,7 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
 // state hold the values an eager implementation would
 int aae_sync(aae_handle h, void* stream) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    TRY(join_deferred(h, S(stream)));
     return lazy_flush(h, S(stream));
 }
 
@@ -1282,6 +1364,7 @@ int aae_load_linear(aae_handle h, int net, int layer, const float* w, const floa
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid = param_id(net, layer);
     if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    TRY(join_host(h));
     TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     return put_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
@@ -1290,6 +1373,7 @@ int aae_store_linear(aae_handle h, int net, int layer, float* w, float* b) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid = param_id(net, layer);
     if (pid < 0) return fail(AAE_EINVAL, "bad net/layer");
+    TRY(join_host(h));
     TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     return get_linear(h, pid, h->P[pid], pid == P_W1T ? &h->P[P_B1] : nullptr, w, b);
@@ -1310,6 +1394,7 @@ int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const fl
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid, set;
     if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    TRY(join_host(h));
     TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
@@ -1336,6 +1421,7 @@ int aae_store_adam(aae_handle h, int which, int layer, float* m_w, float* v_w, f
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     int pid, set;
     if (adam_sel(which, layer, &pid, &set)) return fail(AAE_EINVAL, "bad optimiser/layer");
+    TRY(join_host(h));
     TRY(lazy_flush(h, nullptr));
     HIPCHK(hipDeviceSynchronize());
     const Ten* mb = pid == P_W1T ? &h->M[set][P_B1] : nullptr;
@@ -1364,6 +1450,7 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));       // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        m->stamp, m->ucount, m->losses);
     if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
@@ -1444,6 +1531,38 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             fa.ts = ts_dev;
         }
         const int grid = std::min(ntiles, m->n_cu);
+        fa.Gt = m->Gt;
+        if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && fa.dbg_skip == 0) {
+            // ---- split form: the critical launch here, the optimiser launch on the side stream behind the rest of the step
+            TRY(join_deferred(m, s));                   // (a step-opening entry point already did; cheap when nothing is pending)
+            {
+                // "this launch is done" rides on the kernel's own completion signal (a hipEventRecord behind the launch is a
+                // marker packet the next kernel of the stream waits for: +30 us per step); when the launch is being timed,
+                // the timing pair's stop event doubles as that event
+                hipEvent_t start = nullptr, stop = m->ev_crit;
+                (void)prof_pair(m, AAE_K_DEC_CRIT, &start, &stop);
+                switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
+                }
+                LAUNCHCHK("dec_fused (critical launch)");
+                HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
+            }
+            {
+                const int g2 = std::min(ntiles, std::min(m->split_wgs, m->n_cu));
+                hipEvent_t start = nullptr, stop = nullptr;
+                (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
+                switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
+                }
+                LAUNCHCHK("dec_fused (optimiser launch)");
+            }
+            HIPCHK(hipEventRecord(m->ev_opt, m->side));
+            m->opt_pending = true;
+        } else
         {
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
             if (m->bf16) switch (m->fused_nb) {
@@ -1597,6 +1716,7 @@ int aae_decoder_step(aae_handle m, const aae_batch* batch, const float* zin_dev,
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));       // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        m->stamp, m->ucount, m->losses);
     LAUNCHCHK("advance_step");
@@ -1617,6 +1737,7 @@ int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, co
     TRY(set_batch(m, batch));
     remember_inject(m, nullptr, true);
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        m->stamp, m->ucount, m->losses);
     LAUNCHCHK("advance_step");
@@ -1644,6 +1765,7 @@ int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev,
         return fail(AAE_EINVAL, "out_dev must be 16-byte aligned with out_ld >= n_items and out_ld % 4 == 0");
     TRY(set_batch(m, batch));
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
     if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
     TRY(gather_first_layer(m, false, nullptr, 0, s));
     TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
@@ -1702,6 +1824,7 @@ int aae_output_layer_step(aae_handle m, const aae_batch* batch, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->vae) return fail(AAE_ESTATE, "aae_output_layer_step: not in VAE mode");
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
     if (batch) {
         TRY(set_batch(m, batch));
         remember_inject(m, nullptr, true);
@@ -1868,6 +1991,7 @@ int aae_encode(aae_handle m, const aae_batch* batch, float* z_out, void* stream)
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     TRY(set_batch(m, batch));
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
     if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
     if (m->use_chain) {
         TRY(gather_first_layer(m, false, nullptr, 0, s));
@@ -1896,6 +2020,7 @@ int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
     if (out_ld < m->N || (out_ld & 3) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
         return fail(AAE_EINVAL, "out_dev must be 16-byte aligned with out_ld >= n_items and out_ld % 4 == 0");
     hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
     if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, n_rows, s));
     if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
     else TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));

@@ -70,7 +70,18 @@ struct DecFusedArgs {
     const OptScalars* sc;
     int dbg_skip;                         // timing-only ablation mask (AAE_DEC_SKIP), 0 in production
     unsigned long long* ts;               // debug (AAE_DEC_TS): 100 MHz phase timestamps of workgroup 0, tile 5; else NULL
+    float* Gt;                            // split form: dL/dlogits tile-major [tile][B][32] (written by MODE 1, read by MODE 2)
 };
+
+// MODE of dec_fused_kernel.  The step's critical path needs only dL/d(dh2) from this layer (the decoder's hidden
+// backward waits for it); the weight gradient and the optimiser pass over V3 - all of the layer's HBM traffic - are
+// needed by the NEXT step's forward.  The split form runs them as two launches: kDecCrit on the caller's stream,
+// kDecOpt on a side stream with fewer workgroups than CUs, behind the latency-bound rest of the step (section 3.2c).
+constexpr int kDecFused = 0;   // S0 GEMM1 S2 GEMM2 GEMM3 S5: everything in one launch
+constexpr int kDecCrit = 1;    // S0 GEMM1 S2 GEMM3: logits, BCE, dA2 slabs, loss; stores the tile's dL/dlogits to Gt
+constexpr int kDecOpt = 2;     // S0 GEMM2 S5: dV3 from the stored dL/dlogits + dec_optim.  Its streams (V3, m, v, the stored
+                               // tiles) are non-temporal: with plain loads / stores the 0.5 GB pass evicted the hidden layers'
+                               // weights from L2 under the layer-chain kernels it runs beside (+25 % on each of them)
 
 // LDS bytes the kernel needs for (B, h)
 inline size_t dec_fused_lds_bytes(int B, int h) {
@@ -85,8 +96,12 @@ inline size_t dec_fused_lds_bytes(int B, int h) {
 // kernel (each tile's rows are read and written by the same lanes), so LDS ordering is all it needs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NB>   // NB = ceil((h + 1) / 16) column blocks
+template <int NB, int MODE = kDecFused>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
+    constexpr bool kFwd = MODE != kDecOpt;     // GEMM1, entries, GEMM3, loss, slabs
+    constexpr bool kOpt = MODE != kDecCrit;    // GEMM2, optimiser
+    constexpr bool kIsOpt = MODE == kDecOpt;
+    constexpr int kAux = kIsOpt ? 2 : 0;       // buffer-store cache policy: 2 = nt
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dhs = lds;                                  // [B][kSD]
     float* v3s = dhs + (size_t)a.B * kSD;              // [32][kSD]
@@ -140,7 +155,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const size_t f = f0 + (size_t)(tid + kNT * j);
-            r[j] = reinterpret_cast<const float4*>(base)[f < last_f4 ? f : last_f4];
+            if (kIsOpt) { const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (f < last_f4 ? f : last_f4)); r[j] = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+            else r[j] = reinterpret_cast<const float4*>(base)[f < last_f4 ? f : last_f4];
         }
         // no masking here: a use right after the load would make the wave wait for it; clamped lanes
         // hold finite values that are either never stored or multiplied by zero gradients
@@ -176,11 +192,23 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         const int e = min(lo + tid, last_e);
         ent_b = a.te.eb[e]; ent_n = a.te.en[e]; ent_v = a.te.ev[e];
     };
+    // split form: this thread's float4 of the tile's stored dL/dlogits ([B][32] floats per tile, contiguous)
+    float4 greg = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int g_f4 = B * (kTI / 4);                    // float4 per tile (<= kNT: B <= 16 * kMB <= 128)
+    const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
+    const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(a.Gt ? a.Gt : a.V3a, 0, gbytes, 0x00020000);
+    auto load_g = [&](int t) {
+        if (kIsOpt) { const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.Gt) + (size_t)t * g_f4 + min(tid, g_f4 - 1)); greg = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+        else greg = reinterpret_cast<const float4*>(a.Gt)[(size_t)t * g_f4 + min(tid, g_f4 - 1)];
+    };
     if (tile < ntiles) {
         load_span(a.V3a, tile, vreg);
-        load_range(tile, ne0, ne1);
-        load_range(tile + stride, fe0, fe1);
-        load_entry(ne0);
+        if (kFwd) {
+            load_range(tile, ne0, ne1);
+            load_range(tile + stride, fe0, fe1);
+            load_entry(ne0);
+        }
+        if (kIsOpt) load_g(tile);
     }
 
     // tile-invariant addressing of this thread's NV float4 slots of a tile span (no division in the loop)
@@ -217,13 +245,19 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         }
         ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
         const int my_p = ent_b * kSG + ent_n; const float my_v = ent_v;
+        if (kIsOpt) {
+            if (tid < g_f4) *reinterpret_cast<float4*>(gs + (tid >> 3) * kSG + (tid & 7) * 4) = greg;
+            load_g(min(tile + stride, ntiles - 1));
+        }
         load_span(a.V3a, min(tile + stride, ntiles - 1), vreg);
-        load_range(tile + 2 * stride, fe0, fe1);
-        load_entry(ne0);
+        if (kFwd) {
+            load_range(tile + 2 * stride, fe0, fe1);
+            load_entry(ne0);
+        }
         lds_barrier();
         stamp(1);
 
-        if (!(a.dbg_skip & 1) && wave < 2 * nmb)
+        if (kFwd && !(a.dbg_skip & 1) && wave < 2 * nmb)
         // ---- S1: GEMM1 logits[b][n] = sum_k dh2[b][k] * V3a[n][k]; blocks (mb, nb2) id = mb*2 + nb2,
         // one block per wave; `wave` is a scalar, so waves past the last block skip with a scalar branch and
         // leave the matrix pipe of their SIMD to the others
@@ -263,11 +297,11 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                     }
             }
         }
-        lds_barrier();
+        if (kFwd) lds_barrier();
         stamp(2);
 
         // ---- S2: the CSR entries of the tile (non-zero targets) replace their cell's gradient and loss term
-        {
+        if (kFwd) {
             const int e0 = ce0, e1 = (a.dbg_skip & 2) ? e0 : ce1;
             if (tid < e1 - e0) {                        // the prefetched entry of this thread
                 float g0, l0, g1, l1;
@@ -285,12 +319,19 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 gs[p] = g1;
             }
         }
-        lds_barrier();
+        if (kFwd) lds_barrier();
 
         stamp(3);
+        if (MODE == kDecCrit) {
+            // the finished dL/dlogits tile -> Gt for the deferred launch; the store retires behind GEMM3 (a lane without
+            // a cell gets an offset beyond the descriptor: no branch around the store, see S5)
+            const float4 gq = *reinterpret_cast<const float4*>(gs + (min(tid, g_f4 - 1) >> 3) * kSG + (tid & 7) * 4);
+            const unsigned go = tid < g_f4 ? (unsigned)tid * 16u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, gq), rGt, go, (unsigned)tile * (unsigned)g_f4 * 16u, 0);
+        }
         // the optimiser moments of this tile travel while GEMM2 and GEMM3 run
         // (unconditional: the moment tensors exist in every mode, and a load under a condition is waited for on the spot)
-        load_span(a.M, tile, mreg); load_span(a.V, tile, sreg);
+        if (kOpt) { load_span(a.M, tile, mreg); load_span(a.V, tile, sreg); }
         // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib, a wave owns the ids
         // wave + 16q: they share the item half ib (one G read serves them all) and differ in the column block.
         // k runs over the batch rows in groups of 16: k-step (g, j) multiplies rows 16g + j + 4*fk.  Rows 4
@@ -350,7 +391,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 for (int r = 0; r < 4; ++r) os[(rb + r) * kSO + cb] = c[r];
             }
         };
-        if (!(a.dbg_skip & 4) && wave < 2 * NB) {
+        if (kOpt && !(a.dbg_skip & 4) && wave < 2 * NB) {
             constexpr int Q2 = (2 * NB + kNW - 1) / kNW;
             static_assert(kNW % 2 == 0, "a wave's blocks must share the item half");
             if (wave + kNW * (Q2 - 1) < 2 * NB) gemm2(std::integral_constant<int, Q2>{});     // scalar branch
@@ -359,7 +400,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
 
         // ---- S4: GEMM3 dA2[b][c] += sum_n G[b][n] * V3a[n][c]; blocks id = mb*NB + nb, ids wave + 16q.  It runs
         // after S5 so that the parameter stores retire behind these MFMAs, not at the next tile's first wait.
-        if (!(a.dbg_skip & 8)) {
+        if (kFwd && !(a.dbg_skip & 8)) {
             constexpr int Q3 = (kMB * NB + kNW - 1) / kNW;
             // scalar: the wave's last block exists, or is a duplicate that only keeps the code branch-free (small
             // batches have several duplicates: they still run, and are never stored)
@@ -388,7 +429,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                     }
             }
         }
-        lds_barrier();                               // os complete
+        if (kOpt) lds_barrier();                     // os complete
         stamp(4);
 
         // ---- S5: optimiser on the tile (or gradient export), whole rows, float4 per lane.  The stores are issued on
@@ -396,7 +437,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         // the vocabulary, the moments in SGD / export mode) gets a buffer offset beyond the descriptor's range and the
         // bounds check drops it.  With stores under lane- or mode-dependent branches the compiler's wait counters lose
         // track of how many are in flight, and the next tile's first use of its prefetched V3a waited for all of them.
-        if (!(a.dbg_skip & 16))
+        if (kOpt && !(a.dbg_skip & 16))
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const bool valid = tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < a.N && !(a.dbg_skip & 32);
@@ -413,9 +454,9 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             }
             const float4 out = do_adam ? p : g;
             const unsigned vo2 = (do_adam && !sc.is_sgd) ? vo : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, out), do_adam ? rP : rG, vo, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, out), do_adam ? rP : rG, vo, so, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, kAux);
         }
 
         stamp(5);
@@ -423,6 +464,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     }
 
     if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
+    if (!kFwd) return;
     // ---- dA2 partial of this workgroup -> its slab; loss partial
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll

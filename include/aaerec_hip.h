@@ -346,11 +346,26 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_ENC_W1_ADAM,      /* Adam over the touched rows of the encoder's first layer */
        AAE_K_DEC_FUSED,        /* fused decoder output layer: logits + BCE + dV3/Adam + dA2 (B <= ~104) */
        AAE_K_CHAIN,            /* a layer-chain program: the hidden stacks of one phase (5 launches per step) */
+       AAE_K_DEC_CRIT,         /* split form of the fused output layer, critical launch: logits + BCE + dA2 (+ dL/dlogits tiles) */
+       AAE_K_DEC_OPT,          /* ... deferred launch on the library's side stream: dV3 + dec_optim behind the rest of the step */
        AAE_K_N };
 /* on = 0: off; 1: every kernel id above; otherwise a selection: bit (k + 1) of `on` times kernel id k
  * (an event pair costs a few microseconds of stream time, so a timed run selects only what it reports) */
 int aae_profile_enable(aae_handle h, int on);
 int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* launches);
+
+/* The fused decoder output layer (B <= ~104, fused optimiser) runs as TWO launches: what the rest of the step waits
+ * for (logits, BCE, dL/d(hidden)) on the caller's stream, and the weight gradient + dec_optim pass over DEC_V3 - work
+ * only the NEXT step's forward needs (reference aae.py:709 `self.dec_optim.step()` followed by aae.py:713-743, which
+ * never read dec) - on a stream the handle owns, concurrently with the rest of the step.  Every entry point of this
+ * library that touches DEC_V3, its moments or the step's scratch first makes its `stream` wait for that launch, so
+ * callers that go through the ABI see the reference's ordering.  A caller that reads DEC_V3 / ADAM_DEC + 4,5 through
+ * its own arena views (aae_tensor_info) calls aae_join first: it makes `stream` wait for the deferred launch (a
+ * no-op when none is pending).  aae_sync includes it.  aae_set_split(h, 0) turns the split form off (one launch,
+ * everything on the caller's stream: needed to capture a step into a hipGraph without joining), n > 0 sets the number
+ * of workgroups of the deferred launch (default: 5/8 of the CUs). */
+int aae_join(aae_handle h, void* stream);
+int aae_set_split(aae_handle h, int32_t workgroups);
 
 #ifdef __cplusplus
 }

@@ -102,3 +102,52 @@ def test_c5_share_output_layer_of_one_rank():
     dw, db = _maxdiff(sd["dec.lin3.weight"], ref.p["w"]), _maxdiff(sd["dec.lin3.bias"], ref.p["b"])
     print("C5 share: max |dW|", dw, "max |db|", db)
     assert dw <= 1e-5 and db <= 1e-5
+
+
+def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_deferred_launch():
+    """The fused output layer runs as a critical launch (logits, BCE, dL/d(hidden)) on the caller's stream and a deferred
+    one (dV3 + dec_optim) on the handle's side stream (include/aaerec_hip.h: aae_join / aae_set_split).  Same arithmetic
+    in the same order: after the first step (the forward pass has no atomics) dec.lin3 and both dec_optim moments equal
+    the one-launch form BIT FOR BIT at the benchmark's shape; later steps differ only through the encoder's scatter
+    atomics (2e-6, the bound between the fused and the three-kernel path above; a view that did not wait for the deferred
+    launch would be one Adam step = 1e-3 off).  A view taken right behind a step - while the deferred launch is still
+    running - must already show its result."""
+    from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
+    from tools.synth import init_params, throughput_corpus
+    N, h, c, B, steps = 100000, 200, 50, 100, 6
+    params = init_params(N, h, c, seed=4)
+    X = throughput_corpus(steps * B, N, median_len=20, seed=78)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3, rng_mode="device", seed=99)
+    split, single = HipAAE(N, h, c, max_batch=B, **kw), HipAAE(N, h, c, max_batch=B, **kw)
+    single.set_split(0)
+    for m in (split, single):
+        m.load_params(params)
+    csr = DeviceCSR(X, split.device)
+    tids = (T_DEC_V3, T_ADAM_DEC + 4, T_ADAM_DEC + 5)
+
+    def views():    # taken right behind the steps: tensor() joins the deferred launch before the copy reads the tensor
+        return [(split.tensor(t, padded=True).clone(), single.tensor(t, padded=True).clone()) for t in tids]
+    for s in range(steps):
+        before = split.tensor(T_DEC_V3, padded=True).clone() if s == 0 else None
+        for m in (split, single):
+            m.step(csr, s * B, B)
+        if s == 0:
+            for a, b in views():
+                assert torch.equal(a, b)
+            assert float((split.tensor(T_DEC_V3, padded=True) - before).abs().max()) > 5e-4      # (the step did move it)
+        else:
+            for a, b in views():
+                assert float((a - b).abs().max()) <= 2e-6
+    np.testing.assert_allclose(split.losses(), single.losses(), rtol=1e-5)
+    sa, sb = split.state_dict(), single.state_dict()
+    for k in sa:
+        np.testing.assert_allclose(sa[k], sb[k], atol=2e-6, err_msg=k)
+    # short batches and a batch-size change in mid-run (the deferred launch of a 100-row step is pending when a 37-row
+    # one starts) keep the order as well
+    for s, rows in enumerate((37, 100, 5, 64)):
+        for m in (split, single):
+            m.step(csr, s * B, rows)
+    np.testing.assert_allclose(split.losses(), single.losses(), rtol=1e-5)
+    assert float((split.tensor(T_DEC_V3, padded=True) - single.tensor(T_DEC_V3, padded=True)).abs().max()) <= 2e-6
+    # predict reads DEC_V3 through the ABI: joined inside
+    np.testing.assert_allclose(split.predict(csr, 0, B).cpu().numpy(), single.predict(csr, 0, B).cpu().numpy(), atol=1e-6)
