@@ -88,6 +88,8 @@ _PROTOS = {
     "aae_read_losses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.c_void_p]),
     "aae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_predict_topk": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aae_decode_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AaeBatch), C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
     "aae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_apply_updates": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -777,6 +779,18 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_predict_topk(self.handle, C.byref(b), _ptr(cond), int(k), int(bool(exclude_known)),
                                              _ptr(idx), _ptr(val), self._stream()))
+        return idx, val
+
+    def decode_topk(self, zc, csr, row_start, k, exclude_known=True):
+        """Top-k of decode(zc) for the input rows csr[row_start : row_start + len(zc)] (aae_decode_topk)."""
+        zc = zc.detach().to(self.device, torch.float32).contiguous()
+        n_rows = zc.shape[0]
+        b = self._batch(csr, row_start, n_rows)
+        idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
+        val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_decode_topk(self.handle, _ptr(zc), zc.shape[1], C.byref(b), int(k), int(bool(exclude_known)),
+                                            _ptr(idx), _ptr(val), self._stream()))
         return idx, val
 
     def encode(self, csr, row_start, n_rows):

@@ -566,11 +566,14 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
     """Top-k recommendations without materialising the [n, N] score matrix on the host: the
     reference's predict -> remove_non_missing -> argtopk pipeline (aae.py:840-870,
     evaluation.py:183-199, 20-58) with only [n, k] ids and scaled scores crossing PCIe.
-    Conditions must be of the constant-concatenation kind (or absent)."""
+    Conditions as in predict(): constant concatenation and the device-native CategoricalCondition ride in the fused
+    call, any other plugin imposes itself on the code between aae_encode and aae_decode_topk."""
     self.eval()
     use_condition = _check_conditions(self.conditions, condition_data)
-    if use_condition and not self._is_constant_concat():
-        raise NotImplementedError("predict_topk supports constant concatenated conditions only")
+    if self.conditions:
+        self.conditions.eval()
+    fused = (not use_condition) or self._is_constant_concat()
+    native = use_condition and not fused and self._is_device_native()
     Xs = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
     csr = _hip.DeviceCSR(Xs, self.hip.device)
     self._dp_settle()
@@ -580,10 +583,17 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
     for start in range(0, Xs.shape[0], self.batch_size):
         n = min(self.batch_size, Xs.shape[0] - start)
         cond = None
-        if use_condition:
-            c_batch = [_take(c, slice(start, start + n)) for c in condition_data]
+        c_batch = [_take(c, slice(start, start + n)) for c in condition_data] if use_condition else None
+        if use_condition and fused:
             cond = torch.cat([_hip.upload(c.encode(x), self.hip.device) for c, x in zip(self.conditions.values(), c_batch)], 1)
-        i, v = self.hip.predict_topk(csr, start, n, k, cond=cond, exclude_known=exclude_known)
+        elif native:
+            cond = self._native_cond_block(c_batch, n)
+        if fused or native:
+            i, v = self.hip.predict_topk(csr, start, n, k, cond=cond, exclude_known=exclude_known)
+        else:
+            with torch.no_grad():
+                z = self.hip.encode(csr, start, n)
+                i, v = self.hip.decode_topk(self.conditions.encode_impose(z, c_batch), csr, start, k, exclude_known=exclude_known)
         ids.append(i)
         vals.append(v)
     return torch.cat(ids).cpu().numpy(), torch.cat(vals).cpu().numpy()

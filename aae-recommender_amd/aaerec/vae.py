@@ -8,15 +8,17 @@ its backward incl. the KL gradient).  Parameter names in the kernels' model: enc
 [fc21; fc22], dec.lin1 = fc3, dec.lin3 = fc4.
 
 Like the reference, predict() samples eps as well (vae.py:229-266 runs the same forward in eval mode).
-Conditions: constant concatenated blocks (e.g. PretrainedWordEmbeddingCondition); trainable conditions would need
-the step cut at the condition boundary, which the VAE entry point does not offer (NotImplementedError).
+Conditions: constant concatenated blocks (e.g. PretrainedWordEmbeddingCondition) and CategoricalConditions whose
+table lives on this GPU (encoded and trained by aae_cat_encode / aae_cat_update around the step, as in the AAE -
+condition.py:397-508); a plugin that needs torch autograd between the code and the decoder would need the VAE step cut
+at the condition boundary, which aae_vae_step does not offer (NotImplementedError).
 """
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 from . import _hip
-from .aae import TORCH_OPTIMIZERS, _take, _validate_targets
+from .aae import TORCH_OPTIMIZERS, AdversarialAutoEncoder, _take, _validate_targets
 from .base import Recommender
 from .condition import _check_conditions
 
@@ -48,8 +50,11 @@ class VAE:
         self.training = True
         self.last_loss = None
         code_inc = int(conditions.size_increment()) if conditions else 0
-        if conditions and not all(getattr(c, "constant_concat", False) for c in conditions.values()):
-            raise NotImplementedError("the VAE step supports constant concatenated conditions only")
+        dev_probe = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if conditions and not all(getattr(c, "constant_concat", False) or
+                                  (hasattr(c, "device_native") and c.device_native(dev_probe)) for c in conditions.values()):
+            raise NotImplementedError("the VAE step supports constant concatenated conditions and CategoricalConditions "
+                                      "with their table on the model's GPU (use_cuda=True) only")
         seed = seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
             if rng_mode == "device" else 0
         self.hip = _hip.HipAAE(inp, n_hidden, n_code, cond_inc=code_inc, max_batch=batch_size, max_nnz=batch_size * 4096,
@@ -99,13 +104,19 @@ class VAE:
         """reparametrize()'s torch.randn_like(std) (vae.py:117) off the global CPU generator in 'reference' mode."""
         return torch.randn(B, self.n_code) if self.rng_mode == "reference" else None
 
+    # the condition block of a batch / the update of trainable tables from its gradient: the AAE's helpers
+    _is_constant_concat = AdversarialAutoEncoder._is_constant_concat
+    _native_cond_block = AdversarialAutoEncoder._native_cond_block
+    _native_cond_update = AdversarialAutoEncoder._native_cond_update
+
     def _cond(self, c_batch):
-        blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
-        return torch.cat([_hip.upload(b, self.device) for b in blocks], 1)
+        return self._native_cond_block(c_batch, len(c_batch[0]) if not hasattr(c_batch[0], "shape") else c_batch[0].shape[0])
 
     def _step(self, csr, n_rows, rows, c_batch):
         self.hip.vae_step(csr, 0, n_rows, rows=rows, cond=self._cond(c_batch) if c_batch is not None else None,
                           eps=self._eps(n_rows))
+        if c_batch is not None and not self._is_constant_concat():
+            self._native_cond_update(n_rows)           # conditions.zero_grad / backward / step, vae.py:175-181
         self._last_rows = n_rows
         if self.verbose:
             log_losses(self.loss())

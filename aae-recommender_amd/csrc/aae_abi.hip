@@ -661,6 +661,9 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
             fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
                     cb.P.ops[i].out ? ",st" : "", cb.P.ops[i].out2 ? ",st2" : "", (h[i + 1] - h[i]) * 0.01);
         fprintf(stderr, "\n");
+        if (cb.P.nops > 2)
+            fprintf(stderr, "   [op 2, wave 0 of workgroup 0] loads+mfma+partials=%.2f wait-barrier=%.2f epi-ctx=%.2f epilogue=%.2f barrier=%.2f (us)\n",
+                    (h[21] - h[20]) * 0.01, (h[22] - h[21]) * 0.01, (h[23] - h[22]) * 0.01, (h[24] - h[23]) * 0.01, (h[25] - h[24]) * 0.01);
     }
     return AAE_OK;
 }
@@ -891,7 +894,8 @@ int chain_vae_backward(aae_model* m, const float* part_slabs, size_t slab_stride
     } else {
         cb.add(cop_load(m->gb0.p, m->ldh, 2, h));         // unfused decoder path: gb0 already holds dL/d(pre-activation)
     }
-    cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    ChainOp& dzc = cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    if (cp > c) cop_out(dzc, m->gzc.p, m->ldc);          // dL/d(decoder input): its condition columns train a device-native CategoricalCondition
     cb.add(cop_load(m->mulv.p, (int)m->mulv.ld, 4, 2 * c));
     ChainOp& rb = cb.add(cop(COP_REPARAM_BWD, 3, 5, 2 * c)); rb.yslot = 4; rb.scale = m->grad_scale;
     rb.aux_ptr = m->veps.p; rb.aux_ld = (int)m->veps.ld; cop_out(rb, m->gmulv.p, (int)m->gmulv.ld);
@@ -2060,6 +2064,30 @@ int aae_predict_topk(aae_handle m, const aae_batch* batch, const float* cond_dev
         hipLaunchKernelGGL(topk_rows_kernel<32>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
                            exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
     LAUNCHCHK("topk_rows");
+    return AAE_OK;
+}
+
+// the same for a caller-built decoder input (code | imposed conditions of any plugin kind): the second half of predict
+// (aae.py:855-866) + remove_non_missing / argtopk; `batch` names the input rows whose items are excluded
+int aae_decode_topk(aae_handle m, const float* zc_dev, int64_t zc_ld, const aae_batch* batch, int32_t k,
+                    int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream) {
+    if (!m || !zc_dev || !idx_out_dev || !val_out_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (k < 1 || k > 32 || k > m->N) return fail(AAE_EINVAL, "k must be in [1, min(32, n_items)]");
+    if (zc_ld < m->cp) return fail(AAE_EINVAL, "zc_ld < n_code + cond_inc");
+    TRY(set_batch(m, batch));
+    TRY(aae_decode(m, zc_dev, zc_ld, m->rows, m->G.p, m->ldn, stream));   // scores into the [rows][N] scratch
+    hipStream_t s = S(stream);
+    if (k <= 10)
+        hipLaunchKernelGGL(topk_rows_kernel<10>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    else if (k <= 20)
+        hipLaunchKernelGGL(topk_rows_kernel<20>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    else
+        hipLaunchKernelGGL(topk_rows_kernel<32>, dim3(m->rows), dim3(256), 0, s, m->G.p, m->ldn, m->N, m->bv,
+                           exclude_known, k, reinterpret_cast<int*>(idx_out_dev), val_out_dev);
+    LAUNCHCHK("topk_rows");
+    m->phase = 0;
     return AAE_OK;
 }
 

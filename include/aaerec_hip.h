@@ -303,6 +303,11 @@ int aae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, flo
  * (<= 32) best item ids per row, best first, and their scaled scores: [rows][k]. */
 int aae_predict_topk(aae_handle h, const aae_batch* batch, const float* cond_dev, int32_t k,
                      int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream);
+/* The same behind a decoder input the caller built (AdversarialAutoEncoder.predict's second half, aae.py:855-866:
+ * `z = conditions.encode_impose(z, c_batch)` with plugins of any kind, then dec): zc_dev [batch->n_rows][zc_ld],
+ * zc_ld >= n_code + cond_inc; `batch` names the input rows (their items are the ones exclude_known removes). */
+int aae_decode_topk(aae_handle h, const float* zc_dev, int64_t zc_ld, const aae_batch* batch, int32_t k,
+                    int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream);
 /* split form for generic conditions */
 int aae_encode(aae_handle h, const aae_batch* batch, float* z_out_dev, void* stream);
 int aae_decode(aae_handle h, const float* zc_dev, int64_t zc_ld, int32_t n_rows,

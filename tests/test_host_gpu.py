@@ -284,6 +284,52 @@ def test_predict_topk_equals_host_pipeline():
     assert Xd[np.arange(Xin.shape[0])[:, None], ids].sum() == 0
 
 
+@pytest.mark.parametrize("kind", ["categorical_native", "concat_plus_bias_generic"])
+def test_predict_topk_with_trainable_and_generic_conditions(kind):
+    """predict_topk behind every kind of condition plugin predict() accepts (aae.py:844-865): the device-native
+    CategoricalCondition rides in the fused call, any other plugin imposes itself between aae_encode and aae_decode_topk.
+    Same ids / scaled scores as the host pipeline over predict()'s dense matrix."""
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec import condition as C
+    from aaerec.evaluation import remove_non_missing, argtopk
+    z, Xtr, Xin, Yout = _e2e()
+    rng = np.random.RandomState(5)
+    torch.manual_seed(5)
+    np.random.seed(5)
+
+    class ConstConcat(C.ConcatenationBasedConditioning):
+        def size_increment(self):
+            return 6
+
+        def encode(self, inputs):
+            return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
+
+    class ConstBias(C.ConditionalBiasing):
+        def encode(self, inputs):
+            return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
+
+    def attrs(n):
+        if kind == "categorical_native":
+            return [[["a%d" % rng.randint(1, 30) for _ in range(rng.randint(1, 4))] for _ in range(n)]]
+        return [rng.standard_normal((n, 6)).astype(np.float32), 0.1 * rng.standard_normal((n, 56)).astype(np.float32)]     # (bias over code + the 6 concatenated columns)
+    if kind == "categorical_native":
+        conds = C.ConditionList([("authors", C.CategoricalCondition(8, use_cuda=True, reduce="sum", lr=0.01))])
+        ctr = conds.fit_transform(attrs(Xtr.shape[0]))
+        cte = conds.transform(attrs(Xin.shape[0]))
+    else:
+        conds = C.ConditionList([("title", ConstConcat()), ("b", ConstBias())])
+        ctr, cte = attrs(Xtr.shape[0]), attrs(Xin.shape[0])
+    m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=5, batch_size=100, gen_lr=0.01, reg_lr=0.001,
+                               conditions=conds, verbose=False)
+    m.fit(Xtr, condition_data=ctr)
+    assert m._is_device_native() == (kind == "categorical_native")
+    full = remove_non_missing(m.predict(Xin, condition_data=cte), Xin, copy=True)
+    rows, cols = argtopk(full, 10)
+    ids, vals = m.predict_topk(Xin, k=10, condition_data=cte)
+    np.testing.assert_allclose(vals, full[rows, cols], atol=2e-6)
+    assert np.all((ids == cols) | np.isclose(full[rows, ids], full[rows, cols], atol=1e-7))
+
+
 def test_autoencoder_recommender_learns():
     """AAERecommender(adversarial=False) -> AutoEncoder (reference aae.py:221-458, 953-957)."""
     from aaerec.aae import AAERecommender, AutoEncoder
@@ -502,9 +548,11 @@ def test_denoising_autoencoder_tracks_reference():
     assert abs(kept - 0.8) < 0.02
 
 
-@pytest.mark.parametrize("name", ["step_vae", "step_vae_cond"])
+@pytest.mark.parametrize("name", ["step_vae", "step_vae_cond", "step_vae_cat"])
 def test_vae_tracks_reference(name):
-    """aaerec.vae.VAE against the reference's vae.py fixtures: recorded steps with the recorded eps."""
+    """aaerec.vae.VAE against the reference's vae.py fixtures: recorded steps with the recorded eps (step_vae_cat: behind
+    a trainable CategoricalCondition - embedding sum + SparseAdam, condition.py:397-508 - whose table the library's
+    kernels encode and train around aae_vae_step)."""
     from aaerec.vae import VAE
     from aaerec import condition as C
     from test_parity_abi_gpu import _vae_params
@@ -521,6 +569,23 @@ def test_vae_tracks_reference(name):
             def encode(self, inputs):
                 return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
         conds = C.ConditionList([("title", ConstConcat())])
+    cat = None
+    if cfg["cond"] == "cat":
+        kind = cfg["cat"]
+        cat = C.CategoricalCondition(8, sparse=kind["sparse"], use_cuda=True, reduce=kind["reduce"], lr=kind["lr"])
+        V = fx.z["init.cond.embedding"].shape[0]
+        cat.vocab = {"a%d" % i: i for i in range(1, V)}               # indices are given pre-transformed
+        cat.embedding = torch.nn.Embedding(V, 8, padding_idx=0, sparse=kind["sparse"]).cuda()
+        with torch.no_grad():
+            cat.embedding.weight.copy_(torch.from_numpy(fx.z["init.cond.embedding"]))
+        cat.optimizer = torch.optim.SparseAdam(cat.embedding.parameters(), lr=kind["lr"])
+        conds = C.ConditionList([("authors", cat)])
+
+    def cin(s, prefix="step"):
+        c = fx.cond_inputs(s, prefix=prefix) if prefix != "step" else fx.cond_inputs(s)
+        if cat is not None:     # the fixture stores the batch-padded index lists: strip the padding again
+            c = [[[int(j) for j in row if j != 0] or [0] for row in c[0]]]
+        return c or None
     m = VAE(cfg["N"], cfg["N"], n_hidden=cfg["h"], n_code=cfg["c"], lr=cfg["gen_lr"], batch_size=cfg["B"],
             conditions=conds, verbose=True, rng_mode="reference")
     m.hip.load_params(_vae_params(fx, "init"))
@@ -529,7 +594,13 @@ def test_vae_tracks_reference(name):
         X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
         eps = fx.z[f"step{s}.eps"]
         m._eps = lambda B, eps=eps: torch.from_numpy(eps)
-        m.partial_fit(X, condition_data=fx.cond_inputs(s) or None)
+        m.partial_fit(X, condition_data=cin(s))
+        if cat is not None:
+            np.testing.assert_allclose(cat.embedding.weight.detach().cpu().numpy(), fx.z[f"step{s}.cond.embedding"],
+                                       atol=1e-5, err_msg=f"{name} step {s} embedding")
+            st = cat.optimizer.state[cat.embedding.weight]
+            assert float(st["step"]) == float(fx.z[f"step{s}.cond.t"])
+            np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), fx.z[f"step{s}.cond.m"], atol=1e-8, rtol=1e-4)
         np.testing.assert_allclose(m.last_loss, fx.z[f"step{s}.losses"][0], rtol=2e-5)
         sd = m.state_dict()
         for n in ("fc1", "fc21", "fc22", "fc3", "fc4"):
@@ -539,10 +610,9 @@ def test_vae_tracks_reference(name):
     ip, idx, val = fx.batch(0, prefix="predict")
     Xp = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
     m._eps = lambda B: torch.from_numpy(fx.z["predict.eps"])
-    np.testing.assert_allclose(m.predict(Xp, condition_data=fx.cond_inputs(0, prefix="predict") or None),
-                               fx.z["predict.out"], atol=1e-5)
+    np.testing.assert_allclose(m.predict(Xp, condition_data=cin(0, prefix="predict")), fx.z["predict.out"], atol=1e-5)
     with pytest.raises(ValueError):
-        m.partial_fit(X, y=1, condition_data=fx.cond_inputs(0) or None)
+        m.partial_fit(X, y=1, condition_data=cin(0))
     with pytest.raises(NotImplementedError):
         VAE(cfg["N"], cfg["N"], final_activation="Tanh")
 

@@ -172,12 +172,15 @@ def test_oracle_ae_step_matches_reference_denoising_autoencoder():
     np.testing.assert_allclose(m.predict(ip, idx, val), fx.z["predict.out"], atol=2e-6)
 
 
-VAE_CASES = ["step_vae", "step_vae_cond"]
+VAE_CASES = ["step_vae", "step_vae_cond", "step_vae_cat"]
 VAE_NAMES = ("fc1", "fc21", "fc22", "fc3", "fc4")
 
 
 def build_vae_oracle(fx):
     conds = [O.ConcatConst(30)] if fx.cfg["cond"] == "concat30" else []
+    if fx.cfg["cond"] == "cat":       # trainable CategoricalCondition (embedding sum, SparseAdam) behind the code
+        k = fx.cfg["cat"]
+        conds = [O.CategoricalEmbedding(fx.z["init.cond.embedding"], lr=k["lr"], reduce=k["reduce"], sparse=k["sparse"])]
     params = {f"{n}.{t}": fx.z[f"init.{n}.{t}"] for n in VAE_NAMES for t in ("weight", "bias")}
     return O.OracleVAE(params, lr=fx.cfg["gen_lr"], conditions=conds)
 
@@ -198,6 +201,8 @@ def test_oracle_reproduces_reference_vae(name):
                 assert m.opt.t[k] == float(fx.z[f"step{s}.A.{k}.t"])
                 np.testing.assert_allclose(m.opt.m[k], fx.z[f"step{s}.A.{k}.m"], atol=2e-8, rtol=2e-4)
                 np.testing.assert_allclose(m.opt.v[k], fx.z[f"step{s}.A.{k}.v"], atol=1e-12, rtol=2e-4)
+        if fx.cfg["cond"] == "cat":
+            np.testing.assert_allclose(m.conditions[0].params["w"], fx.z[f"step{s}.cond.embedding"], atol=TOL_PARAM)
     ip, idx, val = fx.batch(0, prefix="predict")
     out = m.predict(ip, idx, val, fx.z["predict.eps"], fx.cond_inputs(0, prefix="predict"))
     np.testing.assert_allclose(out, fx.z["predict.out"], atol=2e-6)

@@ -773,7 +773,7 @@ def gen_dae():
     print("e2e_dae_short written")
 
 
-def gen_vae():
+def gen_vae(only=None):
     """The reference's VAE (vae.py:47-266): step_vae.npz (no condition) and step_vae_cond.npz (30-d constant
     concatenated condition): recorded eps of reparametrize(), losses (loss.item() / B as the reference logs it),
     parameters and Adam state after every step, a (stochastic: eps recorded) predict; e2e_vae_short.npz: 3
@@ -795,6 +795,13 @@ def gen_vae():
                 def encode(self, inputs):
                     return torch.as_tensor(inputs, dtype=torch.float32)
             conditions, inc = ref_cond.ConditionList([("title", ConstConcat())]), 30
+        cc = cdata = None
+        if cond == "cat":          # a trainable CategoricalCondition (condition.py:397-508: embedding sum + SparseAdam)
+            cc = ref_cond.CategoricalCondition(8, sparse=True, use_cuda=False, reduce="sum", lr=1e-2)
+            raw_all = [[f"a{int(x)}" for x in rng.integers(0, 12, size=int(rng.integers(1, 4)))] for _ in range(B * (steps + 1))]
+            cc.fit(raw_all)
+            cdata = cc.transform(raw_all)
+            conditions, inc = ref_cond.ConditionList([("authors", cc)]), 8
         m = ref_vae.VAE(N, N, n_hidden=h, n_code=c, lr=lr, batch_size=B, n_epochs=1, conditions=conditions,
                         verbose=True, device=torch.device("cpu"))
         eps_log, loss_log = [], []
@@ -806,8 +813,11 @@ def gen_vae():
             return e
         ref_vae.log_losses = lambda l: loss_log.append(l)
         out = {}
-        cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="concat30" if cond else "", cond_inc=inc, n_hidden=h,
-                   n_code=c, vae=1, gen_lr=lr, reg_lr=lr, dropout=[0.0, 0.0])
+        cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="cat" if cc is not None else "concat30" if cond else "", cond_inc=inc,
+                   n_hidden=h, n_code=c, vae=1, gen_lr=lr, reg_lr=lr, dropout=[0.0, 0.0])
+        if cc is not None:
+            out["init.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+            cfg["cat"] = dict(sparse=True, reduce="sum", concat=False, lr=1e-2)
         for n in names:
             lin = getattr(m, n)
             out[f"init.{n}.weight"] = lin.weight.detach().numpy().copy()
@@ -820,11 +830,21 @@ def gen_vae():
                 out[f"step{s}.indices"] = X.indices.astype(np.int32)
                 out[f"step{s}.values"] = X.data.astype(np.float32)
                 cb = None
-                if cond:
+                if cc is not None:
+                    lists = cdata[s * B:(s + 1) * B]
+                    out[f"step{s}.cond0"] = _pad_lists(lists)
+                    cb = [lists]
+                elif cond:
                     cv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
                     out[f"step{s}.cond0"] = cv
                     cb = [cv]
                 m.partial_fit(X, condition_data=cb)
+                if cc is not None:
+                    out[f"step{s}.cond.embedding"] = cc.embedding.weight.detach().numpy().copy()
+                    st = cc.optimizer.state[cc.embedding.weight]
+                    out[f"step{s}.cond.m"] = st["exp_avg"].numpy().copy()
+                    out[f"step{s}.cond.v"] = st["exp_avg_sq"].numpy().copy()
+                    out[f"step{s}.cond.t"] = np.asarray(float(st["step"]))
                 out[f"step{s}.eps"] = eps_log[-1]
                 out[f"step{s}.losses"] = np.asarray([loss_log[-1], 0.0, 0.0], dtype=np.float64)   # (BCE + KLD) / B
                 params = list(m.parameters())
@@ -842,7 +862,11 @@ def gen_vae():
             out["predict.indices"] = Xp.indices.astype(np.int32)
             out["predict.values"] = Xp.data.astype(np.float32)
             pc = None
-            if cond:
+            if cc is not None:
+                lists = cdata[steps * B:(steps + 1) * B]
+                out["predict.cond0"] = _pad_lists(lists)
+                pc = [lists]
+            elif cond:
                 pcv = (rng.standard_normal((B, 30)) * 0.5).astype(np.float32)
                 out["predict.cond0"] = pcv
                 pc = [pcv]
@@ -855,8 +879,13 @@ def gen_vae():
         out["config_json"] = np.asarray(json.dumps(cfg))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
         print(f"{name}: losses {[round(float(l), 5) for l in loss_log]}")
+    if only:
+        run(*{"step_vae": ("step_vae", 51, False), "step_vae_cond": ("step_vae_cond", 52, True),
+              "step_vae_cat": ("step_vae_cat", 53, "cat")}[only])
+        return
     run("step_vae", 51, False)
     run("step_vae_cond", 52, True)
+    run("step_vae_cat", 53, "cat")
     # 3 epochs of fit() on the C1 corpus with the reference's seeds; predict() itself is stochastic, so the pinned
     # quantity is the encoder mean of the first rows (deterministic given the trained weights)
     z = np.load(os.path.join(OUT, "e2e_c1.npz"))
@@ -936,6 +965,8 @@ def main():
         gen_dae()
     if want("vae"):
         gen_vae()
+    if "vae_cat" in which:      # (only the VAE + trainable CategoricalCondition case)
+        gen_vae(only="step_vae_cat")
     if want("vectorizer"):
         gen_embedded_vectorizer()
     if want("metrics"):
