@@ -8,6 +8,7 @@ There is NO CPU fallback: importing this module without the built library, or cr
 model without a GPU, raises.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -113,6 +114,7 @@ _PROTOS = {
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "aae_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
 }
 K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN, K_DEC_CRIT, K_DEC_OPT = range(9)
@@ -122,6 +124,17 @@ _lib = None
 
 class AaeHipError(RuntimeError):
     pass
+
+
+def _destroy_handle(lib, handle, arena, pid):
+    # (a fork()ed child - e.g. a multiprocessing.Manager server started by the process that owns the model - inherits
+    # the Python object but not a usable HIP runtime: only the creating process talks to the library)
+    if os.getpid() == pid:
+        try:
+            lib.aae_destroy(handle)
+        except Exception:
+            pass
+    del arena
 
 
 def load_library():
@@ -382,16 +395,17 @@ class HipAAE:
             _check(lib.aae_create(C.byref(cfg), C.c_void_p(self.arena.data_ptr()), nbytes.value, self._stream(),
                                   C.byref(h)))
         self.handle = h
+        # aae_destroy waits for the handle's side stream (the deferred dec_optim launch of the last step reads and writes
+        # the arena): it must run BEFORE the arena's memory can go back to the driver - also at interpreter exit, where
+        # __del__ is not guaranteed to.  The finalizer owns a reference to the arena, so the order is fixed.
+        self._finalizer = weakref.finalize(self, _destroy_handle, lib, h, self.arena, os.getpid())
         _check(lib.aae_set_lr(self.handle, float(gen_lr), float(reg_lr)))
         self._keep = []   # device buffers of the running step
 
-    def __del__(self):
-        try:
-            if getattr(self, "handle", None):
-                self.lib.aae_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+    def close(self):
+        """Destroy the handle now (waits for its side stream)."""
+        self._finalizer()
+        self.handle = None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -551,6 +565,13 @@ class HipAAE:
         return inj
 
     # ---- the step --------------------------------------------------------------------
+    def prefetch(self, csr, row_start, n_rows, rows=None):
+        """Name the batch of the step AFTER the next one (aae_prefetch_batch): its unique-item list and deferred-Adam
+        catch-up run beside the next step.  `rows` (device int32 row ids) must stay alive and unchanged until then."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        self._pf_keep = (csr, rows)
+        _check(self.lib.aae_prefetch_batch(self.handle, C.byref(b)))
+
     def step(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
         """One partial_fit without generic conditions (cond: device tensor [n_rows, cond_inc])."""
         b = self._batch(csr, row_start, n_rows, rows)

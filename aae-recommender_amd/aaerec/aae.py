@@ -461,6 +461,10 @@ class AdversarialAutoEncoder:
                             self._g_c_batch = [_take(c, perm[start:stop]) for c in condition_data]
                     start, stop = lo, hi
                 rows = perm_dev[start:stop]
+                nxt = start + self.batch_size           # (single process) the batch after this one: see _hip.prefetch
+                if self._dp is None and nxt < n_docs:
+                    self.hip.prefetch(csr, 0, min(nxt + self.batch_size, n_docs) - nxt,
+                                      perm_dev[nxt:min(nxt + self.batch_size, n_docs)])
                 c_batch = None
                 if use_condition:
                     idx = perm[start:stop]

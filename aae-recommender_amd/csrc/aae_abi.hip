@@ -124,6 +124,11 @@ struct aae_model {
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
+    // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
+    // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
+    int* mark2; int* ulist2; int* ucount2; int* stamp2;
+    aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
+    bool pf_pending; hipEvent_t ev_head, ev_pf;
 };
 
 namespace {
@@ -251,6 +256,13 @@ size_t layout(aae_model* m, char* base, bool dry) {
     }
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
+    m->mark2 = m->ulist2 = m->ucount2 = m->stamp2 = nullptr;
+    if (c.grad_mode == AAE_GRAD_FUSED) {      // second list set for aae_prefetch_batch (single-process training only)
+        m->mark2 = reinterpret_cast<int*>(a.take(N, nullptr));
+        m->ulist2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ucount2 = reinterpret_cast<int*>(a.take(4, nullptr));
+        m->stamp2 = m->ucount2 ? m->ucount2 + 1 : nullptr;
+    }
     m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
     {
         const size_t nt = (size_t)(N + kTI - 1) / kTI + 1;
@@ -306,16 +318,21 @@ bool prof_pair(aae_model* m, int k, hipEvent_t* a, hipEvent_t* b) {
 // The previous step's deferred optimiser launch (dec_fused.h kDecOpt on m->side) writes DEC_V3 and its moments and
 // reads dh2 / the G scratch / the decoder's step scalars: everything that touches those waits for it here.
 int join_deferred(aae_model* m, hipStream_t s) {
-    if (!m->opt_pending) return AAE_OK;
-    HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
-    m->opt_pending = false;
+    if (m->opt_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));      // (one stream, in order: the later record covers the earlier)
+    else if (m->pf_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0));
+    m->opt_pending = m->pf_pending = false;
+    return AAE_OK;
+}
+// behind work enqueued on the side stream: what join_deferred waits for
+int side_done(aae_model* m, hipEvent_t ev) {
+    HIPCHK(hipEventRecord(ev, m->side));
     return AAE_OK;
 }
 // ... for the entry points without a stream (host-synchronous state import / export)
 int join_host(aae_model* m) {
-    if (!m->opt_pending) return AAE_OK;
+    if (!m->opt_pending && !m->pf_pending) return AAE_OK;
     HIPCHK(hipStreamSynchronize(m->side));
-    m->opt_pending = false;
+    m->opt_pending = m->pf_pending = false;
     return AAE_OK;
 }
 
@@ -848,15 +865,52 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
     return AAE_OK;
 }
 
-int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t sid1, hipStream_t s) {
+// done_ev: an event that rides on the launch's completion signal (the side stream's "the step has begun" mark)
+// head: tell the side stream that the main stream has passed this launch (ev_head rides on its completion signal)
+int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t sid1, hipStream_t s, bool head = false) {
     const int B = m->rows, h = m->h;
     DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
     ProfScope ps(m, AAE_K_ENC_GATHER, s);
     size_t shm = (size_t)16 * r4(h) * sizeof(float);
-    hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), shm, s, m->bv, m->P[P_W1T].p, m->ldw1, m->P[P_B1].p, h,
-                       m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation, d1, m->cfg.seed,
-                       m->step_ctr, m->rscale);
+    hipExtLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), (uint32_t)shm, s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
+                          (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
+                          m->a1.p, m->eh1.p, m->ldh, (int)m->cfg.activation, d1, (uint64_t)m->cfg.seed,
+                          (const long long*)m->step_ctr, m->rscale);
     LAUNCHCHK("enc_gather");
+    return AAE_OK;
+}
+
+static bool same_batch(const aae_batch& a, const aae_batch& b) {
+    return a.indptr_dev == b.indptr_dev && a.indices_dev == b.indices_dev && a.values_dev == b.values_dev &&
+           a.rows_dev == b.rows_dev && a.row_start == b.row_start && a.n_rows == b.n_rows;
+}
+
+// aae_prefetch_batch, second half: the hinted batch's unique-item list + deferred-Adam catch-up (through the RUNNING
+// step, whose scalars advance_step has published by the time ev_head fires) on the side stream, into the second list
+// set.  Rows of the running batch are skipped: the step's own updates bring them to the same step.
+int launch_prefetch(aae_model* m) {
+    const aae_batch& b = m->pf_batch;
+    m->pf_armed = false;
+    if (!m->side || !m->mark2 || !m->lazy) return AAE_OK;
+    BatchView bv; bv.indptr = b.indptr_dev; bv.indices = b.indices_dev; bv.values = b.values_dev;
+    bv.rows = b.rows_dev; bv.row_start = b.row_start; bv.n_rows = b.n_rows;
+    const int mr = b.max_row_nnz > 0 ? b.max_row_nnz : 1024;
+    const int chunks = std::max(1, std::min(64, (mr + 15) / 16));
+    const int gy = std::max(1, std::min(16, chunks / 16 + 1));
+    hipStream_t q = m->side;
+    HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));
+    hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
+    hipLaunchKernelGGL(uniq_items_kernel, dim3(b.n_rows, gy), dim3(256), 0, q, bv, m->mark2, m->stamp2, m->ulist2, m->ucount2);
+    if (m->cfg.optimizer == AAE_OPT_ADAM) {
+        const int grid = std::min(m->cfg.max_nnz, std::max(256, b.n_rows * 32));
+        hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, q, m->ulist2, m->ucount2, m->N, m->tsync,
+                           m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,
+                           m->ldw1, m->h, m->tab, m->step_ctr, 0, m->mark, m->stamp);
+    }
+    LAUNCHCHK("prefetch (unique items + catch-up of the next batch)");
+    TRY(side_done(m, m->ev_pf));
+    m->pf_pending = true;
+    m->pf_built = true; m->pf_step = m->hstep + 1; m->pf_built_batch = b;
     return AAE_OK;
 }
 
@@ -1064,16 +1118,29 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->split_ok = false; m->opt_pending = false; m->side = nullptr; m->ev_crit = m->ev_opt = nullptr;
     m->split_wgs = std::max(1, m->n_cu / 2);
     { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
-    if (m->fused_ok && !m->bf16 && cfg->grad_mode == AAE_GRAD_FUSED && m->split_wgs > 0 &&
-        (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
+    m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->ev_head = m->ev_pf = nullptr;
+    bool side_ok = false;
+    if (cfg->grad_mode == AAE_GRAD_FUSED) {
+        // the handle's side stream (lowest priority) for work off the step's critical path: the deferred optimiser
+        // launch of the output layer and the next batch's deferred-Adam catch-up.  The events order work of this device
+        // only: no system-scope release (an L2 write-back) at the record
         int lo = 0, hi = 0;
-        // both events order work of this device only: no system-scope release (an L2 write-back) at the record
-        unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
-        { const char* e = getenv("AAE_SPLIT_EVFLAGS"); if (e) evflags = (unsigned)strtoul(e, nullptr, 0); }
-        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+        const unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
+        side_ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
                   hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) == hipSuccess &&
                   hipEventCreateWithFlags(&m->ev_crit, evflags) == hipSuccess &&
-                  hipEventCreateWithFlags(&m->ev_opt, evflags) == hipSuccess;
+                  hipEventCreateWithFlags(&m->ev_opt, evflags) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_head, evflags) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_pf, evflags) == hipSuccess;
+        if (!side_ok) {
+            if (m->side) (void)hipStreamDestroy(m->side);
+            m->side = nullptr;
+        }
+        (void)hipGetLastError();
+    }
+    if (side_ok && m->fused_ok && !m->bf16 && m->split_wgs > 0 &&
+        (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
+        bool ok = true;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -1113,6 +1180,8 @@ int aae_destroy(aae_handle h) {
     }
     if (h->ev_crit) (void)hipEventDestroy(h->ev_crit);
     if (h->ev_opt) (void)hipEventDestroy(h->ev_opt);
+    if (h->ev_head) (void)hipEventDestroy(h->ev_head);
+    if (h->ev_pf) (void)hipEventDestroy(h->ev_pf);
     if (h->prof_ev) {
         for (int k = 0; k < AAE_K_N; ++k)
             for (auto& pr : h->prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1229,6 +1298,16 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
         *total_ms += ms; *launches += 1;
     }
     h->prof_used[kernel_id] = 0;
+    return AAE_OK;
+}
+
+int aae_prefetch_batch(aae_handle h, const aae_batch* next) {
+    if (!h || !next) return fail(AAE_EINVAL, "NULL argument");
+    if (!next->indptr_dev || !next->indices_dev || !next->values_dev) return fail(AAE_EINVAL, "batch pointers are NULL");
+    if (next->n_rows < 1 || next->n_rows > h->R) return fail(AAE_EINVAL, "batch n_rows outside [1, max_batch]");
+    if (next->nnz_bound > h->cfg.max_nnz) return fail(AAE_EINVAL, "batch nnz_bound > max_nnz");
+    h->pf_batch = *next;
+    h->pf_armed = true;
     return AAE_OK;
 }
 
@@ -1455,12 +1534,20 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
     TRY(join_deferred(m, s));       // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2
+    m->hstep++;
+    // the list of this batch's distinct items and their catch-up were built while the previous step ran
+    const bool ahead = m->pf_built && m->pf_step == m->hstep && same_batch(m->pf_built_batch, *batch) && m->lazy;
+    m->pf_built = false;
+    if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
-                       m->stamp, m->ucount, m->losses);
-    if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+                       ahead ? (int*)nullptr : m->stamp, ahead ? (int*)nullptr : m->ucount, m->losses);
+    if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
     m->dec_hidden_done = false; m->enc_bwd_done = false;
+    const bool pf = m->pf_armed && m->side && m->mark2 && m->lazy && m->use_chain;
+    if (m->pf_armed && !pf) m->pf_armed = false;
     if (m->use_chain) {
-        TRY(gather_first_layer(m, true, m->inj.masks_dev[0], 0, s));
+        TRY(gather_first_layer(m, true, m->inj.masks_dev[0], 0, s, pf));
+        if (pf) TRY(launch_prefetch(m));
         TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
         m->phase = 1;
         return AAE_OK;
@@ -1538,7 +1625,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.Gt = m->Gt;
         if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && fa.dbg_skip == 0) {
             // ---- split form: the critical launch here, the optimiser launch on the side stream behind the rest of the step
-            TRY(join_deferred(m, s));                   // (a step-opening entry point already did; cheap when nothing is pending)
+            if (m->opt_pending) TRY(join_deferred(m, s));   // (never: every step-opening entry point joins)
             {
                 // "this launch is done" rides on the kernel's own completion signal (a hipEventRecord behind the launch is a
                 // marker packet the next kernel of the stream waits for: +30 us per step); when the launch is being timed,
@@ -1564,7 +1651,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 }
                 LAUNCHCHK("dec_fused (optimiser launch)");
             }
-            HIPCHK(hipEventRecord(m->ev_opt, m->side));
+            TRY(side_done(m, m->ev_opt));
             m->opt_pending = true;
         } else
         {
@@ -1721,6 +1808,7 @@ int aae_decoder_step(aae_handle m, const aae_batch* batch, const float* zin_dev,
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
     TRY(join_deferred(m, s));       // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2
+    m->hstep++; m->pf_armed = false;
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        m->stamp, m->ucount, m->losses);
     LAUNCHCHK("advance_step");
@@ -1742,6 +1830,7 @@ int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, co
     remember_inject(m, nullptr, true);
     hipStream_t s = S(stream);
     TRY(join_deferred(m, s));
+    m->hstep++; m->pf_armed = false;
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        m->stamp, m->ucount, m->losses);
     LAUNCHCHK("advance_step");
@@ -1832,6 +1921,7 @@ int aae_output_layer_step(aae_handle m, const aae_batch* batch, void* stream) {
     if (batch) {
         TRY(set_batch(m, batch));
         remember_inject(m, nullptr, true);
+        m->hstep++; m->pf_armed = false;
         hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                            m->stamp, m->ucount, m->losses);
         LAUNCHCHK("advance_step");

@@ -507,13 +507,17 @@ __global__ __launch_bounds__(256) void w1_catchup_kernel(const int* __restrict__
                                                          float* __restrict__ V1, float* __restrict__ M3,
                                                          float* __restrict__ V3, int ld, int h,
                                                          const LazyTab* __restrict__ tab, const long long* step_ctr,
-                                                         int upto_off) {
+                                                         int upto_off, const int* __restrict__ skip_mark = nullptr,
+                                                         const int* __restrict__ skip_stamp = nullptr) {
     __shared__ LazyTab stab[kLazyReplay];
     const int upto = (int)*step_ctr + upto_off;
     const int cnt = ulist ? *ucount : n_rows_all;
+    // skip_mark (the prefetch of the NEXT batch's rows while a step runs): rows of the RUNNING batch are left alone -
+    // the step's own two updates bring them to `upto`
+    const int skip = skip_mark ? *skip_stamp : 0;
     for (int r = blockIdx.x; r < cnt; r += gridDim.x) {
         const int row = ulist ? ulist[r] : r;
-        const int t0 = tsync[row];
+        const int t0 = (skip_mark && skip_mark[row] == skip) ? upto : tsync[row];
         if (t0 < upto) {
             const int nl = min(upto - t0, kLazyReplay);
             for (int j = threadIdx.x; j < nl; j += 256) stab[j] = tab[(t0 + 1 + j) & (kLazyTabCap - 1)];
@@ -812,7 +816,8 @@ __global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucoun
 __global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount,
                                     float* losses) {
     const int i = threadIdx.x;
-    if (i == 0) { *ctr += 1; *stamp += 1; *ucount = 0; losses[1] = 0.f; losses[2] = 0.f; }
+    // (stamp == NULL: the step's unique-item list was built ahead of time, aae_prefetch_batch)
+    if (i == 0) { *ctr += 1; if (stamp) { *stamp += 1; *ucount = 0; } losses[1] = 0.f; losses[2] = 0.f; }
     if (i >= 4) return;
     OptScalars s = sc[i];
     s.t += 1;

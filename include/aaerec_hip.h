@@ -370,6 +370,14 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
  * everything on the caller's stream: needed to capture a step into a hipGraph without joining), n > 0 sets the number
  * of workgroups of the deferred launch (default: 5/8 of the CUs). */
 int aae_join(aae_handle h, void* stream);
+/* The epoch loop (aae.py:808-831) knows the batch AFTER the one it is about to run.  Named here before the step that
+ * precedes it (aae_step / aae_ae_encode / aae_ae_forward), that batch's share of the step-opening work - the list of
+ * its distinct items and the replay of the deferred zero-gradient Adam steps on their enc.lin1 rows (what
+ * torch.optim.Adam did eagerly in enc_optim.step() / gen_optim.step(), aae.py:706,742) - runs on the handle's side
+ * stream while the step before it executes, instead of opening the next step.  A hint, not a promise: a next step on
+ * any other batch (other pointers / row window) ignores it and does the work itself; the row-id buffer `rows_dev`
+ * must keep its contents until that step ran.  grad_mode = fused only (otherwise accepted and ignored). */
+int aae_prefetch_batch(aae_handle h, const aae_batch* next);
 int aae_set_split(aae_handle h, int32_t workgroups);
 
 #ifdef __cplusplus

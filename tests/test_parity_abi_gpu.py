@@ -132,10 +132,14 @@ def test_abi_rejects_bad_calls():
         m.step(csr, 0, fx.cfg["B"] + 1)    # more rows than max_batch
 
 
-def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps():
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps(prefetch):
     """The lazy W1T optimiser (rows of absent items are updated when next read, replay truncated
-    after 192 steps) against the oracle's eager dense Adam: 260 steps over a 900-item vocabulary
-    where most items are seen only a few times, so gaps of 0..250 steps all occur."""
+    after 128 steps) against the oracle's eager dense Adam: 260 steps over a 900-item vocabulary
+    where most items are seen only a few times, so gaps of 0..250 steps all occur.
+    prefetch: every batch is named one step ahead (aae_prefetch_batch: its unique-item list and catch-up are built on
+    the side stream while the step before it runs) - except that every 7th hint is left out and every 11th names a
+    batch that does not come (both must fall back to the step's own catch-up)."""
     from aaerec._hip import HipAAE, DeviceCSR
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
@@ -149,13 +153,17 @@ def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps():
     # skewed popularity: items 0..19 in most batches, the tail rarely
     p = 1.0 / np.arange(1, N + 1) ** 1.3
     p /= p.sum()
+    batches = []
     for s in range(steps):
         rows = [np.sort(rng.choice(N, size=int(rng.integers(1, 6)), replace=False, p=p)) for _ in range(B)]
         ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
         idx = np.concatenate(rows).astype(np.int32)
         val = np.ones(len(idx), dtype=np.float32)
         zr = rng.standard_normal((B, c)).astype(np.float32)
-        csr = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+        batches.append((ip, idx, val, zr, DeviceCSR.from_arrays(ip, idx, val, N, dev.device)))
+    for s, (ip, idx, val, zr, csr) in enumerate(batches):
+        if prefetch and s + 1 < steps and s % 7 != 3:
+            dev.prefetch(batches[(s + 5) % steps if s % 11 == 5 else s + 1][4], 0, B)
         dev.step(csr, 0, B, z_real=zr)
         want = ora.partial_fit(ip, idx, val, zr)
         if s % 20 == 0 or s == steps - 1:
