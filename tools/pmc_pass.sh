@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" --no-cpu --steps 20 --warmup 5 > "$out/bench.log" 2>&1 || true
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" --no-cpu --no-extra --steps 20 --warmup 5 > "$out/bench.log" 2>&1 || true
 python3 - "$out" <<'PY' > "$root/gpurun_out/pmc_$tag.txt"
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_fetch.txt + pmc_write.txt (tools/pmc_pass.sh) -> profiles/<tag>_pmc_traffic.json: HBM bytes per
+launch of the instrumented kernels, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts a wide
+16-byte/lane streaming read at half its bytes: read bytes = 2 * FETCH_SIZE KiB * 1024; WRITE_SIZE is exact for 16-byte
+stores).  Usage: python3 tools/pmc_to_json.py <tag> [n_items n_hidden batch]"""
+import ast, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+N, h, B = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (100000, 200, 100)
+NAMES = [("dec_fused_kernel<13, 1>", "dec_crit"), ("dec_fused_kernel<13, 2>", "dec_opt"), ("dec_fused_kernel<13>", "dec_fused"),
+         ("dec_fused_kernel<13, 0>", "dec_fused"), ("enc_gather_kernel", "enc_gather"), ("w1_sparse_adam_kernel", "enc_w1_adam"),
+         ("chain4_kernel", "chain"), ("w1_catchup_kernel", "w1_catchup"), ("grouped_dw_kernel", "grouped_dw")]
+
+
+def read(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(.*?) (\{.*\}) launches (\d+)", line.strip())
+        if not m:
+            continue
+        for pat, name in NAMES:
+            if pat in m.group(1) and name not in out:
+                out[name] = list(ast.literal_eval(m.group(2)).values())[0]
+    return out
+
+
+f = read(os.path.join(ROOT, "gpurun_out", "pmc_fetch.txt"))
+w = read(os.path.join(ROOT, "gpurun_out", "pmc_write.txt"))
+kernels = {k: {"FETCH_SIZE_KiB": f[k], "WRITE_SIZE_KiB": w[k], "traffic_bytes": int(2 * f[k] * 1024 + w[k] * 1024)}
+           for k in f if k in w}
+doc = {"command": "bash tools/pmc_pass.sh fetch FETCH_SIZE ; bash tools/pmc_pass.sh write WRITE_SIZE  (rocprofv3 --pmc <counter> "
+                  "--kernel-trace -- python3 bench.py --no-cpu --steps 20 --warmup 5; two separate passes; mean per dispatch)",
+       "units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (x1024 = bytes); gfx950 correction per MI355X_MICROARCH.md: wide "
+                "16-B/lane streaming reads are counted at 1/2 -> read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE exact for 16-B stores",
+       "config": {"n_items": N, "n_hidden": h, "batch": B}, "kernels": kernels}
+path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+json.dump(doc, open(path, "w"), indent=1)
+print(path, json.dumps(kernels))
