@@ -344,7 +344,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32"):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -376,6 +376,11 @@ class HipAAE:
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
         cfg.reserved[3] = 1 if dtype == "bf16" else 0
+        # batches beyond one fused launch's 112 rows as row-blocked launches of the fused output layer (up to 1664 rows;
+        # DESIGN.md 3.2e) instead of the three-kernel path.  Built for the item slices of the vocabulary-sharded scheme
+        # (VERDICT r1 item 3), measured SLOWER than the three GEMMs there (0.50 -> 0.87 ms of per-rank compute at world
+        # 8): opt-in, off everywhere by default
+        cfg.reserved[4] = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
         self.dtype = dtype
         self.ae_only, self.vae = bool(ae_only or vae), bool(vae)
         self.dp_world = int(dp_world)

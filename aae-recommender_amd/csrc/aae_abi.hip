@@ -124,6 +124,7 @@ struct aae_model {
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
+    bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
@@ -150,6 +151,9 @@ struct Arena {
     }
 };
 
+// row-blocked fused output layer: at most kMaxRowBlocks launches of at most kRowBlock rows each
+constexpr int kRowBlock = 104, kMaxRowBlocks = 16;
+
 // layer widths the fused decoder output-layer kernel (dec_fused.h) is instantiated for
 inline bool fused_width_ok(int h, int ldh) {
     return (h + 1 + 15) / 16 <= 13 && ldh <= 256 && (ldh % 4) == 0 && ldh <= kSD - 2;
@@ -170,7 +174,8 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 4; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 5; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[4] != 0 && c->reserved[4] != 1) return fail(AAE_EINVAL, "reserved[4] must be 0 or 1 (row-blocked fused output layer)");
     if (c->reserved[3] != 0 && c->reserved[3] != 1) return fail(AAE_EINVAL, "reserved[3] must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
     if (c->reserved[3] == 1 && c->reserved[2] == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
     if (c->reserved[2] < 0 || c->reserved[2] > 3 || c->reserved[2] == 2)
@@ -219,7 +224,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
     m->dh1 = a.mat(R, h + 1, m->ldh); m->dh2 = a.mat(R, h + 1, m->ldh);
-    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1);   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
+    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1 + (c.reserved[4] ? kMaxRowBlocks : 0));   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
     // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
@@ -228,6 +233,8 @@ size_t layout(aae_model* m, char* base, bool dry) {
         // 16 * kMB rows: a model with a larger max_batch still takes it for its short (tail) batches
         int64_t slab_rows = (int64_t)m->max_slabs * R;
         if (fused_width_ok(h, m->ldh)) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * std::min(R, 16 * kMB));
+        // row-blocked form: every workgroup's slab spans the whole batch (each launch fills its rows)
+        if (fused_width_ok(h, m->ldh) && c.reserved[4] && R <= kMaxRowBlocks * kRowBlock) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * R);
         m->slabs = a.mat(slab_rows, h, m->ldh);
     }
     m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
@@ -239,10 +246,12 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
     m->da2 = a.mat(R, h + 1, m->ldh);
+    m->Gacc = Ten();
+    if (c.reserved[4] && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
     if (c.reserved[2] == 3) {
         m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
     }
-    m->bce_partials_cap = std::max(512, ((N + 31) / 32) * ((R + 31) / 32));
+    m->bce_partials_cap = std::max(512 * (c.reserved[4] ? kMaxRowBlocks : 1), ((N + 31) / 32) * ((R + 31) / 32));
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
     m->fix_partials = a.take((size_t)R * 64, nullptr);
     m->rscale = a.take(R, nullptr);
@@ -734,10 +743,14 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 
 // The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
 // as one extra workgroup (chain.h), off the critical path.
+static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m->rows + kRowBlock - 1) / kRowBlock; }
 static bool fused_decoder_applies(const aae_model* m) {
-    return m->fused_ok && !m->force_unfused && m->rows <= 16 * kMB &&
+    const bool one = m->rows <= 16 * kMB;
+    const bool blocked = !one && m->blocked_ok && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
+                         m->cfg.grad_mode == AAE_GRAD_FUSED;
+    return m->fused_ok && !m->force_unfused && (one || blocked) &&
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
-           (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes(m->rows, m->h)) <= 160 * 1024;
+           (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
 }
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const int ntiles = (m->N + kTI - 1) / kTI;
@@ -1072,6 +1085,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
     m->vae = cfg->reserved[2] == 3; m->vae_bwd = false;
     m->bf16 = cfg->reserved[3] == 1;
+    m->blocked_ok = cfg->reserved[4] == 1;
     m->ae_only = cfg->reserved[2] == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
@@ -1146,7 +1160,10 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         m->split_ok = ok;
         (void)hipGetLastError();
     }
@@ -1584,7 +1601,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
-    const size_t fused_lds = m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(B, h);
+    // row blocks of the fused output layer: one launch covers at most 112 rows; larger batches (cfg.reserved[4]) run as
+    // nblk launches of the split form over equal row blocks
+    const int nblk = m->have_batch ? row_blocks(m) : 1;
+    const int Bb = (B + nblk - 1) / nblk;                        // rows per block (the last one may be shorter)
+    const size_t fused_lds = m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(Bb, h);
     const float* chain_part = nullptr; size_t chain_stride = 0;
     if (fused_decoder_applies(m)) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
@@ -1611,8 +1632,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.gradV3 = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_V3].p : nullptr;
         fa.N = N; fa.B = B; fa.h = h; fa.gscale = gscale;
         fa.te.start = m->tstart; fa.te.eb = m->teb; fa.te.en = m->ten; fa.te.ev = m->tev;
-        fa.slabs = m->slabs.p; fa.slab_stride = (size_t)std::min(m->R, 16 * kMB) * m->ldh; fa.ld_slab = m->ldh;
+        fa.slabs = m->slabs.p; fa.slab_stride = (size_t)(nblk > 1 ? B : std::min(m->R, 16 * kMB)) * m->ldh; fa.ld_slab = m->ldh;
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
+        fa.erow0 = 0; fa.acc = nullptr;
         { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
         static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile
         static unsigned long long* ts_dev = nullptr;
@@ -1623,31 +1645,53 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         }
         const int grid = std::min(ntiles, m->n_cu);
         fa.Gt = m->Gt;
+        int n_loss_partials = grid;
         if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && fa.dbg_skip == 0) {
-            // ---- split form: the critical launch here, the optimiser launch on the side stream behind the rest of the step
+            // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
+            // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
+            // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3
+            // to the partial of the blocks before it - the last one runs the optimiser.
             if (m->opt_pending) TRY(join_deferred(m, s));   // (never: every step-opening entry point joins)
-            {
+            auto block_args = [&](int r) {
+                DecFusedArgs b = fa;
+                const int r0 = r * Bb;
+                b.B = std::min(Bb, B - r0); b.erow0 = r0;
+                b.dh2 = fa.dh2 + (size_t)r0 * m->ldh;
+                b.slabs = fa.slabs + (size_t)r0 * m->ldh;
+                b.partials = fa.partials + (size_t)r * grid;
+                b.Gt = fa.Gt + (size_t)r * ntiles * Bb * kTI;
+                return b;
+            };
+            n_loss_partials = grid * nblk;
+            for (int r = 0; r < nblk; ++r) {
                 // "this launch is done" rides on the kernel's own completion signal (a hipEventRecord behind the launch is a
                 // marker packet the next kernel of the stream waits for: +30 us per step); when the launch is being timed,
-                // the timing pair's stop event doubles as that event
-                hipEvent_t start = nullptr, stop = m->ev_crit;
+                // the timing pair's stop event doubles as that event.  Only the LAST block's launch carries it.
+                const DecFusedArgs b = block_args(r);
+                hipEvent_t start = nullptr, stop = r == nblk - 1 ? m->ev_crit : nullptr;
                 (void)prof_pair(m, AAE_K_DEC_CRIT, &start, &stop);
                 switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
-                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
-                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, fa); break;
+                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                 }
                 LAUNCHCHK("dec_fused (critical launch)");
-                HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
+                if (r == nblk - 1) HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
             }
-            {
-                const int g2 = std::min(ntiles, std::min(m->split_wgs, m->n_cu));
+            const int g2 = std::min(ntiles, std::min(m->split_wgs, m->n_cu));
+            for (int r = 0; r < nblk; ++r) {
+                DecFusedArgs b = block_args(r);
+                if (nblk > 1) { b.acc = m->Gacc.p; b.gradV3 = r == nblk - 1 ? nullptr : m->Gacc.p; }
                 hipEvent_t start = nullptr, stop = nullptr;
                 (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
-                switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
-                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
-                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, fa); break;
+                if (r == 0) switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                } else switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                 }
                 LAUNCHCHK("dec_fused (optimiser launch)");
             }
@@ -1691,7 +1735,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         float* part = m->slabs.p + (size_t)304 * fa.slab_stride;
         const size_t n4 = (size_t)B * m->ldh / 4;
         hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
-                           fa.slab_stride, n4, part, fa.slab_stride, m->bce_partials, grid,
+                           fa.slab_stride, n4, part, fa.slab_stride, m->bce_partials, n_loss_partials,
                            1.0f / ((float)B * (float)N), m->losses, 0);
         if (m->only_output_layer) {
             hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, part, 16,
@@ -1746,8 +1790,22 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                            m->step_ctr);
         LAUNCHCHK("slab_reduce");
     }
-    // dV3 = G^T * dh2 -> dec_optim on V3 (the 24 B/param streaming kernel)
-    {
+    // dV3 = G^T * dh2 -> dec_optim on V3 (the 24 B/param streaming kernel).  Like the fused path's optimiser half
+    // (section 3.2c) only the NEXT step reads its result: with the fused optimiser it goes to the handle's low-priority
+    // side stream, behind the rest of the step (G and dh2 stay untouched until the next step's join).
+    static const bool defer_dv3 = getenv("AAE_NO_DEFER_DV3") == nullptr;
+    // (not for the item slices of the vocabulary-sharded scheme: there the background GEMM slowed the replica handle's
+    // kernels by more than it saved - 0.496 -> 0.560 ms of per-rank compute at world 8, tools/vocab_rank_time.py)
+    if (defer_dv3 && m->side && m->cfg.grad_mode == AAE_GRAD_FUSED && !m->bf16 && !m->only_output_layer) {
+        HIPCHK(hipEventRecord(m->ev_crit, s));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_crit, 0));
+        {
+            ProfScope ps(m, AAE_K_DEC_DV3_ADAM, m->side);
+            TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, m->side));
+        }
+        TRY(side_done(m, m->ev_opt));
+        m->opt_pending = true;
+    } else {
         ProfScope ps(m, AAE_K_DEC_DV3_ADAM, s);
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
     }

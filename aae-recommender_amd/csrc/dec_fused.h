@@ -71,6 +71,12 @@ struct DecFusedArgs {
     int dbg_skip;                         // timing-only ablation mask (AAE_DEC_SKIP), 0 in production
     unsigned long long* ts;               // debug (AAE_DEC_TS): 100 MHz phase timestamps of workgroup 0, tile 5; else NULL
     float* Gt;                            // split form: dL/dlogits tile-major [tile][B][32] (written by MODE 1, read by MODE 2)
+    // row-blocked form (batches beyond one launch's 112 rows, section 3.2e of DESIGN.md): this launch covers rows
+    // [erow0, erow0 + B) of the batch - dh2 / slabs / partials / Gt already point at the block, the tile's entry lists
+    // name rows of the WHOLE batch; acc (kDecOptAcc) = the dV3 partial of the earlier row blocks, added before the
+    // optimiser (or before the partial is stored again: gradV3 != NULL)
+    int erow0;
+    const float* acc;
 };
 
 // MODE of dec_fused_kernel.  The step's critical path needs only dL/d(dh2) from this layer (the decoder's hidden
@@ -79,6 +85,7 @@ struct DecFusedArgs {
 // kDecOpt on a side stream with fewer workgroups than CUs, behind the latency-bound rest of the step (section 3.2c).
 constexpr int kDecFused = 0;   // S0 GEMM1 S2 GEMM2 GEMM3 S5: everything in one launch
 constexpr int kDecCrit = 1;    // S0 GEMM1 S2 GEMM3: logits, BCE, dA2 slabs, loss; stores the tile's dL/dlogits to Gt
+constexpr int kDecOptAcc = 3;  // kDecOpt with a.acc added to the tile's gradient first
 constexpr int kDecOpt = 2;     // S0 GEMM2 S5: dV3 from the stored dL/dlogits + dec_optim.  Its streams (V3, m, v, the stored
                                // tiles) are non-temporal: with plain loads / stores the 0.5 GB pass evicted the hidden layers'
                                // weights from L2 under the layer-chain kernels it runs beside (+25 % on each of them)
@@ -98,9 +105,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <int NB, int MODE = kDecFused>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
-    constexpr bool kFwd = MODE != kDecOpt;     // GEMM1, entries, GEMM3, loss, slabs
+    constexpr bool kFwd = MODE != kDecOpt && MODE != kDecOptAcc;     // GEMM1, entries, GEMM3, loss, slabs
     constexpr bool kOpt = MODE != kDecCrit;    // GEMM2, optimiser
-    constexpr bool kIsOpt = MODE == kDecOpt;
+    constexpr bool kIsOpt = MODE == kDecOpt || MODE == kDecOptAcc;
+    constexpr bool kAccIn = MODE == kDecOptAcc;
     constexpr int kAux = kIsOpt ? 2 : 0;       // buffer-store cache policy: 2 = nt
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dhs = lds;                                  // [B][kSD]
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     // loads return in order - one such load exposes the whole prefetch):
     //   V3a(t+1), the CSR entries of tile t+1 and the entry range of tile t+2 are requested in S0(t),
     //   m/v(t) before GEMM2(t); parameter stores of S5(t) retire behind GEMM3(t).
-    float4 vreg[NV], mreg[NV], sreg[NV];
+    float4 vreg[NV], mreg[NV], sreg[NV], areg[NV];
     typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
     const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.N * ldv * sizeof(float));
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
@@ -244,7 +252,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             }
         }
         ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
-        const int my_p = ent_b * kSG + ent_n; const float my_v = ent_v;
+        const int my_rb = ent_b - a.erow0;              // (row-blocked launches: entries of other row blocks are not ours)
+        const int my_p = my_rb * kSG + ent_n; const float my_v = ent_v;
         if (kIsOpt) {
             if (tid < g_f4) *reinterpret_cast<float4*>(gs + (tid >> 3) * kSG + (tid & 7) * 4) = greg;
             load_g(min(tile + stride, ntiles - 1));
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         // ---- S2: the CSR entries of the tile (non-zero targets) replace their cell's gradient and loss term
         if (kFwd) {
             const int e0 = ce0, e1 = (a.dbg_skip & 2) ? e0 : ce1;
-            if (tid < e1 - e0) {                        // the prefetched entry of this thread
+            if (tid < e1 - e0 && (unsigned)my_rb < (unsigned)B) {      // the prefetched entry of this thread
                 float g0, l0, g1, l1;
                 bce_elem_t0(raw[my_p], a.gscale, g0, l0);
                 bce_elem(raw[my_p], my_v, a.gscale, g1, l1);
@@ -311,7 +320,9 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 gs[my_p] = g1;
             }
             for (int e = e0 + kNT + tid; e < e1; e += kNT) { // tiles with more than 1024 entries (tiny vocabularies)
-                const int p = a.te.eb[e] * kSG + a.te.en[e];
+                const int rb = a.te.eb[e] - a.erow0;
+                if ((unsigned)rb >= (unsigned)B) continue;
+                const int p = rb * kSG + a.te.en[e];
                 float g0, l0, g1, l1;
                 bce_elem_t0(raw[p], a.gscale, g0, l0);
                 bce_elem(raw[p], a.te.ev[e], a.gscale, g1, l1);
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         // the optimiser moments of this tile travel while GEMM2 and GEMM3 run
         // (unconditional: the moment tensors exist in every mode, and a load under a condition is waited for on the spot)
         if (kOpt) { load_span(a.M, tile, mreg); load_span(a.V, tile, sreg); }
+        if (kAccIn) load_span(a.acc, tile, areg);
         // ---- S3: GEMM2 dV3a[item][c] = sum_b G[b][item] * dh2[b][c]; blocks id = nb*2 + ib, a wave owns the ids
         // wave + 16q: they share the item half ib (one G read serves them all) and differ in the column block.
         // k runs over the batch rows in groups of 16: k-step (g, j) multiplies rows 16g + j + 4*fk.  Rows 4
@@ -441,7 +453,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const bool valid = tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < a.N && !(a.dbg_skip & 32);
-            const float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
+            float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
+            if (kAccIn) { g.x += areg[j].x; g.y += areg[j].y; g.z += areg[j].z; g.w += areg[j].w; }
             // the tile span is contiguous: byte offset = (i0 * ldv + 4 * slot) * 4
             const unsigned so = (unsigned)((size_t)((a.dbg_skip & 128) ? (int)blockIdx.x * kTI : i0) * ldv) * 4u;
             const unsigned vo = valid ? (unsigned)(tid + kNT * j) * 16u : 0x80000000u;

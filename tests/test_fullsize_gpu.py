@@ -151,3 +151,41 @@ def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_defe
     assert float((split.tensor(T_DEC_V3, padded=True) - single.tensor(T_DEC_V3, padded=True)).abs().max()) <= 2e-6
     # predict reads DEC_V3 through the ABI: joined inside
     np.testing.assert_allclose(split.predict(csr, 0, B).cpu().numpy(), single.predict(csr, 0, B).cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("Ns,B", [(12500, 105), (12500, 800), (25000, 512), (4587, 1000), (50000, 200)])
+def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B):
+    """Batches beyond one fused launch (112 rows) on a model created with blocked_output=True - what the item slices of the
+    vocabulary-sharded scheme run at every world size > 1 (slice x the global batch, aae_output_layer_step): one critical
+    launch per row block of <= 104 rows, the deferred launches accumulating dV3 over the blocks before ONE optimiser pass.
+    Against the three-kernel path of the same model (itself pinned by the reference's fixtures and the C5-share test
+    above): dL/d(dh2), loss, parameters and both moments after two consecutive steps."""
+    from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
+    from tools.synth import throughput_corpus
+    h, c = 200, 50
+    rng = np.random.default_rng(Ns + B)
+    k = 1.0 / np.sqrt(h)
+    full = {"dec.lin3.weight": ((rng.random((Ns, h)) * 2 - 1) * k).astype(np.float32),
+            "dec.lin3.bias": ((rng.random(Ns) * 2 - 1) * k).astype(np.float32)}
+    X = throughput_corpus(2 * B, Ns, median_len=6, seed=Ns)
+    blocked = HipAAE(Ns, h, c, max_batch=B, rng_mode="inject", blocked_output=True)
+    plain = HipAAE(Ns, h, c, max_batch=B, rng_mode="inject", unfused_decoder=True)
+    for m in (blocked, plain):
+        m.load_params(full)
+        m.set_grad_scale(0.25)
+    csr = DeviceCSR(X, blocked.device)
+    for s in range(2):
+        dh2 = np.abs(rng.standard_normal((B, h + 1))).astype(np.float32) * 0.5
+        dh2[rng.random((B, h + 1)) < 0.4] = 0.0
+        dh2[:, h] = 1.0
+        for m in (blocked, plain):
+            m.dh2_rows(B)[:, :h + 1].copy_(torch.from_numpy(dh2))
+            m.output_layer_step(csr, s * B, B)
+        np.testing.assert_allclose(blocked.losses()[0], plain.losses()[0], rtol=1e-5)
+        got, want = blocked.da2_rows(B)[:, :h].cpu().numpy(), plain.da2_rows(B)[:, :h].cpu().numpy()
+        scale = float(np.abs(want).max())
+        assert _maxdiff(got, want) <= 2e-5 * scale + 1e-12, (s, _maxdiff(got, want), scale)
+    for tid in (T_DEC_V3, T_ADAM_DEC + 4, T_ADAM_DEC + 5):
+        a, b = blocked.tensor(tid).cpu().numpy(), plain.tensor(tid).cpu().numpy()
+        tol = 2e-6 if tid == T_DEC_V3 else 1e-9
+        assert _maxdiff(a, b) <= tol + 1e-4 * float(np.abs(b).max()), (tid, _maxdiff(a, b))

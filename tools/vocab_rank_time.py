@@ -89,7 +89,8 @@ m.load_params(params)
 sp = dict(params)
 sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
 sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
-sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256)
+BLOCKED = os.environ.get("VR_BLOCKED", "0") != "0"      # 1: row-blocked fused launches for the slice (default: the three-kernel path)
+sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED)
 sl.load_params(sp)
 slice_csr = DeviceCSR(X[:, lo:hi], dev)
 d2 = EchoDist(world)
@@ -99,14 +100,14 @@ sl.profile_enable(True)
 for i in range(50):
     vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)
 torch.cuda.synchronize()
-names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused"]
+names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt"]
 parts = []
-for k in range(6):
+for k in range(9):
     ms, n = sl.profile_read(k)
     if n:
-        parts.append(f"{names[k]} {1e3 * ms / n:.1f} us")
+        parts.append(f"{names[k]} {n // 50} x {1e3 * ms / n:.1f} us")
 sl.profile_enable(False)
 print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
 per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d2.bytes.items()}
-print(f"world {world}: vocabulary-sharded   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
+print(f"world {world}: vocabulary-sharded ({'row-blocked fused' if BLOCKED else 'three-kernel'} output layer)   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
       + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
