@@ -1646,7 +1646,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         const int grid = std::min(ntiles, m->n_cu);
         fa.Gt = m->Gt;
         int n_loss_partials = grid;
-        if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && fa.dbg_skip == 0) {
+        if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && (fa.dbg_skip & ~256) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3

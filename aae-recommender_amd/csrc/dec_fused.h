@@ -128,6 +128,15 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     const int kch1 = (((K1 + 7) >> 3) + 1) & ~1;       // GEMM1: 8-k chunks over the h+1 hidden columns (even count;
                                                        // columns >= ldh of both LDS images are zero), 8 * kch1 <= kSD
     const int nmb = (B + 15) >> 4;                      // 16-row blocks actually present (<= kMB)
+    // A last row block of at most 4 rows (the reference's default batch: 100 = 6 * 16 + 4) does not run as a 7th 16-row
+    // block - 12 of its 16 rows would be padding in GEMM1 and GEMM3 - but on v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4 x 4
+    // per instruction, 8 cycles: the same 64 flop/clk/SIMD with a quarter of the rows), spread over waves that have room:
+    // GEMM1 on waves 12..15 (8 items x 8 k-eighths each, reduced over the k-eighths by lane shuffles), GEMM3 on all 16
+    // (64 columns x an item quarter each; the four item quarters of a column group meet in LDS at the kernel's end).
+    const bool tail4 = kFwd && nmb > 1 && B - 16 * (nmb - 1) <= 4 && !(a.dbg_skip & 256);      // (256: A/B switch back to the 7th block)
+    const int nfb = tail4 ? nmb - 1 : nmb;              // full 16-row blocks of the forward products
+    const int kq = (((K1 + 7) >> 3) + 1) & ~1;          // GEMM1 tail: k-steps per eighth (even; 8 * kq <= kSD)
+    f32x4 acc3t = (f32x4){0.f, 0.f, 0.f, 0.f};          // GEMM3 tail: rows 16 nfb + 0..3 of column 64 (wave & 3) + lane
     const int ntiles = (a.N + kTI - 1) / kTI;
     const int f4_per_row = ldv / 4;                    // ldv % 4 == 0
     const int tile_f4 = kTI * f4_per_row;              // float4 per tile span
@@ -266,7 +275,42 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         lds_barrier();
         stamp(1);
 
-        if (kFwd && !(a.dbg_skip & 1) && wave < 2 * nmb)
+        if (kFwd && !(a.dbg_skip & 1) && tail4 && wave >= kNW - 4) {
+            // ---- S1, tail rows: logits[16 nfb + i][8 w4 + 4g + j] over the k-eighth ke; lane = 8 ke + 4 g + j
+            const int w4 = wave - (kNW - 4);
+            const int j4 = lane & 3, ke = lane >> 3;
+            const int item = 8 * w4 + (lane & 7);
+            const float* pa = dhs + min(16 * nfb + j4, B - 1) * kSD + ke * kq;
+            const float* pb = v3s + v3_row(item) * kSD + ke * kq + oz;
+            f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = t0;
+            for (int k = 0; k < kq; k += 2) {
+                const float2 xa = *reinterpret_cast<const float2*>(pa + k);
+                const float2 xb = *reinterpret_cast<const float2*>(pb + k);
+                t0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.x, xb.x, t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.y, xb.y, t1, 0, 0, 0);
+            }
+            t0 += t1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = t0[r];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                t0[r] = v;
+            }
+            if (lane < 8) {
+                const int rb = 16 * nfb, cb = item;
+                const bool item_ok = i0 + cb < a.N && !(a.dbg_skip & 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rb + r < B) {
+                        float g = 0.f, l = 0.f;
+                        if (item_ok) bce_elem_t0(t0[r], a.gscale, g, l);
+                        gs[(rb + r) * kSG + cb] = g;
+                        raw[(rb + r) * kSG + cb] = t0[r];
+                        loss += l;
+                    }
+            }
+        } else
+        if (kFwd && !(a.dbg_skip & 1) && wave < 2 * nfb)
         // ---- S1: GEMM1 logits[b][n] = sum_k dh2[b][k] * V3a[n][k]; blocks (mb, nb2) id = mb*2 + nb2,
         // one block per wave; `wave` is a scalar, so waves past the last block skip with a scalar branch and
         // leave the matrix pipe of their SIMD to the others
@@ -416,11 +460,11 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             constexpr int Q3 = (kMB * NB + kNW - 1) / kNW;
             // scalar: the wave's last block exists, or is a duplicate that only keeps the code branch-free (small
             // batches have several duplicates: they still run, and are never stored)
-            const bool full3 = wave + kNW * (Q3 - 1) < nmb * NB || nmb < kMB;
+            const bool full3 = wave + kNW * (Q3 - 1) < nfb * NB || (nmb < kMB && !tail4);
             const float* pg[Q3]; const float* pv[Q3];
 #pragma unroll
             for (int q = 0; q < Q3; ++q) {
-                const int id = min(wave + kNW * q, nmb * NB - 1);
+                const int id = min(wave + kNW * q, nfb * NB - 1);
                 const int mb = id / NB, nb = id - mb * NB;
                 pg[q] = gs + (mb * 16 + frz) * kSG + 2 * fk;        // G[b][n = 8c + 2fk + j]: float2 per chunk
                 pv[q] = v3s + (((fk & 1) << 2) | (fk & 2)) * kSD + nb * 16 + frz;   // V3a row v3_row(8c + 2fk + j) = 8c + this + j
@@ -439,6 +483,15 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                         acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].x, y0[q], acc3[q], 0, 0, 0);
                         acc3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].y, y1[q], acc3[q], 0, 0, 0);
                     }
+            }
+            if (tail4 && 64 * (wave & 3) < 16 * NB) {
+                // tail rows: dA2[16 nfb + i][64 cg + lane] += sum over the item quarter n = 8 kq3 .. + 7 of G[row][n] * V3a[n][col]
+                const int cg = wave & 3, kq3 = wave >> 2;
+                const float* pgt = gs + (16 * nfb + (lane & 3)) * kSG + 8 * kq3 + oz;
+                const float* pvt = v3s + min(64 * cg + lane, kSD - 1);
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc3t = __builtin_amdgcn_mfma_f32_4x4x1f32(pgt[n], pvt[v3_row(8 * kq3 + n) * kSD], acc3t, 0, 0, 0);
             }
         }
         if (kOpt) lds_barrier();                     // os complete
@@ -480,10 +533,25 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     if (!kFwd) return;
     // ---- dA2 partial of this workgroup -> its slab; loss partial
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    if (tail4) {
+        // the tail rows' four item-quarter partials of every column meet in LDS (the dV3a / raw-logit buffer is free now)
+        __syncthreads();
+        float* tl = os;                                    // [4 item quarters][4 rows][256 columns]
+        const int cg = wave & 3, kq3 = wave >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl[((kq3 * 4 + r) << 8) + 64 * cg + lane] = acc3t[r];
+        __syncthreads();
+        {
+            const int r = tid >> 8, cc = tid & 255;         // 1024 threads = 4 rows x 256 columns
+            const int row = 16 * nfb + r;
+            if (row < B && cc < a.ld_slab)
+                slab[(size_t)row * a.ld_slab + cc] = (tl[(r << 8) + cc] + tl[((4 + r) << 8) + cc]) + (tl[((8 + r) << 8) + cc] + tl[((12 + r) << 8) + cc]);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < (kMB * NB + kNW - 1) / kNW; ++q) {
         const int id = wave + kNW * q;
-        if (id < nmb * NB) {
+        if (id < nfb * NB) {
             const int mb = id / NB, nb = id - mb * NB;
             const int rb = mb * 16 + fk * 4, cb = nb * 16 + fr;
 #pragma unroll
