@@ -114,6 +114,7 @@ _PROTOS = {
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "aae_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_set_input_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
 }
@@ -344,7 +345,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False, dense_noise=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -381,6 +382,8 @@ class HipAAE:
         # (VERDICT r1 item 3), measured SLOWER than the three GEMMs there (0.50 -> 0.87 ms of per-rank compute at world
         # 8): opt-in, off everywhere by default
         cfg.reserved[4] = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
+        # DenoisingAutoEncoder(corrupt='gauss'): room for the dense noisy encoder input (set_input_noise before a step)
+        cfg.reserved[5] = 1 if dense_noise else 0
         self.dtype = dtype
         self.ae_only, self.vae = bool(ae_only or vae), bool(vae)
         self.dp_world = int(dp_world)
@@ -576,6 +579,14 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows, rows)
         self._pf_keep = (csr, rows)
         _check(self.lib.aae_prefetch_batch(self.handle, C.byref(b)))
+
+    def set_input_noise(self, noise):
+        """The NEXT training step's encoder reads the dense batch + `noise` ([rows, n_items] float32, already scaled by
+        the noise factor) instead of the sparse rows (aae_set_input_noise; DenoisingAutoEncoder corrupt='gauss')."""
+        noise = noise.to(self.device, torch.float32).contiguous()
+        assert noise.shape[1] == self.N
+        self._noise_keep = noise
+        _check(self.lib.aae_set_input_noise(self.handle, _ptr(noise), noise.shape[1]))
 
     def step(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
         """One partial_fit without generic conditions (cond: device tensor [n_rows, cond_inc])."""

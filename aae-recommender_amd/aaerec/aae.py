@@ -219,7 +219,7 @@ class AdversarialAutoEncoder:
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
             grad_mode="export" if dist is not None else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
-            unfused_decoder=self._unfused_decoder)
+            unfused_decoder=self._unfused_decoder, dense_noise=getattr(self, "_dense_noise", False))
         self.hip.load_params(params)
         self.enc, self.dec, self.disc = (_NetView(self, n) for n in ("enc", "dec", "disc"))
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")

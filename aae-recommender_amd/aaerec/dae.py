@@ -5,8 +5,10 @@ reference's ae_step: aae.py:676-711 == dae.py:189-210) on a corrupted batch.  Th
 corruption, ``corrupt='zeros'`` (dae.py:48-52), sets a random subset of the batch tensor to zero IN PLACE,
 so the encoder input and the BCE target are both the thinned bag: on CSR data that is a per-entry keep
 flag, applied to the values on the device.  ``corrupt='gauss'`` (dae.py:40-45) adds dense N(0, noise_factor)
-noise to every one of the N input columns, which makes the encoder's first layer a dense [B,N]x[N,h]
-product with a dense weight gradient - not built (NotImplementedError, no silent fallback).
+noise to every one of the N input columns and returns a NEW tensor: the encoder's first layer becomes a dense
+[B,N]x[N,h] product with a dense weight gradient and an eager Adam over every row of enc.lin1 for those steps
+(`aae_set_input_noise` before the step: `dense_input_kernel` + the split-K GEMM of csrc/gemm_f32.h), the BCE target
+stays the clean batch.
 """
 import numpy as np
 import scipy.sparse as sp
@@ -33,9 +35,9 @@ class DenoisingAutoEncoder(AutoEncoder):
         if corrupt.lower() not in NOISE_TYPES:
             raise KeyError(corrupt.lower())                      # NOISE_TYPES[corrupt.lower()], dae.py:173
         self.corrupt = corrupt.lower()
-        if self.corrupt == "gauss":
-            raise NotImplementedError("corrupt='gauss' adds dense noise to all N input columns (dae.py:40-45): the "
-                                      "sparse first-layer kernels do not cover it; use corrupt='zeros' (the default)")
+        # corrupt='gauss' adds N(0, noise_factor) to ALL N input columns (dae.py:40-45): the encoder's first layer runs as
+        # a dense product for those steps (aae_set_input_noise); the BCE target stays the clean batch
+        self._dense_noise = self.corrupt == "gauss"
 
     def __str__(self):
         return "Denoising " + super().__str__()
@@ -48,10 +50,18 @@ class DenoisingAutoEncoder(AutoEncoder):
         out.values = csr.values * keep.to(csr.values.dtype)
         return out
 
+    def _gauss_noise(self, n_rows):
+        """gauss_noise's `torch.randn(batch.size()) * noise_factor` (dae.py:42): off the global CPU generator in the
+        reference's draw order (rng_mode='reference'), else drawn on the device."""
+        n_items = self.hip.N
+        if self.rng_mode == "reference":
+            return torch.randn(n_rows, n_items) * self.noise_factor
+        return torch.randn(n_rows, n_items, device=self.hip.device) * self.noise_factor
+
     def _epoch_csr(self, csr):
         # every row is visited once per epoch, so thinning the whole resident corpus once per epoch with fresh
         # randomness is the per-batch zeros_noise of the reference (dae.py:48-52, 191) in distribution
-        if self.rng_mode == "reference":
+        if self.corrupt == "gauss" or self.rng_mode == "reference":
             return csr                                           # drawn per batch, in the reference's order
         return self._thinned(csr, torch.rand_like(csr.values) >= self.noise_factor)
 
@@ -62,6 +72,11 @@ class DenoisingAutoEncoder(AutoEncoder):
         return ~mask[torch.from_numpy(rows), torch.from_numpy(X_batch.indices.astype(np.int64))]
 
     def _run_step(self, csr, row_start, n_rows, rows, c_batch):
+        if self.corrupt == "gauss":
+            # the encoder of THIS step reads the dense batch + noise (corruption is drawn before the dropout masks);
+            # the BCE target stays the clean batch (gauss_noise returns a new tensor, dae.py:40-45)
+            self.hip.set_input_noise(self._gauss_noise(n_rows))
+            return super()._run_step(csr, row_start, n_rows, rows, c_batch)
         if self.rng_mode == "reference" and getattr(self, "_in_fit", False):
             # the reference's draw order within a step: corruption mask first, then the dropout masks
             idx = rows.cpu().numpy() if rows is not None else np.arange(row_start, row_start + n_rows)
@@ -74,9 +89,9 @@ class DenoisingAutoEncoder(AutoEncoder):
         return super()._run_step(csr, row_start, n_rows, rows, c_batch)
 
     # ---- public API (dae.py:212-314) ---------------------------------------------------------------
-    def partial_fit(self, X, y=None, condition_data=None, step=None, keep=None):
+    def partial_fit(self, X, y=None, condition_data=None, step=None, keep=None, noise=None):
         """ Performs one denoising reconstruction step.  keep: optional per-entry keep flags (CSR order) that
-        replace the random corruption (parity runs). """
+        replace the random corruption (parity runs); noise: the same for corrupt='gauss' ([rows, n_items], scaled). """
         use_condition = _check_conditions(self.conditions, condition_data)
         if y is not None:
             raise ValueError("(Semi-)supervised usage not supported")
@@ -88,6 +103,15 @@ class DenoisingAutoEncoder(AutoEncoder):
         if Xs.shape[0] > self.hip.max_batch:
             raise ValueError("batch of {} rows exceeds batch_size={}".format(Xs.shape[0], self.hip.max_batch))
         csr = _hip.DeviceCSR(Xs, self.hip.device)
+        if self.corrupt == "gauss":
+            self.train()
+            self.hip.set_input_noise(torch.as_tensor(noise, dtype=torch.float32) if noise is not None
+                                     else self._gauss_noise(Xs.shape[0]))
+            AutoEncoder._run_step(self, csr, 0, Xs.shape[0], None, condition_data if use_condition else None)
+            if self.verbose:
+                self.last_losses = self.hip.losses()
+                log_losses(self.last_losses[0], 0, 0)
+            return self
         if keep is not None:
             kp = torch.as_tensor(np.asarray(keep), device=self.hip.device) != 0
         elif self.rng_mode == "reference":

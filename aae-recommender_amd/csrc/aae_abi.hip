@@ -124,6 +124,7 @@ struct aae_model {
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
+    Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.reserved[5]: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
@@ -174,7 +175,10 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 5; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    for (int i = 6; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[5] != 0 && c->reserved[5] != 1) return fail(AAE_EINVAL, "reserved[5] must be 0 or 1 (dense noisy encoder input)");
+    if (c->reserved[5] == 1 && (c->reserved[2] != 1 || c->grad_mode != AAE_GRAD_FUSED || c->reserved[3] != 0))
+        return fail(AAE_EINVAL, "reserved[5] = 1 (dense noisy encoder input) needs the plain autoencoder (reserved[2] = 1), fp32, fused optimiser");
     if (c->reserved[4] != 0 && c->reserved[4] != 1) return fail(AAE_EINVAL, "reserved[4] must be 0 or 1 (row-blocked fused output layer)");
     if (c->reserved[3] != 0 && c->reserved[3] != 1) return fail(AAE_EINVAL, "reserved[3] must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
     if (c->reserved[3] == 1 && c->reserved[2] == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
@@ -246,6 +250,8 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->dout = a.mat(R2, 1, 4);
     m->zsave = a.mat(R, cc, m->ldz);
     m->da2 = a.mat(R, h + 1, m->ldh);
+    m->Xn = Ten();
+    if (c.reserved[5] == 1) m->Xn = a.mat(R, N, m->ldn);
     m->Gacc = Ten();
     if (c.reserved[4] && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
     if (c.reserved[2] == 3) {
@@ -719,6 +725,7 @@ struct DwBuilder {
         w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
         w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
         w.ncol = (m->h + 63) / 64;
+        if (m->dense_step) w.ny = 0;            // dense noisy input: no scatter (the dense dW1T product follows), bias blocks only
     }
     int launch(hipStream_t s) {
         int blocks = tiles;
@@ -858,6 +865,19 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
     const int B = m->rows, h = m->h;
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    if (m->dense_step) {
+        // dW1T [N][h] = x^T [N][B] * dL/da1 [B][h] with the fused optimiser on EVERY row (torch.optim.Adam is dense), then
+        // all rows carry this step
+        if (!merged) {
+            hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
+                               m->M[set][P_B1].p, m->V[set][P_B1].p, (float*)nullptr, m->sc + which);
+            LAUNCHCHK("colsum_adam");
+        }
+        TRY(linear_dw(m, m->Xn.p, m->ldn, B, ga1, m->ldh, P_W1T, which, s));
+        hipLaunchKernelGGL(fill_tsync_kernel, dim3(grid1d((size_t)m->N)), dim3(256), 0, s, m->tsync, m->N, m->step_ctr);
+        LAUNCHCHK("fill_tsync");
+        return AAE_OK;
+    }
     if (!merged) {
     hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
                        m->Gr[P_W1T].p, m->ldw1, 0);
@@ -1086,6 +1106,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->vae = cfg->reserved[2] == 3; m->vae_bwd = false;
     m->bf16 = cfg->reserved[3] == 1;
     m->blocked_ok = cfg->reserved[4] == 1;
+    m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->reserved[2] == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
@@ -1328,6 +1349,14 @@ int aae_prefetch_batch(aae_handle h, const aae_batch* next) {
     return AAE_OK;
 }
 
+int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    if (!h->Xn.p) return fail(AAE_ESTATE, "aae_set_input_noise: the model was not created with cfg.reserved[5] = 1");
+    if (noise_dev && noise_ld < h->N) return fail(AAE_EINVAL, "noise_ld < n_items");
+    h->noise_next = noise_dev; h->noise_ld = noise_ld;
+    return AAE_OK;
+}
+
 int aae_join(aae_handle h, void* stream) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     return join_deferred(h, S(stream));
@@ -1558,6 +1587,42 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
                        ahead ? (int*)nullptr : m->stamp, ahead ? (int*)nullptr : m->ucount, m->losses);
+    m->dense_step = m->noise_next != nullptr;
+    const float* noise = m->noise_next; m->noise_next = nullptr;
+    if (m->dense_step) {
+        if (!m->use_chain) return fail(AAE_ESTATE, "the dense noisy input needs the layer-chain kernels");
+        // every row of W1T is read: all of them through the previous step (a scan of tsync after the first such step)
+        if (m->lazy && m->cfg.optimizer == AAE_OPT_ADAM) {
+            hipLaunchKernelGGL(w1_catchup_kernel, dim3(std::min(m->N, 8192)), dim3(256), 0, s, (const int*)nullptr,
+                               (const int*)nullptr, m->N, m->tsync, m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p,
+                               m->M[1][P_W1T].p, m->V[1][P_W1T].p, m->ldw1, m->h, m->tab, m->step_ctr, -1);
+            LAUNCHCHK("w1_catchup all");
+        }
+        hipLaunchKernelGGL(uniq_items_kernel, dim3(m->rows, std::max(1, std::min(16, m->chunks / 16 + 1))), dim3(256), 0, s, m->bv,
+                           m->mark, m->stamp, m->ulist, m->ucount);       // (the list later phases of the step expect)
+        hipLaunchKernelGGL(dense_input_kernel, dim3(m->rows), dim3(1024), 0, s, m->bv, noise, m->noise_ld, m->N,
+                           (int)m->cfg.normalize_inputs, m->Xn.p, m->ldn);
+        LAUNCHCHK("dense_input");
+        const int B = m->rows, h = m->h, N = m->N;
+        int tiles = ((B + 63) / 64) * ((h + 63) / 64);
+        int splits = std::max(1, std::min(m->max_slabs, 2048 / tiles));
+        int kps = ((N + splits - 1) / splits + 63) / 64 * 64;
+        splits = (N + kps - 1) / kps;
+        GemmShape g{m->Xn.p, m->P[P_W1T].p, B, h, N, m->ldn, m->ldw1, kps};
+        EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
+        (void)launch_gemm_mode<0, 0, true>(false, g, e, splits, s);
+        LAUNCHCHK("dense first layer");
+        DropSpec d1 = make_drop(m, 0, true, m->inj.masks_dev[0], nullptr, B, h, 0);
+        hipLaunchKernelGGL(slab_reduce_fwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
+                           e.slab_stride, B, h, m->ldh, m->P[P_B1].p, m->a1.p, m->eh1.p, (int)m->cfg.activation, d1,
+                           (uint64_t)m->cfg.seed, m->step_ctr);
+        LAUNCHCHK("slab_reduce_fwd");
+        m->dec_hidden_done = false; m->enc_bwd_done = false;
+        TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
+        m->phase = 1;
+        if (m->pf_armed) m->pf_armed = false;
+        return AAE_OK;
+    }
     if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
     m->dec_hidden_done = false; m->enc_bwd_done = false;
     const bool pf = m->pf_armed && m->side && m->mark2 && m->lazy && m->use_chain;

@@ -308,6 +308,61 @@ __global__ void slab_reduce_actbwd_kernel(const float* __restrict__ slabs, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// DenoisingAutoEncoder(corrupt='gauss'), reference dae.py:40-45, 191: the encoder reads the DENSE batch + noise on all
+// N columns, so its first layer is a dense [B, N] x [N, h] product (and its weight gradient a dense [N, B] x [B, h]
+// one with an eager Adam over every row) instead of the sparse gather / scatter.
+//   dense_input_kernel: x[b][:] = noise[b][:] + the batch's row b, L1-normalised over ALL columns (F.normalize(x, 1),
+//                       aae.py:132-133) - one workgroup per document;
+//   slab_reduce_fwd_kernel: a1 = sum of the split-K slabs of x * W1T + b1, y = act(dropout(a1)) - the dense
+//                       counterpart of enc_gather_kernel's epilogue;
+//   fill_tsync_kernel:  every row of W1T has received this step's update (the dense Adam touched all of them).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dense_input_kernel(BatchView bv, const float* __restrict__ noise, int64_t ld_noise,
+                                                          int N, int normalize, float* __restrict__ X, int ldx) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* row = X + (size_t)b * ldx;
+    const float* nz = noise + (size_t)b * ld_noise;
+    for (int n = tid; n < ldx; n += 1024) row[n] = n < N ? nz[n] : 0.f;
+    __syncthreads();
+    const int dc = bv.doc(b);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    for (int64_t e = lo + tid; e < hi; e += 1024) row[bv.indices[e]] += bv.values[e];      // (column ids are unique within a row)
+    __syncthreads();
+    if (!normalize) return;
+    float acc = 0.f;
+    for (int n = tid; n < N; n += 1024) acc += fabsf(row[n]);
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    float l1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) l1 += red[w];
+    const float sc = 1.f / fmaxf(l1, 1e-12f);
+    for (int n = tid; n < N; n += 1024) row[n] *= sc;
+}
+
+__global__ void slab_reduce_fwd_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int rows, int h,
+                                       int ld, const float* __restrict__ b1, float* __restrict__ a1, float* __restrict__ y,
+                                       int act, DropSpec d, uint64_t seed, const long long* step_ctr) {
+    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * h; i += gridDim.x * blockDim.x) {
+        const int r = i / h, c = i - r * h;
+        float v = 0.f;
+        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * slab_stride + (size_t)r * ld + c];
+        v += b1[c];
+        a1[(size_t)r * ld + c] = v;
+        if (d.enabled) v = drop_fwd(d, drop_keep(d, key, r, c), v);
+        y[(size_t)r * ld + c] = act_fwd(act, v);
+    }
+}
+
+__global__ void fill_tsync_kernel(int* __restrict__ tsync, int n, const long long* step_ctr) {
+    const int t = (int)*step_ctr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) tsync[i] = t;
+}
+
 // losses[slot] = scale * sum(partials[0..n))  in a fixed order (deterministic), one workgroup
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ pa, int na,
                                                             const float* __restrict__ pb, int nb, float scale,

@@ -77,7 +77,8 @@ typedef struct aae_config {
     float prior_scale;        /* used when has_prior_scale != 0 (aae.py:717-718) */
     int32_t has_prior_scale;
     uint64_t seed;            /* device rng */
-    int32_t reserved[8];      /* must be zero, except [0] = 1: keep the decoder output layer on the unfused
+    int32_t reserved[8];      /* must be zero, except [4] = 1: row-blocked fused output layer for batches > 112 rows
+                               * (opt-in), [5] = 1: room for aae_set_input_noise; [0] = 1: keep the decoder output layer on the unfused
                                  three-kernel path (A/B measurements); [1] = number of data-parallel
                                  peers whose packed rows aae_w1_import may receive (0 = 1); [2] = 1:
                                  plain AutoEncoder (reference aae.py:221-458): the step ends after the
@@ -369,6 +370,13 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
  * no-op when none is pending).  aae_sync includes it.  aae_set_split(h, 0) turns the split form off (one launch,
  * everything on the caller's stream: needed to capture a step into a hipGraph without joining), n > 0 sets the number
  * of workgroups of the deferred launch (default: 5/8 of the CUs). */
+/* DenoisingAutoEncoder(corrupt='gauss'), reference dae.py:40-45 and 191: `self.enc(self.corrupt(batch, noise_factor))`
+ * with gauss_noise = batch + randn(batch.size()) * noise_factor - the encoder of the NEXT step-opening call reads the
+ * DENSE batch plus noise_dev [rows][noise_ld >= n_items] (already scaled) on all n_items columns, L1-normalised over all
+ * of them (aae.py:132-133); its first layer runs as a dense product, its weight gradient as a dense product with the
+ * optimiser on every row of ENC_W1T.  The BCE target stays the clean batch.  Needs cfg.reserved[5] = 1 (room for the
+ * dense input; plain autoencoder, fp32, fused optimiser); noise_dev must stay valid until the step has run. */
+int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld);
 int aae_join(aae_handle h, void* stream);
 /* The epoch loop (aae.py:808-831) knows the batch AFTER the one it is about to run.  Named here before the step that
  * precedes it (aae_step / aae_ae_encode / aae_ae_forward), that batch's share of the step-opening work - the list of

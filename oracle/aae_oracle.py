@@ -398,7 +398,21 @@ class OracleAAE:
             np.add.at(g.T, indices[lo:hi], np.outer(xn, ga1[b]).astype(f32))
         return g
 
-    def encode(self, indptr, indices, values, masks=None):
+    def encode(self, indptr, indices, values, masks=None, input_noise=None):
+        """input_noise [B, N]: the DenoisingAutoEncoder's corrupt='gauss' (dae.py:40-45, 191): the encoder sees the DENSE
+        batch + noise (already scaled by noise_factor); F.normalize(x, 1) then runs over all N columns (aae.py:132-133)."""
+        if input_noise is not None:
+            B = len(indptr) - 1
+            X = np.asarray(input_noise, dtype=f32).copy()
+            for b in range(B):
+                X[b, indices[indptr[b]:indptr[b + 1]]] += values[indptr[b]:indptr[b + 1]]
+            if self.normalize:
+                l1 = np.abs(X).sum(axis=1, dtype=f32)
+                X = (X / np.maximum(l1, TINY)[:, None]).astype(f32)
+            a1 = (X @ self.p["enc.lin1.weight"].T + self.p["enc.lin1.bias"]).astype(f32)
+            a3, cache = self._mlp_fwd("enc", None, masks, first_pre=a1)
+            cache["a1"], cache["s"], cache["xdense"] = a1, None, X
+            return self._enc_final_fwd(a3), cache
         s = self._row_scale(indptr, values)
         a1 = self._first_layer(indptr, indices, values, s)
         a3, cache = self._mlp_fwd("enc", None, masks, first_pre=a1)
@@ -428,11 +442,11 @@ class OracleAAE:
         glog = (gx * xhat * (f32(1) - xhat)).astype(f32)
         return loss, glog, xhat
 
-    def ae_step(self, indptr, indices, values, masks, cond_inputs=None):
+    def ae_step(self, indptr, indices, values, masks, cond_inputs=None, input_noise=None):
         """masks = [enc.drop1, enc.drop2, dec.drop1, dec.drop2] keep-masks or None."""
         mk = masks if masks is not None else [None] * 4
         B, N = len(indptr) - 1, self.N
-        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]))
+        z, ec = self.encode(indptr, indices, values, (mk[0], mk[1]), input_noise=input_noise)
         zc = z
         for cond, inp in zip(self.conditions, cond_inputs or []):
             zc = cond.fwd(zc, inp)
@@ -445,7 +459,10 @@ class OracleAAE:
             gz = cond.bwd(gz)
         ga3 = self._enc_final_bwd(z, gz)
         Ge, ga1, _ = self._mlp_bwd("enc", ga3, ec, need_dx=False)
-        Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, ec["s"], ga1)
+        if "xdense" in ec:
+            Ge["enc.lin1.weight"] = (ga1.T @ ec["xdense"]).astype(f32)
+        else:
+            Ge["enc.lin1.weight"] = self._enc_w1_grad(indptr, indices, values, ec["s"], ga1)
         self.opt_enc.step(self.p, Ge)
         self.opt_dec.step(self.p, Gd)
         for cond in self.conditions:

@@ -485,6 +485,52 @@ def test_decoding_recommender_learns_from_conditions():
     assert METRICS["mrr@10"](Y[1000:].toarray(), pred)[0] > 0.5
 
 
+def test_denoising_autoencoder_gauss_tracks_reference():
+    """DenoisingAutoEncoder(corrupt='gauss') (dae.py:40-45, 191): the encoder reads the DENSE batch + N(0, noise_factor)
+    on all N columns - a dense first layer, a dense weight gradient and an eager Adam over every row of enc.lin1 - while
+    the BCE target stays the clean batch.  (a) the reference's recorded steps with the recorded noise and dropout masks;
+    (b) production randomness: the model still learns, steps of both kinds of first layer mix (predict is sparse)."""
+    from aaerec.dae import DenoisingAutoEncoder
+    from aaerec.evaluation import remove_non_missing, METRICS
+    fx = Fixture("step_dae_gauss")
+    cfg = fx.cfg
+    m = DenoisingAutoEncoder(n_hidden=cfg["h"], n_code=cfg["c"], lr=cfg["gen_lr"], batch_size=cfg["B"],
+                             dropout=tuple(cfg["dropout"]), noise_factor=cfg["noise_factor"], corrupt="gauss", verbose=True,
+                             rng_mode="reference")
+    m._build(cfg["N"], 0)
+    m.hip.load_params(fx.init_params())
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        X = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+        masks = fx.masks(s)
+        m._host_randomness = lambda B, masks=masks: (masks + [None] * 8, None)
+        m.partial_fit(X, noise=fx.z[f"step{s}.noise"])
+        np.testing.assert_allclose(m.last_losses[0], fx.z[f"step{s}.losses"][0], rtol=1e-5)
+        got = m.hip.state_dict()
+        for k, w in fx.expected_params(s).items():
+            if not k.startswith("disc."):
+                np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=f"dae gauss step {s} {k}")
+        st = m.hip.adam_state("enc")
+        em, ev, et = fx.expected_adam(s)[("A_enc", "enc.lin1.weight")]
+        assert st["step"] == et
+        np.testing.assert_allclose(st["lin1.weight"][0], em, atol=2e-9, rtol=1e-4)
+        np.testing.assert_allclose(st["lin1.weight"][1], ev, atol=1e-12, rtol=2e-4)
+    ip, idx, val = fx.batch(0, prefix="predict")
+    Xp = sp.csr_matrix((val, idx, ip), shape=(len(ip) - 1, cfg["N"]))
+    np.testing.assert_allclose(m.predict(Xp), fx.z["predict.out"], atol=1e-5)
+    # (b)
+    z, Xtr, Xin, Yout = _e2e()
+    torch.manual_seed(3)
+    np.random.seed(3)
+    # (dense noise on 1 000 columns swamps a bag of 8 items after L1 normalisation unless it is small: 0.002 * 1 000
+    # columns * 0.8 = 1.6 against 8; the plain autoencoder itself needs ~100 epochs on this corpus, see below)
+    d = DenoisingAutoEncoder(n_hidden=50, n_code=50, n_epochs=100, batch_size=100, lr=0.01, noise_factor=0.002, corrupt="gauss",
+                             verbose=False)
+    d.fit(Xtr)
+    pred = remove_non_missing(d.predict(Xin), Xin, copy=True)
+    assert METRICS["mrr@10"](Yout.toarray(), pred)[0] > 0.02         # (a random ranking gives ~0.003)
+
+
 def test_denoising_autoencoder_tracks_reference():
     """aaerec.dae.DenoisingAutoEncoder against the reference's dae.py: (a) recorded steps with the recorded
     corruption and dropout masks injected; (b) 3 epochs of fit() with rng_mode='reference' and the reference's
@@ -511,8 +557,6 @@ def test_denoising_autoencoder_tracks_reference():
                 np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=f"dae step {s} {k}")
     with pytest.raises(ValueError):
         m.partial_fit(X, y=1)
-    with pytest.raises(NotImplementedError):
-        DenoisingAutoEncoder(corrupt="gauss")
     with pytest.raises(KeyError):
         DenoisingAutoEncoder(corrupt="salt")
     # (b)

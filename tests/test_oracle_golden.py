@@ -172,6 +172,21 @@ def test_oracle_ae_step_matches_reference_denoising_autoencoder():
     np.testing.assert_allclose(m.predict(ip, idx, val), fx.z["predict.out"], atol=2e-6)
 
 
+def test_oracle_ae_step_matches_reference_denoising_autoencoder_gauss():
+    """DenoisingAutoEncoder, corrupt='gauss' (dae.py:40-45, 191): the encoder reads the dense batch + the recorded N(0,
+    noise_factor) on all N columns, the BCE target is the clean batch."""
+    fx = Fixture("step_dae_gauss")
+    m = build_oracle(fx)
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        loss = m.ae_step(ip, idx, val, fx.masks(s), input_noise=fx.z[f"step{s}.noise"])
+        np.testing.assert_allclose(loss, fx.z[f"step{s}.losses"][0], rtol=TOL_LOSS)
+        for k, w in fx.expected_params(s).items():
+            np.testing.assert_allclose(m.p[k], w, atol=TOL_PARAM, rtol=0, err_msg=k)
+    ip, idx, val = fx.batch(0, prefix="predict")
+    np.testing.assert_allclose(m.predict(ip, idx, val), fx.z["predict.out"], atol=2e-6)
+
+
 VAE_CASES = ["step_vae", "step_vae_cond", "step_vae_cat"]
 VAE_NAMES = ("fc1", "fc21", "fc22", "fc3", "fc4")
 

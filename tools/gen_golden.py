@@ -773,6 +773,71 @@ def gen_dae():
     print("e2e_dae_short written")
 
 
+def gen_dae_gauss():
+    """DenoisingAutoEncoder(corrupt='gauss') (dae.py:40-45, 191): the encoder input is the dense batch + N(0, noise_factor)
+    on ALL N columns (recorded), the BCE target the clean batch.  step_dae_gauss.npz: three recorded steps."""
+    import_reference()
+    import aaerec.dae as ref_dae
+    import aaerec.aae as ref_aae
+    N, h, c, B, steps, seed, lr, nf, dropout = 300, 20, 10, 16, 3, 43, 2e-3, 0.2, (0.2, 0.2)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(4000 + seed)
+    m = ref_dae.DenoisingAutoEncoder(n_hidden=h, n_code=c, lr=lr, batch_size=B, n_epochs=1, dropout=dropout,
+                                     noise_factor=nf, corrupt='gauss', verbose=True)
+    m.enc = ref_dae.Encoder(N, h, c, final_activation='linear', normalize_inputs=m.normalize_inputs,
+                            dropout=m.dropout, activation=m.activation)
+    m.dec = ref_dae.Decoder(c, h, N, dropout=m.dropout, activation=m.activation)
+    og = ref_dae.TORCH_OPTIMIZERS[m.optimizer]
+    m.enc_optim, m.dec_optim = og(m.enc.parameters(), lr=m.lr), og(m.dec.parameters(), lr=m.lr)
+    masks_log, noisy, loss_log = [], [], []
+    for net_name, net in (("enc", m.enc), ("dec", m.dec)):
+        for li, attr in enumerate(("drop1", "drop2")):
+            setattr(net, attr, RecDropout(m.dropout[li], masks_log, f"{net_name}.{attr}"))
+    orig_corrupt = m.corrupt
+
+    def rec_corrupt(batch, noise_factor):
+        clean = batch.detach().numpy().copy()
+        out = orig_corrupt(batch, noise_factor)
+        noisy.append(out.detach().numpy() - clean)          # the scaled noise itself
+        return out
+    m.corrupt = rec_corrupt
+    ref_dae.log_losses = lambda *l: loss_log.append(l)
+    out = {}
+    cfg = dict(N=N, h=h, c=c, B=B, steps=steps, cond="", cond_inc=0, n_hidden=h, n_code=c, ae_only=1, gen_lr=lr,
+               reg_lr=lr, dropout=list(dropout), noise_factor=nf, corrupt="gauss")
+    disc = ref_aae.Discriminator(c, h)
+    for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", disc)):
+        for k, v in state_np(net).items():
+            out[f"init.{net_name}.{k}"] = v
+    for s in range(steps):
+        X = make_batch(rng, B, N, max_len=12)
+        out[f"step{s}.indptr"] = X.indptr.astype(np.int64)
+        out[f"step{s}.indices"] = X.indices.astype(np.int32)
+        out[f"step{s}.values"] = X.data.astype(np.float32)
+        n0 = len(masks_log)
+        m.partial_fit(X.toarray())
+        out[f"step{s}.noise"] = noisy[-1].astype(np.float32)
+        out[f"step{s}.losses"] = np.asarray(loss_log[-1], dtype=np.float64)
+        out[f"step{s}.z_real"] = np.zeros((B, c), dtype=np.float32)
+        for j, (tag, mk) in enumerate(masks_log[n0:]):
+            out[f"step{s}.mask{j}"] = mk
+        for net_name, net in (("enc", m.enc), ("dec", m.dec), ("disc", disc)):
+            for k, v in state_np(net).items():
+                out[f"step{s}.{net_name}.{k}"] = v
+        ep, dp = list(m.enc.parameters()), list(m.dec.parameters())
+        for tag, opt, ps in (("A_enc", m.enc_optim, ep), ("A_dec", m.dec_optim, dp)):
+            for k, v in optim_np(opt, ps).items():
+                out[f"step{s}.{tag}.{k}"] = v
+    Xp = make_batch(rng, B, N)
+    out["predict.indptr"] = Xp.indptr.astype(np.int64)
+    out["predict.indices"] = Xp.indices.astype(np.int32)
+    out["predict.values"] = Xp.data.astype(np.float32)
+    out["predict.out"] = m.predict(Xp).astype(np.float32)
+    out["config_json"] = np.asarray(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, "step_dae_gauss.npz"), **out)
+    print("step_dae_gauss: losses", [l[0] for l in loss_log])
+
+
 def gen_vae(only=None):
     """The reference's VAE (vae.py:47-266): step_vae.npz (no condition) and step_vae_cond.npz (30-d constant
     concatenated condition): recorded eps of reparametrize(), losses (loss.item() / B as the reference logs it),
@@ -965,6 +1030,8 @@ def main():
         gen_dae()
     if want("vae"):
         gen_vae()
+    if "dae_gauss" in which:    # (only the DenoisingAutoEncoder(corrupt='gauss') case)
+        gen_dae_gauss()
     if "vae_cat" in which:      # (only the VAE + trainable CategoricalCondition case)
         gen_vae(only="step_vae_cat")
     if want("vectorizer"):
