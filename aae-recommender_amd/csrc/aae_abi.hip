@@ -753,7 +753,7 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m->rows + kRowBlock - 1) / kRowBlock; }
 static bool fused_decoder_applies(const aae_model* m) {
     const bool one = m->rows <= 16 * kMB;
-    const bool blocked = !one && m->blocked_ok && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
+    const bool blocked = !one && m->blocked_ok && !m->bf16 && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
                          m->cfg.grad_mode == AAE_GRAD_FUSED;
     return m->fused_ok && !m->force_unfused && (one || blocked) &&
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
@@ -1171,6 +1171,16 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             if (m->side) (void)hipStreamDestroy(m->side);
             m->side = nullptr;
         }
+        (void)hipGetLastError();
+    }
+    if (side_ok && m->fused_ok && m->bf16 && m->split_wgs > 0 &&
+        (size_t)((m->N + kBU - 1) / kBU) * kBU * bf_stride(4) <= (size_t)m->R * m->ldn) {      // (room for the stored gT images in the G scratch)
+        m->split_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<4, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<7, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<13, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<4, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<7, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
     }
     if (side_ok && m->fused_ok && !m->bf16 && m->split_wgs > 0 &&
@@ -1735,7 +1745,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 const DecFusedArgs b = block_args(r);
                 hipEvent_t start = nullptr, stop = r == nblk - 1 ? m->ev_crit : nullptr;
                 (void)prof_pair(m, AAE_K_DEC_CRIT, &start, &stop);
-                switch (m->fused_nb) {
+                if (m->bf16) switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                } else switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
@@ -1749,7 +1763,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 if (nblk > 1) { b.acc = m->Gacc.p; b.gradV3 = r == nblk - 1 ? nullptr : m->Gacc.p; }
                 hipEvent_t start = nullptr, stop = nullptr;
                 (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
-                if (r == 0) switch (m->fused_nb) {
+                if (m->bf16) switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                } else if (r == 0) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;

@@ -83,8 +83,13 @@ inline size_t dec_fused_bf16_lds_bytes(int NB) {
                             (size_t)kBU * S2 + (size_t)2 * kGR * kBfSR + (size_t)kBU * kSO + 64);
 }
 
-template <int NB>   // NB = ceil((h + 1) / 16) column blocks (<= 16)
+// MODE as in dec_fused.h (section 3.2c): kDecCrit = S0, GEMM1, BCE, entries, GEMM3 (what the step waits for) and the
+// unit's transposed bf16 dL/dlogits image gT [16][S2] stored to a.Gt; kDecOpt = that image back into LDS, GEMM2, the
+// optimiser - on the side stream, beside the rest of the step, with non-temporal streams.
+template <int NB, int MODE = kDecFused>   // NB = ceil((h + 1) / 16) column blocks (<= 16)
 __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
+    constexpr bool kFwd = MODE != kDecOpt, kOpt = MODE != kDecCrit, kIsOpt = MODE == kDecOpt;
+    constexpr int kAux = kIsOpt ? 2 : 0;        // buffer cache policy of the streams: 2 = nt
     constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
     constexpr int KR = 4;                       // 32-wide k-steps over the (<= 112 -> 128) batch rows
     constexpr int S1 = bf_stride(KC1), S2 = bf_stride(KR), S3 = bf_stride(1);
@@ -173,7 +178,17 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
         return (unsigned)((size_t)u * kBU * ldv) * 4u;
     };
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int u) {
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, unit_so(u), 0));
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, unit_so(u), kAux));
+    };
+    // split form: the unit's gT image ([16][S2] dwords, 4 KB, padding included) as stored / re-read: thread t its t-th dword
+    // (+ the 64 beyond 1024 by the first wave)
+    constexpr int kGtD = kBU * S2;
+    unsigned* gtg = reinterpret_cast<unsigned*>(a.Gt);
+    unsigned g_nxt0 = 0u, g_nxt1 = 0u;
+    auto load_gt = [&](int u) {
+        const unsigned* src = gtg + (size_t)u * kGtD;
+        g_nxt0 = __builtin_nontemporal_load(src + min(tid, kGtD - 1));
+        g_nxt1 = __builtin_nontemporal_load(src + min(kBT + lane, kGtD - 1));
     };
     float4 p_cur, p_nxt, mreg, sreg;
     int unit = blockIdx.x;
@@ -201,7 +216,8 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
     };
     if (unit < nunits) {
         p_nxt = ld4(rP, unit);
-        if (wave == ewave) {
+        if (kIsOpt) load_gt(unit);
+        if (kFwd && wave == ewave) {
             load_range(unit, ne0, ne1);
             load_range(unit + stride, fe0, fe1);
             load_entry(ne0);
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
         // the 48 KB burst of a unit's loads: the image building below runs beside that), then this unit's V3a (fp32
         // registers) -> bf16 LDS images
         int my_b = 0, my_n = 0; float my_v = 0.f;
-        if (wave == ewave) {
+        if (kFwd && wave == ewave) {
             ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
             my_b = ent_b; my_n = ent_n; my_v = ent_v;
             if (lane == 0) { reinterpret_cast<int*>(red)[32] = ce0; reinterpret_cast<int*>(red)[33] = ce1; }
@@ -236,9 +252,13 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
         // (all three unconditional - the moment tensors exist in every mode: a load under a condition is waited for on
         // the spot and its result is carried in duplicate registers down both paths)
         p_nxt = ld4(rP, min(unit + stride, nunits - 1));
-        mreg = ld4(rM, unit);
-        sreg = ld4(rV, unit);
-        if (t_ok) {
+        if (kOpt) { mreg = ld4(rM, unit); sreg = ld4(rV, unit); }
+        if (kIsOpt) {
+            if (tid < kGtD) gT[tid] = g_nxt0;
+            if (wave == 0 && kBT + lane < kGtD) gT[kBT + lane] = g_nxt1;
+            load_gt(min(unit + stride, nunits - 1));
+        }
+        if (kFwd && t_ok) {
             float4 p = p_cur;
             if (i0 + t_n >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<uint2*>(v3K + t_n * S1 + (t_c0 >> 1)) = make_uint2(bf16_pack(p.x, p.y), bf16_pack(p.z, p.w));
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
 
         // ---- GEMM1: logits[b][n]: wave w < 14 takes row block w >> 1 and every second k-step (w & 1) -> its half's raw
         // tile (fp32; the BCE phase adds the halves).  C map: row = 4 fk + r -> batch row, col = fr -> item
-        if (wave < 2 * kMB) {
+        if (kFwd && wave < 2 * kMB) {
             const int mb = wave >> 1, kh = wave & 1;
             f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
             const unsigned* pa = dhA + (16 * mb + fr) * S1 + 2 * fk + 16 * kh;
@@ -270,11 +290,11 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
             for (int r = 0; r < 4; ++r) rw[r * kBfSR] = c[r];
         }
         wstamp(2);
-        lds_barrier();
+        if (kFwd) lds_barrier();
         stamp(2);
         // ---- BCE against a zero target, every thread: cell id = tid + 1024 j -> (b = id >> 4, n = id & 15); dL/dlogit
         // -> gK, gT (bf16), loss.  (As GEMM1's epilogue the 7 waves that own a row block did this alone.)
-        {
+        if (kFwd) {
             unsigned short* k16 = reinterpret_cast<unsigned short*>(gK);
             unsigned short* t16 = reinterpret_cast<unsigned short*>(gT);
 #pragma unroll
@@ -293,11 +313,11 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
             }
         }
         wstamp(3);
-        lds_barrier();
+        if (kFwd) lds_barrier();
 
         // ---- S2: the CSR entries of this half of the 32-item tile (non-zero targets) replace their cell's gradient
         // and loss term
-        {
+        if (kFwd) {
             unsigned short* k16 = reinterpret_cast<unsigned short*>(gK);
             unsigned short* t16 = reinterpret_cast<unsigned short*>(gT);
             auto patch = [&](int b, int n32, float v) {
@@ -316,11 +336,16 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
             const int r0 = reinterpret_cast<const int*>(red)[32], r1 = reinterpret_cast<const int*>(red)[33];
             for (int e = r0 + 64 + tid; e < r1; e += kBT) patch(a.te.eb[e], a.te.en[e], a.te.ev[e]);
         }
-        lds_barrier();
+        if (kFwd) lds_barrier();
         stamp(3);
+        if (MODE == kDecCrit) {      // the finished image -> a.Gt for the deferred launch (the store retires behind GEMM3)
+            unsigned* dst = gtg + (size_t)unit * kGtD;
+            if (tid < kGtD) dst[tid] = gT[tid];
+            if (wave == 0 && kBT + lane < kGtD) dst[kBT + lane] = gT[kBT + lane];
+        }
 
         // ---- GEMM2: dV3a^T[c][n] = sum_b dh2[b][c] G[b][n]; lane holds columns 16 cb + 4 fk ..+3 of item fr -> os
-        if (own) {
+        if (kOpt && own) {
             f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < KR; ++kc)
@@ -338,11 +363,11 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
             for (int q = 0; q < kMB; ++q)       // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
                 acc3[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_frag(pg, 0, 0, 0, 0) , vt, acc3[q], 0, 0, 0), pg += 16 * S3;
         };
-        if (own && par) gemm3();
+        if (kFwd && own && par) gemm3();
         wstamp(0);
-        lds_barrier();                                   // os complete
+        if (kOpt) lds_barrier();                         // os complete
         // ---- S5: optimiser on the unit in row-major order.  The three stores are issued on every path (see above).
-        {
+        if (kOpt) {
             const float4 g = *reinterpret_cast<const float4*>(os + t_n * kSO + t_c0);
             const unsigned so = unit_so(unit);
             const bool valid = t_ok && i0 + t_n < N;
@@ -357,13 +382,14 @@ __global__ __launch_bounds__(kBT) void dec_fused_bf16_kernel(DecFusedArgs a) {
             const float4 out = do_adam ? p : g;
             const unsigned vo = valid ? lane_off : kOob;
             const unsigned vo2 = (valid && do_adam && !sc.is_sgd) ? lane_off : kOob;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, out), do_adam ? rP : rG, vo, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, mm), rM, vo2, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv), rV, vo2, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, out), do_adam ? rP : rG, vo, so, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, mm), rM, vo2, so, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv), rV, vo2, so, kAux);
         }
         stamp(6);
     }
     if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
+    if (!kFwd) return;
     if (iter & 1) {                                     // an odd number of units: the last one's half is still to be added
         lds_barrier();
         for (int i = tid; i < kGR * 8; i += kBT) gK[(i >> 3) * S3 + 8 + (i & 7)] = 0u;      // k-half 1 of gK <- 0

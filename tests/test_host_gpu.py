@@ -816,7 +816,7 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
     import torch.multiprocessing as mp
     import aaerec.aae                               # noqa: F401  (seeds torch at import: import before seeding below)
     port = free_port()
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:       # (a fork()ed manager process would inherit this process's GPU objects)
         ret = mgr.dict()
         mp.spawn(_fit_worker, args=(2, port, mode, ret, None, adversarial), nprocs=2, join=True)
         got = dict(ret)
@@ -844,7 +844,7 @@ def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce):
     import torch.multiprocessing as mp
     from aaerec.aae import AutoEncoder
     port = free_port()
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:       # (a fork()ed manager process would inherit this process's GPU objects)
         ret = mgr.dict()
         mp.spawn(_fit_worker, args=(2, port, "vocab", ret, reduce), nprocs=2, join=True)
         got = dict(ret)
