@@ -80,6 +80,9 @@ _PROTOS = {
     "aae_vae_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_void_p]),
     "aae_vae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
+    "aae_vae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "aae_vae_decode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "aae_vae_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_decoder_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int64, C.POINTER(AaeRngInject),
                                    C.c_void_p, C.c_void_p]),
     "aae_ae_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -682,6 +685,31 @@ class HipAAE:
         self._keep = keep
         with torch.cuda.device(self.device):
             _check(self.lib.aae_vae_step(self.handle, C.byref(b), _ptr(cond), _ptr(eps), self._stream()))
+
+    def vae_encode(self, csr, row_start, n_rows, rows=None, eps=None, train=True):
+        """z [n_rows, n_code] of the VAE's encoder + reparametrisation (aae_vae_encode); train=True opens a step."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        if eps is not None:
+            eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
+        z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
+        self._keep = [eps, z]
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_vae_encode(self.handle, C.byref(b), _ptr(eps), _ptr(z), int(bool(train)), self._stream()))
+        return z
+
+    def vae_decode_backward(self, zc):
+        zc = zc.detach().to(self.device, torch.float32).contiguous()
+        dzc = torch.empty_like(zc)
+        self._keep = self._keep + [zc, dzc]
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_vae_decode_backward(self.handle, _ptr(zc), zc.shape[1], _ptr(dzc), self._stream()))
+        return dzc
+
+    def vae_encoder_backward(self, dz):
+        dz = dz.detach().to(self.device, torch.float32).contiguous()
+        self._keep = self._keep + [dz]
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_vae_encoder_backward(self.handle, _ptr(dz), dz.shape[1], self._stream()))
 
     def vae_predict(self, csr, row_start, n_rows, cond=None, eps=None):
         b = self._batch(csr, row_start, n_rows)

@@ -9,9 +9,10 @@ its backward incl. the KL gradient).  Parameter names in the kernels' model: enc
 
 Like the reference, predict() samples eps as well (vae.py:229-266 runs the same forward in eval mode).
 Conditions: constant concatenated blocks (e.g. PretrainedWordEmbeddingCondition) and CategoricalConditions whose
-table lives on this GPU (encoded and trained by aae_cat_encode / aae_cat_update around the step, as in the AAE -
-condition.py:397-508); a plugin that needs torch autograd between the code and the decoder would need the VAE step cut
-at the condition boundary, which aae_vae_step does not offer (NotImplementedError).
+table lives on this GPU ride in aae_vae_step (encoded and trained by aae_cat_encode / aae_cat_update around the step, as
+in the AAE - condition.py:397-508); any other plugin runs with torch autograd between the code and the decoder: the step
+is cut at the condition boundary (aae_vae_encode -> encode_impose -> aae_vae_decode_backward -> the plugins' backward and
+step -> aae_vae_encoder_backward).
 """
 import numpy as np
 import scipy.sparse as sp
@@ -51,10 +52,12 @@ class VAE:
         self.last_loss = None
         code_inc = int(conditions.size_increment()) if conditions else 0
         dev_probe = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        if conditions and not all(getattr(c, "constant_concat", False) or
-                                  (hasattr(c, "device_native") and c.device_native(dev_probe)) for c in conditions.values()):
-            raise NotImplementedError("the VAE step supports constant concatenated conditions and CategoricalConditions "
-                                      "with their table on the model's GPU (use_cuda=True) only")
+        # conditions the kernels produce / train themselves ride in aae_vae_step; any other plugin gets the step cut at
+        # the condition boundary and runs with torch autograd in between (aae_vae_encode / _decode_backward / ...)
+        self._cond_native = not conditions or all(
+            getattr(c, "constant_concat", False) or (hasattr(c, "device_native") and c.device_native(dev_probe))
+            for c in conditions.values())
+        self._dp = None
         seed = seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) \
             if rng_mode == "device" else 0
         self.hip = _hip.HipAAE(inp, n_hidden, n_code, cond_inc=code_inc, max_batch=batch_size, max_nnz=batch_size * 4096,
@@ -112,7 +115,18 @@ class VAE:
     def _cond(self, c_batch):
         return self._native_cond_block(c_batch, len(c_batch[0]) if not hasattr(c_batch[0], "shape") else c_batch[0].shape[0])
 
+    _cond_fn = AdversarialAutoEncoder._cond_fn
+
     def _step(self, csr, n_rows, rows, c_batch):
+        if c_batch is not None and not self._cond_native:
+            # the step cut at the condition boundary (vae.py:120-130, 175-181)
+            z = self.hip.vae_encode(csr, 0, n_rows, rows=rows, eps=self._eps(n_rows), train=True)
+            zc, back = self._cond_fn(c_batch)(z)
+            self.hip.vae_encoder_backward(back(self.hip.vae_decode_backward(zc)))
+            self._last_rows = n_rows
+            if self.verbose:
+                log_losses(self.loss())
+            return
         self.hip.vae_step(csr, 0, n_rows, rows=rows, cond=self._cond(c_batch) if c_batch is not None else None,
                           eps=self._eps(n_rows))
         if c_batch is not None and not self._is_constant_concat():
@@ -180,8 +194,13 @@ class VAE:
             for start in range(0, Xs.shape[0], self.batch_size):
                 n = min(self.batch_size, Xs.shape[0] - start)
                 cond = None
+                c_batch = [_take(c, slice(start, start + n)) for c in condition_data] if use_condition else None
+                if use_condition and not self._cond_native:
+                    z = self.hip.vae_encode(csr, start, n, eps=self._eps(n), train=False)
+                    pred.put(start, self.hip.decode(self.conditions.encode_impose(z, c_batch)))
+                    continue
                 if use_condition:
-                    cond = self._cond([_take(c, slice(start, start + n)) for c in condition_data])
+                    cond = self._cond(c_batch)
                 pred.put(start, self.hip.vae_predict(csr, start, n, cond=cond, eps=self._eps(n)))
         return pred.numpy()
 

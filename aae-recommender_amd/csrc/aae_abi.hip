@@ -88,6 +88,7 @@ struct aae_model {
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
     bool bf16;               // cfg.reserved[3] = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
     bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
+    bool vae_cut;            // ... cut at the condition boundary (aae_vae_encode / _decode_backward / _encoder_backward)
     Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
     bool use_chain4;         // ... with 4 rows per workgroup (chain4.h) where a program allows it
@@ -969,6 +970,58 @@ int chain_vae_forward(aae_model* m, const float* cond_dev, const float* eps_dev,
     return launch_chain(m, cb, s);
 }
 
+// the two halves of chain_vae_forward for a caller that imposes its conditions between them (aae_vae_encode / the
+// decoder half inside aae_vae_decode_backward and aae_decode)
+int chain_vae_encode(aae_model* m, const float* eps_dev, float* z_out, int rows, hipStream_t s) {
+    const int h = m->h, c = m->c;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    ChainOp& ml = cb.add(cop_fwd(m, P_W3, 0, 1, h + 1, 2 * c, CEPI_NONE, s));
+    cop_out(ml, m->mulv.p, (int)m->mulv.ld);
+    ChainOp& rp = cb.add(cop(COP_REPARAM, 1, 2, c));
+    rp.W = eps_dev; rp.ldw = c; rp.aux = 12; rp.aux_ptr = m->veps.p; rp.aux_ld = (int)m->veps.ld;
+    ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, m->zc.p, m->ldc);
+    if (z_out) { st.out2 = z_out; st.ldo2 = c; }
+    return launch_chain(m, cb, s);
+}
+int chain_vae_dec_hidden(aae_model* m, int rows, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 2, cp)); l.one_col = cp;
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
+    v1.one_col = h; cop_out(v1, m->dh2.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+// ... and of chain_vae_backward: down to dL/d(decoder input) (-> gzc and the caller), then from dL/dz on
+int chain_vae_backward_dec(aae_model* m, const float* part_slabs, size_t slab_stride, float* dzc_out, hipStream_t s) {
+    const int B = m->rows, h = m->h, cp = m->cp;
+    ChainBuilder cb(m, B);
+    if (part_slabs) {
+        ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+        cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
+        ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1; cop_out(ab, m->gb0.p, m->ldh);
+    } else {
+        cb.add(cop_load(m->gb0.p, m->ldh, 2, h));
+    }
+    ChainOp& dzc = cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    cop_out(dzc, m->gzc.p, m->ldc);
+    if (dzc_out) { dzc.out2 = dzc_out; dzc.ldo2 = cp; }
+    return launch_chain(m, cb, s);
+}
+int chain_vae_backward_enc(aae_model* m, const float* dz_dev, int ld_dz, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 1;                                   // KL sum -> losses[1]
+    cb.add(cop_load(dz_dev, ld_dz, 3, c));
+    cb.add(cop_load(m->mulv.p, (int)m->mulv.ld, 4, 2 * c));
+    ChainOp& rb = cb.add(cop(COP_REPARAM_BWD, 3, 5, 2 * c)); rb.yslot = 4; rb.scale = m->grad_scale;
+    rb.aux_ptr = m->veps.p; rb.aux_ld = (int)m->veps.ld; cop_out(rb, m->gmulv.p, (int)m->gmulv.ld);
+    cb.add(cop_load(m->eh1.p, m->ldh, 6, h));
+    ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 5, 7, m->P[P_W3], 2 * c, h, CEPI_ACTBWD)); x1.yslot = 6;
+    cop_out(x1, m->gb3.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
 // backward below the output layer: dL/d(dh2) -> fc3 -> dz -> (dmu, dlogvar) incl. the KL term -> [fc21; fc22] -> ga1
 int chain_vae_backward(aae_model* m, const float* part_slabs, size_t slab_stride, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
@@ -1103,7 +1156,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
-    m->vae = cfg->reserved[2] == 3; m->vae_bwd = false;
+    m->vae = cfg->reserved[2] == 3; m->vae_bwd = false; m->vae_cut = false;
     m->bf16 = cfg->reserved[3] == 1;
     m->blocked_ok = cfg->reserved[4] == 1;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
@@ -1894,6 +1947,16 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     }
     if (m->only_output_layer) { m->phase = 2; return AAE_OK; }
     }
+    if (m->use_chain && m->vae_bwd && m->vae_cut) {
+        // cut at the condition boundary: stop at dL/d(decoder input); fc3's weight gradient + optimiser here, the rest
+        // of the backward pass comes with the caller's dL/dz (aae_vae_encoder_backward)
+        TRY(chain_vae_backward_dec(m, chain_part, chain_stride, dzc_out, s));
+        DwBuilder dw;
+        dw.add(m, m->gb0.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
+        TRY(dw.launch(s));
+        m->phase = 2;
+        return AAE_OK;
+    }
     if (m->use_chain && m->vae_bwd) {
         TRY(chain_vae_backward(m, chain_part, chain_stride, s));
         DwBuilder dw;
@@ -1979,7 +2042,7 @@ int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, co
     TRY(gather_first_layer(m, false, nullptr, 0, s));                 // eh1 = act(fc1(normalize(x))), vae.py:111-113
     TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
     m->dec_hidden_done = true; m->enc_bwd_done = false; m->fuse_enc_bwd = false;
-    m->vae_bwd = true; m->phase = 1;
+    m->vae_bwd = true; m->vae_cut = false; m->phase = 1;
     const int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, nullptr, stream);
     m->vae_bwd = false;
     if (rc != AAE_OK) return rc;
@@ -2006,6 +2069,64 @@ int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev,
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
     TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s, m->bf16));
     m->phase = 0;
+    return AAE_OK;
+}
+
+// The VAE step cut at the condition boundary (vae.py:120-130: `z = self.conditions.encode_impose(z, condition_data)`
+// between reparametrize and decode), for condition plugins that run in the host framework:
+//   aae_vae_encode            x -> fc1 -> (mu, logvar) -> z = mu + eps * exp(logvar / 2)     (train != 0 opens a step)
+//   [host: zc = conditions.encode_impose(z, c)]
+//   aae_vae_decode_backward   fc3 -> fc4 -> BCE, backward to dL/dzc, fc3 / fc4 updates
+//   [host: backprop dzc through the conditions -> dz; conditions.step()]
+//   aae_vae_encoder_backward  reparametrize' + KL gradient -> [fc21; fc22] -> fc1, their updates
+int aae_vae_encode(aae_handle m, const aae_batch* batch, const float* eps_dev, float* z_out_dev, int32_t train, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
+    TRY(set_batch(m, batch));
+    remember_inject(m, nullptr, true);
+    hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
+    if (train) {
+        m->hstep++; m->pf_armed = false;
+        hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                           m->stamp, m->ucount, m->losses);
+        LAUNCHCHK("advance_step");
+        if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+    } else if (m->lazy) TRY(lazy_prepare(m, 0, true, s));
+    TRY(gather_first_layer(m, false, nullptr, 0, s));
+    TRY(chain_vae_encode(m, eps_dev, z_out_dev, m->rows, s));
+    m->dec_hidden_done = false; m->enc_bwd_done = false; m->fuse_enc_bwd = false;
+    m->phase = train ? 1 : 0; m->vae_cut = train != 0;
+    return AAE_OK;
+}
+
+int aae_vae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, float* dzc_out_dev, void* stream) {
+    if (!m || !zc_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (!m->vae || m->phase != 1 || !m->vae_cut) return fail(AAE_ESTATE, "aae_vae_decode_backward without aae_vae_encode(train)");
+    if (zc_ld < m->cp) return fail(AAE_EINVAL, "zc_ld < n_code + cond_inc");
+    hipStream_t s = S(stream);
+    TRY(stage_zc(m, zc_dev, zc_ld, m->rows, s));
+    TRY(chain_vae_dec_hidden(m, m->rows, s));
+    m->dec_hidden_done = true; m->vae_bwd = true;
+    const int rc = aae_ae_decode_backward(m, nullptr, 0, nullptr, dzc_out_dev, stream);
+    m->vae_bwd = false;
+    return rc;
+}
+
+int aae_vae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, void* stream) {
+    if (!m || !dz_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (!m->vae || m->phase != 2 || !m->vae_cut) return fail(AAE_ESTATE, "aae_vae_encoder_backward without aae_vae_decode_backward");
+    if (dz_ld < m->c) return fail(AAE_EINVAL, "dz_ld < n_code");
+    hipStream_t s = S(stream);
+    const int B = m->rows;
+    TRY(chain_vae_backward_enc(m, dz_dev, (int)dz_ld, s));
+    DwBuilder dw;
+    dw.add(m, m->gmulv.p, (int)m->gmulv.ld, m->eh1.p, m->ldh, B, P_W3, O_ENC);
+    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+    TRY(dw.launch(s));
+    TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
+    m->phase = 0; m->vae_cut = false;
     return AAE_OK;
 }
 
@@ -2257,7 +2378,8 @@ int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
     hipStream_t s = S(stream);
     TRY(join_deferred(m, s));
     if (zc_dev) TRY(stage_zc(m, zc_dev, zc_ld, n_rows, s));
-    if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
+    if (m->vae) TRY(chain_vae_dec_hidden(m, n_rows, s));       // (VAE: one hidden layer, fc3)
+    else if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
     else TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
     TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s, m->bf16));

@@ -227,6 +227,17 @@ int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev,
 int aae_vae_step(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream);
 int aae_vae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, const float* eps_dev,
                     float* out_dev, int64_t out_ld, void* stream);
+/* The VAE step cut at the condition boundary, for ConditionList plugins whose encode_impose runs in the host framework
+ * (vae.py:120-130: `z = self.conditions.encode_impose(z, condition_data)` between reparametrize and decode):
+ *   aae_vae_encode            x -> fc1 -> (mu, logvar) -> z = mu + eps * exp(logvar / 2) -> z_out_dev [rows][n_code];
+ *                             train != 0 opens a training step, 0 = the forward half of VAE.predict (then aae_decode)
+ *   [host: zc = conditions.encode_impose(z, c)]
+ *   aae_vae_decode_backward   fc3 -> fc4 -> BCE, backward to dzc_out_dev [rows][n_code + cond_inc], fc3 / fc4 updates
+ *   [host: backprop dzc through the conditions -> dz; conditions.step()]                              (vae.py:175-181)
+ *   aae_vae_encoder_backward  reparametrize' + the KL gradient -> [fc21; fc22] -> fc1, their updates */
+int aae_vae_encode(aae_handle h, const aae_batch* batch, const float* eps_dev, float* z_out_dev, int32_t train, void* stream);
+int aae_vae_decode_backward(aae_handle h, const float* zc_dev, int64_t zc_ld, float* dzc_out_dev, void* stream);
+int aae_vae_encoder_backward(aae_handle h, const float* dz_dev, int64_t dz_ld, void* stream);
 /* The ae phase (aae.py:676-711) cut at the decoder's output layer, for vocabulary-sharded data parallelism: the output
  * layer holds ~all of the decoder's parameters and every item receives gradient, so instead of exchanging its
  * [n_items][n_hidden + 1] gradient each rank owns the rows of a slice of the items (a second handle created with
