@@ -80,7 +80,7 @@ struct aae_model {
     // transposed copies [in + 1][out] of the hidden layers' augmented weights: chain.h's dX ops read rows [0, in) with
     // the forward layers' access pattern, chain4.h's forward layers read all of it (n contiguous).  Kept in step by the fused / grouped optimiser kernels;
     // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
-    Ten PT[NP]; bool pt_ok[NP];
+    Ten PT[NP]; Ten D4[NP]; bool pt_ok[NP];      // PT = the F4 copy, D4 = the dX copy (device_common.h W4Copies)
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
@@ -221,10 +221,14 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
-    for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->pt_ok[i] = false; }
+    for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
     if (h + 1 <= 208 && cp + 1 <= 208 && c.reserved[2] != 3)          // layer-chain models (not the VAE's programs)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
-            m->PT[pid] = a.mat(m->P[pid].cols, m->P[pid].rows, r4((int)m->P[pid].rows), 16);     // [in + 1][out]: the bias is its last row
+        {
+            const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;
+            m->PT[pid] = a.mat((Nc + 3) / 4, 4 * M, 4 * M, 1);      // F4 [(in + 1 + 3) / 4][out][4]: k = input column (the bias is k = in)
+            m->D4[pid] = a.mat((M + 3) / 4, 4 * Nc, 4 * Nc, 1);     // D4 [(out + 3) / 4][in + 1][4]: k = output row
+        }
     const int R = m->R, R2 = m->R2;
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
@@ -620,33 +624,31 @@ ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int e
 }
 void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
 
-// (re-)derive the transposed copy of a hidden layer after something other than the optimiser kernels wrote the weights
+W4Copies w4_of(const aae_model* m, int pid) {
+    return W4Copies{m->PT[pid].p, m->D4[pid].p, (int)m->P[pid].rows, (int)m->P[pid].cols};
+}
+// (re-)derive the k4-interleaved copies of a hidden layer after something other than the optimiser kernels wrote the weights
 void ensure_pt(aae_model* m, int pid, hipStream_t s) {
     const Ten& T = m->PT[pid];
     if (!T.p || m->pt_ok[pid]) return;
     const Ten& W = m->P[pid];
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((W.cols + 31) / 32), (unsigned)((W.rows + 31) / 32)), dim3(256), 0,
-                       s, W.p, (int)W.ld, (int)W.rows, (int)W.cols, T.p, (int)T.ld);
+    hipLaunchKernelGGL(interleave4_kernel, dim3(grid1d((size_t)W.rows * ((W.cols + 3) / 4))), dim3(256), 0, s, W.p, (int)W.ld,
+                       w4_of(m, pid));
     m->pt_ok[pid] = true;
 }
 
 // forward layer: dst[rows][N] = epi(src[rows][K] * W[N][K]^T), K = in + 1 (the bias input is the last column)
 ChainOp cop_fwd(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
     ChainOp o = cop_linear(COP_LINEAR, src, dst, m->P[pid], K, N, epi);
-    if (m->PT[pid].p) { ensure_pt(m, pid, s); o.Wkn = m->PT[pid].p; o.ldkn = (int)m->PT[pid].ld; }
+    if (m->PT[pid].p) { ensure_pt(m, pid, s); o.W4 = m->PT[pid].p; o.ns4 = (int)m->P[pid].rows; }
     return o;
 }
 
-// dX of a hidden layer: dst[rows][N] = epi(src[rows][K] * W[K][0:N]).  chain.h: with the transposed copy PT[pid] (rows
-// [0, N): W[:, 0:N]^T, k-contiguous) this IS a forward layer - 16-byte weight loads instead of the 4-byte ones of the
-// n-contiguous walk; chain4.h reads the matrix itself (k-major for this product).
+// dX of a hidden layer: dst[rows][N] = epi(src[rows][K] * W[K][0:N]).  chain4.h reads the D4 copy (k = output row) with
+// 16-byte loads, or the matrix itself (k-major for this product); chain.h walks the matrix.
 ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
-    const Ten& T = m->PT[pid];
-    static const bool off = getenv("AAE_NO_PT") != nullptr;
-    if (!T.p || off) return cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);
-    ensure_pt(m, pid, s);
-    ChainOp o = cop_linear(COP_LINEAR, src, dst, T, K, N, epi);
-    o.Wkn = m->P[pid].p; o.ldkn = (int)m->P[pid].ld;
+    ChainOp o = cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);       // (Wkn = the matrix itself: k-major for this product)
+    if (m->D4[pid].p) { ensure_pt(m, pid, s); o.W4 = m->D4[pid].p; o.ns4 = (int)m->P[pid].cols; }
     return o;
 }
 
@@ -674,7 +676,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     // 4-row workgroups (chain4.h) whenever every linear op of the program has its k-major matrix (all but the VAE's)
     bool four = m->use_chain4;
     for (int i = 0; i < cb.P.nops && four; ++i)
-        if ((cb.P.ops[i].kind == COP_LINEAR || cb.P.ops[i].kind == COP_LINEAR_DX) && !cb.P.ops[i].Wkn) four = false;
+        if ((cb.P.ops[i].kind == COP_LINEAR || cb.P.ops[i].kind == COP_LINEAR_DX) && !cb.P.ops[i].Wkn && !cb.P.ops[i].W4) four = false;
     for (int i = 0; i < cb.P.nops && four; ++i)
         if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
     if (four) {
@@ -712,7 +714,7 @@ struct DwBuilder {
         J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
         J.p = W.p; J.m = m->M[set][pid].p; J.v = m->V[set][pid].p; J.ld = (int)W.ld; J.sc = m->sc + which;
         J.grad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[pid].p : nullptr;
-        J.pt = m->PT[pid].p; J.ldt = (int)m->PT[pid].ld;      // (fused optimiser: the transposed copy follows p)
+        J.w4 = w4_of(m, pid);                                  // (fused optimiser: the k4-interleaved copies follow p)
         J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
         tiles += ((J.M + 31) / 32) * J.tiles_n;
     }
@@ -2574,7 +2576,7 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
             AdamJob& j = grp.jobs[grp.njobs++];
             j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p; j.g = m->Gr[pid].p;
             j.n4 = (unsigned)n4; j.blk0 = blocks;
-            j.pt = m->PT[pid].p; j.ld = (int)m->P[pid].ld; j.ldt = (int)m->PT[pid].ld; j.nt = (int)m->P[pid].cols;
+            j.w4 = w4_of(m, pid); j.ld = (int)m->P[pid].ld;
             blocks += (unsigned)((n4 + 255) / 256);
             continue;
         }

@@ -54,6 +54,7 @@ struct ChainOp {
     int kind, src, dst, K, N;
     const float* W; int ldw;            // weights / global source (COP_LOAD, COP_SLABSUM)
     const float* Wkn; int ldkn;         // the same layer's matrix in k-major form [K][N] (n contiguous) for chain4.h
+    const float* W4; int ns4;           // ... and k4-interleaved [(K + 3) / 4][ns4][4] (device_common.h), or NULL
     int epi, yslot;                     // epilogue; slot holding y for ACTBWD / FINAL_BWD
     DropSpec d;
     float* out; int ldo; int out_row0;  // optional global store of dst[:, 0:N] at rows out_row0 + r
@@ -603,7 +604,7 @@ struct DwJob {
     const float* G; int ldg; const float* X; int ldx; int rows;   // K = rows
     int M, N;                                                      // out, in+1
     float* p; float* m; float* v; float* grad; int ld;             // grad != NULL: export
-    float* pt; int ldt;                                            // transposed copy of p[:, 0:N-1] kept in step (or NULL)
+    W4Copies w4;                                                   // k4-interleaved copies of p kept in step (f4 == NULL: none)
     const OptScalars* sc;
     int tile0;                                                     // first linear tile id of this job
     int tiles_n;                                                   // tiles along N
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
             EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
         } else {
             EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
-            e.pt = J.pt; e.ldt = J.ldt; e.nt = J.N;        // (the transposed copy includes the bias row)
+            e.w4 = J.w4;
             EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
         }
     }

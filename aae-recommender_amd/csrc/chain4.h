@@ -43,9 +43,24 @@ __device__ __forceinline__ void chain4_linear(const ChainOp& op, const float* sr
     const int n = min(64 * cg + lane, N - 1);
     // all weight loads of the layer in flight before the first MFMA; row index clamped (the A operand is zero beyond K)
     float w[MK];
-    const float* wp = op.Wkn + n;
+    if (op.W4) {
+        // k4-interleaved copy: four consecutive k of this lane's column in one 16-byte load, a wave-instruction = 1 KB
+        // (buffer addressing: the matrix in a scalar descriptor, the k-chunk's byte offset in a scalar register, the lane's
+        // column in ONE vector register for all loads of the layer - per-load 64-bit vector addresses spilled the kernel)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.W4), 0, 0x7FFFFFF0, 0x00020000);
+        const unsigned vo = (unsigned)n * 16u;
+        const int kc0 = k0 >> 2, kcmax = (K - 1) >> 2;
 #pragma unroll
-    for (int i = 0; i < MK; ++i) w[i] = wp[(size_t)min(k0 + i, K - 1) * ld];
+        for (int j = 0; j < MK / 4; ++j) {
+            const unsigned so = (unsigned)(min(kc0 + j, kcmax) * op.ns4) * 16u;
+            const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0));
+            w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
+        }
+    } else {
+        const float* wp = op.Wkn + n;
+#pragma unroll
+        for (int i = 0; i < MK; ++i) w[i] = wp[(size_t)min(k0 + i, K - 1) * ld];
+    }
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const float* a = src + (lane & 3) * kCL;
 #pragma unroll

@@ -140,3 +140,28 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 }  // namespace aae
+
+namespace aae {
+// ---------------------------------------------------------------------------------------------
+// k4-interleaved copies of a hidden layer's augmented weights P [M = out][N = in + 1] for chain4.h, whose lanes each own
+// ONE output column and walk k: with four consecutive k of a column contiguous a lane takes them in one 16-byte load and
+// a wave-instruction is one contiguous 1 KB (a quarter of the vector-memory instructions of the k-major form - the
+// layer ops are bound by getting their weights through the CU's memory pipeline):
+//   F4 (forward, k = input column i, n = output row o):   F4[((i >> 2) * M + o) * 4 + (i & 3)]
+//   D4 (dX,      k = output row o,   n = input column i): D4[((o >> 2) * N + i) * 4 + (o & 3)]
+// Both are kept in step with P by the optimiser epilogues that write P (w4_put4 / w4_put1) and re-derived by
+// interleave4_kernel after any other writer.
+// ---------------------------------------------------------------------------------------------
+struct W4Copies { float* f4; float* d4; int M, N; };      // f4 == NULL: the layer has none
+// element (o, i) of P just became v
+__device__ __forceinline__ void w4_put1(const W4Copies& c, int o, int i, float v) {
+    c.f4[((size_t)(i >> 2) * c.M + o) * 4 + (i & 3)] = v;
+    c.d4[((size_t)(o >> 2) * c.N + i) * 4 + (o & 3)] = v;
+}
+// elements (o, i .. i + 3), i % 4 == 0, i + 3 < N
+__device__ __forceinline__ void w4_put4(const W4Copies& c, int o, int i, float4 v) {
+    *reinterpret_cast<float4*>(c.f4 + ((size_t)(i >> 2) * c.M + o) * 4) = v;
+    float* d = c.d4 + ((size_t)(o >> 2) * c.N + i) * 4 + (o & 3);
+    d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+}
+}  // namespace aae

@@ -338,9 +338,8 @@ struct EpiBce {
 // SURVEY 2.1), or plain store of the gradient (data-parallel export mode).
 struct EpiAdam : EpiNoState {
     float* p; float* m; float* v; int ld; const OptScalars* sc;
-    // optional transposed copy of the weight block kept in step with p (the layer chains' dX ops read it with the
-    // forward layers' access pattern): pt[col][row] for col < nt (the bias column of an augmented matrix has none)
-    float* pt = nullptr; int ldt = 0, nt = 0;
+    // optional k4-interleaved copies of the weight block kept in step with p (chain4.h's layer ops read them, device_common.h)
+    W4Copies w4 = {nullptr, nullptr, 0, 0};
     __device__ void apply(State&, int gm, int gn, int N, float4 g, int) const {
         OptScalars s = *sc;
         size_t off = (size_t)gm * ld + gn;
@@ -352,11 +351,7 @@ struct EpiAdam : EpiNoState {
             adam_update(pp.z, mm.z, vv.z, g.z, s); adam_update(pp.w, mm.w, vv.w, g.w, s);
             *reinterpret_cast<float4*>(p + off) = pp;
             if (!s.is_sgd) { *reinterpret_cast<float4*>(m + off) = mm; *reinterpret_cast<float4*>(v + off) = vv; }
-            if (pt) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (gn + i < nt) pt[(size_t)(gn + i) * ldt + gm] = (&pp.x)[i];
-            }
+            if (w4.f4) w4_put4(w4, gm, gn, pp);
             return;
         }
         for (int i = 0; i < 4 && gn + i < N; ++i) {
@@ -364,7 +359,7 @@ struct EpiAdam : EpiNoState {
             adam_update(pp, mm, vv, (&g.x)[i], s);
             p[off + i] = pp;
             if (!s.is_sgd) { m[off + i] = mm; v[off + i] = vv; }
-            if (pt && gn + i < nt) pt[(size_t)(gn + i) * ldt + gm] = pp;
+            if (w4.f4) w4_put1(w4, gm, gn + i, pp);
         }
     }
 };

@@ -157,7 +157,7 @@ __global__ void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, 
 // The same update for up to 8 small tensors of one optimiser in ONE launch (data-parallel replicas apply the
 // all-reduced gradients of every hidden layer after each phase: twelve ~4 us launches per step otherwise).
 struct AdamJob { float* p; float* m; float* v; float* g; unsigned n4; unsigned blk0;       // blk0: first block of the job
-                 float* pt; int ld, ldt, nt; };        // pt != NULL: transposed copy of p[:, 0:nt] kept in step (p rows are ld wide)
+                 W4Copies w4; int ld; };               // w4.f4 != NULL: the k4-interleaved copies of p kept in step (p rows are ld wide)
 struct AdamGroup { int njobs; AdamJob jobs[8]; };
 
 __global__ __launch_bounds__(256) void adam_group_kernel(AdamGroup grp, const OptScalars* sc) {
@@ -177,24 +177,25 @@ __global__ __launch_bounds__(256) void adam_group_kernel(AdamGroup grp, const Op
     adam_update(pp.z, mm.z, vv.z, gg.z, s); adam_update(pp.w, mm.w, vv.w, gg.w, s);
     reinterpret_cast<float4*>(job.p)[i] = pp;
     if (!s.is_sgd) { reinterpret_cast<float4*>(job.m)[i] = mm; reinterpret_cast<float4*>(job.v)[i] = vv; }
-    if (job.pt) {
+    if (job.w4.f4) {
         const unsigned row = (i * 4u) / (unsigned)job.ld, col = (i * 4u) % (unsigned)job.ld;     // ld is a multiple of 4
+        if ((int)col + 3 < job.w4.N) w4_put4(job.w4, (int)row, (int)col, pp);
+        else
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((int)col + k < job.nt) job.pt[(size_t)(col + k) * job.ldt + row] = (&pp.x)[k];
+            for (int k = 0; k < 4; ++k)
+                if ((int)col + k < job.w4.N) w4_put1(job.w4, (int)row, (int)col + k, (&pp.x)[k]);
     }
 }
 
-// pt[c][r] = w[r][c] for r < rows, c < cols: the transposed weight copy the layer chains' dX ops read
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, int ld, int rows, int cols,
-                                                        float* __restrict__ pt, int ldt) {
-    __shared__ float tile[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)
-        tile[j][tx] = (r0 + j < rows && c0 + tx < cols) ? w[(size_t)(r0 + j) * ld + c0 + tx] : 0.f;
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < cols && r0 + tx < rows) pt[(size_t)(c0 + j) * ldt + r0 + tx] = tile[tx][j];
+// both k4-interleaved copies of w [c.M][c.N] (row stride ld) from scratch: after a writer that is not an optimiser epilogue
+__global__ __launch_bounds__(256) void interleave4_kernel(const float* __restrict__ w, int ld, W4Copies c) {
+    const int per_row = (c.N + 3) >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < c.M * per_row; i += gridDim.x * 256) {
+        const int o = i / per_row, c0 = (i - o * per_row) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < c.N) w4_put1(c, o, c0 + k, w[(size_t)o * ld + c0 + k]);
+    }
 }
 
 // bias gradient of the first encoder layer: db1[c] = sum_b ga1[b][c], then its optimiser
