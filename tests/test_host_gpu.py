@@ -248,6 +248,40 @@ def test_recommender_with_bags_and_evaluation_harness(capsys):
     assert "Training took" in out and "- mrr@10:" in out
 
 
+def test_per_step_buffers_are_released_every_step():
+    """the list that keeps a step's device operands alive (condition blocks, packets, decoder inputs) must not
+    grow with the number of steps - 120 conditioned steps in the default rng mode, on every path that appends to it."""
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec import condition as C
+    z, Xtr, Xin, Yout = _e2e()
+    rng = np.random.RandomState(0)
+
+    class ConstConcat(C.ConcatenationBasedConditioning):
+        constant_concat = True
+
+        def size_increment(self):
+            return 6
+
+        def encode(self, inputs):
+            return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
+
+    class Bias(C.ConditionalBiasing):
+        def encode(self, inputs):
+            return torch.as_tensor(np.asarray(inputs), dtype=torch.float32, device="cuda")
+    cases = [([("t", ConstConcat())], [rng.standard_normal((Xtr.shape[0], 6)).astype(np.float32)]),
+             ([("t", ConstConcat()), ("b", Bias())], [rng.standard_normal((Xtr.shape[0], 6)).astype(np.float32),
+                                                      0.1 * rng.standard_normal((Xtr.shape[0], 56)).astype(np.float32)])]
+    for items, data in cases:
+        m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=1, batch_size=20, conditions=C.ConditionList(items),
+                                   verbose=False)
+        sizes = []
+        for k, _ in enumerate(m.fit_steps(Xtr[:2400], condition_data=[d[:2400] for d in data])):
+            sizes.append(len(m.hip._keep))
+            if k >= 119:
+                break
+        assert max(sizes) <= 8 and sizes[-1] <= max(sizes[:10]), sizes[-5:]
+
+
 def test_partial_fit_rejects_duplicate_items():
     from aaerec.aae import AdversarialAutoEncoder
     m = AdversarialAutoEncoder(n_hidden=8, n_code=4, batch_size=4, verbose=False)
