@@ -1776,7 +1776,12 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         const int grid = std::min(ntiles, m->n_cu);
         fa.Gt = m->Gt;
         int n_loss_partials = grid;
-        if (m->split_ok && m->split_wgs > 0 && fa.gradV3 == nullptr && !want_ts && (fa.dbg_skip & ~256) == 0) {
+        // The split pays when the deferred half FITS beside the rest of the step and the layer is big enough to matter:
+        // below ~2 tiles per CU the two event hops cost more than the optimiser pass they hide (C1, N = 1 k: 0.173 -> 0.184
+        // ms/step), and beyond ~32 M parameters the deferred launch on half the CUs outlasts the rest of the step and the
+        // next step waits for it (one rank's C5 share, 442 M parameters: 3.5 -> 4.8 ms/step) - both take the single launch.
+        const bool split_fits = nblk > 1 || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
+        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && !want_ts && (fa.dbg_skip & ~256) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3

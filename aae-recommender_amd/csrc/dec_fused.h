@@ -133,7 +133,10 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     // per instruction, 8 cycles: the same 64 flop/clk/SIMD with a quarter of the rows), spread over waves that have room:
     // GEMM1 on waves 12..15 (8 items x 8 k-eighths each, reduced over the k-eighths by lane shuffles), GEMM3 on all 16
     // (64 columns x an item quarter each; the four item quarters of a column group meet in LDS at the kernel's end).
-    const bool tail4 = kFwd && nmb > 1 && B - 16 * (nmb - 1) <= 4 && !(a.dbg_skip & 256);      // (256: A/B switch back to the 7th block)
+    // (Only the critical launch of the split carries it: in the one-launch form the extra accumulators on top of the
+    //  optimiser's V/m/v registers push the kernel over 128 VGPRs - 15 spilled, 13 % slower on a 2.2M-item shard.)
+    constexpr bool kTail = MODE == kDecCrit;
+    const bool tail4 = kTail && nmb > 1 && B - 16 * (nmb - 1) <= 4 && !(a.dbg_skip & 256);     // (256: A/B switch back to the 7th block)
     const int nfb = tail4 ? nmb - 1 : nmb;              // full 16-row blocks of the forward products
     const int kq = (((K1 + 7) >> 3) + 1) & ~1;          // GEMM1 tail: k-steps per eighth (even; 8 * kq <= kSD)
     f32x4 acc3t = (f32x4){0.f, 0.f, 0.f, 0.f};          // GEMM3 tail: rows 16 nfb + 0..3 of column 64 (wave & 3) + lane

@@ -104,17 +104,20 @@ def test_c5_share_output_layer_of_one_rank():
     assert dw <= 1e-5 and db <= 1e-5
 
 
-def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_deferred_launch():
+@pytest.mark.parametrize("B", [96, 100])
+def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_deferred_launch(B):
     """The fused output layer runs as a critical launch (logits, BCE, dL/d(hidden)) on the caller's stream and a deferred
     one (dV3 + dec_optim) on the handle's side stream (include/aaerec_hip.h: aae_join / aae_set_split).  Same arithmetic
-    in the same order: after the first step (the forward pass has no atomics) dec.lin3 and both dec_optim moments equal
-    the one-launch form BIT FOR BIT at the benchmark's shape; later steps differ only through the encoder's scatter
-    atomics (2e-6, the bound between the fused and the three-kernel path above; a view that did not wait for the deferred
-    launch would be one Adam step = 1e-3 off).  A view taken right behind a step - while the deferred launch is still
-    running - must already show its result."""
+    in the same order at 96 rows (whole 16-row blocks): after the first step (the forward pass has no atomics) dec.lin3
+    and both dec_optim moments equal the one-launch form BIT FOR BIT; later steps differ only through the encoder's
+    scatter atomics (2e-6, the bound between the fused and the three-kernel path above; a view that did not wait for the
+    deferred launch would be one Adam step = 1e-3 off).  At the benchmark's 100 rows the critical launch takes the last 4
+    rows on 4x4 matrix-core blocks (another summation order of the same products; the one-launch form has no registers
+    left for it, dec_fused.h): 2e-6 from the first step on.  A view taken right behind a step - while the deferred launch
+    is still running - must already show its result."""
     from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
     from tools.synth import init_params, throughput_corpus
-    N, h, c, B, steps = 100000, 200, 50, 100, 6
+    N, h, c, steps = 100000, 200, 50, 6
     params = init_params(N, h, c, seed=4)
     X = throughput_corpus(steps * B, N, median_len=20, seed=78)
     kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3, rng_mode="device", seed=99)
@@ -133,7 +136,7 @@ def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_defe
             m.step(csr, s * B, B)
         if s == 0:
             for a, b in views():
-                assert torch.equal(a, b)
+                assert torch.equal(a, b) if B % 16 == 0 else float((a - b).abs().max()) <= 2e-6
             assert float((split.tensor(T_DEC_V3, padded=True) - before).abs().max()) > 5e-4      # (the step did move it)
         else:
             for a, b in views():
@@ -146,7 +149,7 @@ def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_defe
     # one starts) keep the order as well
     for s, rows in enumerate((37, 100, 5, 64)):
         for m in (split, single):
-            m.step(csr, s * B, rows)
+            m.step(csr, s * B, min(rows, B))
     np.testing.assert_allclose(split.losses(), single.losses(), rtol=1e-5)
     assert float((split.tensor(T_DEC_V3, padded=True) - single.tensor(T_DEC_V3, padded=True)).abs().max()) <= 2e-6
     # predict reads DEC_V3 through the ABI: joined inside
