@@ -29,6 +29,7 @@ GRAD_FUSED, GRAD_EXPORT = 0, 1
 T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3 = range(10)
 T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, T_GRAD = 16, 32, 48, 64, 80
 T_ACT_Z, T_ACT_LOSSES, T_ACT_A1, T_ACT_DZC, T_ACT_DH2, T_ACT_DA2 = 96, 97, 98, 99, 100, 101
+T_ACT_GA1 = 102
 CAT_SUM, CAT_MEAN = 0, 1
 CAT_SPARSE_ADAM, CAT_ADAM = 0, 1
 O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
@@ -106,6 +107,10 @@ _PROTOS = {
     "aae_ae_forward": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
     "aae_output_layer_step": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p]),
     "aae_ae_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "aae_set_doc_l1": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_set_first_layer_external": (C.c_int, [C.c_void_p, C.c_int]),
+    "aae_first_layer_forward": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
+    "aae_first_layer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "aae_cat_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p]),
     "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -451,7 +456,15 @@ class HipAAE:
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2), self._span(T_GRAD + T_DEC_V3, T_GRAD + T_DEC_V3)]
         if which == "dec_small":
             return [self._span(T_GRAD + T_DEC_V1, T_GRAD + T_DEC_V2)]
+        if which == "enc_small":        # (first layer external: its bias, W2, W3)
+            return [self._span(T_GRAD + T_ENC_B1, T_GRAD + T_ENC_W3)]
+        if which == "enc_dec_small":    # b1, W2, W3, V1, V2: one contiguous span of the arena
+            return [self._span(T_GRAD + T_ENC_B1, T_GRAD + T_DEC_V2)]
         return [self._span(T_GRAD + T_DISC_D1, T_GRAD + T_DISC_D3)]
+
+    def params_changed(self):
+        """Parameters were written through arena views: derived copies are rebuilt before their next use."""
+        _check(self.lib.aae_params_changed(self.handle))
 
     def join(self):
         """Make the current stream wait for the last step's deferred dec_optim launch (aae_join; no-op when none)."""
@@ -629,6 +642,44 @@ class HipAAE:
         with torch.cuda.device(self.device):
             _check(self.lib.aae_ae_backward(self.handle, _ptr(da2), da2.stride(0) if da2 is not None else 0,
                                             self._stream()))
+
+    # ---- the first encoder layer sharded over the vocabulary as well (include/aaerec_hip.h: aae_first_layer_*) ------
+    def set_doc_l1(self, doc_l1):
+        """Slice handle: L1 norms of the complete documents (float32 device tensor indexed by document id; None = the
+        batch's own rows are complete)."""
+        if doc_l1 is not None:
+            assert doc_l1.is_cuda and doc_l1.dtype == torch.float32 and doc_l1.is_contiguous()
+        self._doc_l1 = doc_l1                      # (keeps the buffer alive as long as the handle uses it)
+        _check(self.lib.aae_set_doc_l1(self.handle, _ptr(doc_l1)))
+
+    def set_first_layer_external(self, on=True):
+        """Replica handle: a1_rows() is filled by the caller, dL/d(a1) comes back in ga1_rows(); enc.lin1 stays untouched."""
+        _check(self.lib.aae_set_first_layer_external(self.handle, 1 if on else 0))
+
+    def first_layer_forward(self, csr=None, row_start=0, n_rows=0, rows=None, bias=None):
+        """This handle's items' share of the first layer's pre-activations -> a1_rows(); csr = None: the running batch
+        again with the weights as they are now.  bias: the replicas' enc.lin1 bias (device tensor) on exactly one share."""
+        b = self._batch(csr, row_start, n_rows, rows) if csr is not None else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_first_layer_forward(self.handle, C.byref(b) if b is not None else None, _ptr(bias),
+                                                    self._stream()))
+
+    def first_layer_update(self, which):
+        """enc.lin1's rows of this handle's items (+ the bias) from ga1_rows() of the running batch, optimiser `which`."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_first_layer_update(self.handle, None, 0, int(which), self._stream()))
+
+    def first_layer_bias(self):
+        """enc.lin1's bias as a device view (what one share of first_layer_forward adds)."""
+        return self.tensor(T_ENC_B1, padded=True)
+
+    def a1_rows(self, n_rows):
+        """[n_rows, ld] view of the first layer's pre-activations."""
+        return self.tensor(T_ACT_A1, padded=True)[:n_rows]
+
+    def ga1_rows(self, n_rows):
+        """[n_rows, ld] view of dL/d(a1) of the last encoder backward."""
+        return self.tensor(T_ACT_GA1, padded=True)[:n_rows]
 
     def dh2_rows(self, n_rows):
         """[n_rows, ld] view of the decoder's last hidden activation (with its bias-input column and padding)."""

@@ -112,10 +112,12 @@ class AdversarialAutoEncoder:
         if rng_mode not in ("device", "reference"):
             raise ValueError("rng_mode must be 'device' or 'reference'")
         self.device, self.rng_mode, self.seed, self.data_parallel = device, rng_mode, seed, data_parallel
-        if dp_mode not in ("vocab", "replicated"):
-            raise ValueError("dp_mode must be 'vocab' or 'replicated'")
-        # data_parallel (torch.distributed, one process per GPU): 'vocab' shards the decoder's output layer over the
-        # vocabulary (aaerec.parallel.VocabParallelAAE), 'replicated' keeps it on every rank and exchanges its gradient
+        if dp_mode not in ("vocab", "vocab_out", "replicated"):
+            raise ValueError("dp_mode must be 'vocab', 'vocab_out' or 'replicated'")
+        # data_parallel (torch.distributed, one process per GPU): 'vocab' shards both vocabulary-wide matrices - the
+        # decoder's output layer and the encoder's first layer - over the items (aaerec.parallel.VocabParallelAAE: the
+        # ranks exchange [global batch, n_hidden] activations only), 'vocab_out' the output layer alone (the first
+        # layer's row-sparse gradient travels as packed rows), 'replicated' keeps everything on every rank
         self.dp_mode = dp_mode
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core inputs, fp32 "
@@ -241,7 +243,8 @@ class AdversarialAutoEncoder:
                     seed=seed, device=self.device, ae_only=self._ae_only, dtype=self.dtype,
                     unfused_decoder=self._unfused_decoder)
                 self._slice.load_params(sl_params)
-                self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group)
+                self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
+                                            shard_first_layer=self.dp_mode == "vocab")
             else:
                 self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
 
@@ -249,7 +252,7 @@ class AdversarialAutoEncoder:
         """dp_mode='vocab' applies when the step has no cut at the condition boundary (no conditions, constant
         concatenated blocks, CategoricalConditions the kernels train themselves) and the batches are the corpus' own
         rows (no per-epoch corruption hook)."""
-        if self.dp_mode != "vocab" or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
+        if self.dp_mode not in ("vocab", "vocab_out") or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
             return False
         return not self.conditions or code_inc == 0 or self._is_constant_concat() or self._is_device_native()
 
@@ -421,6 +424,9 @@ class AdversarialAutoEncoder:
         row_len = X.getnnz(1)
         if self._slice is not None:                     # this rank's items of the corpus, ids rebased to the slice
             self._slice_csr = _hip.DeviceCSR(X[:, self._dp.item_lo:self._dp.item_hi], self.hip.device)
+            if self._dp.shard_first:                    # the slice holds its columns only: F.normalize's whole-row norms
+                self._slice.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1),
+                                                       device=self.hip.device))
         n_docs = X.shape[0]
         self.train()
         step = 0

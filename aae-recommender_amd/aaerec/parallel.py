@@ -277,12 +277,18 @@ class VocabParallelAAE(DataParallelAAE):
     restricted to this rank's items with ids rebased to the slice; every rank walks the same permutation, so the
     global batch needs no exchange."""
 
-    def __init__(self, model, slice_model, dist, n_items, group=None):
+    def __init__(self, model, slice_model, dist, n_items, group=None, shard_first_layer=False):
         super().__init__(model, dist, group=group, shard_decoder=False)
         self.slice = slice_model
         self.n_items = n_items
         self.item_lo, self.item_hi = item_slice(n_items, dist.get_rank(group), self.world)
         slice_model.set_grad_scale((self.item_hi - self.item_lo) / float(n_items))
+        # shard_first_layer: enc.lin1 - the other [n_items, n_hidden] matrix - lives with the item slices as well (see
+        # _step_both_sharded); the caller gives the slice model the documents' complete L1 norms (set_doc_l1)
+        self.shard_first = bool(shard_first_layer)
+        self._pk = self._pk_all = None
+        if self.shard_first:
+            model.set_first_layer_external(True)
 
     def step(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None, cond=None,
              masks=None, z_real=None):
@@ -294,6 +300,9 @@ class VocabParallelAAE(DataParallelAAE):
         self._coll = [0, 0]
         m.set_grad_scale(n_rows / float(global_rows))
         self._set_rng_rows(n_rows, global_rows)
+        if self.shard_first:
+            return self._step_both_sharded(csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows, g_rows, cond,
+                                           masks, z_real)
         m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
         self._count(m.dh2_rows(n_rows))
         d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
@@ -312,6 +321,84 @@ class VocabParallelAAE(DataParallelAAE):
             m.apply_updates(O_DISC)
             m.gen_step()
             self._exchange_encoder(O_GEN)
+        self._gathered = False
+        self._coll_last = tuple(self._coll)
+
+    # ---- both vocabulary-wide matrices with their item slices -----------------------------------------------------
+    def _first_layer(self, n_rows, global_rows, open_step=None):
+        """The slices' shares of x * enc.lin1^T for the global batch, summed, this rank's rows -> model.a1_rows
+        (rank 0's share carries the bias)."""
+        m, sl, d = self.model, self.slice, self.dist
+        bias = m.first_layer_bias() if d.get_rank(self.group) == 0 else None
+        if open_step is not None:
+            slice_csr, g_row_start, g_rows = open_step
+            sl.first_layer_forward(slice_csr, g_row_start, global_rows, rows=g_rows, bias=bias)
+        else:
+            sl.first_layer_forward(bias=bias)
+        part = sl.a1_rows(global_rows)
+        self._count(part)
+        d.reduce_scatter_tensor(m.a1_rows(n_rows).view(-1), part.view(-1), op=d.ReduceOp.SUM, group=self.group)
+
+    def _exchange_ga1(self, n_rows, global_rows, riders):
+        """dL/d(a1) of every rank's documents -> the slice model's ga1_rows (rank-major = global batch order); `riders`
+        (small gradient spans due at the same point) travel behind the rows and come back summed over the ranks in one
+        fixed order - bitwise the same everywhere."""
+        import torch
+        m, sl, d = self.model, self.slice, self.dist
+        ga1 = m.ga1_rows(n_rows)
+        n0 = ga1.numel()
+        total = n0 + sum(t.numel() for t in riders)
+        if self._pk is None or self._pk.numel() != total:
+            self._pk = ga1.new_empty(total)
+            self._pk_all = ga1.new_empty(total * self.world)
+        pk, allp = self._pk, self._pk_all
+        torch.cat([ga1.reshape(-1)] + [t.reshape(-1) for t in riders], out=pk)
+        if self.world == 1:
+            allp = pk
+        else:
+            self._count(pk)
+            d.all_gather_into_tensor(allp, pk, group=self.group)
+        peers = allp.view(self.world, total)
+        sl.ga1_rows(global_rows).view(self.world, n0).copy_(peers[:, :n0])
+        off = n0
+        for t in riders:
+            torch.sum(peers[:, off:off + t.numel()], dim=0, out=t.reshape(-1))
+            off += t.numel()
+
+    def _step_both_sharded(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows, g_rows, cond, masks,
+                           z_real):
+        """enc.lin1 ([n_hidden, n_items]) with the item slices like dec.lin3: under replication its row-sparse gradient
+        is the largest exchange of the step (packed rows of every rank: ~60 MB gathered at 8 x 100 documents) and every
+        rank carries the whole matrix with two optimisers' moments.  Here a slice computes its items' share of the first
+        layer's pre-activations for the GLOBAL batch (it holds those columns of the corpus anyway), the shares are
+        reduce-scattered ([global rows, n_hidden]: 0.6 MB), and dL/d(a1) travels back by all-gather with the small
+        layers' gradients behind it (the first layer's bias is one of them: it stays replicated, the slice of rank 0 adds
+        it to its share); every owner applies enc_optim / gen_optim to its rows.  7 collectives per step, all small:
+            a1 reduce-scatter | dh2 all-gather | dA2 reduce-scatter | ga1 + enc/dec small all-gather |
+            a1 reduce-scatter (Enc_eval) | disc all-reduce | ga1 + enc small all-gather."""
+        m, sl, d = self.model, self.slice, self.dist
+        self._first_layer(n_rows, global_rows, open_step=(slice_csr, g_row_start, g_rows))
+        m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
+        self._count(m.dh2_rows(n_rows))
+        d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
+        sl.output_layer_step()                      # continues the slice model's step (opened by first_layer_forward)
+        self._count(sl.da2_rows(global_rows))
+        d.reduce_scatter_tensor(m.da2_rows(n_rows).view(-1), sl.da2_rows(global_rows).view(-1), op=d.ReduceOp.SUM,
+                                group=self.group)
+        m.ae_backward()
+        self._exchange_ga1(n_rows, global_rows, m.grad_buckets("enc_dec_small"))
+        m.apply_updates(O_ENC)
+        m.apply_updates(O_DEC, skip=m.big_tensor_id)
+        sl.first_layer_update(O_ENC)
+        if not getattr(m, "ae_only", False):
+            self._first_layer(n_rows, global_rows)
+            m.disc_step()
+            self._allreduce(O_DISC)
+            m.apply_updates(O_DISC)
+            m.gen_step()
+            self._exchange_ga1(n_rows, global_rows, m.grad_buckets("enc_small"))
+            m.apply_updates(O_GEN)
+            sl.first_layer_update(O_GEN)
         self._gathered = False
         self._coll_last = tuple(self._coll)
 
@@ -340,6 +427,20 @@ class VocabParallelAAE(DataParallelAAE):
         for r in range(self.world):
             lo, hi = item_slice(self.n_items, r, self.world)
             full[lo:hi] = recv[r * rows:r * rows + (hi - lo)]
+        if self.shard_first:
+            # enc.lin1 the same way (stored transposed: one row per item), and the bias every owner keeps
+            from ._hip import T_ENC_W1T
+            sl.sync()                                   # (the slice's deferred Adam on its rows, replayed)
+            m.sync()
+            full, mine = m.tensor(T_ENC_W1T, padded=True), sl.tensor(T_ENC_W1T, padded=True)
+            send = torch.zeros(rows, full.shape[1], dtype=full.dtype, device=full.device)
+            send[:mine.shape[0]] = mine
+            recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
+            d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            for r in range(self.world):
+                lo, hi = item_slice(self.n_items, r, self.world)
+                full[lo:hi] = recv[r * rows:r * rows + (hi - lo)]
+            m.params_changed()
         self._gathered = True
 
     def recon_loss(self):

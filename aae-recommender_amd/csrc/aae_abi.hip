@@ -84,6 +84,8 @@ struct aae_model {
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
+    const float* doc_l1;     // aae_set_doc_l1: L1 norms of the complete documents (a handle that holds an item slice of them)
+    bool ext_first;          // aae_set_first_layer_external: AAE_T_ACT_A1 comes from the caller, dL/d(a1) goes back to it
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
     bool bf16;               // cfg.reserved[3] = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
@@ -484,7 +486,7 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
         size_t shm = (size_t)16 * r4(h) * sizeof(float);
         hipLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), shm, s, m->bv, m->P[P_W1T].p, m->ldw1,
                            m->P[P_B1].p, h, m->cfg.normalize_inputs, m->a1.p, m->eh1.p, m->ldh, m->cfg.activation,
-                           d1, m->cfg.seed, m->step_ctr, m->rscale);
+                           d1, m->cfg.seed, m->step_ctr, m->rscale, m->doc_l1);
         LAUNCHCHK("enc_gather");
     } else {
         hipLaunchKernelGGL(drop_act_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->a1.p, m->eh1.p, B, h,
@@ -729,6 +731,7 @@ struct DwBuilder {
         w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
         w.ncol = (m->h + 63) / 64;
         if (m->dense_step) w.ny = 0;            // dense noisy input: no scatter (the dense dW1T product follows), bias blocks only
+        if (m->ext_first) w.ny = 0;             // the weight rows live with their item slices (aae_first_layer_update): bias blocks only
     }
     int launch(hipStream_t s) {
         int blocks = tiles;
@@ -742,9 +745,16 @@ struct DwBuilder {
 // Encoder hidden stack from the gathered first layer (eh1 in global): lin2, lin3, output activation.
 // ops appended to `cb`; z ends in slot 2.
 void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_t* mk2, uint32_t sid2, int rows,
-                        float* eh2_out, hipStream_t s) {
+                        float* eh2_out, hipStream_t s, const uint8_t* mk1 = nullptr, uint32_t sid1 = 0) {
     const int h = m->h;
-    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    if (m->ext_first) {
+        // the first layer lives with the caller (aae_set_first_layer_external): a1 -> dropout -> activation here
+        cb.add(cop_load(m->a1.p, m->ldh, 3, h));
+        ChainOp& e1 = cb.add(cop(COP_DROPACT, 3, 0, h));
+        e1.d = make_drop(m, 0, train, mk1, nullptr, rows, h, sid1); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
+    } else {
+        ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    }
     ChainOp& a = cb.add(cop_fwd(m, P_W2, 0, 1, h + 1, h, CEPI_DROPACT, s));
     a.d = make_drop(m, 1, train, mk2, nullptr, rows, h, sid2); a.one_col = h;
     if (eh2_out) cop_out(a, eh2_out, m->ldh);
@@ -779,7 +789,7 @@ int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* 
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
     piggyback_buckets(m, cb);
-    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p, s);
+    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p, s, I.masks_dev[0], 0);
     // the encoder's output activation; the identity (gauss prior, aae.py:97-101) is no op of its own: its stores and
     // bias-input column ride on the last linear layer
     ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
@@ -911,7 +921,7 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
     hipExtLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), (uint32_t)shm, s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
                           (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
                           m->a1.p, m->eh1.p, m->ldh, (int)m->cfg.activation, d1, (uint64_t)m->cfg.seed,
-                          (const long long*)m->step_ctr, m->rscale);
+                          (const long long*)m->step_ctr, m->rscale, m->doc_l1);
     LAUNCHCHK("enc_gather");
     return AAE_OK;
 }
@@ -1051,7 +1061,7 @@ int chain_vae_backward(aae_model* m, const float* part_slabs, size_t slab_stride
 int chain_disc_step(aae_model* m, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c;
     const aae_rng_inject& I = m->inj;
-    TRY(gather_first_layer(m, false, nullptr, 0, s));
+    if (!m->ext_first) TRY(gather_first_layer(m, false, nullptr, 0, s));     // (external: the caller refreshed AAE_T_ACT_A1)
     {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
         ChainBuilder cb(m, B);
         chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
@@ -1128,6 +1138,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
     dw.add_first_layer(m, m->gb3.p, O_GEN);
     TRY(dw.launch(s));
+    if (m->ext_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
     return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
 }
 
@@ -1484,6 +1495,7 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
     else if (id == AAE_T_ACT_A1) t = &h->a1;
     else if (id == AAE_T_ACT_DH2) t = &h->dh2;
     else if (id == AAE_T_ACT_DA2) t = &h->da2;
+    else if (id == AAE_T_ACT_GA1) t = &h->gb3;
     else if (id == AAE_T_ACT_DZC) { tmp = h->gzc; tmp.cols = h->cp; t = &tmp; }
     else if (id == AAE_T_ACT_LOSSES) {
         tmp.rows = 1; tmp.cols = 4; tmp.ld = 4; tmp.off = (size_t)((char*)h->losses - h->base); t = &tmp;
@@ -1686,6 +1698,14 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
         TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
         m->phase = 1;
         if (m->pf_armed) m->pf_armed = false;
+        return AAE_OK;
+    }
+    if (m->ext_first) {
+        // the first layer is the caller's (aae_set_first_layer_external): AAE_T_ACT_A1 holds this batch's pre-activations
+        if (!m->use_chain || m->vae) return fail(AAE_ESTATE, "an external first layer needs the layer-chain kernels (and no VAE mode)");
+        m->dec_hidden_done = false; m->enc_bwd_done = false; m->pf_armed = false;
+        TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
+        m->phase = 1;
         return AAE_OK;
     }
     if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
@@ -2150,7 +2170,7 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
             dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
             TRY(dw.launch(s));
         }
-        TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
+        if (!m->ext_first) TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
         m->phase = 3;
         return AAE_OK;
     }
@@ -2224,11 +2244,92 @@ int aae_ae_backward(aae_handle m, const float* dA2_dev, int64_t dA2_ld, void* st
     dw.add(m, m->gb1.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
-    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;      // (external first layer: its bias blocks only)
     TRY(dw.launch(s));
     m->enc_bwd_done = true;
     m->phase = 2;
     return aae_ae_encoder_backward(m, nullptr, 0, stream);
+}
+
+// ---- the first encoder layer sharded over the vocabulary (with the decoder's output layer: both [n_items, n_hidden]
+// matrices live with the owner of their item slice, the ranks exchange [global rows, n_hidden] activations) ----------
+int aae_set_doc_l1(aae_handle m, const float* doc_l1_dev) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    m->doc_l1 = doc_l1_dev;
+    return AAE_OK;
+}
+
+int aae_set_first_layer_external(aae_handle m, int on) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (on && (!m->use_chain || m->vae)) return fail(AAE_ESTATE, "an external first layer needs the layer-chain kernels (and no VAE mode)");
+    m->ext_first = on != 0;
+    return AAE_OK;
+}
+
+// This handle's share of the first layer's pre-activations for the batch: sum over ITS items of x[b][i] * enc.lin1[:, i]
+// (+ bias_dev[n_hidden] when given: the bias stays with the replicas, exactly one share adds it) -> AAE_T_ACT_A1
+// [rows][n_hidden].
+//   batch != NULL: a new step of this handle (step scalars advance, the batch's rows of the deferred Adam are caught up);
+//   batch == NULL: the running batch again with the weights as they are now (disc_step's Enc_eval after enc_optim).
+int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* bias_dev, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->vae || m->cfg.grad_mode != AAE_GRAD_FUSED) return fail(AAE_ESTATE, "aae_first_layer_forward: fused optimiser, no VAE mode");
+    hipStream_t s = S(stream);
+    TRY(join_deferred(m, s));
+    if (batch) {
+        TRY(set_batch(m, batch));
+        remember_inject(m, nullptr, true);
+        m->hstep++; m->pf_armed = false; m->pf_built = false;
+        hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
+                           m->stamp, m->ucount, m->losses);
+        LAUNCHCHK("advance_step");
+        if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+        m->enc_bwd_done = false; m->fuse_enc_bwd = false; m->dense_step = false;
+    } else if (!m->have_batch) {
+        return fail(AAE_ESTATE, "aae_first_layer_forward(batch = NULL) without a running batch");
+    }
+    {
+        ProfScope ps(m, AAE_K_ENC_GATHER, s);
+        const size_t shm = (size_t)16 * r4(m->h) * sizeof(float);
+        DropSpec none; memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(enc_gather_kernel, dim3(m->rows), dim3(1024), (uint32_t)shm, s, m->bv, (const float*)m->P[P_W1T].p,
+                           m->ldw1, bias_dev, m->h,
+                           (int)m->cfg.normalize_inputs, m->a1.p, (float*)nullptr, m->ldh, (int)m->cfg.activation, none,
+                           (uint64_t)m->cfg.seed, (const long long*)m->step_ctr, m->rscale, m->doc_l1);
+        LAUNCHCHK("enc_gather (partial)");
+    }
+    if (batch) { m->phase = 1; m->dec_hidden_done = true; }       // aae_output_layer_step(batch = NULL) may follow on this handle
+    return AAE_OK;
+}
+
+// The first layer's weight gradient from dL/d(a1) of the running batch (ga1_dev [rows][ld], NULL = AAE_T_ACT_GA1 of this
+// handle) restricted to this handle's items, and optimiser `which` (enc_optim 0 / gen_optim 2) on its rows.  (The bias is
+// a small replicated parameter: its gradient is a column sum of the replicas' own dL/d(a1), aae_ae_backward / aae_gen_step
+// export it with the other small layers'.)
+int aae_first_layer_update(aae_handle m, const float* ga1_dev, int64_t ld, int which, void* stream) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->vae || m->cfg.grad_mode != AAE_GRAD_FUSED) return fail(AAE_ESTATE, "aae_first_layer_update: fused optimiser, no VAE mode");
+    if (which != O_ENC && which != O_GEN) return fail(AAE_EINVAL, "which must be enc_optim (0) or gen_optim (2)");
+    if (!m->have_batch) return fail(AAE_ESTATE, "aae_first_layer_update without a running batch");
+    if (ga1_dev && ld != m->ldh) return fail(AAE_EINVAL, "aae_first_layer_update: ld must equal the leading dimension of AAE_T_ACT_GA1");
+    hipStream_t s = S(stream);
+    const float* ga1 = ga1_dev ? ga1_dev : m->gb3.p;
+    // rows of an item slice are short (a few entries each, a rare long one): 1/8 of the workgroups the longest row
+    // would fill in one pass, each looping over its share of the entries
+    const int ny = std::max(2, std::min(m->chunks * 4, (m->chunks + 1) / 2));
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(m->rows, ny), dim3(256), 0, s, m->bv, ga1, m->ldh, m->h, m->rscale,
+                       m->Gr[P_W1T].p, m->ldw1, 0);
+    LAUNCHCHK("enc_scatter (slice)");
+    const int set = which == O_GEN ? 1 : 0;
+    {
+        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
+        const int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
+                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, m->h, m->sc + which,
+                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
+        LAUNCHCHK("w1_sparse_adam (slice)");
+    }
+    return AAE_OK;
 }
 
 // disc_step (aae.py:713-732)
@@ -2323,6 +2424,7 @@ int aae_disc_gen(aae_handle m, const aae_rng_inject* inj, void* stream) {
 
 int aae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inj, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->ext_first) return fail(AAE_ESTATE, "aae_step: the first layer is external (aae_set_first_layer_external): drive the phases");
     if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
     hipStream_t s = S(stream);
     TRY(ae_encode_impl(m, batch, inj, nullptr, true, cond_dev, stream));

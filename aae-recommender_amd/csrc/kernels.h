@@ -24,7 +24,9 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
                                                          const float* __restrict__ b1, int h, int normalize,
                                                          float* __restrict__ a1, float* __restrict__ y, int ld,
                                                          int act, DropSpec d, uint64_t seed, const long long* step_ctr,
-                                                         float* __restrict__ rscale) {
+                                                         float* __restrict__ rscale, const float* __restrict__ doc_l1 = nullptr) {
+    // doc_l1 != NULL: the L1 norms of the COMPLETE documents, indexed by document (the batch holds only the columns of one
+    // item slice of them, aae_set_doc_l1); b1 == NULL: no bias (a partial sum that meets the other slices' elsewhere)
     extern __shared__ __attribute__((aligned(16))) float part[];   // [16][hp]
     __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
     float s = 1.f;
-    if (normalize) {
+    if (normalize && doc_l1) {
+        s = 1.f / fmaxf(doc_l1[dc], 1e-12f);
+    } else if (normalize) {
         float l1 = 0.f;
         for (int64_t e = lo + tid; e < hi; e += 1024) l1 += fabsf(bv.values[e]);
         l1 = wave_sum(l1);
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += part[w * hp + c];
-        v += b1[c];
+        if (b1) v += b1[c];
         a1[(size_t)b * ld + c] = v;
         if (y) {
             if (d.enabled) v = drop_fwd(d, drop_keep(d, key, b, c), v);

@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-512 extra line")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
-    ap.add_argument("--dp", choices=("vocab", "replicated"), default="vocab",
+    ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated"), default="vocab",
                     help="N > 1: 'vocab' shards the decoder's output layer over the vocabulary (ranks exchange hidden "
                          "activations, aaerec.parallel.VocabParallelAAE); 'replicated' keeps a replica of it on every "
                          "rank and exchanges its dense gradient (DataParallelAAE)")

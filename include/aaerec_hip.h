@@ -136,6 +136,7 @@ enum {
     AAE_T_ACT_A1 = 98,     /* first-layer pre-activations of the last encode [rows][n_hidden] */
     AAE_T_ACT_DH2 = 100,   /* the decoder's last hidden activation [rows][n_hidden + 1] (last column = 1: the bias input) */
     AAE_T_ACT_DA2 = 101,   /* dL/d(ACT_DH2) written by aae_output_layer_step, same layout */
+    AAE_T_ACT_GA1 = 102,   /* dL/d(ACT_A1) of the last encoder backward [rows][n_hidden] */
     AAE_T_ACT_DZC = 99     /* dL/d(decoder input) of the last ae phase [rows][n_code + cond_inc]: columns n_code.. are
                             * the gradient of the condition block handed to aae_step (trainable conditions) */
 };
@@ -257,6 +258,31 @@ int aae_vae_encoder_backward(aae_handle h, const float* dz_dev, int64_t dz_ld, v
 int aae_ae_forward(aae_handle h, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inject, void* stream);
 int aae_output_layer_step(aae_handle h, const aae_batch* batch, void* stream);
 int aae_ae_backward(aae_handle h, const float* dA2_dev, int64_t dA2_ld, void* stream);
+/* ... and the FIRST encoder layer sharded the same way (r2): enc.lin1 is the other [n_items][n_hidden] matrix
+ * (reference aae.py:116, 132-135), and under replication its row-sparse gradient is the step's largest exchange (the
+ * packed rows of aae_w1_export: ~60 MB gathered per step at 8 x 100 documents).  The slice handle already holds the
+ * columns of its items; with these entries it also computes and trains them, and the ranks exchange
+ * [global rows][n_hidden] blocks instead (0.6 MB):
+ *   aae_set_doc_l1                 slice handle: L1 norms of the COMPLETE documents, indexed by document id (the batch it
+ *                                  sees holds only its own columns; F.normalize(x, 1) divides by the whole row,
+ *                                  aae.py:133)
+ *   aae_set_first_layer_external   replica handle: AAE_T_ACT_A1 is filled by the caller before aae_ae_forward /
+ *                                  aae_disc_step, dL/d(a1) of the ae / gen phase is left in AAE_T_ACT_GA1, enc.lin1 is
+ *                                  neither read nor updated here; the bias (AAE_T_ENC_B1) stays a small replicated
+ *                                  parameter: its gradient is exported with the other small layers'
+ *   aae_first_layer_forward        slice handle: its items' share of x * enc.lin1^T for the (global) batch -> its
+ *                                  AAE_T_ACT_A1; bias_dev (the replica's AAE_T_ENC_B1) on exactly one share, else
+ *                                  NULL.  batch != NULL opens the handle's step
+ *                                  (aae_output_layer_step(batch = NULL) continues it), NULL = the running batch again
+ *                                  (Enc_eval of disc_step, aae.py:722, after enc_optim's update)
+ *   [reduce-scatter the slices' ACT_A1 over the ranks -> the replica's ACT_A1 rows]
+ *   [all-gather the replicas' ACT_GA1 -> the slice handle's ACT_GA1]
+ *   aae_first_layer_update         slice handle: x^T * dL/d(a1) on its rows of enc.lin1 and optimiser `which` (0
+ *                                  enc_optim after the ae phase, 2 gen_optim after gen_step) on them */
+int aae_set_doc_l1(aae_handle h, const float* doc_l1_dev);
+int aae_set_first_layer_external(aae_handle h, int on);
+int aae_first_layer_forward(aae_handle h, const aae_batch* batch, const float* bias_dev, void* stream);
+int aae_first_layer_update(aae_handle h, const float* ga1_dev, int64_t ld, int which, void* stream);
 
 /* CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute, reduced over the
  * document's (batch-padded) value list and concatenated to the code.  The table and its optimiser state belong to

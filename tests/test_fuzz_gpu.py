@@ -159,6 +159,8 @@ def test_random_long_run_and_execution_paths_match_oracle(seed):
     from oracle.dense_torch_port import init_params
     r = np.random.default_rng(5000 + seed)
     path = str(r.choice(["fused", "replicated", "vocab", "wide"]))
+    if path == "vocab" and seed % 2:
+        path = "vocab2"                             # enc.lin1 with the item slice as well (aae_first_layer_*)
     N = int(r.integers(40, 400))
     h = int(r.integers(208, 300)) if path == "wide" else int(r.integers(8, 120))
     c = int(r.integers(2, 40))
@@ -183,7 +185,7 @@ def test_random_long_run_and_execution_paths_match_oracle(seed):
         else:
             sl = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
             sl.load_params(params)
-            dp = VocabParallelAAE(dev, sl, _Solo(), N)
+            dp = VocabParallelAAE(dev, sl, _Solo(), N, shard_first_layer=path == "vocab2")
             run = lambda csr, Bs, zr: dp.step(csr, 0, Bs, csr, 0, Bs, z_real=zr)                   # noqa: E731
             losses = lambda: (dp.recon_loss(),) + tuple(dev.losses()[1:])                          # noqa: E731
     for s in range(steps):
@@ -194,7 +196,7 @@ def test_random_long_run_and_execution_paths_match_oracle(seed):
         want = ora.partial_fit(ip, idx, val, zr)
         if s % 8 == 0 or s == steps - 1:
             np.testing.assert_allclose(losses(), want, rtol=2e-4, atol=5e-6, err_msg=f"{path} N={N} h={h} c={c} B={B} step {s}")
-    if path == "vocab":
+    if path in ("vocab", "vocab2"):
         dp.gather_output_layer()
     got = dev.state_dict()
     for k, w in ora.p.items():
@@ -291,7 +293,7 @@ def test_random_decoder_and_vae_steps_match_oracle(seed):
         _close_enough(got[k], w, 5e-5, 6e-3, f"vae N={N} h={h} c={c} inc={inc} B={B} {k}")
 
 
-@pytest.mark.parametrize("scheme", ["vocab", "replicated"])
+@pytest.mark.parametrize("scheme", ["vocab", "replicated", "vocab2"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "6"))))
 def test_random_multi_rank_runs_match_oracle(seed, scheme):
     """Both data-parallel drivers with 2-4 ranks as threads on this GPU over random shapes: vocabularies that do not
@@ -353,16 +355,20 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
             sl = HipAAE(hi - lo, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", **kw)
             sl.load_params(sp_params)
             slices[rk] = sl
-            vp = VocabParallelAAE(m, sl, dist, N)
+            vp = VocabParallelAAE(m, sl, dist, N, shard_first_layer=scheme == "vocab2")
             for ip, idx, val, masks, zr, cond, want in steps:
                 X = sp.csr_matrix((val, idx, ip), shape=(B, N))
                 mk = None if masks is None else [k[rk * Bl:(rk + 1) * Bl] for k in masks]
+                if scheme == "vocab2":                   # the slice sees its columns only: the rows' complete L1 norms
+                    sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=m.device))
                 vp.step(DeviceCSR(X, m.device), rk * Bl, Bl, DeviceCSR(X[:, lo:hi], m.device), 0, B,
                         cond=torch.as_tensor(cond[rk * Bl:(rk + 1) * Bl], device=m.device) if inc else None, masks=mk,
                         z_real=zr[rk * Bl:(rk + 1) * Bl])
                 loss = vp.recon_loss()
                 if rk == 0:
                     np.testing.assert_allclose(loss, want[0], rtol=5e-5)
+            if scheme == "vocab2":
+                vp.gather_output_layer()                 # enc.lin1 and dec.lin3 of every slice into every replica
         except BaseException as e:              # noqa: B902 - a dead rank must not leave the others at a barrier
             errors.append((rk, e))
             dist.bar.abort()

@@ -849,10 +849,11 @@ def _dp_corpus():
 
 
 @pytest.mark.parametrize("adversarial", [False, True])
-@pytest.mark.parametrize("mode", ["vocab", "replicated"])
+@pytest.mark.parametrize("mode", ["vocab", "vocab_out", "replicated"])
 def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
     """fit() on two ranks - batches of 40 documents, 20 per rank, in 'vocab' mode each rank owning 250 of the 500 items'
-    output rows - against one process: same parameters, same predictions.  Plain AutoEncoder without dropout, and the
+    rows of dec.lin3 AND columns of enc.lin1 ('vocab_out': of dec.lin3 only) - against one process: same parameters, same
+    predictions.  Plain AutoEncoder without dropout, and the
     adversarial model with dropout + prior drawn by the device generator (keyed by global row, one seed)."""
     import torch.multiprocessing as mp
     import aaerec.aae                               # noqa: F401  (seeds torch at import: import before seeding below)
@@ -861,7 +862,7 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
         ret = mgr.dict()
         mp.spawn(_fit_worker, args=(2, port, mode, ret, None, adversarial), nprocs=2, join=True)
         got = dict(ret)
-    assert got["sliced"] == (mode == "vocab")
+    assert got["sliced"] == (mode != "replicated")
     X = _dp_corpus()
     np.random.seed(5)
     torch.manual_seed(5)
@@ -873,7 +874,7 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
         d = np.abs(got["state"][k] - w)
         assert (d > tol).sum() <= max(8, 0.01 * d.size) and d.max() < 0.02, f"{mode} {k}: {(d > tol).sum()} off, max {d.max():.2e}"
     np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=10 * tol)
-    if mode == "vocab":          # (the replicated scheme reports each rank's loss over its own share)
+    if mode != "replicated":     # (the replicated scheme reports each rank's loss over its own share)
         assert abs(got["loss"] - one.last_losses[0]) < 1e-5
 
 

@@ -3,7 +3,7 @@
 w=${1:-8}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-VR_STEPS=100 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/vr_prof -o run -- python3 $root/tools/vocab_rank_time.py $w > $root/gpurun_out/vr_prof.log 2>&1
+VR_STEPS=100 VR_SCHEMES=${VR_SCHEMES:-vocab} rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/vr_prof -o run -- python3 $root/tools/vocab_rank_time.py $w > $root/gpurun_out/vr_prof.log 2>&1
 cd $root
 find gpurun_out/vr_prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/vr_world${w}_kernel_stats.csv \;
 rm -rf gpurun_out/vr_prof

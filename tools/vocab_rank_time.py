@@ -70,44 +70,62 @@ def timeit(step, steps=int(os.environ.get('VR_STEPS', 200)), warm=int(os.environ
 
 
 csr = DeviceCSR(X, dev)
+SCHEMES = os.environ.get("VR_SCHEMES", "replicated,vocab,both").split(",")
 # ---- replicated decoder (the current default for N > 1) -------------------------------------------------------
-m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
-m.load_params(params)
-d1 = EchoDist(world)
-dp = DataParallelAAE(m, d1, shard_decoder=True if N % world == 0 else False)
-t_dp = timeit(lambda i: dp.step(csr, (i % NB) * Bg, B, global_rows=Bg))
-dp.wait_pending()
-per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d1.bytes.items()}
-print(f"world {world}: replicated decoder   {t_dp:.3f} ms/step of compute per rank; exchanged per step: "
-      + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
-del dp, m
-torch.cuda.empty_cache()
+if "replicated" in SCHEMES:
+    m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
+    m.load_params(params)
+    d1 = EchoDist(world)
+    dp = DataParallelAAE(m, d1, shard_decoder=True if N % world == 0 else False)
+    t_dp = timeit(lambda i: dp.step(csr, (i % NB) * Bg, B, global_rows=Bg))
+    dp.wait_pending()
+    per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d1.bytes.items()}
+    print(f"world {world}: replicated decoder   {t_dp:.3f} ms/step of compute per rank; exchanged per step: "
+          + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
+    del dp, m
+    torch.cuda.empty_cache()
 # ---- vocabulary-sharded output layer ---------------------------------------------------------------------------
 lo, hi = item_slice(N, 0, world)
-m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
-m.load_params(params)
 sp = dict(params)
 sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
 sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
 BLOCKED = os.environ.get("VR_BLOCKED", "0") != "0"      # 1: row-blocked fused launches for the slice (default: the three-kernel path)
-sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED)
-sl.load_params(sp)
 slice_csr = DeviceCSR(X[:, lo:hi], dev)
-d2 = EchoDist(world)
-vp = VocabParallelAAE(m, sl, d2, N)
-t_vp = timeit(lambda i: vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg))
-sl.profile_enable(True)
-for i in range(50):
-    vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)
-torch.cuda.synchronize()
-names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt"]
-parts = []
-for k in range(9):
-    ms, n = sl.profile_read(k)
-    if n:
-        parts.append(f"{names[k]} {n // 50} x {1e3 * ms / n:.1f} us")
-sl.profile_enable(False)
-print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
-per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d2.bytes.items()}
-print(f"world {world}: vocabulary-sharded ({'row-blocked fused' if BLOCKED else 'three-kernel'} output layer)   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
-      + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
+if "vocab" in SCHEMES:
+    m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
+    m.load_params(params)
+    sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED)
+    sl.load_params(sp)
+    d2 = EchoDist(world)
+    vp = VocabParallelAAE(m, sl, d2, N)
+    t_vp = timeit(lambda i: vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg))
+    sl.profile_enable(True)
+    for i in range(50):
+        vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)
+    torch.cuda.synchronize()
+    names = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt"]
+    parts = []
+    for k in range(9):
+        ms, n = sl.profile_read(k)
+        if n:
+            parts.append(f"{names[k]} {n // 50} x {1e3 * ms / n:.1f} us")
+    sl.profile_enable(False)
+    print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
+    per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d2.bytes.items()}
+    print(f"world {world}: vocabulary-sharded ({'row-blocked fused' if BLOCKED else 'three-kernel'} output layer)   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
+          + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
+    del vp, m, sl
+    torch.cuda.empty_cache()
+# ---- both vocabulary-wide matrices with the item slices (enc.lin1 too) ------------------------------------------
+if "both" in SCHEMES:
+    m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
+    m.load_params(params)
+    sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED)
+    sl.load_params(sp)
+    sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=dev))
+    d3 = EchoDist(world)
+    vp = VocabParallelAAE(m, sl, d3, N, shard_first_layer=True)
+    t_vp2 = timeit(lambda i: vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg))
+    per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d3.bytes.items()}
+    print(f"world {world}: both vocabulary-wide layers sharded   {t_vp2:.3f} ms/step of compute per rank; exchanged per step: "
+          + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
