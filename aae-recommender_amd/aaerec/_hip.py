@@ -110,7 +110,7 @@ _PROTOS = {
     "aae_set_doc_l1": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_set_first_layer_external": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_first_layer_forward": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
-    "aae_first_layer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "aae_first_layer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
     "aae_cat_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p]),
     "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -122,6 +122,7 @@ _PROTOS = {
     "aae_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "aae_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_join_output_layer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_set_input_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -417,6 +418,7 @@ class HipAAE:
         self._finalizer = weakref.finalize(self, _destroy_handle, lib, h, self.arena, os.getpid())
         _check(lib.aae_set_lr(self.handle, float(gen_lr), float(reg_lr)))
         self._keep = []   # device buffers of the running step
+        self._ga1_ld = None
 
     def close(self):
         """Destroy the handle now (waits for its side stream)."""
@@ -430,7 +432,10 @@ class HipAAE:
     def tensor(self, tid, padded=False):
         """float32 view [rows, cols] (strided by ld) of a tensor of the model.  (The current stream first waits for the
         deferred optimiser launch of the last step, if one is pending: a view is about to read or write what it touches.)"""
-        self.join()
+        if tid >= T_ACT_Z:          # activations: only the deferred optimiser launch reads them (a prefetch does not)
+            _check(self.lib.aae_join_output_layer(self.handle, self._stream()))
+        else:
+            self.join()
         info = AaeTensor()
         _check(self.lib.aae_tensor_info(self.handle, tid, C.byref(info)))
         flat = self.arena[info.byte_offset: info.byte_offset + info.rows * info.ld * 4].view(torch.float32)
@@ -664,10 +669,18 @@ class HipAAE:
             _check(self.lib.aae_first_layer_forward(self.handle, C.byref(b) if b is not None else None, _ptr(bias),
                                                     self._stream()))
 
-    def first_layer_update(self, which):
-        """enc.lin1's rows of this handle's items (+ the bias) from ga1_rows() of the running batch, optimiser `which`."""
+    def first_layer_update(self, which, ga1=None, rows_per_block=0, block_stride=0):
+        """enc.lin1's rows of this handle's items from dL/d(a1) of the running batch, optimiser `which`.  ga1 = None:
+        ga1_rows(); else a float32 device tensor holding blocks of `rows_per_block` rows (leading dimension = ga1_rows()'s),
+        `block_stride` floats apart (the ranks' packets of an all-gather, read where they landed)."""
+        if ga1 is not None:         # (the caller's buffer: it must stay alive until the stream has passed this call)
+            assert ga1.is_cuda and ga1.dtype == torch.float32 and ga1.is_contiguous()
+        if ga1 is not None and self._ga1_ld is None:
+            self._ga1_ld = self.ga1_rows(1).stride(0)
+        ld = self._ga1_ld if ga1 is not None else 0
         with torch.cuda.device(self.device):
-            _check(self.lib.aae_first_layer_update(self.handle, None, 0, int(which), self._stream()))
+            _check(self.lib.aae_first_layer_update(self.handle, _ptr(ga1), ld, int(rows_per_block), int(block_stride),
+                                                   int(which), self._stream()))
 
     def first_layer_bias(self):
         """enc.lin1's bias as a device view (what one share of first_layer_forward adds)."""

@@ -458,6 +458,9 @@ class AdversarialAutoEncoder:
                     if lo is None:
                         continue
                     self._dp.global_rows = stop - start
+                    # (naming the slice model's next batch with _hip.prefetch is possible - aae_first_layer_forward
+                    #  honours it - but measured as a loss there: the cross-stream marks cost the 40-launch step of a
+                    #  rank more than the 16 us of list building they move off it, tools/vocab_rank_time.py VR_PREFETCH=1)
                     # first-layer packets: no share of this batch names more distinct items than it has entries
                     shares = np.array_split(row_len[perm[start:stop]], self._dp.world)
                     self._dp.w1_rows = int(max(sh.sum() for sh in shares)) + 8

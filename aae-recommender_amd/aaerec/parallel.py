@@ -287,6 +287,7 @@ class VocabParallelAAE(DataParallelAAE):
         # _step_both_sharded); the caller gives the slice model the documents' complete L1 norms (set_doc_l1)
         self.shard_first = bool(shard_first_layer)
         self._pk = self._pk_all = None
+        self._view_cache = {}
         if self.shard_first:
             model.set_first_layer_external(True)
 
@@ -325,45 +326,61 @@ class VocabParallelAAE(DataParallelAAE):
         self._coll_last = tuple(self._coll)
 
     # ---- both vocabulary-wide matrices with their item slices -----------------------------------------------------
-    def _first_layer(self, n_rows, global_rows, open_step=None):
+    def _views(self, n_rows, global_rows):
+        """The arena views a step exchanges, looked up once per batch shape (each lookup is a few library calls: the
+        step is a chain of ~40 short launches and the host must stay ahead of it).  Views do not wait for a deferred
+        optimiser launch of the slice model: step() joins it once."""
+        key = (n_rows, global_rows)
+        v = self._view_cache.get(key)
+        if v is None:
+            m, sl = self.model, self.slice
+            v = dict(a1=m.a1_rows(n_rows).view(-1), a1_all=sl.a1_rows(global_rows).view(-1),
+                     dh2=m.dh2_rows(n_rows).view(-1), dh2_all=sl.dh2_rows(global_rows).view(-1),
+                     da2=m.da2_rows(n_rows).view(-1), da2_all=sl.da2_rows(global_rows).view(-1),
+                     ga1=m.ga1_rows(n_rows).reshape(-1),
+                     bias=m.first_layer_bias() if self.dist.get_rank(self.group) == 0 else None,
+                     small_ae=[t.reshape(-1) for t in m.grad_buckets("enc_dec_small")],
+                     small_gen=[t.reshape(-1) for t in m.grad_buckets("enc_small")],
+                     disc=m.grad_buckets(O_DISC))
+            self._view_cache = {key: v}               # (one shape at a time: the tail batch of an epoch replaces it)
+        return v
+
+    def _first_layer(self, v, open_step=None):
         """The slices' shares of x * enc.lin1^T for the global batch, summed, this rank's rows -> model.a1_rows
         (rank 0's share carries the bias)."""
-        m, sl, d = self.model, self.slice, self.dist
-        bias = m.first_layer_bias() if d.get_rank(self.group) == 0 else None
+        sl, d = self.slice, self.dist
         if open_step is not None:
-            slice_csr, g_row_start, g_rows = open_step
-            sl.first_layer_forward(slice_csr, g_row_start, global_rows, rows=g_rows, bias=bias)
+            slice_csr, g_row_start, global_rows, g_rows = open_step
+            sl.first_layer_forward(slice_csr, g_row_start, global_rows, rows=g_rows, bias=v["bias"])
         else:
-            sl.first_layer_forward(bias=bias)
-        part = sl.a1_rows(global_rows)
-        self._count(part)
-        d.reduce_scatter_tensor(m.a1_rows(n_rows).view(-1), part.view(-1), op=d.ReduceOp.SUM, group=self.group)
+            sl.first_layer_forward(bias=v["bias"])
+        self._count(v["a1_all"])
+        d.reduce_scatter_tensor(v["a1"], v["a1_all"], op=d.ReduceOp.SUM, group=self.group)
 
-    def _exchange_ga1(self, n_rows, global_rows, riders):
-        """dL/d(a1) of every rank's documents -> the slice model's ga1_rows (rank-major = global batch order); `riders`
-        (small gradient spans due at the same point) travel behind the rows and come back summed over the ranks in one
-        fixed order - bitwise the same everywhere."""
+    def _exchange_ga1(self, n_rows, ga1, riders):
+        """dL/d(a1) of every rank's documents gathered (rank-major = global batch order; returned as (buffer, rows per
+        block, block stride) for first_layer_update); `riders` (small gradient spans due at the same point) travel behind
+        the rows and come back summed over the ranks in one fixed order - bitwise the same everywhere."""
         import torch
-        m, sl, d = self.model, self.slice, self.dist
-        ga1 = m.ga1_rows(n_rows)
+        d = self.dist
         n0 = ga1.numel()
         total = n0 + sum(t.numel() for t in riders)
         if self._pk is None or self._pk.numel() != total:
             self._pk = ga1.new_empty(total)
             self._pk_all = ga1.new_empty(total * self.world)
         pk, allp = self._pk, self._pk_all
-        torch.cat([ga1.reshape(-1)] + [t.reshape(-1) for t in riders], out=pk)
+        torch.cat([ga1] + riders, out=pk)
         if self.world == 1:
             allp = pk
         else:
             self._count(pk)
             d.all_gather_into_tensor(allp, pk, group=self.group)
         peers = allp.view(self.world, total)
-        sl.ga1_rows(global_rows).view(self.world, n0).copy_(peers[:, :n0])
         off = n0
         for t in riders:
-            torch.sum(peers[:, off:off + t.numel()], dim=0, out=t.reshape(-1))
+            torch.sum(peers[:, off:off + t.numel()], dim=0, out=t)
             off += t.numel()
+        return allp, n_rows, total          # the slice reads the rows where they landed (first_layer_update(ga1=...))
 
     def _step_both_sharded(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows, g_rows, cond, masks,
                            z_real):
@@ -377,28 +394,31 @@ class VocabParallelAAE(DataParallelAAE):
             a1 reduce-scatter | dh2 all-gather | dA2 reduce-scatter | ga1 + enc/dec small all-gather |
             a1 reduce-scatter (Enc_eval) | disc all-reduce | ga1 + enc small all-gather."""
         m, sl, d = self.model, self.slice, self.dist
-        self._first_layer(n_rows, global_rows, open_step=(slice_csr, g_row_start, g_rows))
+        sl.join()                                   # (a deferred optimiser launch of the slice model's last step, if any)
+        v = self._views(n_rows, global_rows)
+        self._first_layer(v, open_step=(slice_csr, g_row_start, global_rows, g_rows))
         m.ae_forward(csr, row_start, n_rows, rows=rows, cond=cond, masks=masks, z_real=z_real)
-        self._count(m.dh2_rows(n_rows))
-        d.all_gather_into_tensor(sl.dh2_rows(global_rows).view(-1), m.dh2_rows(n_rows).view(-1), group=self.group)
+        self._count(v["dh2"])
+        d.all_gather_into_tensor(v["dh2_all"], v["dh2"], group=self.group)
         sl.output_layer_step()                      # continues the slice model's step (opened by first_layer_forward)
-        self._count(sl.da2_rows(global_rows))
-        d.reduce_scatter_tensor(m.da2_rows(n_rows).view(-1), sl.da2_rows(global_rows).view(-1), op=d.ReduceOp.SUM,
-                                group=self.group)
+        self._count(v["da2_all"])
+        d.reduce_scatter_tensor(v["da2"], v["da2_all"], op=d.ReduceOp.SUM, group=self.group)
         m.ae_backward()
-        self._exchange_ga1(n_rows, global_rows, m.grad_buckets("enc_dec_small"))
+        g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"])
         m.apply_updates(O_ENC)
         m.apply_updates(O_DEC, skip=m.big_tensor_id)
-        sl.first_layer_update(O_ENC)
+        sl.first_layer_update(O_ENC, g, rpb, bs)
         if not getattr(m, "ae_only", False):
-            self._first_layer(n_rows, global_rows)
+            self._first_layer(v)
             m.disc_step()
-            self._allreduce(O_DISC)
+            for t in v["disc"]:
+                self._count(t)
+                d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
             m.apply_updates(O_DISC)
             m.gen_step()
-            self._exchange_ga1(n_rows, global_rows, m.grad_buckets("enc_small"))
+            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"])
             m.apply_updates(O_GEN)
-            sl.first_layer_update(O_GEN)
+            sl.first_layer_update(O_GEN, g, rpb, bs)
         self._gathered = False
         self._coll_last = tuple(self._coll)
 

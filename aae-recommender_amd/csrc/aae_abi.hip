@@ -1433,6 +1433,14 @@ int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld) 
     return AAE_OK;
 }
 
+// ... the deferred optimiser launch alone (activation views: the next batch's prefetch - aae_prefetch_batch - touches
+// enc.lin1 and its bookkeeping only, and keeps running beside the step)
+int aae_join_output_layer(aae_handle h, void* stream) {
+    if (!h) return fail(AAE_EINVAL, "handle is NULL");
+    if (h->opt_pending) { HIPCHK(hipStreamWaitEvent(S(stream), h->ev_opt, 0)); h->opt_pending = h->pf_pending = false; }
+    return AAE_OK;
+}
+
 int aae_join(aae_handle h, void* stream) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
     return join_deferred(h, S(stream));
@@ -2206,7 +2214,7 @@ int aae_output_layer_step(aae_handle m, const aae_batch* batch, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->vae) return fail(AAE_ESTATE, "aae_output_layer_step: not in VAE mode");
     hipStream_t s = S(stream);
-    TRY(join_deferred(m, s));
+    if (batch || m->opt_pending) TRY(join_deferred(m, s));      // (batch = NULL: a prefetch started by this step keeps running)
     if (batch) {
         TRY(set_batch(m, batch));
         remember_inject(m, nullptr, true);
@@ -2276,15 +2284,23 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
     if (m->vae || m->cfg.grad_mode != AAE_GRAD_FUSED) return fail(AAE_ESTATE, "aae_first_layer_forward: fused optimiser, no VAE mode");
     hipStream_t s = S(stream);
     TRY(join_deferred(m, s));
+    bool pf = false;
     if (batch) {
         TRY(set_batch(m, batch));
         remember_inject(m, nullptr, true);
-        m->hstep++; m->pf_armed = false; m->pf_built = false;
+        m->hstep++;
+        // (as in aae_step: the list of this batch's distinct items and their catch-up were built while the previous step
+        //  ran, if the caller named the batch with aae_prefetch_batch)
+        const bool ahead = m->pf_built && m->pf_step == m->hstep && same_batch(m->pf_built_batch, *batch) && m->lazy;
+        m->pf_built = false;
+        if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
         hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
-                           m->stamp, m->ucount, m->losses);
+                           ahead ? (int*)nullptr : m->stamp, ahead ? (int*)nullptr : m->ucount, m->losses);
         LAUNCHCHK("advance_step");
-        if (m->lazy) TRY(lazy_prepare(m, -1, false, s));
+        if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
         m->enc_bwd_done = false; m->fuse_enc_bwd = false; m->dense_step = false;
+        pf = m->pf_armed && m->side && m->mark2 && m->lazy;
+        if (m->pf_armed && !pf) m->pf_armed = false;
     } else if (!m->have_batch) {
         return fail(AAE_ESTATE, "aae_first_layer_forward(batch = NULL) without a running batch");
     }
@@ -2292,33 +2308,38 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         ProfScope ps(m, AAE_K_ENC_GATHER, s);
         const size_t shm = (size_t)16 * r4(m->h) * sizeof(float);
         DropSpec none; memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(enc_gather_kernel, dim3(m->rows), dim3(1024), (uint32_t)shm, s, m->bv, (const float*)m->P[P_W1T].p,
-                           m->ldw1, bias_dev, m->h,
-                           (int)m->cfg.normalize_inputs, m->a1.p, (float*)nullptr, m->ldh, (int)m->cfg.activation, none,
-                           (uint64_t)m->cfg.seed, (const long long*)m->step_ctr, m->rscale, m->doc_l1);
+        hipExtLaunchKernelGGL(enc_gather_kernel, dim3(m->rows), dim3(1024), (uint32_t)shm, s, nullptr, pf ? m->ev_head : nullptr, 0,
+                              m->bv, (const float*)m->P[P_W1T].p, m->ldw1, bias_dev, m->h, (int)m->cfg.normalize_inputs,
+                              m->a1.p, (float*)nullptr, m->ldh, (int)m->cfg.activation, none, (uint64_t)m->cfg.seed,
+                              (const long long*)m->step_ctr, m->rscale, m->doc_l1);
         LAUNCHCHK("enc_gather (partial)");
     }
+    if (pf) TRY(launch_prefetch(m));
     if (batch) { m->phase = 1; m->dec_hidden_done = true; }       // aae_output_layer_step(batch = NULL) may follow on this handle
     return AAE_OK;
 }
 
 // The first layer's weight gradient from dL/d(a1) of the running batch (ga1_dev [rows][ld], NULL = AAE_T_ACT_GA1 of this
-// handle) restricted to this handle's items, and optimiser `which` (enc_optim 0 / gen_optim 2) on its rows.  (The bias is
+// handle; rows_per_block > 0: blocks of that many rows, block_stride floats apart - the ranks' packets of an all-gather
+// read where they landed) restricted to this handle's items, and optimiser `which` (enc_optim 0 / gen_optim 2) on its rows.  (The bias is
 // a small replicated parameter: its gradient is a column sum of the replicas' own dL/d(a1), aae_ae_backward / aae_gen_step
 // export it with the other small layers'.)
-int aae_first_layer_update(aae_handle m, const float* ga1_dev, int64_t ld, int which, void* stream) {
+int aae_first_layer_update(aae_handle m, const float* ga1_dev, int64_t ld, int32_t rows_per_block, int64_t block_stride,
+                           int which, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->vae || m->cfg.grad_mode != AAE_GRAD_FUSED) return fail(AAE_ESTATE, "aae_first_layer_update: fused optimiser, no VAE mode");
     if (which != O_ENC && which != O_GEN) return fail(AAE_EINVAL, "which must be enc_optim (0) or gen_optim (2)");
     if (!m->have_batch) return fail(AAE_ESTATE, "aae_first_layer_update without a running batch");
     if (ga1_dev && ld != m->ldh) return fail(AAE_EINVAL, "aae_first_layer_update: ld must equal the leading dimension of AAE_T_ACT_GA1");
+    if (rows_per_block < 0 || (rows_per_block > 0 && (!ga1_dev || block_stride < (int64_t)rows_per_block * ld)))
+        return fail(AAE_EINVAL, "aae_first_layer_update: blocks need ga1_dev and block_stride >= rows_per_block * ld");
     hipStream_t s = S(stream);
     const float* ga1 = ga1_dev ? ga1_dev : m->gb3.p;
     // rows of an item slice are short (a few entries each, a rare long one): 1/8 of the workgroups the longest row
     // would fill in one pass, each looping over its share of the entries
     const int ny = std::max(2, std::min(m->chunks * 4, (m->chunks + 1) / 2));
     hipLaunchKernelGGL(enc_scatter_kernel, dim3(m->rows, ny), dim3(256), 0, s, m->bv, ga1, m->ldh, m->h, m->rscale,
-                       m->Gr[P_W1T].p, m->ldw1, 0);
+                       m->Gr[P_W1T].p, m->ldw1, 0, (int)rows_per_block, (size_t)block_stride);
     LAUNCHCHK("enc_scatter (slice)");
     const int set = which == O_GEN ? 1 : 0;
     {

@@ -93,10 +93,12 @@ __global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__
 // atomics run at full rate for).  zero != 0: store zeros instead (resets the touched rows after
 // the optimiser consumed them).
 // ---------------------------------------------------------------------------------------
+// rpb > 0: ga1 comes in blocks of rpb rows, bstride floats apart (the ranks' packets of an all-gather, read where they landed)
 __device__ __forceinline__ void enc_scatter_body(const BatchView& bv, const float* __restrict__ ga1, int ld, int h,
                                                  const float* __restrict__ rscale, float* __restrict__ gW1T, int ldw,
-                                                 int zero, int b, int by, int ny) {
+                                                 int zero, int b, int by, int ny, int rpb = 0, size_t bstride = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* grow = rpb > 0 ? ga1 + (size_t)(b / rpb) * bstride + (size_t)(b % rpb) * ld : ga1 + (size_t)b * ld;
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
     const float s = zero ? 0.f : rscale[b];
@@ -108,15 +110,16 @@ __device__ __forceinline__ void enc_scatter_body(const BatchView& bv, const floa
         float* dst = gW1T + (size_t)idx * ldw;
         for (int c = lane; c < h; c += 64) {
             if (zero) dst[c] = 0.f;
-            else atomicAdd(dst + c, x * ga1[(size_t)b * ld + c]);
+            else atomicAdd(dst + c, x * grow[c]);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
                                                           int h, const float* __restrict__ rscale,
-                                                          float* __restrict__ gW1T, int ldw, int zero) {
-    enc_scatter_body(bv, ga1, ld, h, rscale, gW1T, ldw, zero, blockIdx.x, blockIdx.y, gridDim.y);
+                                                          float* __restrict__ gW1T, int ldw, int zero, int rpb = 0,
+                                                          size_t bstride = 0) {
+    enc_scatter_body(bv, ga1, ld, h, rscale, gW1T, ldw, zero, blockIdx.x, blockIdx.y, gridDim.y, rpb, bstride);
 }
 
 // bias gradient of the first encoder layer for 64 columns, 256 threads (4 waves stride the rows), then its

@@ -278,11 +278,16 @@ int aae_ae_backward(aae_handle h, const float* dA2_dev, int64_t dA2_ld, void* st
  *   [reduce-scatter the slices' ACT_A1 over the ranks -> the replica's ACT_A1 rows]
  *   [all-gather the replicas' ACT_GA1 -> the slice handle's ACT_GA1]
  *   aae_first_layer_update         slice handle: x^T * dL/d(a1) on its rows of enc.lin1 and optimiser `which` (0
- *                                  enc_optim after the ae phase, 2 gen_optim after gen_step) on them */
+ *                                  enc_optim after the ae phase, 2 gen_optim after gen_step) on them; ga1_dev = NULL:
+ *                                  its ACT_GA1, else [rows][ld] - or, rows_per_block > 0, the gathered packets
+ *                                  themselves: block r = rows r * rows_per_block .. at ga1_dev + r * block_stride floats
+ * aae_prefetch_batch on the slice handle names the NEXT global batch: its distinct-item list and deferred-Adam catch-up
+ * then run beside the running step, as for aae_step. */
 int aae_set_doc_l1(aae_handle h, const float* doc_l1_dev);
 int aae_set_first_layer_external(aae_handle h, int on);
 int aae_first_layer_forward(aae_handle h, const aae_batch* batch, const float* bias_dev, void* stream);
-int aae_first_layer_update(aae_handle h, const float* ga1_dev, int64_t ld, int which, void* stream);
+int aae_first_layer_update(aae_handle h, const float* ga1_dev, int64_t ld, int32_t rows_per_block, int64_t block_stride,
+                           int which, void* stream);
 
 /* CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute, reduced over the
  * document's (batch-padded) value list and concatenated to the code.  The table and its optimiser state belong to
@@ -415,6 +420,9 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
  * dense input; plain autoencoder, fp32, fused optimiser); noise_dev must stay valid until the step has run. */
 int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld);
 int aae_join(aae_handle h, void* stream);
+/* ... the deferred optimiser launch alone: enough before reading or writing the AAE_T_ACT_* tensors (a prefetch started
+ * with aae_prefetch_batch touches enc.lin1 and its bookkeeping only and keeps running). */
+int aae_join_output_layer(aae_handle h, void* stream);
 /* The epoch loop (aae.py:808-831) knows the batch AFTER the one it is about to run.  Named here before the step that
  * precedes it (aae_step / aae_ae_encode / aae_ae_forward), that batch's share of the step-opening work - the list of
  * its distinct items and the replay of the deferred zero-gradient Adam steps on their enc.lin1 rows (what
