@@ -254,6 +254,20 @@ def item_slice(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class _Views:
+    """name -> view, looked up once (stable) or on every access."""
+
+    def __init__(self, make, stable):
+        self.make, self.stable, self.have = make, stable, {}
+
+    def __getitem__(self, k):
+        if not self.stable:
+            return self.make[k]()
+        if k not in self.have:
+            self.have[k] = self.make[k]()
+        return self.have[k]
+
+
 class VocabParallelAAE(DataParallelAAE):
     """Documents are sharded over the ranks for everything except the decoder's output layer, which is sharded over
     the VOCABULARY.
@@ -327,21 +341,23 @@ class VocabParallelAAE(DataParallelAAE):
 
     # ---- both vocabulary-wide matrices with their item slices -----------------------------------------------------
     def _views(self, n_rows, global_rows):
-        """The arena views a step exchanges, looked up once per batch shape (each lookup is a few library calls: the
-        step is a chain of ~40 short launches and the host must stay ahead of it).  Views do not wait for a deferred
-        optimiser launch of the slice model: step() joins it once."""
+        """The arena views a step exchanges, looked up once per batch shape (each lookup is a few library calls, and
+        the step is a chain of ~40 short launches).  Views do not wait for a deferred optimiser launch of the slice
+        model: step() joins it once.  (A model whose buffers are not fixed arena views - the CPU stand-ins of the gloo
+        tests - says so with stable_views = False and is asked every time.)"""
         key = (n_rows, global_rows)
         v = self._view_cache.get(key)
         if v is None:
             m, sl = self.model, self.slice
-            v = dict(a1=m.a1_rows(n_rows).view(-1), a1_all=sl.a1_rows(global_rows).view(-1),
-                     dh2=m.dh2_rows(n_rows).view(-1), dh2_all=sl.dh2_rows(global_rows).view(-1),
-                     da2=m.da2_rows(n_rows).view(-1), da2_all=sl.da2_rows(global_rows).view(-1),
-                     ga1=m.ga1_rows(n_rows).reshape(-1),
-                     bias=m.first_layer_bias() if self.dist.get_rank(self.group) == 0 else None,
-                     small_ae=[t.reshape(-1) for t in m.grad_buckets("enc_dec_small")],
-                     small_gen=[t.reshape(-1) for t in m.grad_buckets("enc_small")],
-                     disc=m.grad_buckets(O_DISC))
+            v = _Views(dict(
+                a1=lambda: m.a1_rows(n_rows).view(-1), a1_all=lambda: sl.a1_rows(global_rows).view(-1),
+                dh2=lambda: m.dh2_rows(n_rows).view(-1), dh2_all=lambda: sl.dh2_rows(global_rows).view(-1),
+                da2=lambda: m.da2_rows(n_rows).view(-1), da2_all=lambda: sl.da2_rows(global_rows).view(-1),
+                ga1=lambda: m.ga1_rows(n_rows).reshape(-1),
+                bias=lambda: m.first_layer_bias() if self.dist.get_rank(self.group) == 0 else None,
+                small_ae=lambda: [t.reshape(-1) for t in m.grad_buckets("enc_dec_small")],
+                small_gen=lambda: [t.reshape(-1) for t in m.grad_buckets("enc_small")],
+                disc=lambda: m.grad_buckets(O_DISC)), getattr(m, "stable_views", True))
             self._view_cache = {key: v}               # (one shape at a time: the tail batch of an epoch replaces it)
         return v
 

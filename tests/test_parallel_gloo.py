@@ -395,3 +395,200 @@ def test_two_ranks_with_vocabulary_sharded_output_layer_equal_single_process(nam
     np.testing.assert_allclose(np.concatenate([got["v3w0"], got["v3w1"]]), want["dec.lin3.weight"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(np.concatenate([got["v3b0"], got["v3b1"]]), want["dec.lin3.bias"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)
+
+
+# ---- both vocabulary-wide layers with the item slices (VocabParallelAAE(shard_first_layer=True)) -------------------
+class BothLocalReplica(VocabLocalReplica):
+    """The replica with an EXTERNAL first layer (include/aaerec_hip.h: aae_set_first_layer_external): a1_rows() is filled
+    by the caller before ae_forward / disc_step, dL/d(a1) comes back in ga1_rows(); enc.lin1.weight is never touched, its
+    bias stays a replicated small parameter."""
+    stable_views = False            # (numpy buffers, re-created per step: the driver must not cache views of them)
+
+    def __init__(self, params, **kw):
+        super().__init__(params, **kw)
+        h = params["enc.lin1.weight"].shape[0]
+        self._h, self._a1, self._ga1 = h, None, None
+        o = self.o
+        o.encode = self._encode_ext                      # disc_step / gen_step: Enc(...) from the caller's a1
+        o._enc_w1_grad = self._take_ga1                   # ... and dL/d(a1) instead of the first layer's weight gradient
+
+    def set_first_layer_external(self, on=True):
+        pass
+
+    def _buf(self, n):
+        if self._a1 is None or self._a1.shape[0] != n:
+            self._a1, self._ga1 = torch.zeros(n, self._h), torch.zeros(n, self._h)
+
+    def a1_rows(self, n):
+        self._buf(n)
+        return self._a1
+
+    def ga1_rows(self, n):
+        self._buf(n)
+        return self._ga1
+
+    def first_layer_bias(self):
+        return torch.from_numpy(self.o.p["enc.lin1.bias"])
+
+    def _encode_ext(self, indptr, indices, values, masks=None, input_noise=None):
+        o = self.o
+        a1 = self._a1.numpy().copy()
+        a3, cache = o._mlp_fwd("enc", None, masks, first_pre=a1)
+        cache["a1"], cache["s"] = a1, None
+        return o._enc_final_fwd(a3), cache
+
+    def _take_ga1(self, indptr, indices, values, s, ga1):
+        self._ga1.copy_(torch.from_numpy(np.ascontiguousarray(ga1)))
+        return None
+
+    def ae_forward(self, csr, row_start, n_rows, rows=None, cond=None, masks=None, z_real=None):
+        o = self.o
+        o._b = (np.arange(n_rows + 1), None, None)        # (only the row count is read downstream)
+        o._mk = masks if masks is not None else [None] * 12
+        o._zr = z_real
+        z, o._ec = self._encode_ext(None, None, None, (o._mk[0], o._mk[1]))
+        o._z = z
+        _, self._dc = o._mlp_fwd("dec", z, (o._mk[2], o._mk[3]))
+        self._zc = z
+        h = self._dc["h2"].shape[1]
+        self._dh2 = torch.zeros(n_rows, h + 1)
+        self._dh2[:, :h] = torch.from_numpy(self._dc["h2"])
+        self._dh2[:, h] = 1.0
+        self._da2 = torch.zeros(n_rows, h + 1)
+
+    def ae_backward(self):
+        super().ae_backward()                             # (-> o.ae_encoder_backward -> _take_ga1)
+        del self.o.G[0]["enc.lin1.weight"]
+
+    def gen_step(self):
+        self.o.gen_step()
+        del self.o.G[2]["enc.lin1.weight"]
+
+    def grad_buckets(self, which):
+        G = self.o.G
+        if which == "enc_dec_small":
+            return [torch.from_numpy(g) for g in list(G[0].values()) + list(G[1].values())]
+        if which == "enc_small":
+            return [torch.from_numpy(g) for g in G[2].values()]
+        return super().grad_buckets(which)
+
+
+class BothSliceReplica(VocabSliceReplica):
+    """The item-slice model with its columns of enc.lin1 as well: aae_first_layer_forward / aae_first_layer_update
+    (enc_optim and gen_optim keep separate moments, as torch's two Adam instances over the encoder do)."""
+
+    def __init__(self, params, lo, hi, lr, reg_lr, normalize=True):
+        from oracle.aae_oracle import Adam
+        super().__init__(params, lo, hi, lr)
+        self.w1 = {"w1": params["enc.lin1.weight"][:, lo:hi].copy()}
+        self.opt_w1 = {0: Adam(lr), 2: Adam(reg_lr)}
+        self.normalize, self.l1 = normalize, None
+        self._a1 = None
+
+    def join(self):
+        pass
+
+    def set_doc_l1(self, l1):
+        self.l1 = np.asarray(l1, dtype=np.float32)
+
+    def a1_rows(self, n):
+        if self._a1 is None or self._a1.shape[0] != n:
+            self._a1 = torch.zeros(n, self.w1["w1"].shape[0])
+        return self._a1
+
+    def _rows(self):
+        from oracle.aae_oracle import TINY, f32
+        ip, idx, val = self._csr
+        for b in range(self._B):
+            r = self._r0 + b
+            lo, hi = ip[r], ip[r + 1]
+            s = f32(1) / max(self.l1[r], TINY) if self.normalize else f32(1)
+            yield b, idx[lo:hi], (val[lo:hi] * s).astype(f32)
+
+    def first_layer_forward(self, csr=None, row_start=0, n_rows=0, rows=None, bias=None):
+        from oracle.aae_oracle import f32
+        if csr is not None:
+            self._csr, self._r0, self._B = csr, row_start, n_rows
+        W = self.w1["w1"]
+        a1 = np.zeros((self._B, W.shape[0]), dtype=f32)
+        for b, cols, xn in self._rows():
+            a1[b] = W[:, cols] @ xn
+        if bias is not None:
+            a1 += bias.numpy()
+        self.a1_rows(self._B).copy_(torch.from_numpy(a1))
+
+    def output_layer_step(self, *a, **kw):
+        super().output_layer_step(self._csr, self._r0, self._B)
+
+    def first_layer_update(self, which, ga1=None, rows_per_block=0, block_stride=0):
+        from oracle.aae_oracle import f32
+        h = self.w1["w1"].shape[0]
+        blocks = ga1.numpy().reshape(-1, block_stride)[:, :rows_per_block * h].reshape(-1, h)      # rank-major rows
+        g = np.zeros_like(self.w1["w1"])
+        for b, cols, xn in self._rows():
+            np.add.at(g.T, cols, np.outer(xn, blocks[b]).astype(f32))
+        self.opt_w1[which].step(self.w1, {"w1": g})
+
+
+def _worker_both(rank, world, port, name, ret):
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.parallel import VocabParallelAAE, item_slice
+    fx = Fixture(name)
+    N = fx.cfg["N"]
+    lo, hi = item_slice(N, rank, world)
+    kw = fx.model_kwargs()
+    model = BothLocalReplica(fx.init_params(), **kw)
+    sl = BothSliceReplica(fx.init_params(), lo, hi, kw.get("gen_lr", 1e-3), kw.get("reg_lr", 1e-3),
+                          normalize=kw.get("normalize_inputs", True))
+    vp = VocabParallelAAE(model, sl, dist, N, shard_first_layer=True)
+    losses = []
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        B = len(ip) - 1
+        Bl = B // world
+        X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+        Xs = X[:, lo:hi].tocsr()
+        sl.set_doc_l1(np.asarray(abs(X).sum(1)).reshape(-1))
+        masks = fx.masks(s)
+        if masks is not None:
+            masks = [m[rank * Bl:(rank + 1) * Bl] for m in masks]
+        vp.step((ip, idx, val), rank * Bl, Bl, (Xs.indptr, Xs.indices, Xs.data), 0, B, masks=masks,
+                z_real=fx.z[f"step{s}.z_real"][rank * Bl:(rank + 1) * Bl])
+        losses.append(vp.recon_loss())
+    if rank == 0:
+        ret.update({k: v.copy() for k, v in model.o.p.items() if not k.startswith("dec.lin3") and k != "enc.lin1.weight"})
+        ret["recon_losses"] = losses
+    ret[f"v3w{rank}"], ret[f"v3b{rank}"], ret[f"w1{rank}"] = sl.p["w"].copy(), sl.p["b"].copy(), sl.w1["w1"].copy()
+    flat = torch.from_numpy(np.concatenate([v.ravel() for k, v in model.o.p.items()
+                                            if not k.startswith("dec.lin3") and k != "enc.lin1.weight"]))
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(other[0], o) for o in other)          # replicated small layers: bitwise the same
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["step_masks", "step_nodrop_gauss"])
+def test_two_ranks_with_both_vocabulary_wide_layers_sharded_equal_single_process(name):
+    """VocabParallelAAE(shard_first_layer=True) over real gloo collectives (reduce-scatter of the first layer's shares,
+    all-gather of dL/d(a1) with the small layers' gradients behind it, ...): rank r holds half the documents, half the
+    items' rows of dec.lin3 AND half the items' columns of enc.lin1; every parameter and the reconstruction loss equal the
+    reference's single-process fixtures."""
+    port = free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_both, args=(2, port, name, ret), nprocs=2, join=True)
+        got = dict(ret)
+    fx = Fixture(name)
+    want = fx.expected_params(fx.steps - 1)
+    for k, w in want.items():
+        if not k.startswith("dec.lin3") and k != "enc.lin1.weight":
+            np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+    np.testing.assert_allclose(np.concatenate([got["v3w0"], got["v3w1"]]), want["dec.lin3.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(np.concatenate([got["v3b0"], got["v3b1"]]), want["dec.lin3.bias"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(np.concatenate([got["w10"], got["w11"]], axis=1), want["enc.lin1.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)
