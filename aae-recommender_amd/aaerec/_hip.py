@@ -111,6 +111,7 @@ _PROTOS = {
     "aae_set_first_layer_external": (C.c_int, [C.c_void_p, C.c_int]),
     "aae_first_layer_forward": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
     "aae_first_layer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int, C.c_void_p]),
+    "aae_apply_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "aae_cat_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p]),
     "aae_cat_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -685,6 +686,13 @@ class HipAAE:
     def first_layer_bias(self):
         """enc.lin1's bias as a device view (what one share of first_layer_forward adds)."""
         return self.tensor(T_ENC_B1, padded=True)
+
+    def apply_gathered(self, which_a, which_b, packets, peer_stride, n_peers, span_offset):
+        """Optimiser which_a (+ dec_optim's small layers when which_b == O_DEC, else -1) on the replica's small layers
+        from the gathered packets (aae_apply_gathered): one launch, the peers summed in rank order inside it."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.aae_apply_gathered(self.handle, int(which_a), int(which_b), _ptr(packets), int(peer_stride),
+                                               int(n_peers), int(span_offset), self._stream()))
 
     def a1_rows(self, n_rows):
         """[n_rows, ld] view of the first layer's pre-activations."""

@@ -373,10 +373,11 @@ class VocabParallelAAE(DataParallelAAE):
         self._count(v["a1_all"])
         d.reduce_scatter_tensor(v["a1"], v["a1_all"], op=d.ReduceOp.SUM, group=self.group)
 
-    def _exchange_ga1(self, n_rows, ga1, riders):
+    def _exchange_ga1(self, n_rows, ga1, riders, fused_apply=False):
         """dL/d(a1) of every rank's documents gathered (rank-major = global batch order; returned as (buffer, rows per
         block, block stride) for first_layer_update); `riders` (small gradient spans due at the same point) travel behind
-        the rows and come back summed over the ranks in one fixed order - bitwise the same everywhere."""
+        the rows and come back summed over the ranks in one fixed order - bitwise the same everywhere (fused_apply: the
+        caller's optimiser launch sums them itself, model.apply_gathered)."""
         import torch
         d = self.dist
         n0 = ga1.numel()
@@ -391,11 +392,12 @@ class VocabParallelAAE(DataParallelAAE):
         else:
             self._count(pk)
             d.all_gather_into_tensor(allp, pk, group=self.group)
-        peers = allp.view(self.world, total)
-        off = n0
-        for t in riders:
-            torch.sum(peers[:, off:off + t.numel()], dim=0, out=t)
-            off += t.numel()
+        if not (fused_apply and len(riders) == 1):
+            peers = allp.view(self.world, total)
+            off = n0
+            for t in riders:
+                torch.sum(peers[:, off:off + t.numel()], dim=0, out=t)
+                off += t.numel()
         return allp, n_rows, total          # the slice reads the rows where they landed (first_layer_update(ga1=...))
 
     def _step_both_sharded(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows, g_rows, cond, masks,
@@ -420,9 +422,13 @@ class VocabParallelAAE(DataParallelAAE):
         self._count(v["da2_all"])
         d.reduce_scatter_tensor(v["da2"], v["da2_all"], op=d.ReduceOp.SUM, group=self.group)
         m.ae_backward()
-        g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"])
-        m.apply_updates(O_ENC)
-        m.apply_updates(O_DEC, skip=m.big_tensor_id)
+        fused = hasattr(m, "apply_gathered")        # one launch: the peers' sum + enc_optim + dec_optim's small layers
+        g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"], fused)
+        if fused:
+            m.apply_gathered(O_ENC, O_DEC, g, bs, self.world, v["ga1"].numel())
+        else:
+            m.apply_updates(O_ENC)
+            m.apply_updates(O_DEC, skip=m.big_tensor_id)
         sl.first_layer_update(O_ENC, g, rpb, bs)
         if not getattr(m, "ae_only", False):
             self._first_layer(v)
@@ -432,8 +438,11 @@ class VocabParallelAAE(DataParallelAAE):
                 d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
             m.apply_updates(O_DISC)
             m.gen_step()
-            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"])
-            m.apply_updates(O_GEN)
+            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"], fused)
+            if fused:
+                m.apply_gathered(O_GEN, -1, g, bs, self.world, v["ga1"].numel())
+            else:
+                m.apply_updates(O_GEN)
             sl.first_layer_update(O_GEN, g, rpb, bs)
         self._gathered = False
         self._coll_last = tuple(self._coll)

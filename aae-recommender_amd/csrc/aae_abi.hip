@@ -2705,6 +2705,7 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
             j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p; j.g = m->Gr[pid].p;
             j.n4 = (unsigned)n4; j.blk0 = blocks;
             j.w4 = w4_of(m, pid); j.ld = (int)m->P[pid].ld;
+            j.sc = nullptr; j.npeers = 0; j.pstride = 0;
             blocks += (unsigned)((n4 + 255) / 256);
             continue;
         }
@@ -2717,6 +2718,37 @@ int aae_apply_updates_except(aae_handle m, int which, int skip_tensor_id, void* 
         hipLaunchKernelGGL(adam_group_kernel, dim3(blocks), dim3(256), 0, s, grp, m->sc + which);
         LAUNCHCHK("adam_group");
     }
+    return AAE_OK;
+}
+
+// The small layers of optimiser which_a (enc_optim 0 / gen_optim 2: enc.lin1's bias, enc.lin2, enc.lin3) and, which_b = 1,
+// of dec_optim (dec.lin1, dec.lin2) in ONE launch, their gradients read as the sum over n_peers gathered packets: packet q
+// holds at packets_dev + q * peer_stride + span_offset (floats) a copy of the arena span that starts at AAE_T_GRAD +
+// AAE_T_ENC_B1 (the spans the ranks of the both-sharded scheme all-gather behind their dL/d(a1) rows).
+// Summed in peer order: bitwise the same on every rank.  Handles with an external first layer only.
+int aae_apply_gathered(aae_handle m, int which_a, int which_b, const float* packets_dev, int64_t peer_stride,
+                       int32_t n_peers, int64_t span_offset, void* stream) {
+    if (!m || !packets_dev) return fail(AAE_EINVAL, "NULL argument");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT || !m->ext_first) return fail(AAE_ESTATE, "aae_apply_gathered: grad_mode=export with an external first layer");
+    if ((which_a != O_ENC && which_a != O_GEN) || (which_b != -1 && which_b != O_DEC)) return fail(AAE_EINVAL, "aae_apply_gathered: which_a enc/gen, which_b -1/dec");
+    if (n_peers < 1 || (peer_stride & 3) || (span_offset & 3)) return fail(AAE_EINVAL, "aae_apply_gathered: n_peers >= 1, strides in whole float4");
+    AdamGroup grp; grp.njobs = 0;
+    unsigned blocks = 0;
+    const size_t base = m->Gr[P_B1].off;
+    auto add = [&](int pid, int which) {
+        const int set = which == O_GEN ? 1 : 0;
+        AdamJob& j = grp.jobs[grp.njobs++];
+        j.p = m->P[pid].p; j.m = m->M[set][pid].p; j.v = m->V[set][pid].p;
+        j.g = const_cast<float*>(packets_dev) + span_offset + (m->Gr[pid].off - base) / sizeof(float);
+        j.n4 = (unsigned)(m->P[pid].floats() / 4); j.blk0 = blocks;
+        j.w4 = w4_of(m, pid); j.ld = (int)m->P[pid].ld;
+        j.sc = m->sc + which; j.npeers = n_peers; j.pstride = peer_stride;
+        blocks += (j.n4 + 255) / 256;
+    };
+    for (int pid = P_B1; pid <= P_W3; ++pid) add(pid, which_a);
+    if (which_b == O_DEC) for (int pid = P_V1; pid < P_V3; ++pid) add(pid, O_DEC);
+    hipLaunchKernelGGL(adam_group_kernel, dim3(blocks), dim3(256), 0, S(stream), grp, m->sc + which_a);
+    LAUNCHCHK("adam_group (gathered)");
     return AAE_OK;
 }
 

@@ -164,7 +164,10 @@ __global__ void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, 
 // The same update for up to 8 small tensors of one optimiser in ONE launch (data-parallel replicas apply the
 // all-reduced gradients of every hidden layer after each phase: twelve ~4 us launches per step otherwise).
 struct AdamJob { float* p; float* m; float* v; float* g; unsigned n4; unsigned blk0;       // blk0: first block of the job
-                 W4Copies w4; int ld; };               // w4.f4 != NULL: the k4-interleaved copies of p kept in step (p rows are ld wide)
+                 W4Copies w4; int ld;                  // w4.f4 != NULL: the k4-interleaved copies of p kept in step (p rows are ld wide)
+                 const OptScalars* sc;                 // != NULL: this job's optimiser (a launch that serves two of them)
+                 int npeers; long long pstride; };     // npeers > 0: g = the first of npeers gathered copies, pstride floats apart:
+                                                       // the gradient is their sum in peer order (identical on every rank)
 struct AdamGroup { int njobs; AdamJob jobs[8]; };
 
 __global__ __launch_bounds__(256) void adam_group_kernel(AdamGroup grp, const OptScalars* sc) {
@@ -173,11 +176,15 @@ __global__ __launch_bounds__(256) void adam_group_kernel(AdamGroup grp, const Op
     for (int i = 1; i < 8; ++i)
         if (i < grp.njobs && blockIdx.x >= grp.jobs[i].blk0) j = i;
     const AdamJob job = grp.jobs[j];
-    const OptScalars s = *sc;
+    const OptScalars s = job.sc ? *job.sc : *sc;
     const unsigned i = (blockIdx.x - job.blk0) * 256u + threadIdx.x;
     if (i >= job.n4) return;
     float4 pp = reinterpret_cast<float4*>(job.p)[i];
-    const float4 gg = reinterpret_cast<const float4*>(job.g)[i];
+    float4 gg = reinterpret_cast<const float4*>(job.g)[i];
+    for (int q = 1; q < job.npeers; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(job.g + (size_t)q * job.pstride)[i];
+        gg.x += t.x; gg.y += t.y; gg.z += t.z; gg.w += t.w;
+    }
     float4 mm = make_float4(0, 0, 0, 0), vv = mm;
     if (!s.is_sgd) { mm = reinterpret_cast<float4*>(job.m)[i]; vv = reinterpret_cast<float4*>(job.v)[i]; }
     adam_update(pp.x, mm.x, vv.x, gg.x, s); adam_update(pp.y, mm.y, vv.y, gg.y, s);

@@ -61,9 +61,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-512 extra line")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
     ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated"), default="vocab",
-                    help="N > 1: 'vocab' shards the decoder's output layer over the vocabulary (ranks exchange hidden "
-                         "activations, aaerec.parallel.VocabParallelAAE); 'replicated' keeps a replica of it on every "
-                         "rank and exchanges its dense gradient (DataParallelAAE)")
+                    help="N > 1: 'vocab' shards both vocabulary-wide matrices (decoder output layer, encoder first "
+                         "layer) over the items, the ranks exchange [global batch, n_hidden] blocks only "
+                         "(aaerec.parallel.VocabParallelAAE); 'vocab_out' shards the output layer alone; 'replicated' keeps "
+                         "everything on every rank and exchanges dense gradients (DataParallelAAE)")
     ap.add_argument("--unfused-decoder", action="store_true", help="A/B: keep the three-kernel decoder path")
     a = ap.parse_args()
     if a.items is None:
@@ -410,7 +411,9 @@ def main():
                        "timed_repeats": len(dts), "repeat_ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts],
                        "profiled_repeat": 0,
                        "parallelism": (f"dp{world}" if not use_dp else
-                                       f"dp{world}, decoder output layer sharded over the vocabulary" if vocab else
+                                       (f"dp{world}, decoder output layer and encoder first layer sharded over the vocabulary"
+                                        if getattr(model._dp, "shard_first", False) else
+                                        f"dp{world}, decoder output layer sharded over the vocabulary") if vocab else
                                        f"dp{world}, replicated decoder")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
             **({"roofline_critical": roofline_critical} if roofline_critical else {}),

@@ -288,6 +288,13 @@ int aae_set_first_layer_external(aae_handle h, int on);
 int aae_first_layer_forward(aae_handle h, const aae_batch* batch, const float* bias_dev, void* stream);
 int aae_first_layer_update(aae_handle h, const float* ga1_dev, int64_t ld, int32_t rows_per_block, int64_t block_stride,
                            int which, void* stream);
+/* The replica's small layers after such an all-gather, in ONE launch: optimiser which_a (0 enc_optim / 2 gen_optim:
+ * enc.lin1's bias, enc.lin2, enc.lin3) and, which_b = 1, dec_optim's dec.lin1, dec.lin2 (which_b = -1: none), their
+ * gradients read as the sum over the n_peers packets in peer order (bitwise the same on every rank): packet q holds at
+ * packets_dev + q * peer_stride + span_offset (floats, multiples of 4) a copy of the arena span that starts at
+ * AAE_T_GRAD + AAE_T_ENC_B1.  Replaces a reduction over the peers + aae_apply_updates per optimiser. */
+int aae_apply_gathered(aae_handle h, int which_a, int which_b, const float* packets_dev, int64_t peer_stride,
+                       int32_t n_peers, int64_t span_offset, void* stream);
 
 /* CategoricalCondition (condition.py:397-508): a trainable embedding of a categorical attribute, reduced over the
  * document's (batch-padded) value list and concatenated to the code.  The table and its optimiser state belong to
