@@ -20,6 +20,8 @@ Build-only keyword arguments (all optional, defaults keep the reference behaviou
     dtype       'f32' (default: the reference's arithmetic) or 'bf16': the GEMM-shaped products take bf16 matrix-core
                 inputs with fp32 accumulation; master weights, optimiser state, losses stay fp32 (BASELINE config C2)
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import sklearn  # noqa: F401  (sklearn.utils.shuffle semantics are reproduced with np.random below)
@@ -241,7 +243,10 @@ class AdversarialAutoEncoder:
                     optimizer=self.optimizer, normalize_inputs=self.normalize_inputs, dropout=self.dropout,
                     gen_lr=self.gen_lr, reg_lr=self.reg_lr, rng_mode="device" if self.rng_mode == "device" else "inject",
                     seed=seed, device=self.device, ae_only=self._ae_only, dtype=self.dtype,
-                    unfused_decoder=self._unfused_decoder)
+                    unfused_decoder=self._unfused_decoder,
+                    # the slice sees world x batch rows: beyond one fused launch's 112 they run as row blocks of the
+                    # split form (one critical launch for all blocks, one deferred optimiser launch), DESIGN.md 7.3
+                    blocked_output=os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
                 self._slice.load_params(sl_params)
                 self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
                                             shard_first_layer=self.dp_mode == "vocab")

@@ -128,6 +128,7 @@ struct aae_model {
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.reserved[5]: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
+    bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
     bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
@@ -1205,6 +1206,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 2048);
+            m->bucket_wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 16384) == hipSuccess;
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) m->fused_ok = false;
             if (m->bf16 &&
                 (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess ||
@@ -1260,7 +1262,10 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         m->split_ok = ok;
         (void)hipGetLastError();
     }
@@ -1774,6 +1779,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
             hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
                                m->tev);
+        } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
+            // (the global batch of an item slice: one launch instead of four, 25 -> 9 us in front of the critical launch)
+            const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
+            hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
+                               m->tev);
         } else {
             const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
             hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
@@ -1792,7 +1802,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.te.start = m->tstart; fa.te.eb = m->teb; fa.te.en = m->ten; fa.te.ev = m->tev;
         fa.slabs = m->slabs.p; fa.slab_stride = (size_t)(nblk > 1 ? B : std::min(m->R, 16 * kMB)) * m->ldh; fa.ld_slab = m->ldh;
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
-        fa.erow0 = 0; fa.acc = nullptr;
+        fa.erow0 = 0; fa.acc = nullptr; fa.nblk = 1; fa.Bb = B;
         { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
         static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile
         static unsigned long long* ts_dev = nullptr;
@@ -1803,7 +1813,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         }
         const int grid = std::min(ntiles, m->n_cu);
         fa.Gt = m->Gt;
-        int n_loss_partials = grid;
+        int n_loss_partials = grid, crit_slabs = grid;
         // The split pays when the deferred half FITS beside the rest of the step and the layer is big enough to matter:
         // below ~2 tiles per CU the two event hops cost more than the optimiser pass they hide (C1, N = 1 k: 0.173 -> 0.184
         // ms/step), and beyond ~32 M parameters the deferred launch on half the CUs outlasts the rest of the step and the
@@ -1825,12 +1835,22 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 b.Gt = fa.Gt + (size_t)r * ntiles * Bb * kTI;
                 return b;
             };
-            n_loss_partials = grid * nblk;
-            for (int r = 0; r < nblk; ++r) {
+            // nblk > 1: ONE critical launch for all row blocks - workgroup w works on block w % nblk with its block of dh2
+            // in LDS and takes every (grid / nblk)-th tile (dec_fused.h); 8 launches of 1.5 tile rounds each (-> 2, plus an
+            // 84 KB prologue per workgroup and launch) cost 8 x 26.5 us on a 12.5 k-item slice, one launch of 12.2 rounds
+            // what the 100-row step's critical launch costs
+            const int wgs = nblk > 1 ? std::max(1, m->n_cu / nblk) : grid;
+            const int crit_grid = nblk > 1 ? wgs * nblk : grid;
+            n_loss_partials = crit_grid;
+            crit_slabs = wgs;
+            {
                 // "this launch is done" rides on the kernel's own completion signal (a hipEventRecord behind the launch is a
                 // marker packet the next kernel of the stream waits for: +30 us per step); when the launch is being timed,
-                // the timing pair's stop event doubles as that event.  Only the LAST block's launch carries it.
-                const DecFusedArgs b = block_args(r);
+                // the timing pair's stop event doubles as that event.
+                DecFusedArgs b = fa;
+                b.nblk = nblk; b.Bb = Bb;
+                const int grid = crit_grid;
+                const int r = nblk - 1;
                 hipEvent_t start = nullptr, stop = r == nblk - 1 ? m->ev_crit : nullptr;
                 (void)prof_pair(m, AAE_K_DEC_CRIT, &start, &stop);
                 if (m->bf16) switch (m->fused_nb) {
@@ -1846,6 +1866,25 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 if (r == nblk - 1) HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
             }
             const int g2 = std::min(ntiles, std::min(m->split_wgs, m->n_cu));
+            // nblk > 1 and at most kOBT tiles per workgroup on the chip: the deferred half of every block in ONE launch
+            // (dec_opt_blocks_kernel), else one launch per block with the dV3 partial going through Gacc
+            static const bool no_obk = getenv("AAE_NO_OPT_BLOCKS") != nullptr;
+            const bool one_opt = nblk > 1 && !m->bf16 && !no_obk && ntiles <= kOBT * m->n_cu &&
+                                 dec_opt_blocks_lds_bytes(Bb) <= 160 * 1024;
+            if (one_opt) {
+                DecFusedArgs b = fa;
+                b.nblk = nblk; b.Bb = Bb;
+                const int g3 = std::max(std::min(g2, ntiles), (ntiles + kOBT - 1) / kOBT);
+                const uint32_t lds3 = (uint32_t)dec_opt_blocks_lds_bytes(Bb);
+                hipEvent_t start = nullptr, stop = nullptr;
+                (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
+                switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_opt_blocks_kernel<4>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_opt_blocks_kernel<7>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_opt_blocks_kernel<13>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                }
+                LAUNCHCHK("dec_opt_blocks");
+            } else
             for (int r = 0; r < nblk; ++r) {
                 DecFusedArgs b = block_args(r);
                 if (nblk > 1) { b.acc = m->Gacc.p; b.gradV3 = r == nblk - 1 ? nullptr : m->Gacc.p; }
@@ -1905,7 +1944,16 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // launch reduces the per-workgroup loss partials
         float* part = m->slabs.p + (size_t)304 * fa.slab_stride;
         const size_t n4 = (size_t)B * m->ldh / 4;
-        hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, grid,
+        if (m->only_output_layer && crit_slabs <= 64) {
+            // (row blocks in one launch: 256 / nblk slabs - one pass sums them straight into dL/d(dh2), with the loss)
+            hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, m->slabs.p, crit_slabs,
+                               fa.slab_stride, n4, m->da2.p, (size_t)0, m->bce_partials, n_loss_partials,
+                               1.0f / ((float)B * (float)N), m->losses, 0);
+            LAUNCHCHK("slabs -> da2");
+            m->phase = 2;
+            return AAE_OK;
+        }
+        hipLaunchKernelGGL(slab_partial_kernel, dim3((unsigned)((n4 + 255) / 256), 16), dim3(256), 0, s, m->slabs.p, crit_slabs,
                            fa.slab_stride, n4, part, fa.slab_stride, m->bce_partials, n_loss_partials,
                            1.0f / ((float)B * (float)N), m->losses, 0);
         if (m->only_output_layer) {
@@ -2283,9 +2331,10 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
     if (m->vae || m->cfg.grad_mode != AAE_GRAD_FUSED) return fail(AAE_ESTATE, "aae_first_layer_forward: fused optimiser, no VAE mode");
     hipStream_t s = S(stream);
-    TRY(join_deferred(m, s));
     bool pf = false;
     if (batch) {
+        TRY(join_deferred(m, s));       // (batch = NULL: a deferred optimiser launch of the output layer keeps running - it
+                                        //  touches dec.lin3, its moments, the stored dL/dlogits and dh2, nothing of this layer)
         TRY(set_batch(m, batch));
         remember_inject(m, nullptr, true);
         m->hstep++;

@@ -19,13 +19,17 @@ constexpr int kBucketMaxTiles = 32 * 1024;   // LDS: (tiles + 1 + docs + 1 + 102
 // One 1024-thread workgroup; bk_lds: (ntiles + 1 + kBucketMaxDocs + 1 + 1024) ints of LDS.  Runs either as a
 // kernel of its own or as an extra workgroup of the step's first layer-chain launch (chain.h), where it costs
 // no launch and no time on the critical path (the chain's workgroups occupy a handful of CUs).
+// MAXD: documents the instance can take (kBucketMaxDocs, or kBucketWideDocs = 1024 for the global batch an item slice of
+// the vocabulary-sharded scheme sees: 8 ranks x 100 documents)
+constexpr int kBucketWideDocs = 1024;
+template <int MAXD = kBucketMaxDocs>
 __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles, int* __restrict__ tstart,
                                                  int* __restrict__ eb, int* __restrict__ en, float* __restrict__ ev,
                                                  int* bk_lds) {
     int* cnt = bk_lds;                               // [ntiles + 1]  histogram, then fill cursor
     int* dbeg = cnt + ntiles + 1;                    // [docs + 1]    first flat entry of each document
-    int* part = dbeg + kBucketMaxDocs + 1;           // [1024]        scan scratch
-    __shared__ long long dlo[kBucketMaxDocs];        // CSR offset of each document's first entry
+    int* part = dbeg + MAXD + 1;                     // [1024]        scan scratch
+    __shared__ long long dlo[MAXD];                  // CSR offset of each document's first entry
     const int t = threadIdx.x, docs = bv.n_rows;
     for (int i = t; i <= ntiles; i += 1024) cnt[i] = 0;
     int len = 0;
@@ -38,14 +42,14 @@ __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles
     // exclusive scan of the document lengths (docs <= 112 <= 2 waves): plain Hillis-Steele in LDS
     part[t] = len;
     __syncthreads();
-    for (int o = 1; o < kBucketMaxDocs; o <<= 1) {
-        const int v = (t >= o && t < kBucketMaxDocs) ? part[t - o] : 0;
+    for (int o = 1; o < MAXD; o <<= 1) {
+        const int v = (t >= o && t < MAXD) ? part[t - o] : 0;
         __syncthreads();
-        if (t < kBucketMaxDocs) part[t] += v;
+        if (t < MAXD) part[t] += v;
         __syncthreads();
     }
     if (t < docs) dbeg[t] = part[t] - len;
-    if (t == 0) dbeg[docs] = part[kBucketMaxDocs - 1];
+    if (t == 0) dbeg[docs] = part[MAXD - 1];
     __syncthreads();
     const int total = dbeg[docs];
     auto doc_of = [&](int f) {                       // largest d with dbeg[d] <= f
@@ -95,7 +99,14 @@ __global__ __launch_bounds__(1024) void tile_bucket_kernel(BatchView bv, int nti
                                                            int* __restrict__ eb, int* __restrict__ en,
                                                            float* __restrict__ ev) {
     extern __shared__ int bk_lds_dyn[];
-    tile_bucket_body(bv, ntiles, tstart, eb, en, ev, bk_lds_dyn);
+    tile_bucket_body<kBucketMaxDocs>(bv, ntiles, tstart, eb, en, ev, bk_lds_dyn);
+}
+// ... for up to 1024 documents; LDS: (ntiles + 1 + kBucketWideDocs + 1 + 1024) ints
+__global__ __launch_bounds__(1024) void tile_bucket_wide_kernel(BatchView bv, int ntiles, int* __restrict__ tstart,
+                                                                int* __restrict__ eb, int* __restrict__ en,
+                                                                float* __restrict__ ev) {
+    extern __shared__ int bk_lds_dyn[];
+    tile_bucket_body<kBucketWideDocs>(bv, ntiles, tstart, eb, en, ev, bk_lds_dyn);
 }
 
 struct BucketJob {           // piggy-backed on a chain launch when enabled

@@ -77,6 +77,11 @@ struct DecFusedArgs {
     // optimiser (or before the partial is stored again: gradV3 != NULL)
     int erow0;
     const float* acc;
+    // ... all row blocks in ONE critical launch (kDecCrit, nblk > 1): workgroup w takes row block w % nblk (Bb rows each,
+    // the last one the remainder of B) and the tiles w / nblk, + gridDim.x / nblk, ...; B, dh2, slabs, partials, Gt and
+    // erow0 then describe the WHOLE batch and the kernel derives its block's.  Slab (w / nblk) receives the rows of every
+    // block once: gridDim.x / nblk slabs in all.
+    int nblk, Bb;
 };
 
 // MODE of dec_fused_kernel.  The step's critical path needs only dL/d(dh2) from this layer (the decoder's hidden
@@ -111,8 +116,19 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     constexpr bool kAccIn = MODE == kDecOptAcc;
     constexpr int kAux = kIsOpt ? 2 : 0;       // buffer-store cache policy: 2 = nt
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // row blocks of one launch (the critical launch only): this workgroup's block and its share of the tiles
+    constexpr bool kBlk = MODE == kDecCrit;
+    const int nblk = kBlk && a.nblk > 1 ? a.nblk : 1;
+    const int blk = nblk > 1 ? (int)blockIdx.x % nblk : 0, wgi = nblk > 1 ? (int)blockIdx.x / nblk : (int)blockIdx.x;
+    const int wgs = nblk > 1 ? (int)gridDim.x / nblk : (int)gridDim.x;
+    if (nblk > 1 && wgi >= wgs) return;                // (a grid that does not divide by the block count: the rest idles)
+    const int erow0 = nblk > 1 ? blk * a.Bb : a.erow0;
+    const int B = nblk > 1 ? min(a.Bb, a.B - erow0) : a.B;
+    const float* dh2_blk = nblk > 1 ? a.dh2 + (size_t)erow0 * a.ldh : a.dh2;
+    float* slabs_blk = nblk > 1 ? a.slabs + (size_t)erow0 * a.ld_slab : a.slabs;
+    float* Gt_blk = nblk > 1 ? a.Gt + (size_t)blk * ((a.N + kTI - 1) / kTI) * a.Bb * kTI : a.Gt;
     float* dhs = lds;                                  // [B][kSD]
-    float* v3s = dhs + (size_t)a.B * kSD;              // [32][kSD]
+    float* v3s = dhs + (size_t)B * kSD;                // [32][kSD]
     float* gs = v3s + kTI * kSD;                       // [kGR][kSG]  logits, then dL/dlogits
     float* os = gs + kGR * kSG;                        // [32][kSO]   dV3a tile
     float* red = os + kTI * kSO;                       // [64]
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block ids below are scalars
     const int fr = lane & 15, fk = lane >> 4;
-    const int B = a.B, K1 = a.h + 1, ldv = a.ldv;
+    const int K1 = a.h + 1, ldv = a.ldv;
     // k-steps rounded up to the unroll factor 4: the extra ones multiply zero padding (columns >= ldh
     // of both LDS images are zeroed once, G rows >= B are zero)
     const int kch1 = (((K1 + 7) >> 3) + 1) & ~1;       // GEMM1: 8-k chunks over the h+1 hidden columns (even count;
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     // ---- once per workgroup: dh2 -> LDS, zero the G tile (rows >= B stay zero)
     for (int f = tid; f < B * (a.ldh / 4); f += kNT) {
         int r = f / (a.ldh / 4), c4 = f % (a.ldh / 4);
-        float4 x = *reinterpret_cast<const float4*>(a.dh2 + (size_t)r * a.ldh + c4 * 4);
+        float4 x = *reinterpret_cast<const float4*>(dh2_blk + (size_t)r * a.ldh + c4 * 4);
         float* d = dhs + r * kSD + c4 * 4;
         *reinterpret_cast<float2*>(d) = make_float2(x.x, x.y);
         *reinterpret_cast<float2*>(d + 2) = make_float2(x.z, x.w);
@@ -194,8 +210,8 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
-    int tile = blockIdx.x;
-    const int stride = gridDim.x;
+    int tile = wgi;
+    const int stride = wgs;
     const int last_e = max(a.te.start[ntiles] - 1, 0);        // clamp for the unconditional entry loads
     // (VECTOR loads through an index the compiler cannot prove uniform: as scalar loads they sit in lgkmcnt, and the
     // LDS-only barrier of the phase that issues them - s_waitcnt lgkmcnt(0) - waits out their L2 round trip once per tile)
@@ -216,10 +232,10 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     float4 greg = make_float4(0.f, 0.f, 0.f, 0.f);
     const int g_f4 = B * (kTI / 4);                    // float4 per tile (<= kNT: B <= 16 * kMB <= 128)
     const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
-    const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(a.Gt ? a.Gt : a.V3a, 0, gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(Gt_blk ? Gt_blk : a.V3a, 0, gbytes, 0x00020000);
     auto load_g = [&](int t) {
-        if (kIsOpt) { const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.Gt) + (size_t)t * g_f4 + min(tid, g_f4 - 1)); greg = make_float4(t4[0], t4[1], t4[2], t4[3]); }
-        else greg = reinterpret_cast<const float4*>(a.Gt)[(size_t)t * g_f4 + min(tid, g_f4 - 1)];
+        if (kIsOpt) { const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Gt_blk) + (size_t)t * g_f4 + min(tid, g_f4 - 1)); greg = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+        else greg = reinterpret_cast<const float4*>(Gt_blk)[(size_t)t * g_f4 + min(tid, g_f4 - 1)];
     };
     if (tile < ntiles) {
         load_span(a.V3a, tile, vreg);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             }
         }
         ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
-        const int my_rb = ent_b - a.erow0;              // (row-blocked launches: entries of other row blocks are not ours)
+        const int my_rb = ent_b - erow0;              // (row-blocked launches: entries of other row blocks are not ours)
         const int my_p = my_rb * kSG + ent_n; const float my_v = ent_v;
         if (kIsOpt) {
             if (tid < g_f4) *reinterpret_cast<float4*>(gs + (tid >> 3) * kSG + (tid & 7) * 4) = greg;
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
                 gs[my_p] = g1;
             }
             for (int e = e0 + kNT + tid; e < e1; e += kNT) { // tiles with more than 1024 entries (tiny vocabularies)
-                const int rb = a.te.eb[e] - a.erow0;
+                const int rb = a.te.eb[e] - erow0;
                 if ((unsigned)rb >= (unsigned)B) continue;
                 const int p = rb * kSG + a.te.en[e];
                 float g0, l0, g1, l1;
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
     if (!kFwd) return;
     // ---- dA2 partial of this workgroup -> its slab; loss partial
-    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    float* slab = slabs_blk + (size_t)wgi * a.slab_stride;
     if (tail4) {
         // the tail rows' four item-quarter partials of every column meet in LDS (the dV3a / raw-logit buffer is free now)
         __syncthreads();
@@ -571,6 +587,142 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
         for (int w = 0; w < kNW; ++w) s += red[w];
         a.partials[blockIdx.x] = s;
         if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The deferred half for ALL row blocks of a row-blocked step in one launch (fp32): dV3 = sum over the blocks of
+// G_r^T * dh2_r from the tiles the critical launch stored, then dec_optim.  A workgroup owns up to kOBT tiles (wg, wg +
+// gridDim.x, ...) and keeps their dV3 in registers while it walks the row blocks: a block's dh2 is loaded into LDS once
+// and serves every tile of the workgroup.  (One launch per block - kDecOpt / kDecOptAcc with the partial sums going
+// through HBM - costs 8 x 30 us on a 12.5 k-item slice, most of it prologue and pipeline fill for 3 tiles per workgroup.)
+// Summation order over the rows is the per-block launches' (blocks in order, the same k walk inside a block).
+// ---------------------------------------------------------------------------------------------
+constexpr int kOBT = 4;        // tiles per workgroup of dec_opt_blocks_kernel
+inline size_t dec_opt_blocks_lds_bytes(int Bb) { return sizeof(float) * ((size_t)Bb * kSD + (size_t)kGR * kSG + (size_t)kTI * kSO); }
+
+template <int NB>
+__global__ __launch_bounds__(kNT) void dec_opt_blocks_kernel(DecFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dhs = lds;                                  // [Bb][kSD]
+    float* gs = dhs + (size_t)a.Bb * kSD;              // [kGR][kSG]
+    float* os = gs + kGR * kSG;                        // [32][kSO]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ldv = a.ldv, ntiles = (a.N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;
+    constexpr int Q2 = (2 * NB + kNW - 1) / kNW;
+    const OptScalars sc = *a.sc;
+    typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
+
+    f32x4 acc[kOBT][Q2];
+#pragma unroll
+    for (int j = 0; j < kOBT; ++j)
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < kGR * kSG; i += kNT) gs[i] = 0.f;          // rows >= the block's stay zero
+
+    const float* pg = gs + 4 * fk * kSG + (wave & 1) * 16 + fr;      // G[b = 16g + j + 4fk][item]
+    const float* pd[Q2];
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) pd[q] = dhs + (min(wave + kNW * q, 2 * NB - 1) >> 1) * 16 + fr;
+    const bool live[2] = {wave < 2 * NB, wave + kNW < 2 * NB};
+
+    for (int r = 0; r < a.nblk; ++r) {
+        const int r0 = r * a.Bb, Br = min(a.Bb, a.B - r0);
+        const int g_f4 = Br * (kTI / 4);
+        const f32x4* Gr = reinterpret_cast<const f32x4*>(a.Gt + (size_t)r * ntiles * a.Bb * kTI);
+        lds_barrier();                                 // the previous block's readers of dhs / gs are done
+        if (Br < a.Bb) for (int i = tid; i < kGR * kSG; i += kNT) gs[i] = 0.f;      // (a shorter last block: stale rows)
+        for (int f = tid; f < Br * (a.ldh / 4); f += kNT) {
+            const int row = f / (a.ldh / 4), c4 = f % (a.ldh / 4);
+            const float4 x = *reinterpret_cast<const float4*>(a.dh2 + (size_t)(r0 + row) * a.ldh + c4 * 4);
+            *reinterpret_cast<float4*>(dhs + row * kSD + c4 * 4) = x;
+        }
+        f32x4 gq = __builtin_nontemporal_load(Gr + (size_t)min((int)blockIdx.x, ntiles - 1) * g_f4 + min(tid, g_f4 - 1));
+#pragma unroll
+        for (int j = 0; j < kOBT; ++j) {
+            const int tile = blockIdx.x + j * gridDim.x;
+            if (tile >= ntiles) break;                 // (uniform)
+            lds_barrier();                             // readers of the previous tile's G are done (first tile: dhs visible below)
+            if (tid < g_f4) *reinterpret_cast<float4*>(gs + (tid >> 3) * kSG + (tid & 7) * 4) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+            {   // the next tile's G travels behind this tile's product
+                const int nt = min(tile + (int)gridDim.x, ntiles - 1);
+                gq = __builtin_nontemporal_load(Gr + (size_t)nt * g_f4 + min(tid, g_f4 - 1));
+            }
+            lds_barrier();
+            // GEMM2 (dec_fused_kernel's walk): k-step (g, jj) multiplies rows 16g + jj + 4 fk
+            const int nfull = Br >> 4;
+            for (int g = 0; g <= nfull; ++g) {
+                if (g == nfull && !(Br & 15)) break;
+                float x[4], y[4][Q2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = 16 * g + jj;
+                    const int rowc = min(row + 4 * fk, Br - 1) * kSD;      // (rows past the block: clamped, their G rows are zero)
+                    x[jj] = pg[row * kSG];
+#pragma unroll
+                    for (int q = 0; q < Q2; ++q) y[jj][q] = pd[q][rowc];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int q = 0; q < Q2; ++q)
+                        if (live[q]) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[jj], y[jj][q], acc[j][q], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the optimiser on the workgroup's tiles
+#pragma unroll
+    for (int j = 0; j < kOBT; ++j) {
+        const int tile = blockIdx.x + j * gridDim.x;
+        if (tile >= ntiles) break;
+        const int i0 = tile * kTI;
+        float4 pr[NV], mr[NV], vr[NV];
+        const size_t last_f4 = ((size_t)a.N * ldv) / 4 - 1;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const size_t f = (size_t)tile * kTI * f4_per_row + (size_t)(tid + kNT * u);
+            const size_t fc = f < last_f4 ? f : last_f4;
+            const f32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.V3a) + fc);
+            const f32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.M) + fc);
+            const f32x4 t2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.V) + fc);
+            pr[u] = make_float4(t0[0], t0[1], t0[2], t0[3]); mr[u] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+            vr[u] = make_float4(t2[0], t2[1], t2[2], t2[3]);
+        }
+        lds_barrier();                                 // the previous tile's readers of os are done
+#pragma unroll
+        for (int q = 0; q < Q2; ++q)
+            if (live[q]) {
+                const int id = wave + kNW * q;
+                const int rb = (id & 1) * 16 + fk * 4, cb = (id >> 1) * 16 + fr;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) os[(rb + rr) * kSO + cb] = acc[j][q][rr];
+            }
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int slot = tid + kNT * u;
+            const int fc = min(slot, tile_f4 - 1), row = fc / f4_per_row, c4 = fc - row * f4_per_row;
+            const bool valid = slot < tile_f4 && i0 + row < a.N;
+            const float4 g = *reinterpret_cast<const float4*>(os + row * kSO + c4 * 4);
+            float4 p = pr[u], mm = mr[u], vv = vr[u];
+            adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
+            adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
+            const unsigned so = (unsigned)((size_t)i0 * ldv) * 4u;
+            const unsigned vo = valid ? (unsigned)slot * 16u : 0x80000000u;
+            const unsigned vo2 = !sc.is_sgd ? vo : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, p), rP, vo, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, 2);
+        }
     }
 }
 

@@ -352,7 +352,7 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
                             z_real=zr[rk * Bl:(rk + 1) * Bl])
                     dp.wait_pending()
                 return
-            sl = HipAAE(hi - lo, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", **kw)
+            sl = HipAAE(hi - lo, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", blocked_output=bool(seed % 2), **kw)
             sl.load_params(sp_params)
             slices[rk] = sl
             vp = VocabParallelAAE(m, sl, dist, N, shard_first_layer=scheme == "vocab2")

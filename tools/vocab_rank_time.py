@@ -89,7 +89,7 @@ lo, hi = item_slice(N, 0, world)
 sp = dict(params)
 sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
 sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
-BLOCKED = os.environ.get("VR_BLOCKED", "0") != "0"      # 1: row-blocked fused launches for the slice (default: the three-kernel path)
+BLOCKED = os.environ.get("VR_BLOCKED", "1") != "0"      # row-blocked fused launches for the slice (what fit() uses); 0: the three-kernel path
 slice_csr = DeviceCSR(X[:, lo:hi], dev)
 if "vocab" in SCHEMES:
     m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
