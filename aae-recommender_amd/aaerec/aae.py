@@ -246,7 +246,9 @@ class AdversarialAutoEncoder:
                     unfused_decoder=self._unfused_decoder,
                     # the slice sees world x batch rows: beyond one fused launch's 112 they run as row blocks of the
                     # split form (one critical launch for all blocks, one deferred optimiser launch), DESIGN.md 7.3
-                    blocked_output=os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
+                    # (with the output layer ALONE sharded the packed-row exchange of the first layer reads the slice's
+                    #  tensors between the phases and would wait for the deferred launch: three GEMMs stay faster there)
+                    blocked_output=self.dp_mode == "vocab" and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
                 self._slice.load_params(sl_params)
                 self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
                                             shard_first_layer=self.dp_mode == "vocab")

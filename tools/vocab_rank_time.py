@@ -89,12 +89,13 @@ lo, hi = item_slice(N, 0, world)
 sp = dict(params)
 sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
 sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
-BLOCKED = os.environ.get("VR_BLOCKED", "1") != "0"      # row-blocked fused launches for the slice (what fit() uses); 0: the three-kernel path
+BLOCKED = os.environ.get("VR_BLOCKED", "1") != "0"      # 'both' scheme: row-blocked fused launches for the slice (what fit() uses); 0: three GEMMs
+BLOCKED_OUT = os.environ.get("VR_BLOCKED_OUT", "0") != "0"   # 'vocab' (output layer alone) scheme: three GEMMs is what fit() uses there
 slice_csr = DeviceCSR(X[:, lo:hi], dev)
 if "vocab" in SCHEMES:
     m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
     m.load_params(params)
-    sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED)
+    sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED_OUT)
     sl.load_params(sp)
     d2 = EchoDist(world)
     vp = VocabParallelAAE(m, sl, d2, N)
@@ -112,7 +113,7 @@ if "vocab" in SCHEMES:
     sl.profile_enable(False)
     print(f"world {world}: slice handle ({hi - lo} items x {Bg} rows) output-layer kernels: " + ", ".join(parts), flush=True)
     per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d2.bytes.items()}
-    print(f"world {world}: vocabulary-sharded ({'row-blocked fused' if BLOCKED else 'three-kernel'} output layer)   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
+    print(f"world {world}: vocabulary-sharded ({'row-blocked fused' if BLOCKED_OUT else 'three-kernel'} output layer)   {t_vp:.3f} ms/step of compute per rank; exchanged per step: "
           + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
     del vp, m, sl
     torch.cuda.empty_cache()
