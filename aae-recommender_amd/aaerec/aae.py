@@ -229,15 +229,17 @@ class AdversarialAutoEncoder:
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")
         self.gen_optim, self.disc_optim = _OptimView(self, "gen"), _OptimView(self, "disc")
         if dist is not None:
-            from .parallel import DataParallelAAE, VocabParallelAAE, item_slice
+            from .parallel import DataParallelAAE, VocabParallelAAE, item_items
             if self._vocab_sharded(code_inc):
-                lo, hi = item_slice(n_items, dist.get_rank(dist_group), dist_world)
+                # this rank's items: rank, rank + world, ... (the vocabulary is frequency-sorted: interleaving gives
+                # every rank the same share of each batch's entries)
+                items = item_items(n_items, dist.get_rank(dist_group), dist_world, True)
                 sl_params = dict(params)
-                sl_params["dec.lin3.weight"] = params["dec.lin3.weight"][lo:hi]
-                sl_params["dec.lin3.bias"] = params["dec.lin3.bias"][lo:hi]
-                sl_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+                sl_params["dec.lin3.weight"] = np.ascontiguousarray(params["dec.lin3.weight"][items])
+                sl_params["dec.lin3.bias"] = np.ascontiguousarray(params["dec.lin3.bias"][items])
+                sl_params["enc.lin1.weight"] = np.ascontiguousarray(params["enc.lin1.weight"][:, items])
                 self._slice = _hip.HipAAE(
-                    hi - lo, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
+                    len(sl_params["dec.lin3.bias"]), self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
                     max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
                     activation=self.activation, prior=self.prior, prior_scale=self.prior_scale,
                     optimizer=self.optimizer, normalize_inputs=self.normalize_inputs, dropout=self.dropout,
@@ -251,7 +253,7 @@ class AdversarialAutoEncoder:
                     blocked_output=self.dp_mode == "vocab" and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
                 self._slice.load_params(sl_params)
                 self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
-                                            shard_first_layer=self.dp_mode == "vocab")
+                                            shard_first_layer=self.dp_mode == "vocab", interleaved=True)
             else:
                 self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
 
@@ -430,7 +432,7 @@ class AdversarialAutoEncoder:
         self._fit_X = X                                 # (host copy; subclasses with host-side randomness use it)
         row_len = X.getnnz(1)
         if self._slice is not None:                     # this rank's items of the corpus, ids rebased to the slice
-            self._slice_csr = _hip.DeviceCSR(X[:, self._dp.item_lo:self._dp.item_hi], self.hip.device)
+            self._slice_csr = _hip.DeviceCSR(X[:, self._dp.items].tocsr(), self.hip.device)
             if self._dp.shard_first:                    # the slice holds its columns only: F.normalize's whole-row norms
                 self._slice.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1),
                                                        device=self.hip.device))

@@ -254,6 +254,20 @@ def item_slice(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def item_items(n_items, rank, world, interleaved=True):
+    """The items rank `rank` of `world` owns, as a slice object (indexes NumPy / torch / SciPy-CSR columns alike).
+    interleaved: items rank, rank + world, rank + 2 world, ... - vocabularies are frequency-sorted (datasets.py: the most
+    frequent token first), so contiguous slices would hand rank 0 the popular head and most of every batch's entries
+    (the slowest rank sets the step: 0.443 -> 0.432 ms of per-rank compute at world 8); else item_slice()'s [lo, hi)."""
+    if interleaved:
+        return slice(rank, n_items, world)
+    return slice(*item_slice(n_items, rank, world))
+
+
+def _slice_len(sl, n):
+    return len(range(*sl.indices(n)))
+
+
 class _Views:
     """name -> view, looked up once (stable) or on every access."""
 
@@ -291,12 +305,16 @@ class VocabParallelAAE(DataParallelAAE):
     restricted to this rank's items with ids rebased to the slice; every rank walks the same permutation, so the
     global batch needs no exchange."""
 
-    def __init__(self, model, slice_model, dist, n_items, group=None, shard_first_layer=False):
+    def __init__(self, model, slice_model, dist, n_items, group=None, shard_first_layer=False, interleaved=False):
         super().__init__(model, dist, group=group, shard_decoder=False)
         self.slice = slice_model
         self.n_items = n_items
-        self.item_lo, self.item_hi = item_slice(n_items, dist.get_rank(group), self.world)
-        slice_model.set_grad_scale((self.item_hi - self.item_lo) / float(n_items))
+        # interleaved: the slice model holds items rank, rank + world, ... (item_items) instead of a contiguous range
+        self.interleaved = bool(interleaved)
+        self.items = item_items(n_items, dist.get_rank(group), self.world, self.interleaved)
+        self.n_slice = _slice_len(self.items, n_items)
+        self.item_lo, self.item_hi = item_slice(n_items, dist.get_rank(group), self.world)     # (contiguous form only)
+        slice_model.set_grad_scale(self.n_slice / float(n_items))
         # shard_first_layer: enc.lin1 - the other [n_items, n_hidden] matrix - lives with the item slices as well (see
         # _step_both_sharded); the caller gives the slice model the documents' complete L1 norms (set_doc_l1)
         self.shard_first = bool(shard_first_layer)
@@ -470,8 +488,8 @@ class VocabParallelAAE(DataParallelAAE):
         recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
         d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
         for r in range(self.world):
-            lo, hi = item_slice(self.n_items, r, self.world)
-            full[lo:hi] = recv[r * rows:r * rows + (hi - lo)]
+            it = item_items(self.n_items, r, self.world, self.interleaved)
+            full[it] = recv[r * rows:r * rows + _slice_len(it, self.n_items)]
         if self.shard_first:
             # enc.lin1 the same way (stored transposed: one row per item), and the bias every owner keeps
             from ._hip import T_ENC_W1T
@@ -483,15 +501,15 @@ class VocabParallelAAE(DataParallelAAE):
             recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
             d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
             for r in range(self.world):
-                lo, hi = item_slice(self.n_items, r, self.world)
-                full[lo:hi] = recv[r * rows:r * rows + (hi - lo)]
+                it = item_items(self.n_items, r, self.world, self.interleaved)
+                full[it] = recv[r * rows:r * rows + _slice_len(it, self.n_items)]
             m.params_changed()
         self._gathered = True
 
     def recon_loss(self):
         """Reconstruction loss of the last step over all items: the slices' means weighted by their sizes."""
         import torch
-        part = torch.tensor([self.slice.losses()[0] * (self.item_hi - self.item_lo) / float(self.n_items)],
+        part = torch.tensor([self.slice.losses()[0] * self.n_slice / float(self.n_items)],
                             dtype=torch.float64)
         nccl = str(self.dist.get_backend(self.group)).lower() == "nccl"
         buf = part.to(self.model.device) if nccl else part

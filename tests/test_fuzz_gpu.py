@@ -304,7 +304,7 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
     import scipy.sparse as sp
     import torch
     from aaerec._hip import HipAAE, DeviceCSR
-    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
+    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_items
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
     from test_parity_abi_gpu import _ThreadDist
@@ -332,12 +332,13 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
     def rank_main(rk):
         try:
             dist.bind(rk)
-            lo, hi = item_slice(N, rk, world)
+            inter = scheme == "vocab2" and seed % 3 != 0      # items rk, rk + world, ... (what fit() uses) or [lo, hi)
+            items = item_items(N, rk, world, inter)
             m = HipAAE(N, h, c, cond_inc=inc, max_batch=Bl, rng_mode="inject", grad_mode="export", dp_world=world, **kw)
             m.load_params(params)
             sp_params = dict(params)
-            sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
-            sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+            sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][items], params["dec.lin3.bias"][items]
+            sp_params["enc.lin1.weight"] = params["enc.lin1.weight"][:, items]
             locals_[rk] = m
             if scheme == "replicated":
                 dp = DataParallelAAE(m, dist, shard_decoder=True)
@@ -352,16 +353,16 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
                             z_real=zr[rk * Bl:(rk + 1) * Bl])
                     dp.wait_pending()
                 return
-            sl = HipAAE(hi - lo, h, c, cond_inc=inc, max_batch=B, rng_mode="inject", blocked_output=bool(seed % 2), **kw)
+            sl = HipAAE(len(sp_params["dec.lin3.bias"]), h, c, cond_inc=inc, max_batch=B, rng_mode="inject", blocked_output=bool(seed % 2), **kw)
             sl.load_params(sp_params)
             slices[rk] = sl
-            vp = VocabParallelAAE(m, sl, dist, N, shard_first_layer=scheme == "vocab2")
+            vp = VocabParallelAAE(m, sl, dist, N, shard_first_layer=scheme == "vocab2", interleaved=inter)
             for ip, idx, val, masks, zr, cond, want in steps:
                 X = sp.csr_matrix((val, idx, ip), shape=(B, N))
                 mk = None if masks is None else [k[rk * Bl:(rk + 1) * Bl] for k in masks]
                 if scheme == "vocab2":                   # the slice sees its columns only: the rows' complete L1 norms
                     sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=m.device))
-                vp.step(DeviceCSR(X, m.device), rk * Bl, Bl, DeviceCSR(X[:, lo:hi], m.device), 0, B,
+                vp.step(DeviceCSR(X, m.device), rk * Bl, Bl, DeviceCSR(X[:, items].tocsr(), m.device), 0, B,
                         cond=torch.as_tensor(cond[rk * Bl:(rk + 1) * Bl], device=m.device) if inc else None, masks=mk,
                         z_real=zr[rk * Bl:(rk + 1) * Bl])
                 loss = vp.recon_loss()

@@ -86,19 +86,25 @@ if "replicated" in SCHEMES:
     torch.cuda.empty_cache()
 # ---- vocabulary-sharded output layer ---------------------------------------------------------------------------
 lo, hi = item_slice(N, 0, world)
+if os.environ.get("VR_INTERLEAVE", "1") != "0":     # rank 0 owns items 0, world, 2 world, ... (what fit() uses); 0: the first N / world
+    ITEMS = slice(0, N, world)                      # (= the popular head of a frequency-sorted vocabulary: most of every batch's entries)
+    lo, hi = 0, len(range(0, N, world))
+else:
+    ITEMS = slice(lo, hi)
+INTER = ITEMS.step is not None and ITEMS.step > 1
 sp = dict(params)
-sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][lo:hi], params["dec.lin3.bias"][lo:hi]
-sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, lo:hi]
+sp["dec.lin3.weight"], sp["dec.lin3.bias"] = params["dec.lin3.weight"][ITEMS], params["dec.lin3.bias"][ITEMS]
+sp["enc.lin1.weight"] = params["enc.lin1.weight"][:, ITEMS]
 BLOCKED = os.environ.get("VR_BLOCKED", "1") != "0"      # 'both' scheme: row-blocked fused launches for the slice (what fit() uses); 0: three GEMMs
 BLOCKED_OUT = os.environ.get("VR_BLOCKED_OUT", "0") != "0"   # 'vocab' (output layer alone) scheme: three GEMMs is what fit() uses there
-slice_csr = DeviceCSR(X[:, lo:hi], dev)
+slice_csr = DeviceCSR(X[:, ITEMS].tocsr(), dev)
 if "vocab" in SCHEMES:
     m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
     m.load_params(params)
     sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=BLOCKED_OUT)
     sl.load_params(sp)
     d2 = EchoDist(world)
-    vp = VocabParallelAAE(m, sl, d2, N)
+    vp = VocabParallelAAE(m, sl, d2, N, interleaved=INTER)
     t_vp = timeit(lambda i: vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg))
     sl.profile_enable(True)
     for i in range(50):
@@ -125,7 +131,7 @@ if "both" in SCHEMES:
     sl.load_params(sp)
     sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=dev))
     d3 = EchoDist(world)
-    vp = VocabParallelAAE(m, sl, d3, N, shard_first_layer=True)
+    vp = VocabParallelAAE(m, sl, d3, N, shard_first_layer=True, interleaved=INTER)
     PF = os.environ.get("VR_PREFETCH", "0") != "0"     # 1: name the slice model's next batch ahead (measured: 0.472 -> 0.500 ms)
     t_vp2 = timeit(lambda i: ((sl.prefetch(slice_csr, ((i + 1) % NB) * Bg, Bg) if PF else None),
                               vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)))
