@@ -467,9 +467,13 @@ class AdversarialAutoEncoder:
                     if lo is None:
                         continue
                     self._dp.global_rows = stop - start
-                    # (naming the slice model's next batch with _hip.prefetch is possible - aae_first_layer_forward
-                    #  honours it - but measured as a loss there: the cross-stream marks cost the 40-launch step of a
-                    #  rank more than the 16 us of list building they move off it, tools/vocab_rank_time.py VR_PREFETCH=1)
+                    if self._slice is not None and self._dp.shard_first:
+                        # the slice model's next (global) batch: its distinct items and their deferred-Adam catch-up
+                        # run behind this step's deferred optimiser launch (_hip.prefetch)
+                        gn = start + self.batch_size
+                        gs = gn + (min(gn + self.batch_size, n_docs) - gn) // self._dp.world * self._dp.world
+                        if gs > gn:
+                            self._slice.prefetch(self._slice_csr, 0, gs - gn, perm_dev[gn:gs])
                     # first-layer packets: no share of this batch names more distinct items than it has entries
                     shares = np.array_split(row_len[perm[start:stop]], self._dp.world)
                     self._dp.w1_rows = int(max(sh.sum() for sh in shares)) + 8

@@ -135,6 +135,9 @@ struct aae_model {
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
     aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
     bool pf_pending; hipEvent_t ev_head, ev_pf;
+    bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
+    hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
+    bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)
 };
 
 namespace {
@@ -341,8 +344,10 @@ bool prof_pair(aae_model* m, int k, hipEvent_t* a, hipEvent_t* b) {
 // The previous step's deferred optimiser launch (dec_fused.h kDecOpt on m->side) writes DEC_V3 and its moments and
 // reads dh2 / the G scratch / the decoder's step scalars: everything that touches those waits for it here.
 int join_deferred(aae_model* m, hipStream_t s) {
-    if (m->opt_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));      // (one stream, in order: the later record covers the earlier)
-    else if (m->pf_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0));
+    // (one side stream, in order: the later record covers the earlier - the prefetch is enqueued in front of the deferred
+    //  launch by aae_step's path and behind it by an item slice's, so both marks are waited for when both are pending)
+    if (m->opt_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
+    if (m->pf_pending && (!m->opt_pending || m->pf_after_opt)) HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0));
     m->opt_pending = m->pf_pending = false;
     return AAE_OK;
 }
@@ -773,6 +778,28 @@ static bool fused_decoder_applies(const aae_model* m) {
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
 }
+// counting sort of the running batch's entries into the fused output layer's 32-item tiles (buckets.h / dec_fused.h)
+int build_tile_buckets(aae_model* m, hipStream_t s) {
+    const int ntiles = (m->N + kTI - 1) / kTI, B = m->rows;
+    if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
+        const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+        hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
+    } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
+        // (the global batch of an item slice: one launch instead of four, 25 -> 9 us)
+        const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
+        hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
+    } else {
+        const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
+        hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
+        hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
+        hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten, m->tev);
+    }
+    LAUNCHCHK("tile buckets");
+    m->buckets_valid = true;
+    return AAE_OK;
+}
+
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const int ntiles = (m->N + kTI - 1) / kTI;
     const size_t need = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
@@ -935,9 +962,10 @@ static bool same_batch(const aae_batch& a, const aae_batch& b) {
 // aae_prefetch_batch, second half: the hinted batch's unique-item list + deferred-Adam catch-up (through the RUNNING
 // step, whose scalars advance_step has published by the time ev_head fires) on the side stream, into the second list
 // set.  Rows of the running batch are skipped: the step's own updates bring them to the same step.
-int launch_prefetch(aae_model* m) {
+int launch_prefetch(aae_model* m, bool wait_head = true) {
     const aae_batch& b = m->pf_batch;
     m->pf_armed = false;
+    m->pf_after_opt = !wait_head;
     if (!m->side || !m->mark2 || !m->lazy) return AAE_OK;
     BatchView bv; bv.indptr = b.indptr_dev; bv.indices = b.indices_dev; bv.values = b.values_dev;
     bv.rows = b.rows_dev; bv.row_start = b.row_start; bv.n_rows = b.n_rows;
@@ -945,7 +973,7 @@ int launch_prefetch(aae_model* m) {
     const int chunks = std::max(1, std::min(64, (mr + 15) / 16));
     const int gy = std::max(1, std::min(16, chunks / 16 + 1));
     hipStream_t q = m->side;
-    HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));
+    if (wait_head) HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));      // (else: the caller enqueues behind work that is ordered behind the step's head)
     hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
     hipLaunchKernelGGL(uniq_items_kernel, dim3(b.n_rows, gy), dim3(256), 0, q, bv, m->mark2, m->stamp2, m->ulist2, m->ucount2);
     if (m->cfg.optimizer == AAE_OPT_ADAM) {
@@ -1234,7 +1262,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                   hipEventCreateWithFlags(&m->ev_crit, evflags) == hipSuccess &&
                   hipEventCreateWithFlags(&m->ev_opt, evflags) == hipSuccess &&
                   hipEventCreateWithFlags(&m->ev_head, evflags) == hipSuccess &&
-                  hipEventCreateWithFlags(&m->ev_pf, evflags) == hipSuccess;
+                  hipEventCreateWithFlags(&m->ev_pf, evflags) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_bk, evflags) == hipSuccess;
         if (!side_ok) {
             if (m->side) (void)hipStreamDestroy(m->side);
             m->side = nullptr;
@@ -1301,6 +1330,7 @@ int aae_destroy(aae_handle h) {
     if (h->ev_opt) (void)hipEventDestroy(h->ev_opt);
     if (h->ev_head) (void)hipEventDestroy(h->ev_head);
     if (h->ev_pf) (void)hipEventDestroy(h->ev_pf);
+    if (h->ev_bk) (void)hipEventDestroy(h->ev_bk);
     if (h->prof_ev) {
         for (int k = 0; k < AAE_K_N; ++k)
             for (auto& pr : h->prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1773,27 +1803,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (fused_decoder_applies(m)) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
         const int ntiles = (N + kTI - 1) / kTI;
-        if (m->buckets_valid) {
-            // built by the extra workgroup of this step's first chain launch
-        } else if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
-            const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
-            hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
-                               m->tev);
-        } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
-            // (the global batch of an item slice: one launch instead of four, 25 -> 9 us in front of the critical launch)
-            const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
-            hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten,
-                               m->tev);
-        } else {
-            const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
-            hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
-            hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
-            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
-            hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten,
-                               m->tev);
+        if (m->bk_pending) {            // built on the side stream while this step's forward ran (aae_first_layer_forward)
+            HIPCHK(hipStreamWaitEvent(s, m->ev_bk, 0));
+            m->bk_pending = false;
         }
-        LAUNCHCHK("tile buckets");
-        m->buckets_valid = true;
+        if (!m->buckets_valid) TRY(build_tile_buckets(m, s));   // (else: the extra workgroup of this step's first chain launch did)
         DecFusedArgs fa;
         fa.dh2 = m->dh2.p; fa.ldh = m->ldh;
         fa.V3a = m->P[P_V3].p; fa.M = m->M[0][P_V3].p; fa.V = m->V[0][P_V3].p; fa.ldv = m->ldh;
@@ -1907,8 +1921,14 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             }
             TRY(side_done(m, m->ev_opt));
             m->opt_pending = true;
+            m->last_out_split = true;
+            // an item slice's next batch (named ahead): its distinct items and their deferred-Adam catch-up behind the
+            // deferred launch on the same stream (ordered behind this step's head by ev_crit; rows of the running batch
+            // are skipped there, the step's own updates bring them to the same step)
+            if (m->only_output_layer && m->pf_armed && m->mark2 && m->lazy) TRY(launch_prefetch(m, false));
         } else
         {
+            m->last_out_split = false;
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
             if (m->bf16) switch (m->fused_nb) {
                 case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
@@ -2348,8 +2368,20 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         LAUNCHCHK("advance_step");
         if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
         m->enc_bwd_done = false; m->fuse_enc_bwd = false; m->dense_step = false;
-        pf = m->pf_armed && m->side && m->mark2 && m->lazy;
-        if (m->pf_armed && !pf) m->pf_armed = false;
+        // The output layer's tile buckets depend on the batch only: they are built on the side stream beside this
+        // handle's list building and gather (and the caller's forward pass) instead of in front of the critical launch.
+        // The side stream is in order behind the last deferred launch, which waited for the last critical launch - the
+        // last reader of the bucket arrays; without such a launch to order it the build stays where it was.
+        static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
+        if (bk_ahead && m->side && m->ev_bk && m->last_out_split && fused_decoder_applies(m)) {
+            TRY(build_tile_buckets(m, m->side));
+            HIPCHK(hipEventRecord(m->ev_bk, m->side));
+            m->bk_pending = true;
+        }
+        // (a batch named with aae_prefetch_batch stays armed: its list and catch-up are enqueued behind this step's
+        //  deferred optimiser launch - aae_output_layer_step - where they need no mark on this stream; a mark riding on
+        //  the gather below cost the stream more than the 16 us it moved away)
+        if (m->pf_armed && !(m->side && m->mark2 && m->lazy)) m->pf_armed = false;
     } else if (!m->have_batch) {
         return fail(AAE_ESTATE, "aae_first_layer_forward(batch = NULL) without a running batch");
     }

@@ -132,7 +132,7 @@ if "both" in SCHEMES:
     sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=dev))
     d3 = EchoDist(world)
     vp = VocabParallelAAE(m, sl, d3, N, shard_first_layer=True, interleaved=INTER)
-    PF = os.environ.get("VR_PREFETCH", "0") != "0"     # 1: name the slice model's next batch ahead (measured: 0.472 -> 0.500 ms)
+    PF = os.environ.get("VR_PREFETCH", "1") != "0"     # name the slice model's next batch ahead (what fit() does)
     t_vp2 = timeit(lambda i: ((sl.prefetch(slice_csr, ((i + 1) % NB) * Bg, Bg) if PF else None),
                               vp.step(csr, (i % NB) * Bg, B, slice_csr, (i % NB) * Bg, Bg)))
     per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d3.bytes.items()}
