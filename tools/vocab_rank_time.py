@@ -65,7 +65,10 @@ def timeit(step, steps=int(os.environ.get('VR_STEPS', 200)), warm=int(os.environ
     t0 = time.perf_counter()
     for i in range(steps):
         step(warm + i)
+    t_host = time.perf_counter() - t0           # the loop has ENQUEUED everything
     torch.cuda.synchronize()
+    if os.environ.get("VR_HOST"):
+        print(f"   [host: {1e3 * t_host / steps:.3f} ms/step to enqueue, {1e3 * (time.perf_counter() - t0) / steps:.3f} ms/step to finish]", flush=True)
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
