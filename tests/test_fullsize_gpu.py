@@ -192,3 +192,30 @@ def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B):
         a, b = blocked.tensor(tid).cpu().numpy(), plain.tensor(tid).cpu().numpy()
         tol = 2e-6 if tid == T_DEC_V3 else 1e-9
         assert _maxdiff(a, b) <= tol + 1e-4 * float(np.abs(b).max()), (tid, _maxdiff(a, b))
+
+
+@pytest.mark.parametrize("N,B", [(6000, 150), (40000, 224)])
+def test_row_blocked_full_steps_equal_the_three_kernel_steps(N, B):
+    """Whole training steps (aae_step: ae + disc + gen) on ONE handle with 113..256-row batches - what
+    AdversarialAutoEncoder creates for such batch sizes (blocked_output: the output layer as one critical launch for the
+    row blocks + the deferred optimiser launch(es); 6 000 items: dec_opt_blocks_kernel, 40 000: one launch per block) -
+    against the same steps on the three-kernel output layer: losses and every parameter after 3 steps, short batches
+    in between included."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from tools.synth import init_params, throughput_corpus
+    h, c = 200, 50
+    params = init_params(N, h, c, seed=3)
+    X = throughput_corpus(4 * B, N, median_len=10, seed=N)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3, rng_mode="device", seed=5)
+    blocked = HipAAE(N, h, c, max_batch=B, blocked_output=True, **kw)
+    plain = HipAAE(N, h, c, max_batch=B, unfused_decoder=True, **kw)
+    for m in (blocked, plain):
+        m.load_params(params)
+    csr = DeviceCSR(X, blocked.device)
+    for s, rows in enumerate((B, B, 97, B)):          # (97 rows: one fused launch on the same handle)
+        for m in (blocked, plain):
+            m.step(csr, s * B, rows)
+        np.testing.assert_allclose(blocked.losses(), plain.losses(), rtol=2e-5, err_msg=f"step {s}")
+    sa, sb = blocked.state_dict(), plain.state_dict()
+    for k in sa:
+        np.testing.assert_allclose(sa[k], sb[k], atol=4e-6, err_msg=k)
