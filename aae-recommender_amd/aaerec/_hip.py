@@ -355,7 +355,8 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False, dense_noise=False):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False, dense_noise=False,
+                 deterministic=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -392,6 +393,7 @@ class HipAAE:
         # (VERDICT r1 item 3), measured SLOWER than the three GEMMs there (0.50 -> 0.87 ms of per-rank compute at world
         # 8): opt-in, off everywhere by default
         cfg.reserved[4] = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
+        cfg.reserved[6] = 1 if deterministic else 0      # fixed summation order of the first layer's gradient (bit-reproducible runs)
         # DenoisingAutoEncoder(corrupt='gauss'): room for the dense noisy encoder input (set_input_noise before a step)
         cfg.reserved[5] = 1 if dense_noise else 0
         self.dtype = dtype

@@ -129,6 +129,7 @@ struct aae_model {
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.reserved[5]: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
+    bool ordered_w1 = false;       // cfg.reserved[6]: the first layer's weight gradient in a fixed summation order (no float atomics)
     bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
@@ -182,7 +183,8 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    for (int i = 6; i < 8; ++i) if (c->reserved[i]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->reserved[6] != 0 && c->reserved[6] != 1) return fail(AAE_EINVAL, "reserved[6] must be 0 or 1");
+    if (c->reserved[7]) return fail(AAE_EINVAL, "reserved fields must be zero");
     if (c->reserved[5] != 0 && c->reserved[5] != 1) return fail(AAE_EINVAL, "reserved[5] must be 0 or 1 (dense noisy encoder input)");
     if (c->reserved[5] == 1 && (c->reserved[2] != 1 || c->grad_mode != AAE_GRAD_FUSED || c->reserved[3] != 0))
         return fail(AAE_EINVAL, "reserved[5] = 1 (dense noisy encoder input) needs the plain autoencoder (reserved[2] = 1), fp32, fused optimiser");
@@ -539,6 +541,11 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     // lin1: sparse scatter into gW1T, bias column sum
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    if (m->ordered_w1 && m->lazy)
+        hipLaunchKernelGGL(w1_grad_ordered_kernel, dim3(std::min(m->cfg.max_nnz, 4096)), dim3(256), 0, s, m->bv,
+                           (const int*)m->ulist, (const int*)m->ucount, (const float*)m->gb1.p, m->ldh, h,
+                           (const float*)m->rscale, m->Gr[P_W1T].p, m->ldw1);
+    else
     hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
                        m->rscale, m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
@@ -738,6 +745,7 @@ struct DwBuilder {
         w.ncol = (m->h + 63) / 64;
         if (m->dense_step) w.ny = 0;            // dense noisy input: no scatter (the dense dW1T product follows), bias blocks only
         if (m->ext_first) w.ny = 0;             // the weight rows live with their item slices (aae_first_layer_update): bias blocks only
+        if (m->ordered_w1) w.ny = 0;            // fixed summation order: w1_grad_ordered_kernel follows (encoder_first_layer_update)
     }
     int launch(hipStream_t s) {
         int blocks = tiles;
@@ -919,8 +927,14 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
         LAUNCHCHK("fill_tsync");
         return AAE_OK;
     }
+    if (m->ordered_w1) {
+        hipLaunchKernelGGL(w1_grad_ordered_kernel, dim3(std::min(m->cfg.max_nnz, 4096)), dim3(256), 0, s, m->bv,
+                           (const int*)m->ulist, (const int*)m->ucount, ga1, m->ldh, h, (const float*)m->rscale,
+                           m->Gr[P_W1T].p, m->ldw1);
+        LAUNCHCHK("w1_grad_ordered");
+    }
     if (!merged) {
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
+    if (!m->ordered_w1) hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
                        m->Gr[P_W1T].p, m->ldw1, 0);
     LAUNCHCHK("enc_scatter");
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
@@ -1201,6 +1215,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->vae = cfg->reserved[2] == 3; m->vae_bwd = false; m->vae_cut = false;
     m->bf16 = cfg->reserved[3] == 1;
     m->blocked_ok = cfg->reserved[4] == 1;
+    m->ordered_w1 = cfg->reserved[6] == 1;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->reserved[2] == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)

@@ -78,7 +78,9 @@ typedef struct aae_config {
     int32_t has_prior_scale;
     uint64_t seed;            /* device rng */
     int32_t reserved[8];      /* must be zero, except [4] = 1: row-blocked fused output layer for batches > 112 rows
-                               * (opt-in), [5] = 1: room for aae_set_input_noise; [0] = 1: keep the decoder output layer on the unfused
+                               * (DESIGN.md 7.3), [5] = 1: room for aae_set_input_noise; [6] = 1: the sparse first layer's weight
+                               * gradient in a fixed summation order instead of float atomics (bit-reproducible runs; for tests
+                               * and debugging: B x distinct-items bisections per step); [0] = 1: keep the decoder output layer on the unfused
                                  three-kernel path (A/B measurements); [1] = number of data-parallel
                                  peers whose packed rows aae_w1_import may receive (0 = 1); [2] = 1:
                                  plain AutoEncoder (reference aae.py:221-458): the step ends after the
