@@ -422,6 +422,7 @@ class HipAAE:
         _check(lib.aae_set_lr(self.handle, float(gen_lr), float(reg_lr)))
         self._keep = []   # device buffers of the running step
         self._ga1_ld = None
+        self._ext_first = False
 
     def close(self):
         """Destroy the handle now (waits for its side stream)."""
@@ -663,6 +664,21 @@ class HipAAE:
     def set_first_layer_external(self, on=True):
         """Replica handle: a1_rows() is filled by the caller, dL/d(a1) comes back in ga1_rows(); enc.lin1 stays untouched."""
         _check(self.lib.aae_set_first_layer_external(self.handle, 1 if on else 0))
+        self._ext_first = bool(on)
+
+    def ga1_packet(self, n_rows, with_decoder):
+        """(flat view, rows part in floats, offset of the small layers' gradient span in floats): dL/d(a1) of the last
+        encoder backward and, right behind it in the arena, the gradients of enc.lin1's bias, enc.lin2, enc.lin3 (and
+        dec.lin1, dec.lin2 when with_decoder) - ONE contiguous packet for the both-sharded scheme's all-gather.  Export
+        mode with an external first layer only (the library keeps dL/d(a1) right-aligned in front of that span)."""
+        a, b, e = AaeTensor(), AaeTensor(), AaeTensor()
+        _check(self.lib.aae_tensor_info(self.handle, T_ACT_GA1, C.byref(a)))
+        _check(self.lib.aae_tensor_info(self.handle, T_GRAD + T_ENC_B1, C.byref(b)))
+        _check(self.lib.aae_tensor_info(self.handle, T_GRAD + (T_DEC_V2 if with_decoder else T_ENC_W3), C.byref(e)))
+        start = a.byte_offset + (a.rows - n_rows) * a.ld * 4
+        end = e.byte_offset + e.rows * e.ld * 4
+        assert self._ext_first and start + n_rows * a.ld * 4 <= b.byte_offset < end
+        return self.arena[start:end].view(torch.float32), n_rows * a.ld, (b.byte_offset - start) // 4
 
     def first_layer_forward(self, csr=None, row_start=0, n_rows=0, rows=None, bias=None):
         """This handle's items' share of the first layer's pre-activations -> a1_rows(); csr = None: the running batch
@@ -701,8 +717,10 @@ class HipAAE:
         return self.tensor(T_ACT_A1, padded=True)[:n_rows]
 
     def ga1_rows(self, n_rows):
-        """[n_rows, ld] view of dL/d(a1) of the last encoder backward."""
-        return self.tensor(T_ACT_GA1, padded=True)[:n_rows]
+        """[n_rows, ld] view of dL/d(a1) of the last encoder backward (a replica in export mode with an external first
+        layer keeps it in the LAST rows of its buffer: see ga1_packet)."""
+        t = self.tensor(T_ACT_GA1, padded=True)
+        return t[t.shape[0] - n_rows:] if (self._ext_first and self.cfg.grad_mode == GRAD_EXPORT) else t[:n_rows]
 
     def dh2_rows(self, n_rows):
         """[n_rows, ld] view of the decoder's last hidden activation (with its bias-input column and padding)."""

@@ -319,6 +319,7 @@ class VocabParallelAAE(DataParallelAAE):
         # _step_both_sharded); the caller gives the slice model the documents' complete L1 norms (set_doc_l1)
         self.shard_first = bool(shard_first_layer)
         self._pk = self._pk_all = None
+        self._pkt = {}
         self._view_cache = {}
         if self.shard_first:
             model.set_first_layer_external(True)
@@ -391,6 +392,23 @@ class VocabParallelAAE(DataParallelAAE):
         self._count(v["a1_all"])
         d.reduce_scatter_tensor(v["a1"], v["a1_all"], op=d.ReduceOp.SUM, group=self.group)
 
+    def _exchange_packet(self, n_rows, with_decoder):
+        """The same exchange when the model keeps dL/d(a1) and the small layers' gradient span contiguous in its arena
+        (HipAAE.ga1_packet): the packet is a view - no packing launch; returns what first_layer_update / apply_gathered
+        take (buffer, rows per block, block stride, offset of the gradient span)."""
+        d = self.dist
+        ent = self._pkt.get((n_rows, with_decoder))
+        if ent is None:                               # (looked up once per batch shape, like _views)
+            pk, n0, span_off = self.model.ga1_packet(n_rows, with_decoder)
+            ent = (pk, span_off, pk.new_empty(pk.numel() * self.world) if self.world > 1 else pk)
+            self._pkt = {k: v for k, v in self._pkt.items() if k[0] == n_rows}
+            self._pkt[(n_rows, with_decoder)] = ent
+        pk, span_off, allp = ent
+        if self.world > 1:
+            self._count(pk)
+            d.all_gather_into_tensor(allp, pk, group=self.group)
+        return allp, n_rows, pk.numel(), span_off
+
     def _exchange_ga1(self, n_rows, ga1, riders, fused_apply=False):
         """dL/d(a1) of every rank's documents gathered (rank-major = global batch order; returned as (buffer, rows per
         block, block stride) for first_layer_update); `riders` (small gradient spans due at the same point) travel behind
@@ -441,10 +459,15 @@ class VocabParallelAAE(DataParallelAAE):
         d.reduce_scatter_tensor(v["da2"], v["da2_all"], op=d.ReduceOp.SUM, group=self.group)
         m.ae_backward()
         fused = hasattr(m, "apply_gathered")        # one launch: the peers' sum + enc_optim + dec_optim's small layers
-        g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"], fused)
-        if fused:
+        packed = fused and hasattr(m, "ga1_packet")  # ... and the packet a view of the arena: no packing launch
+        if packed:
+            g, rpb, bs, off = self._exchange_packet(n_rows, True)
+            m.apply_gathered(O_ENC, O_DEC, g, bs, self.world, off)
+        elif fused:
+            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"], fused)
             m.apply_gathered(O_ENC, O_DEC, g, bs, self.world, v["ga1"].numel())
         else:
+            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_ae"], fused)
             m.apply_updates(O_ENC)
             m.apply_updates(O_DEC, skip=m.big_tensor_id)
         sl.first_layer_update(O_ENC, g, rpb, bs)
@@ -456,10 +479,14 @@ class VocabParallelAAE(DataParallelAAE):
                 d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
             m.apply_updates(O_DISC)
             m.gen_step()
-            g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"], fused)
-            if fused:
+            if packed:
+                g, rpb, bs, off = self._exchange_packet(n_rows, False)
+                m.apply_gathered(O_GEN, -1, g, bs, self.world, off)
+            elif fused:
+                g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"], fused)
                 m.apply_gathered(O_GEN, -1, g, bs, self.world, v["ga1"].numel())
             else:
+                g, rpb, bs = self._exchange_ga1(n_rows, v["ga1"], v["small_gen"], fused)
                 m.apply_updates(O_GEN)
             sl.first_layer_update(O_GEN, g, rpb, bs)
         self._gathered = False

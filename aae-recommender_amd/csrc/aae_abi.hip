@@ -83,6 +83,7 @@ struct aae_model {
     Ten PT[NP]; Ten D4[NP]; bool pt_ok[NP];      // PT = the F4 copy, D4 = the dX copy (device_common.h W4Copies)
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
+    Ten ga1x;                // export mode: see aae_create
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
     const float* doc_l1;     // aae_set_doc_l1: L1 norms of the complete documents (a handle that holds an item slice of them)
     bool ext_first;          // aae_set_first_layer_external: AAE_T_ACT_A1 comes from the caller, dL/d(a1) goes back to it
@@ -227,6 +228,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
         m->V[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
     }
     m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
+    // export mode: dL/d(a1) of a replica with an external first layer, RIGHT-aligned in a buffer that ends where the small
+    // layers' gradient span begins - [its rows | b1, W2, W3, V1, V2 gradients] is then one contiguous packet for the
+    // all-gather of the both-sharded scheme (no packing launch)
+    if (c.grad_mode == AAE_GRAD_EXPORT) m->ga1x = a.mat(m->R, h + 1, m->ldh);
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
@@ -642,6 +647,10 @@ void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo 
 W4Copies w4_of(const aae_model* m, int pid) {
     return W4Copies{m->PT[pid].p, m->D4[pid].p, (int)m->P[pid].rows, (int)m->P[pid].cols};
 }
+// where dL/d(a1) of the encoder backward goes: gb3, or (external first layer, export mode) the tail of ga1x
+float* ga1_ptr(const aae_model* m) {
+    return (m->ext_first && m->ga1x.p) ? m->ga1x.p + (size_t)(m->R - m->rows) * m->ldh : m->gb3.p;
+}
 // (re-)derive the k4-interleaved copies of a hidden layer after something other than the optimiser kernels wrote the weights
 void ensure_pt(aae_model* m, int pid, hipStream_t s) {
     const Ten& T = m->PT[pid];
@@ -904,7 +913,7 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
         cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
         ChainOp& x2 = cb.add(cop_dx(m, P_W2, 9, 1, h, h, CEPI_ACTBWD, s)); x2.yslot = 0;
         x2.d = make_drop(m, 0, true, I.masks_dev[which == O_GEN ? 8 : 0], nullptr, B, h, which == O_GEN ? 8 : 0);
-        cop_out(x2, m->gb3.p, m->ldh);
+        cop_out(x2, ga1_ptr(m), m->ldh);
     }
     return launch_chain(m, cb, s);
 }
@@ -1174,12 +1183,12 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     ChainOp& w3 = cb.add(cop_dx(m, P_W3, sg, 7, c, h, CEPI_ACTBWD, s)); w3.yslot = 2; w3.d = e2.d;
     cop_out(w3, m->gb2.p, m->ldh);
     ChainOp& w2 = cb.add(cop_dx(m, P_W2, 7, 8, h, h, CEPI_ACTBWD, s)); w2.yslot = 1; w2.d = e1.d;
-    cop_out(w2, m->gb3.p, m->ldh);
+    cop_out(w2, ga1_ptr(m), m->ldh);
     TRY(launch_chain(m, cb, s));
     DwBuilder dw;
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
-    dw.add_first_layer(m, m->gb3.p, O_GEN);
+    dw.add_first_layer(m, ga1_ptr(m), O_GEN);
     TRY(dw.launch(s));
     if (m->ext_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
     return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
@@ -1553,7 +1562,7 @@ int aae_tensor_info(aae_handle h, int id, aae_tensor* out) {
     else if (id == AAE_T_ACT_A1) t = &h->a1;
     else if (id == AAE_T_ACT_DH2) t = &h->dh2;
     else if (id == AAE_T_ACT_DA2) t = &h->da2;
-    else if (id == AAE_T_ACT_GA1) t = &h->gb3;
+    else if (id == AAE_T_ACT_GA1) t = (h->ext_first && h->ga1x.p) ? &h->ga1x : &h->gb3;   // (ga1x: the LAST rows hold the batch)
     else if (id == AAE_T_ACT_DZC) { tmp = h->gzc; tmp.cols = h->cp; t = &tmp; }
     else if (id == AAE_T_ACT_LOSSES) {
         tmp.rows = 1; tmp.cols = 4; tmp.ld = 4; tmp.off = (size_t)((char*)h->losses - h->base); t = &tmp;
@@ -2258,7 +2267,7 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
             DwBuilder dw;
             dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, m->rows, P_W3, O_ENC);
             dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, m->rows, P_W2, O_ENC);
-            dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+            dw.add_first_layer(m, ga1_ptr(m), O_ENC); m->w1_merged = true;
             TRY(dw.launch(s));
         }
         if (!m->ext_first) TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
@@ -2335,7 +2344,7 @@ int aae_ae_backward(aae_handle m, const float* dA2_dev, int64_t dA2_ld, void* st
     dw.add(m, m->gb1.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
-    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;      // (external first layer: its bias blocks only)
+    dw.add_first_layer(m, ga1_ptr(m), O_ENC); m->w1_merged = true;      // (external first layer: its bias blocks only)
     TRY(dw.launch(s));
     m->enc_bwd_done = true;
     m->phase = 2;
