@@ -130,6 +130,7 @@ struct aae_model {
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.reserved[5]: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
+    bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
     bool ordered_w1 = false;       // cfg.reserved[6]: the first layer's weight gradient in a fixed summation order (no float atomics)
     bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
@@ -789,8 +790,12 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m->rows + kRowBlock - 1) / kRowBlock; }
 static bool fused_decoder_applies(const aae_model* m) {
     const bool one = m->rows <= 16 * kMB;
+    // The row-blocked form pays while its deferred half (2 * rows * N * (h + 1) flop of GEMM2 at the optimiser kernel's
+    // ~30 TFLOP/s) fits beside the rest of the step: 800 rows x 12.5 k items (an item slice at world 8) 0.40 against 0.46 ms
+    // per step, 208 x 100 k 0.64 against 0.70; beyond ~32 M cells the next step waits for it and the three GEMMs win
+    // (512 x 100 k: 1.48 against 1.12 ms; 512 x 275 k, a C5 slice: 3.7 against 2.7 ms).  AAE_BLOCKED_ANY lifts the cap (tests).
     const bool blocked = !one && m->blocked_ok && !m->bf16 && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
-                         m->cfg.grad_mode == AAE_GRAD_FUSED;
+                         m->cfg.grad_mode == AAE_GRAD_FUSED && (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20));
     return m->fused_ok && !m->force_unfused && (one || blocked) &&
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
@@ -1224,6 +1229,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->vae = cfg->reserved[2] == 3; m->vae_bwd = false; m->vae_cut = false;
     m->bf16 = cfg->reserved[3] == 1;
     m->blocked_ok = cfg->reserved[4] == 1;
+    m->blocked_any = getenv("AAE_BLOCKED_ANY") != nullptr;
     m->ordered_w1 = cfg->reserved[6] == 1;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->reserved[2] == 1 || m->vae;
