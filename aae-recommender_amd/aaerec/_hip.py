@@ -25,6 +25,17 @@ PRIORS = {"gauss": 0, "categorical": 1, "bernoulli": 2}
 RNG_INJECT, RNG_DEVICE = 0, 1
 GRAD_FUSED, GRAD_EXPORT = 0, 1
 
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
 # tensor ids (aaerec_hip.h)
 T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3 = range(10)
 T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, T_GRAD = 16, 32, 48, 64, 80
@@ -363,6 +374,7 @@ class HipAAE:
         if activation not in ACTIVATIONS:
             raise ValueError(f"activation {activation!r} has no gfx950 kernel (supported: {sorted(ACTIVATIONS)})")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = lib
         cfg = AaeConfig()
         cfg.abi_version = ABI_VERSION
@@ -408,7 +420,7 @@ class HipAAE:
         self.max_batch = max_batch
         nbytes = C.c_size_t()
         _check(lib.aae_arena_bytes(C.byref(cfg), C.byref(nbytes)))
-        with torch.cuda.device(self.device):
+        with self._on_device():
             self.arena = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
             assert self.arena.data_ptr() % 256 == 0
             h = C.c_void_p()
@@ -431,6 +443,14 @@ class HipAAE:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self):
+        """Context with this handle's device current.  One process per GPU is the rule: the device is almost always
+        current already, and torch.cuda.device()'s enter / exit (two runtime calls and a Python context per library call,
+        ~30 calls per data-parallel step) is skipped then."""
+        if torch.cuda.current_device() == self._dev_index:
+            return _NULL_CTX
+        return torch.cuda.device(self.device)
 
     # ---- views into the arena ---------------------------------------------------------
     def tensor(self, tid, padded=False):
@@ -488,7 +508,7 @@ class HipAAE:
     # ---- state_dict in the reference layout ------------------------------------------
     def sync(self):
         """Replay the deferred W1T updates so that arena views show eager-equivalent values."""
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_sync(self.handle, self._stream()))
 
     def load_params(self, params):
@@ -620,7 +640,7 @@ class HipAAE:
         if cond is not None:
             cond = upload(cond, self.device, torch.float32).contiguous()
             self._keep.append(cond)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_step(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
                                      self._stream()))
 
@@ -632,7 +652,7 @@ class HipAAE:
         if cond is not None:
             cond = upload(cond, self.device, torch.float32).contiguous()
             self._keep.append(cond)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_ae_forward(self.handle, C.byref(b), _ptr(cond), C.byref(inj) if inj else None,
                                            self._stream()))
 
@@ -640,7 +660,7 @@ class HipAAE:
         """The decoder's output layer over this handle's items from T_ACT_DH2 -> dL/d(dh2) in T_ACT_DA2; csr = None
         continues the step ae_forward started on this handle."""
         b = self._batch(csr, row_start, n_rows, rows) if csr is not None else None
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_output_layer_step(self.handle, C.byref(b) if b is not None else None, self._stream()))
 
     def ae_backward(self, da2=None):
@@ -648,7 +668,7 @@ class HipAAE:
         if da2 is not None:
             assert da2.is_cuda and da2.dtype == torch.float32 and da2.stride(1) == 1
             self._keep.append(da2)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_ae_backward(self.handle, _ptr(da2), da2.stride(0) if da2 is not None else 0,
                                             self._stream()))
 
@@ -684,7 +704,7 @@ class HipAAE:
         """This handle's items' share of the first layer's pre-activations -> a1_rows(); csr = None: the running batch
         again with the weights as they are now.  bias: the replicas' enc.lin1 bias (device tensor) on exactly one share."""
         b = self._batch(csr, row_start, n_rows, rows) if csr is not None else None
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_first_layer_forward(self.handle, C.byref(b) if b is not None else None, _ptr(bias),
                                                     self._stream()))
 
@@ -697,7 +717,7 @@ class HipAAE:
         if ga1 is not None and self._ga1_ld is None:
             self._ga1_ld = self.ga1_rows(1).stride(0)
         ld = self._ga1_ld if ga1 is not None else 0
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_first_layer_update(self.handle, _ptr(ga1), ld, int(rows_per_block), int(block_stride),
                                                    int(which), self._stream()))
 
@@ -708,7 +728,7 @@ class HipAAE:
     def apply_gathered(self, which_a, which_b, packets, peer_stride, n_peers, span_offset):
         """Optimiser which_a (+ dec_optim's small layers when which_b == O_DEC, else -1) on the replica's small layers
         from the gathered packets (aae_apply_gathered): one launch, the peers summed in rank order inside it."""
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_apply_gathered(self.handle, int(which_a), int(which_b), _ptr(packets), int(peer_stride),
                                                int(n_peers), int(span_offset), self._stream()))
 
@@ -738,7 +758,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows, rows)
         inj = self._inject(masks, z_real)
         z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_ae_encode(self.handle, C.byref(b), C.byref(inj) if inj else None, _ptr(z),
                                           self._stream()))
         return z
@@ -747,7 +767,7 @@ class HipAAE:
         zc = zc.detach().to(self.device, torch.float32).contiguous()
         assert zc.shape[1] == self.c + self.cond_inc, "conditions.size_increment() mismatch"
         dzc = torch.empty_like(zc)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_ae_decode_backward(self.handle, _ptr(zc), zc.shape[1], None, _ptr(dzc), self._stream()))
         return dzc
 
@@ -761,7 +781,7 @@ class HipAAE:
         assert zin.shape == (n_rows, self.c + self.cond_inc), "decoder input width mismatch"
         dz = torch.empty_like(zin) if want_grad else None
         self._keep.append(zin)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_decoder_step(self.handle, C.byref(b), _ptr(zin), zin.shape[1],
                                              C.byref(inj) if inj else None, _ptr(dz), self._stream()))
         return dz
@@ -775,7 +795,7 @@ class HipAAE:
         if eps is not None:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous(); keep.append(eps)
         self._keep = keep
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_vae_step(self.handle, C.byref(b), _ptr(cond), _ptr(eps), self._stream()))
 
     def vae_encode(self, csr, row_start, n_rows, rows=None, eps=None, train=True):
@@ -785,7 +805,7 @@ class HipAAE:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
         z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
         self._keep = [eps, z]
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_vae_encode(self.handle, C.byref(b), _ptr(eps), _ptr(z), int(bool(train)), self._stream()))
         return z
 
@@ -793,14 +813,14 @@ class HipAAE:
         zc = zc.detach().to(self.device, torch.float32).contiguous()
         dzc = torch.empty_like(zc)
         self._keep = self._keep + [zc, dzc]
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_vae_decode_backward(self.handle, _ptr(zc), zc.shape[1], _ptr(dzc), self._stream()))
         return dzc
 
     def vae_encoder_backward(self, dz):
         dz = dz.detach().to(self.device, torch.float32).contiguous()
         self._keep = self._keep + [dz]
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_vae_encoder_backward(self.handle, _ptr(dz), dz.shape[1], self._stream()))
 
     def vae_predict(self, csr, row_start, n_rows, cond=None, eps=None):
@@ -810,7 +830,7 @@ class HipAAE:
             cond = upload(cond, self.device, torch.float32).contiguous()
         if eps is not None:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_vae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(eps), _ptr(out), out.shape[1],
                                             self._stream()))
         return out[:, :self.N]
@@ -818,28 +838,28 @@ class HipAAE:
     def ae_encoder_backward(self, dz):
         dz = dz.detach().to(self.device, torch.float32).contiguous()
         self._keep.append(dz)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_ae_encoder_backward(self.handle, _ptr(dz), dz.shape[1], self._stream()))
 
     def disc_gen(self):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_disc_gen(self.handle, None, self._stream()))
 
     def disc_step(self):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_disc_step(self.handle, None, self._stream()))
 
     def gen_step(self):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_gen_step(self.handle, None, self._stream()))
 
     def apply_updates(self, which, skip=-1):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_apply_updates_except(self.handle, which, skip, self._stream()))
 
     def apply_shard(self, tid, row_begin, row_end, grad_shard, which):
         self._keep.append(grad_shard)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_apply_shard(self.handle, tid, row_begin, row_end, C.c_void_p(grad_shard.data_ptr()),
                                             which, self._stream()))
 
@@ -869,7 +889,7 @@ class HipAAE:
         the default is the model-wide worst case w1_cap - the packet is what the all-gather moves."""
         cap, hdr, total = self._w1_layout(cap)
         pk = self._w1_packet[:total]
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_w1_export(self.handle, C.c_void_p(pk.data_ptr()), C.c_void_p(pk.data_ptr() + 4 * hdr), cap,
                                           self._stream()))
         return pk
@@ -881,7 +901,7 @@ class HipAAE:
         stride = total if stride_floats is None else int(stride_floats)
         assert stride >= total and packets.numel() >= (n_peers - 1) * stride + total
         self._keep.append(packets)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_w1_import(self.handle, C.c_void_p(packets.data_ptr()),
                                           C.c_void_p(packets.data_ptr() + 4 * hdr), cap, n_peers, 4 * stride, which,
                                           self._stream()))
@@ -908,7 +928,7 @@ class HipAAE:
 
     def losses(self):
         out = (C.c_float * 3)()
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_read_losses(self.handle, C.byref(out), self._stream()))
         return float(out[0]), float(out[1]), float(out[2])
 
@@ -922,7 +942,7 @@ class HipAAE:
         out = self._out_buffer(n_rows)
         if cond is not None:
             cond = upload(cond, self.device, torch.float32).contiguous()
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(out), out.shape[1], self._stream()))
         return out[:, :self.N]
 
@@ -933,7 +953,7 @@ class HipAAE:
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
         if cond is not None:
             cond = upload(cond, self.device, torch.float32).contiguous()
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_predict_topk(self.handle, C.byref(b), _ptr(cond), int(k), int(bool(exclude_known)),
                                              _ptr(idx), _ptr(val), self._stream()))
         return idx, val
@@ -945,7 +965,7 @@ class HipAAE:
         b = self._batch(csr, row_start, n_rows)
         idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_decode_topk(self.handle, _ptr(zc), zc.shape[1], C.byref(b), int(k), int(bool(exclude_known)),
                                             _ptr(idx), _ptr(val), self._stream()))
         return idx, val
@@ -953,14 +973,14 @@ class HipAAE:
     def encode(self, csr, row_start, n_rows):
         b = self._batch(csr, row_start, n_rows)
         z = torch.empty(n_rows, self.c, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_encode(self.handle, C.byref(b), _ptr(z), self._stream()))
         return z
 
     def decode(self, zc):
         zc = zc.detach().to(self.device, torch.float32).contiguous()
         out = self._out_buffer(zc.shape[0])
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _check(self.lib.aae_decode(self.handle, _ptr(zc), zc.shape[1], zc.shape[0], _ptr(out), out.shape[1],
                                        self._stream()))
         return out[:, :self.N]
