@@ -592,3 +592,27 @@ def test_two_ranks_with_both_vocabulary_wide_layers_sharded_equal_single_process
     np.testing.assert_allclose(np.concatenate([got["v3b0"], got["v3b1"]]), want["dec.lin3.bias"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(np.concatenate([got["w10"], got["w11"]], axis=1), want["enc.lin1.weight"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)
+
+
+def test_item_ownership_partitions_the_vocabulary():
+    """item_items: every item has exactly one owner, interleaved or contiguous, for vocabularies that do not divide by the
+    world size; the slice object indexes NumPy arrays and SciPy CSR columns alike."""
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    from aaerec.parallel import item_items, item_slice, _slice_len
+    rng = np.random.default_rng(0)
+    for n, world in [(10, 3), (1000, 8), (7, 8), (4587, 4)]:
+        X = sp.random(5, n, density=0.3, format="csr", random_state=1, dtype=np.float32)
+        for inter in (True, False):
+            owned = np.zeros(n, dtype=int)
+            cols = 0
+            for r in range(world):
+                it = item_items(n, r, world, inter)
+                owned[it] += 1
+                assert _slice_len(it, n) == len(np.arange(n)[it]) == X[:, it].shape[1]
+                cols += X[:, it].nnz
+                if not inter:
+                    assert (it.start, it.stop) == item_slice(n, r, world)
+            assert (owned == 1).all() and cols == X.nnz
+        w = rng.standard_normal((n, 3))
+        np.testing.assert_array_equal(w[item_items(n, 1, world, True)], w[1::world])
