@@ -1067,15 +1067,21 @@ def test_mrr_parity_at_10k_test_docs():
           checks, here each replayed run only has to land inside the reference's own spread;
       (b) the production device generator, 16 seeds: the mean over the converged runs lies within 2.5 standard errors
           of the reference's mean (s.e. of the difference ~0.007), the medians within 0.015;
-      (c) bf16 mode (config C2's arithmetic), 8 seeds: the same bands."""
+      (c) bf16 mode (config C2's arithmetic), 8 seeds: the same bands;
+      (d) the production scatter (float atomics in the first layer's weight gradient), 16 seeds: robust statistics only.
+    (a)-(c) run with deterministic=True (cfg.reserved[6]): 4 800 adversarial steps amplify an ulp - a swapped pair of
+    atomic adds - into another trajectory, and a fragile initialisation (host seed 10: the reference's own lowest run) then
+    lands anywhere between 0.35 and 0.55 from one run of this library to the next (tools/debug/mrr_replay_det.py; with the
+    fixed summation order every run of a seed is the same run: 0.5400 / 0.5144 / 0.5431).  The r2 suite had these bands
+    on the atomic path: one failure in six runs of this test on its own."""
     import aaerec.aae  # noqa: F401  (import before seeding: the module seeds torch at import, as the reference's does)
     z, Xtr, Xin, Yout = _big()
     ref = z["ref_mrr10"]
 
-    def run(host_seed, rng_mode, **kw):
+    def run(host_seed, rng_mode, deterministic=True, **kw):
         torch.manual_seed(host_seed)
         np.random.seed(host_seed)
-        m = _big_model(120, rng_mode, **kw)
+        m = _big_model(120, rng_mode, deterministic=deterministic, **kw)
         m.fit(Xtr)
         return _mrr10(m.predict(Xin), Xin, Yout)
     same = {s: run(s, "reference") for s in (0, 3, 10)}
@@ -1102,3 +1108,8 @@ def test_mrr_parity_at_10k_test_docs():
         assert abs(np.median(vals) - np.median(ref)) < 0.015, (np.median(vals), np.median(ref))
     summary("device generator", [run(s, "device", seed=1000 + s) for s in range(16)])
     summary("bf16 mode", [run(s, "device", seed=2000 + s, dtype="bf16") for s in range(8)])
+    # (d) the production path: the same 16 device seeds through the atomic scatter - the runs that collapse differ from
+    # launch to launch, so only the bulk is asserted
+    prod = np.asarray([run(s, "device", deterministic=False, seed=1000 + s) for s in range(16)])
+    print("MRR@10, production scatter:", np.round(prod, 4).tolist(), "median", round(float(np.median(prod)), 4))
+    assert (prod > 0.4).sum() >= 12 and abs(np.median(prod) - np.median(ref)) < 0.03, prod
