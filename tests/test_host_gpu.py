@@ -34,8 +34,8 @@ def test_fit_predict_tracks_reference_with_reference_rng():
     torch.manual_seed(seed)
     np.random.seed(seed)
     m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100, gen_lr=0.01, reg_lr=0.001,
-                               verbose=False, rng_mode="reference")
-    m.fit(Xtr)
+                               verbose=False, rng_mode="reference", deterministic=True)     # (bit-reproducible: see
+    m.fit(Xtr)                                                                               #  test_ranking_metrics_...)
     pred = m.predict(Xin[:40])
     assert pred.dtype == np.float32 and pred.shape == z["pred_short"].shape
     # north star: reconstructions within 1e-4 (fp32)
