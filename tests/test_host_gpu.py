@@ -49,7 +49,7 @@ def _c1_mrr(seed, rng_mode):
     torch.manual_seed(seed)
     np.random.seed(seed)
     m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=100, batch_size=100, gen_lr=0.01, reg_lr=0.001,
-                               verbose=False, rng_mode=rng_mode)
+                               verbose=False, rng_mode=rng_mode, deterministic=True)     # (reproducible outcomes per seed)
     m.fit(Xtr)
     pred = remove_non_missing(m.predict(Xin), Xin, copy=True)
     return METRICS["mrr@10"](Yout.toarray(), pred)[0]
