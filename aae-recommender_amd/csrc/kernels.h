@@ -12,6 +12,37 @@ struct BatchView {
     __device__ __forceinline__ int doc(int b) const { return rows ? rows[b] : row_start + b; }
 };
 
+constexpr int kLazyReplay = 128;
+constexpr int kLazyTabCap = 65536;   // ring of the last 65536 steps' scalars (power of two; a replay reads <= kLazyReplay of them,
+                                     // so a learning rate changed by aae_set_lr at any step is honoured)
+
+struct LazyTab { float nss_gen, nss_reg, ibc2, pad; };   // per step t: -lr_gen/bc1, -lr_reg/bc1, 1/sqrt(bc2)
+
+// The step-opening bookkeeping (its own launch: advance_step_kernel at the end of this file; or the first 4 threads of
+// one workgroup of the step's first gather when nothing in between needs it - a launch costs ~4.5 us however little it does)
+struct AdvanceJob { OptScalars* sc; long long* ctr; LazyTab* tab; float* losses; int enabled; };
+__device__ __forceinline__ void advance_step_body(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount,
+                                                  float* losses, int i) {
+    // (stamp == NULL: the step's unique-item list was built ahead of time, aae_prefetch_batch)
+    if (i == 0) { *ctr += 1; if (stamp) { *stamp += 1; *ucount = 0; } losses[1] = 0.f; losses[2] = 0.f; }
+    if (i >= 4) return;
+    OptScalars s = sc[i];
+    s.t += 1;
+    if (s.is_sgd) { s.neg_step_size = (float)(-s.lr); s.bc2_sqrt = 1.f; s.inv_bc2_sqrt = 1.f; }
+    else {
+        double bc1 = 1.0 - pow(0.9, (double)s.t), bc2 = 1.0 - pow(0.999, (double)s.t);
+        s.neg_step_size = (float)(-(s.lr / bc1));
+        s.bc2_sqrt = (float)sqrt(bc2);
+        s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
+    sc[i] = s;
+    if (tab) {                             // optimiser 0 = enc_optim (gen_lr), 2 = gen_optim (reg_lr)
+        const int slot = (int)(s.t & (kLazyTabCap - 1));
+        if (i == 0) { tab[slot].nss_gen = s.neg_step_size; tab[slot].ibc2 = s.inv_bc2_sqrt; }
+        if (i == 2) tab[slot].nss_reg = s.neg_step_size;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K2+K3 (+K4): sparse multi-hot -> first encoder Linear.  reference: F.normalize(inp, 1) +
 // enc.lin1 (+ drop1, act1), aae.py:132-137.
@@ -24,7 +55,11 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
                                                          const float* __restrict__ b1, int h, int normalize,
                                                          float* __restrict__ a1, float* __restrict__ y, int ld,
                                                          int act, DropSpec d, uint64_t seed, const long long* step_ctr,
-                                                         float* __restrict__ rscale, const float* __restrict__ doc_l1 = nullptr) {
+                                                         float* __restrict__ rscale, const float* __restrict__ doc_l1 = nullptr,
+                                                         AdvanceJob adv = AdvanceJob{nullptr, nullptr, nullptr, nullptr, 0},
+                                                         long long step_val = -1) {
+    // adv.enabled: the last workgroup also opens the step (advance_step_body); every workgroup then takes the step number
+    // from step_val (the host's count of opened steps = what *step_ctr holds once the step is open), not from memory
     // doc_l1 != NULL: the L1 norms of the COMPLETE documents, indexed by document (the batch holds only the columns of one
     // item slice of them, aae_set_doc_l1); b1 == NULL: no bias (a partial sum that meets the other slices' elsewhere)
     extern __shared__ __attribute__((aligned(16))) float part[];   // [16][hp]
@@ -60,7 +95,8 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
         *reinterpret_cast<float4*>(&part[wave * hp + c0]) = acc;
     }
     __syncthreads();
-    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)*step_ctr, 0) : 0;
+    if (adv.enabled && blockIdx.x == gridDim.x - 1 && tid < 64) advance_step_body(adv.sc, adv.ctr, adv.tab, nullptr, nullptr, adv.losses, tid);
+    const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)(step_val >= 0 ? step_val : *step_ctr), 0) : 0;
     for (int c = tid; c < h; c += 1024) {
         float v = 0.f;
 #pragma unroll
@@ -564,11 +600,7 @@ __global__ __launch_bounds__(256) void adv_loss_kernel(const float* __restrict__
 // step): its length IS the kernel's time (14 us at 192, the step's first kernel after the unique-item list).  HBM traffic per step drops from 2 * 28 B * N * h to the
 // touched rows.
 // ---------------------------------------------------------------------------------------
-constexpr int kLazyReplay = 128;
-constexpr int kLazyTabCap = 65536;   // ring of the last 65536 steps' scalars (power of two; a replay reads <= kLazyReplay of them,
-                                     // so a learning rate changed by aae_set_lr at any step is honoured)
-
-struct LazyTab { float nss_gen, nss_reg, ibc2, pad; };   // per step t: -lr_gen/bc1, -lr_reg/bc1, 1/sqrt(bc2)
+// (kLazyReplay / kLazyTabCap / LazyTab: defined at the top of this file, next to advance_step_body)
 
 // distinct items of the batch -> ulist (order arbitrary), *ucount
 __global__ __launch_bounds__(256) void uniq_items_kernel(BatchView bv, int* __restrict__ mark,
@@ -923,25 +955,7 @@ __global__ void bump_stamp_kernel(int* stamp, int* ucount) { *stamp += 1; *ucoun
 // scalars (see OptScalars) + this step's row of the lazy-Adam table.  Thread i = optimiser i.
 __global__ void advance_step_kernel(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount,
                                     float* losses) {
-    const int i = threadIdx.x;
-    // (stamp == NULL: the step's unique-item list was built ahead of time, aae_prefetch_batch)
-    if (i == 0) { *ctr += 1; if (stamp) { *stamp += 1; *ucount = 0; } losses[1] = 0.f; losses[2] = 0.f; }
-    if (i >= 4) return;
-    OptScalars s = sc[i];
-    s.t += 1;
-    if (s.is_sgd) { s.neg_step_size = (float)(-s.lr); s.bc2_sqrt = 1.f; s.inv_bc2_sqrt = 1.f; }
-    else {
-        double bc1 = 1.0 - pow(0.9, (double)s.t), bc2 = 1.0 - pow(0.999, (double)s.t);
-        s.neg_step_size = (float)(-(s.lr / bc1));
-        s.bc2_sqrt = (float)sqrt(bc2);
-        s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    }
-    sc[i] = s;
-    if (tab) {                             // optimiser 0 = enc_optim (gen_lr), 2 = gen_optim (reg_lr)
-        const int slot = (int)(s.t & (kLazyTabCap - 1));
-        if (i == 0) { tab[slot].nss_gen = s.neg_step_size; tab[slot].ibc2 = s.inv_bc2_sqrt; }
-        if (i == 2) tab[slot].nss_reg = s.neg_step_size;
-    }
+    advance_step_body(sc, ctr, tab, stamp, ucount, losses, (int)threadIdx.x);
 }
 
 }  // namespace aae
