@@ -633,7 +633,7 @@ int stage_zc(aae_model* m, const float* src, int64_t ld, int rows, hipStream_t s
 // ==========================================================================================
 ChainOp cop(int kind, int src, int dst, int N) {
     ChainOp o; memset(&o, 0, sizeof(o));
-    o.kind = kind; o.src = src; o.dst = dst; o.N = N; o.one_col = -1; o.scale = 1.f; o.yslot = 0;
+    o.kind = kind; o.src = src; o.dst = dst; o.N = N; o.one_col = -1; o.scale = 1.f; o.yslot = 0; o.fake_slot = -1;
     return o;
 }
 ChainOp cop_load(const float* g, int ld, int dst, int N, int row0 = 0) {
@@ -705,6 +705,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if ((cb.P.ops[i].kind == COP_LINEAR || cb.P.ops[i].kind == COP_LINEAR_DX) && !cb.P.ops[i].Wkn && !cb.P.ops[i].W4) four = false;
     for (int i = 0; i < cb.P.nops && four; ++i)
         if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
+    for (int i = 0; i < cb.P.nops; ++i)
+        if (cb.P.ops[i].row_lo > 0 && !four) return fail(AAE_ESTATE, "a program prefix for the upper rows needs the 4-row chain kernel");
     if (four) {
         const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
         if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
@@ -1125,7 +1127,13 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c;
     const aae_rng_inject& I = m->inj;
     if (!m->ext_first) TRY(gather_first_layer(m, false, nullptr, 0, s));     // (external: the caller refreshed AAE_T_ACT_A1)
-    {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
+    // Enc_eval is row-local like the discriminator program behind it: with 4-row workgroups and a batch that is a
+    // multiple of 4 it runs as a PREFIX of that program in the workgroups of the z_fake rows (ChainOp::row_lo), z_fake
+    // handed over in a slot - one launch (and its ~4.5 us floor) less per step
+    static const bool merge_ok = getenv("AAE_NO_DISC_MERGE") == nullptr;
+    bool merged = merge_ok && m->use_chain4 && B % kR4 == 0 && !m->vae;
+    for (int pid : {P_W2, P_W3, P_D1, P_D2}) merged = merged && m->PT[pid].p != nullptr;
+    if (!merged) {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
         ChainBuilder cb(m, B);
         chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
         ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
@@ -1135,6 +1143,15 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
         ChainBuilder cb(m, 2 * B);
         cb.P.loss_slot = 1;
+        if (merged) {
+            chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
+            if (m->cfg.enc_final != AAE_FINAL_LINEAR) { ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final; }
+            for (int i = 0; i < cb.P.nops; ++i) {
+                ChainOp& o = cb.P.ops[i];
+                o.row_lo = B;                               // program row r >= B = document r - B
+                if (o.kind == COP_LOAD || o.out) o.out_row0 = -B;
+            }
+        }
         // rows [0, B): z_real drawn (or injected) right here; rows [B, 2B): z_fake of the program above
         ChainOp& l = cb.add(cop(COP_PRIOR, 0, 0, c)); l.one_col = c;
         l.W = m->zin.p; l.ldw = m->ldz; l.row_split = B; l.aux = m->cfg.prior;
@@ -1142,6 +1159,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
         l.grow0 = m->rng_row0;
         l.aux_ptr = m->cfg.rng_mode == AAE_RNG_DEVICE ? nullptr : const_cast<float*>(I.z_real_dev); l.aux_ld = c;
         cop_out(l, m->zin.p, m->ldz);                      // the weight-gradient GEMM of D1 reads all 2B rows
+        if (merged) l.fake_slot = 2;                       // (z_fake sits in slot 2 of the workgroup that just computed it)
         ChainOp& d1 = cb.add(cop_fwd(m, P_D1, 0, 1, c + 1, h, CEPI_DROPACT, s));
         d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
         ChainOp& d2 = cb.add(cop_fwd(m, P_D2, 1, 2, h + 1, h, CEPI_DROPACT, s));

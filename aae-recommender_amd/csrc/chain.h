@@ -67,6 +67,9 @@ struct ChainOp {
     int dst_col0;                       // COP_LOAD: first destination column (appending a condition block)
     float* aux_ptr; int aux_ld;         // COP_REPARAM*: the eps buffer [rows][aux_ld] in global memory
     int grow0;                          // COP_PRIOR: global-batch row of this rank's row 0 (the prior draw is keyed by global row)
+    int row_lo;                         // chain4.h: the op runs only in workgroups whose first row is >= row_lo (a program prefix
+                                        // for the upper rows: Enc_eval in front of the discriminator program, aae_abi.hip)
+    int fake_slot;                      // COP_PRIOR, chain4.h: >= 0: rows >= row_split come from this slot instead of from W
 };
 
 struct ChainProgram {

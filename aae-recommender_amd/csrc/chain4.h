@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     for (int oi = 0; oi < P.nops; ++oi) {
         const ChainOp& op = P.ops[oi];
         if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[oi] = wall_clock64();
+        if (r0 < op.row_lo) continue;                  // (workgroup-uniform: an op of the upper rows' program prefix)
         float* dst = slots + op.dst * kR4 * kCL;
         const float* src = slots + op.src * kR4 * kCL;
         const int kind = op.kind;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 const uint64_t k = key ^ (100ull * 0xA0761D6478BD642Full);
                 float v = 0.f;
                 if (erow < nrows && ecol < n) {
-                    if (grow >= op.row_split) v = op.W[(size_t)grow * op.ldw + ecol];
+                    if (grow >= op.row_split) v = op.fake_slot >= 0 ? (slots + op.fake_slot * kR4 * kCL)[erow * kCL + ecol] : op.W[(size_t)grow * op.ldw + ecol];
                     else if (op.aux_ptr) v = op.aux_ptr[(size_t)grow * op.aux_ld + ecol] * op.scale;
                     else if (op.aux == 0) {          // gauss: Box-Muller on two words of the counter generator
                         const uint32_t u1 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * ecol));
