@@ -17,7 +17,7 @@ import torch  # must be imported before the library so both share one HIP runtim
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AAE_HIP_LIB") or os.path.join(_HERE, "libaaerec_hip.so")     # (AAE_HIP_LIB: A/B builds of the library)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5}
 FINALS = {"linear": 0, "softmax": 1, "sigmoid": 2}
 OPTIMIZERS = {"adam": 0, "sgd": 1}
@@ -44,6 +44,8 @@ T_ACT_GA1 = 102
 CAT_SUM, CAT_MEAN = 0, 1
 CAT_SPARSE_ADAM, CAT_ADAM = 0, 1
 O_ENC, O_DEC, O_GEN, O_DISC = 0, 1, 2, 3
+MODEL_AAE, MODEL_AE, MODEL_VAE = 0, 1, 3          # cfg.model_kind
+DTYPE_F32, DTYPE_BF16 = 0, 1                      # cfg.dtype
 
 
 class AaeConfig(C.Structure):
@@ -54,7 +56,9 @@ class AaeConfig(C.Structure):
                 ("prior", C.c_int32), ("grad_mode", C.c_int32), ("dropout1", C.c_float),
                 ("dropout2", C.c_float), ("gen_lr", C.c_float), ("reg_lr", C.c_float),
                 ("prior_scale", C.c_float), ("has_prior_scale", C.c_int32), ("seed", C.c_uint64),
-                ("reserved", C.c_int32 * 8)]
+                ("unfused_decoder", C.c_int32), ("dp_world", C.c_int32), ("model_kind", C.c_int32),
+                ("dtype", C.c_int32), ("blocked_output", C.c_int32), ("dense_noise", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class AaeBatch(C.Structure):
@@ -366,8 +370,7 @@ class HipAAE:
                  activation="ReLU", prior="gauss", prior_scale=None, optimizer="adam",
                  normalize_inputs=True, dropout=(.2, .2), gen_lr=1e-3, reg_lr=1e-3,
                  rng_mode="device", seed=0, grad_mode="fused", device=None, unfused_decoder=False,
-                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False, dense_noise=False,
-                 deterministic=False):
+                 dp_world=1, w1_cap=None, ae_only=False, vae=False, dtype="f32", blocked_output=False, dense_noise=False):
         lib = load_library()
         if not torch.cuda.is_available():
             raise AaeHipError("no HIP device: the AAE step has no CPU fallback")
@@ -394,20 +397,19 @@ class HipAAE:
         cfg.has_prior_scale = int(prior_scale is not None)
         cfg.prior_scale = float(prior_scale) if prior_scale is not None else 1.0
         cfg.seed = int(seed) & (2 ** 64 - 1)
-        cfg.reserved[0] = 1 if unfused_decoder else 0
-        cfg.reserved[1] = int(dp_world) if grad_mode == "export" else 0
-        cfg.reserved[2] = 3 if vae else 1 if ae_only else 0
+        cfg.unfused_decoder = 1 if unfused_decoder else 0
+        cfg.dp_world = int(dp_world) if grad_mode == "export" else 0
+        cfg.model_kind = MODEL_VAE if vae else MODEL_AE if ae_only else MODEL_AAE
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
-        cfg.reserved[3] = 1 if dtype == "bf16" else 0
+        cfg.dtype = DTYPE_BF16 if dtype == "bf16" else DTYPE_F32
         # batches beyond one fused launch's 112 rows as row-blocked launches of the fused output layer (up to 1664 rows;
         # DESIGN.md 3.2e) instead of the three-kernel path.  Built for the item slices of the vocabulary-sharded scheme
         # (VERDICT r1 item 3), measured SLOWER than the three GEMMs there (0.50 -> 0.87 ms of per-rank compute at world
         # 8): opt-in, off everywhere by default
-        cfg.reserved[4] = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
-        cfg.reserved[6] = 1 if deterministic else 0      # fixed summation order of the first layer's gradient (bit-reproducible runs)
+        cfg.blocked_output = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
         # DenoisingAutoEncoder(corrupt='gauss'): room for the dense noisy encoder input (set_input_noise before a step)
-        cfg.reserved[5] = 1 if dense_noise else 0
+        cfg.dense_noise = 1 if dense_noise else 0
         self.dtype = dtype
         self.ae_only, self.vae = bool(ae_only or vae), bool(vae)
         self.dp_world = int(dp_world)

@@ -96,8 +96,7 @@ class AdversarialAutoEncoder:
     def __init__(self, n_hidden=100, n_code=50, gen_lr=0.001, reg_lr=0.001, prior="gauss", prior_scale=None,
                  batch_size=100, n_epochs=500, optimizer="adam", normalize_inputs=True, activation="ReLU",
                  dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab", dtype="f32",
-                 deterministic=False):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab", dtype="f32"):
         self.prior = prior.lower()
         self.prior_scale = prior_scale
         self.prior_sampler = PRIOR_SAMPLERS[self.prior]
@@ -122,9 +121,6 @@ class AdversarialAutoEncoder:
         # ranks exchange [global batch, n_hidden] activations only), 'vocab_out' the output layer alone (the first
         # layer's row-sparse gradient travels as packed rows), 'replicated' keeps everything on every rank
         self.dp_mode = dp_mode
-        # deterministic: the sparse first layer's weight gradient summed in a fixed order instead of with float atomics -
-        # two runs of the same seeds then agree bit for bit (slower; for tests and debugging)
-        self.deterministic = bool(deterministic)
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core inputs, fp32 "
                              "accumulation, fp32 master weights and optimiser state)")
@@ -228,7 +224,6 @@ class AdversarialAutoEncoder:
             grad_mode="export" if dist is not None else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
             unfused_decoder=self._unfused_decoder, dense_noise=getattr(self, "_dense_noise", False),
-            deterministic=self.deterministic,
             # batches of 113..256 rows: the output layer as row blocks of the fused kernel (one critical launch + the
             # deferred optimiser half; 0.70 -> 0.64 ms/step at 208 rows); beyond that the deferred half outlasts the rest
             # of the step and the three GEMMs win (1.12 vs 1.48 ms at 512 rows), DESIGN.md 7.3

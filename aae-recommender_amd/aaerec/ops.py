@@ -30,7 +30,6 @@ _LIB.define(f"predict_topk(int model, {_CSR}, int row_start, int n_rows, int max
             "bool exclude_known) -> (Tensor, Tensor)")
 
 _MODELS = weakref.WeakValueDictionary()
-_ROW_MAX = {}          # (indptr storage, length, version) -> longest row of that CSR matrix
 _IDS = itertools.count(1)
 
 
@@ -60,15 +59,12 @@ class _CsrView:
             raise RuntimeError("aaerec: CSR tensors must live on the GPU (there is no CPU path)")
         self.indptr, self.indices, self.values = indptr.contiguous(), indices.contiguous(), values.contiguous()
         # The library sizes its per-batch scratch lists from rows * max_row_nnz: a bound below the longest row would
-        # let the kernels write past them.  The true maximum is reduced on the device once per CSR (one host sync,
-        # cached by the indptr storage) and the caller's value is checked against it.
-        key = (self.indptr.data_ptr(), self.indptr.numel(), self.indptr._version)
-        true_max = _ROW_MAX.get(key)
-        if true_max is None:
-            true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
-            if len(_ROW_MAX) >= 64:
-                _ROW_MAX.clear()
-            _ROW_MAX[key] = true_max
+        # let the kernels write past them, so the caller's value is checked against the true maximum, reduced on the
+        # device on EVERY call (one small launch + one host sync).  (r2 cached it by (data_ptr, numel, _version): the
+        # caching allocator hands a fresh per-batch indptr the same address and version, and raw-pointer writers such as
+        # aae_dense_to_csr never bump the version - a stale maximum either raised for a valid call or let an undersized
+        # bound through.  The training loop proper - fit() on a resident corpus - does not come through this shim.)
+        true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
         if int(max_row_nnz) < true_max:
             raise ValueError(f"aaerec: max_row_nnz={int(max_row_nnz)} but the CSR matrix has a row of {true_max} entries")
         self.nnz_per_row_max = int(max_row_nnz)

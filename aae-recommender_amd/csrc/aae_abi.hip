@@ -33,6 +33,7 @@
 #include "chain.h"
 #include "chain4.h"
 #include "cond_embed.h"
+#include "w1_update.h"
 
 using namespace aae;
 
@@ -89,7 +90,7 @@ struct aae_model {
     bool ext_first;          // aae_set_first_layer_external: AAE_T_ACT_A1 comes from the caller, dL/d(a1) goes back to it
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
-    bool bf16;               // cfg.reserved[3] = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
+    bool bf16;               // cfg.dtype = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
     bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
     bool vae_cut;            // ... cut at the condition boundary (aae_vae_encode / _decode_backward / _encoder_backward)
     Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
@@ -109,6 +110,10 @@ struct aae_model {
     // fused decoder output layer (dec_fused.h): tile-bucketed batch entries, eligibility
     int n_cu; bool fused_ok; int fused_nb; bool force_unfused;
     int* tcount; int* tstart; int* teb; int* ten; float* tev;
+    // second set of the bucket arrays: every build goes to the set the previous batch is NOT in, so a build on the side
+    // stream (aae_first_layer_forward) never races the previous step's last reader on the caller's stream (the first
+    // layer's gen_optim update, w1_update.h)
+    int* tstart2; int* teb2; int* ten2; float* tev2;
     int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
     int* pslot; int* ptag;   // data parallel, peers > 1: [N][peers] slot of an item's row in each peer's packet / its stamp
     int chunks;              // grid.y of the per-entry kernels for the running batch
@@ -128,11 +133,11 @@ struct aae_model {
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
-    Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.reserved[5]: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
+    Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
+    bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
     bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
-    bool ordered_w1 = false;       // cfg.reserved[6]: the first layer's weight gradient in a fixed summation order (no float atomics)
-    bool blocked_ok; Ten Gacc;   // cfg.reserved[4]: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
+    bool blocked_ok; Ten Gacc;   // cfg.blocked_output: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
@@ -185,20 +190,19 @@ int validate(const aae_config* c) {
     if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
     if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
         return fail(AAE_EINVAL, "dropout must be in [0,1)");
-    if (c->reserved[6] != 0 && c->reserved[6] != 1) return fail(AAE_EINVAL, "reserved[6] must be 0 or 1");
-    if (c->reserved[7]) return fail(AAE_EINVAL, "reserved fields must be zero");
-    if (c->reserved[5] != 0 && c->reserved[5] != 1) return fail(AAE_EINVAL, "reserved[5] must be 0 or 1 (dense noisy encoder input)");
-    if (c->reserved[5] == 1 && (c->reserved[2] != 1 || c->grad_mode != AAE_GRAD_FUSED || c->reserved[3] != 0))
-        return fail(AAE_EINVAL, "reserved[5] = 1 (dense noisy encoder input) needs the plain autoencoder (reserved[2] = 1), fp32, fused optimiser");
-    if (c->reserved[4] != 0 && c->reserved[4] != 1) return fail(AAE_EINVAL, "reserved[4] must be 0 or 1 (row-blocked fused output layer)");
-    if (c->reserved[3] != 0 && c->reserved[3] != 1) return fail(AAE_EINVAL, "reserved[3] must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
-    if (c->reserved[3] == 1 && c->reserved[2] == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
-    if (c->reserved[2] < 0 || c->reserved[2] > 3 || c->reserved[2] == 2)
-        return fail(AAE_EINVAL, "reserved[2] must be 0 (AAE), 1 (plain autoencoder) or 3 (VAE)");
-    if (c->reserved[2] == 3 && (c->n_hidden + 1 > 208 || c->n_code + c->cond_inc + 1 > 208 || 2 * c->n_code > 208))
+    if (c->reserved[0] || c->reserved[1]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->dense_noise != 0 && c->dense_noise != 1) return fail(AAE_EINVAL, "dense_noise must be 0 or 1 (dense noisy encoder input)");
+    if (c->dense_noise == 1 && (c->model_kind != 1 || c->grad_mode != AAE_GRAD_FUSED || c->dtype != 0))
+        return fail(AAE_EINVAL, "dense_noise = 1 (dense noisy encoder input) needs the plain autoencoder (model_kind = 1), fp32, fused optimiser");
+    if (c->blocked_output != 0 && c->blocked_output != 1) return fail(AAE_EINVAL, "blocked_output must be 0 or 1 (row-blocked fused output layer)");
+    if (c->dtype != 0 && c->dtype != 1) return fail(AAE_EINVAL, "dtype must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
+    if (c->dtype == 1 && c->model_kind == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
+    if (c->model_kind < 0 || c->model_kind > 3 || c->model_kind == 2)
+        return fail(AAE_EINVAL, "model_kind must be 0 (AAE), 1 (plain autoencoder) or 3 (VAE)");
+    if (c->model_kind == 3 && (c->n_hidden + 1 > 208 || c->n_code + c->cond_inc + 1 > 208 || 2 * c->n_code > 208))
         return fail(AAE_EINVAL, "VAE mode needs n_hidden <= 207, n_code + cond_inc <= 207, 2 * n_code <= 208");
-    if (c->reserved[1] < 0 || c->reserved[1] > 64) return fail(AAE_EINVAL, "reserved[1] (data-parallel world size) out of range");
-    if (c->reserved[0] != 0 && c->reserved[0] != 1) return fail(AAE_EINVAL, "reserved[0] must be 0 or 1");
+    if (c->dp_world < 0 || c->dp_world > 64) return fail(AAE_EINVAL, "dp_world (data-parallel world size) out of range");
+    if (c->unfused_decoder != 0 && c->unfused_decoder != 1) return fail(AAE_EINVAL, "unfused_decoder must be 0 or 1");
     return AAE_OK;
 }
 
@@ -213,7 +217,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->P[P_W1T] = a.mat(N, h, m->ldw1);
     m->P[P_B1] = a.mat(1, h, m->ldw1);
     m->P[P_W2] = a.mat(h, h + 1, m->ldh, 16);
-    m->P[P_W3] = a.mat(c.reserved[2] == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
+    m->P[P_W3] = a.mat(c.model_kind == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
     m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 16);
     m->P[P_V2] = a.mat(h, h + 1, m->ldh, 16);
     m->P[P_V3] = a.mat(N, h + 1, m->ldh, 2 * kTI);  // (+ two tiles of padding rows: dec_fused_bf16.h reads whole tiles unclamped and parks the stores of lanes without a cell there)
@@ -236,7 +240,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
-    if (h + 1 <= 208 && cp + 1 <= 208 && c.reserved[2] != 3)          // layer-chain models (not the VAE's programs)
+    if (h + 1 <= 208 && cp + 1 <= 208 && c.model_kind != 3)          // layer-chain models (not the VAE's programs)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
         {
             const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;
@@ -247,7 +251,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
     m->zc = a.mat(R, cp + 1, m->ldc);
     m->dh1 = a.mat(R, h + 1, m->ldh); m->dh2 = a.mat(R, h + 1, m->ldh);
-    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1 + (c.reserved[4] ? kMaxRowBlocks : 0));   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
+    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1 + (c.blocked_output ? kMaxRowBlocks : 0));   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
     // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
     {
         int tiles = ((R + 63) / 64) * ((h + 63) / 64);
@@ -257,7 +261,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
         int64_t slab_rows = (int64_t)m->max_slabs * R;
         if (fused_width_ok(h, m->ldh)) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * std::min(R, 16 * kMB));
         // row-blocked form: every workgroup's slab spans the whole batch (each launch fills its rows)
-        if (fused_width_ok(h, m->ldh) && c.reserved[4] && R <= kMaxRowBlocks * kRowBlock) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * R);
+        if (fused_width_ok(h, m->ldh) && c.blocked_output && R <= kMaxRowBlocks * kRowBlock) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * R);
         m->slabs = a.mat(slab_rows, h, m->ldh);
     }
     m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
@@ -270,23 +274,23 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->zsave = a.mat(R, cc, m->ldz);
     m->da2 = a.mat(R, h + 1, m->ldh);
     m->Xn = Ten();
-    if (c.reserved[5] == 1) m->Xn = a.mat(R, N, m->ldn);
+    if (c.dense_noise == 1) m->Xn = a.mat(R, N, m->ldn);
     m->Gacc = Ten();
-    if (c.reserved[4] && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
-    if (c.reserved[2] == 3) {
+    if (c.blocked_output && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
+    if (c.model_kind == 3) {
         m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
     }
-    m->bce_partials_cap = std::max(512 * (c.reserved[4] ? kMaxRowBlocks : 1), ((N + 31) / 32) * ((R + 31) / 32));
+    m->bce_partials_cap = std::max(512 * (c.blocked_output ? kMaxRowBlocks : 1), ((N + 31) / 32) * ((R + 31) / 32));
     m->bce_partials = a.take(m->bce_partials_cap, nullptr);
     m->fix_partials = a.take((size_t)R * 64, nullptr);
     m->rscale = a.take(R, nullptr);
     m->tsync = reinterpret_cast<int*>(a.take(N, nullptr));
     m->mark = reinterpret_cast<int*>(a.take(N, nullptr));
-    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz * (size_t)std::max(1, c.reserved[1]), nullptr));
+    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz * (size_t)std::max(1, c.dp_world), nullptr));
     m->pslot = m->ptag = nullptr;
-    if (c.grad_mode == AAE_GRAD_EXPORT && c.reserved[1] > 1) {
-        m->pslot = reinterpret_cast<int*>(a.take((size_t)N * c.reserved[1], nullptr));
-        m->ptag = reinterpret_cast<int*>(a.take((size_t)N * c.reserved[1], nullptr));
+    if (c.grad_mode == AAE_GRAD_EXPORT && c.dp_world > 1) {
+        m->pslot = reinterpret_cast<int*>(a.take((size_t)N * c.dp_world, nullptr));
+        m->ptag = reinterpret_cast<int*>(a.take((size_t)N * c.dp_world, nullptr));
     }
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
@@ -305,6 +309,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
         m->teb = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
         m->ten = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
         m->tev = a.take((size_t)c.max_nnz, nullptr);
+        m->tstart2 = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->teb2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ten2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->tev2 = a.take((size_t)c.max_nnz, nullptr);
     }
     m->losses = a.take(4, nullptr);
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
@@ -404,7 +412,7 @@ inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n +
 // GEMM wrappers (see gemm_f32.h for operand forms)
 // ------------------------------------------------------------------------------------------
 // Y[rows][out] = epi( X[rows][in+1] * Wa[out][in+1]^T )
-// bf: bf16 matrix-core inputs (cfg.reserved[3]); every forward and dX product of a Linear layer takes them
+// bf: bf16 matrix-core inputs (cfg.dtype); every forward and dX product of a Linear layer takes them
 template <class Epi>
 int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s, bool bf = false) {
     GemmShape g{X, Wa.p, rows, (int)Wa.rows, (int)Wa.cols, ldx, (int)Wa.ld, r4((int)Wa.cols) + 16};
@@ -521,6 +529,8 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
     return AAE_OK;
 }
 
+int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s);
+
 // Encoder backward from dL/dz (gz [rows][ldgz]) + optimiser `which` (O_ENC or O_GEN) on all
 // encoder parameters.  z [rows][ldzz] is the encoder output of the matching forward.
 int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, int ldzz, const uint8_t* mk1,
@@ -545,40 +555,14 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
     TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s, m->bf16));
     TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->eh1.p, m->ldh, P_W2, which, s));
-    // lin1: sparse scatter into gW1T, bias column sum
+    // lin1: bias column sum + its optimiser, then the row-sparse weight gradient + optimiser (w1_update.h)
     const int set = (which == O_GEN) ? 1 : 0;
     const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
-    if (m->ordered_w1 && m->lazy)
-        hipLaunchKernelGGL(w1_grad_ordered_kernel, dim3(std::min(m->cfg.max_nnz, 4096)), dim3(256), 0, s, m->bv,
-                           (const int*)m->ulist, (const int*)m->ucount, (const float*)m->gb1.p, m->ldh, h,
-                           (const float*)m->rscale, m->Gr[P_W1T].p, m->ldw1);
-    else
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
-                       m->rscale, m->Gr[P_W1T].p, m->ldw1, 0);
-    LAUNCHCHK("enc_scatter");
     hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, m->gb1.p, B, h, m->ldh,
                        m->P[P_B1].p, m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr,
                        m->sc + which);
     LAUNCHCHK("colsum_adam");
-    if (exportg) return AAE_OK;
-    if (m->lazy) {
-        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-        int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
-        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
-                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
-                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
-        LAUNCHCHK("w1_sparse_adam");
-    } else if (!exportg) {
-        size_t n4 = m->P[P_W1T].floats() / 4;
-        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-        hipLaunchKernelGGL(adam_dense_kernel, dim3(grid1d(n4)), dim3(256), 0, s, m->P[P_W1T].p, m->M[set][P_W1T].p,
-                           m->V[set][P_W1T].p, m->Gr[P_W1T].p, n4, m->sc + which, 0);
-        LAUNCHCHK("adam_dense W1T");
-        hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, m->gb1.p, m->ldh, h,
-                           m->rscale, m->Gr[P_W1T].p, m->ldw1, 1);
-        LAUNCHCHK("enc_scatter zero");
-    }
-    return AAE_OK;
+    return launch_w1_items(m, m->gb1.p, 0, 0, which, s);
 }
 
 // Discriminator forward on `rows` rows of m->zin (aae.py:195-213) -> m->dout (sigmoid)
@@ -746,23 +730,19 @@ struct DwBuilder {
         J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
         tiles += ((J.M + 31) / 32) * J.tiles_n;
     }
-    // the first encoder layer's scatter + bias update of optimiser `which` ride along (their sparse-row Adam follows
-    // as a launch of its own: encoder_first_layer_update(..., merged = true))
+    // the first encoder layer's bias gradient + update of optimiser `which` ride along (the row-sparse weight gradient +
+    // optimiser follow as a launch of their own: encoder_first_layer_update(..., merged = true))
     void add_first_layer(aae_model* m, const float* ga1, int which) {
         const int set = (which == O_GEN) ? 1 : 0;
         W1Job& w = g.w1;
-        w.enabled = 1; w.bv = m->bv; w.ga1 = ga1; w.ld = m->ldh; w.h = m->h; w.rows = m->rows;
-        w.rscale = m->rscale; w.gW1T = m->Gr[P_W1T].p; w.ldw = m->ldw1; w.ny = m->chunks * 4;
+        w.enabled = 1; w.ga1 = ga1; w.ld = m->ldh; w.h = m->h; w.rows = m->rows;
         w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
         w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
         w.ncol = (m->h + 63) / 64;
-        if (m->dense_step) w.ny = 0;            // dense noisy input: no scatter (the dense dW1T product follows), bias blocks only
-        if (m->ext_first) w.ny = 0;             // the weight rows live with their item slices (aae_first_layer_update): bias blocks only
-        if (m->ordered_w1) w.ny = 0;            // fixed summation order: w1_grad_ordered_kernel follows (encoder_first_layer_update)
     }
     int launch(hipStream_t s) {
         int blocks = tiles;
-        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.rows * g.w1.ny + g.w1.ncol; }
+        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol; }
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
         return AAE_OK;
@@ -804,11 +784,15 @@ static bool fused_decoder_applies(const aae_model* m) {
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
 }
 // counting sort of the running batch's entries into the fused output layer's 32-item tiles (buckets.h / dec_fused.h)
+static void flip_bucket_set(aae_model* m) {
+    std::swap(m->tstart, m->tstart2); std::swap(m->teb, m->teb2); std::swap(m->ten, m->ten2); std::swap(m->tev, m->tev2);
+}
 int build_tile_buckets(aae_model* m, hipStream_t s) {
     const int ntiles = (m->N + kTI - 1) / kTI, B = m->rows;
-    if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs) {
-        const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
-        hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
+    flip_bucket_set(m);
+    const size_t lds1 = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+    if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs && (m->fused_ok || lds1 <= 48 * 1024)) {      // (fused_ok: the LDS limit of the kernel was raised)
+        hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds1, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
     } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
         // (the global batch of an item slice: one launch instead of four, 25 -> 9 us)
         const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
@@ -824,6 +808,38 @@ int build_tile_buckets(aae_model* m, hipStream_t s) {
     m->buckets_valid = true;
     return AAE_OK;
 }
+// the tile buckets of the running batch exist and are visible to stream s (the first layer's update reads them, w1_update.h)
+int ensure_buckets(aae_model* m, hipStream_t s) {
+    if (m->bk_pending) {                // built on the side stream (aae_first_layer_forward)
+        HIPCHK(hipStreamWaitEvent(s, m->ev_bk, 0));
+        m->bk_pending = false;
+    }
+    if (!m->buckets_valid) TRY(build_tile_buckets(m, s));
+    return AAE_OK;
+}
+
+// The sparse first layer's weight gradient over the running batch and optimiser `which` on the touched rows (or the
+// gradient rows -> AAE_T_GRAD + ENC_W1T in export mode), in a fixed summation order (w1_update.h)
+int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s) {
+    TRY(ensure_buckets(m, s));
+    const int set = (which == O_GEN) ? 1 : 0;
+    W1Items a;
+    a.ulist = m->ulist; a.ucount = m->ucount;
+    a.tstart = m->tstart; a.eb = m->teb; a.en = m->ten; a.ev = m->tev;
+    a.ga1 = ga1; a.ld = m->ldh; a.rpb = rpb; a.bstride = bstride;
+    a.rscale = m->rscale; a.rows = m->rows; a.h = m->h;
+    a.W = m->P[P_W1T].p; a.M = m->M[set][P_W1T].p; a.V = m->V[set][P_W1T].p; a.ldw = m->ldw1;
+    a.gout = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_W1T].p : nullptr;
+    a.sc = m->sc + which; a.tsync = m->tsync; a.step_ctr = m->step_ctr;
+    a.mark_synced = (which == O_GEN || m->ae_only) ? 1 : 0;
+    const size_t lds = w1_items_lds_bytes(m->rows);
+    if (lds > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
+    ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
+    const int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+    hipLaunchKernelGGL(w1_item_update_kernel, dim3(grid), dim3(256), lds, s, a);
+    LAUNCHCHK("w1_item_update");
+    return AAE_OK;
+}
 
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const int ntiles = (m->N + kTI - 1) / kTI;
@@ -831,6 +847,7 @@ static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     if (m->buckets_valid || !fused_decoder_applies(m) || ntiles > kBucketMaxTiles || m->rows > kBucketMaxDocs ||
         need > (size_t)kCSlots * kCR * kCL * sizeof(float) || getenv("AAE_NO_PIGGYBACK"))
         return;
+    flip_bucket_set(m);
     BucketJob& b = cb.P.bk;
     b.bv = m->bv; b.ntiles = ntiles; b.tstart = m->tstart; b.eb = m->teb; b.en = m->ten; b.ev = m->tev; b.enabled = 1;
     m->buckets_valid = true;
@@ -944,30 +961,13 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
         LAUNCHCHK("fill_tsync");
         return AAE_OK;
     }
-    if (m->ordered_w1) {
-        hipLaunchKernelGGL(w1_grad_ordered_kernel, dim3(std::min(m->cfg.max_nnz, 4096)), dim3(256), 0, s, m->bv,
-                           (const int*)m->ulist, (const int*)m->ucount, ga1, m->ldh, h, (const float*)m->rscale,
-                           m->Gr[P_W1T].p, m->ldw1);
-        LAUNCHCHK("w1_grad_ordered");
-    }
     if (!merged) {
-    if (!m->ordered_w1) hipLaunchKernelGGL(enc_scatter_kernel, dim3(B, m->chunks * 4), dim3(256), 0, s, m->bv, ga1, m->ldh, h, m->rscale,
-                       m->Gr[P_W1T].p, m->ldw1, 0);
-    LAUNCHCHK("enc_scatter");
-    hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
-                       m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
-    LAUNCHCHK("colsum_adam");
+        hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
+                           m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
+        LAUNCHCHK("colsum_adam");
     }
-    if (exportg) return AAE_OK;        // data parallel: aae_w1_export / exchange / aae_w1_import follow
-    {
-        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-        int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
-        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
-                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, h, m->sc + which,
-                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
-        LAUNCHCHK("w1_sparse_adam");
-    }
-    return AAE_OK;
+    // (export mode: the gradient rows -> AAE_T_GRAD + ENC_W1T; aae_w1_export / exchange / aae_w1_import follow)
+    return launch_w1_items(m, ga1, 0, 0, which, s);
 }
 
 // done_ev: an event that rides on the launch's completion signal (the side stream's "the step has begun" mark)
@@ -1250,13 +1250,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
     m->alpha_mode = cfg->activation == AAE_ACT_SELU;
-    m->vae = cfg->reserved[2] == 3; m->vae_bwd = false; m->vae_cut = false;
-    m->bf16 = cfg->reserved[3] == 1;
-    m->blocked_ok = cfg->reserved[4] == 1;
+    m->vae = cfg->model_kind == 3; m->vae_bwd = false; m->vae_cut = false;
+    m->bf16 = cfg->dtype == 1;
+    m->blocked_ok = cfg->blocked_output == 1;
     m->blocked_any = getenv("AAE_BLOCKED_ANY") != nullptr;
-    m->ordered_w1 = cfg->reserved[6] == 1;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
-    m->ae_only = cfg->reserved[2] == 1 || m->vae;
+    m->ae_only = cfg->model_kind == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
     {
         int dev = 0, cus = 0;
@@ -1281,7 +1280,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
-        m->force_unfused = cfg->reserved[0] == 1;   // debugging / A-B switch: reserved[0] = 1 keeps the 3-kernel path
+        m->force_unfused = cfg->unfused_decoder == 1;   // debugging / A-B switch: unfused_decoder = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
@@ -1297,6 +1296,9 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 m->fused_ok = false;
         }
     }
+    m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)w1_items_lds_bytes(16384)) == hipSuccess;
+    (void)hipGetLastError();
     m->grad_scale = 1.f;
     m->rng_row0 = 0; m->rng_global = 0;
     m->Gt = m->G.p;
@@ -1516,7 +1518,7 @@ int aae_prefetch_batch(aae_handle h, const aae_batch* next) {
 
 int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
-    if (!h->Xn.p) return fail(AAE_ESTATE, "aae_set_input_noise: the model was not created with cfg.reserved[5] = 1");
+    if (!h->Xn.p) return fail(AAE_ESTATE, "aae_set_input_noise: the model was not created with cfg.dense_noise = 1");
     if (noise_dev && noise_ld < h->N) return fail(AAE_EINVAL, "noise_ld < n_items");
     h->noise_next = noise_dev; h->noise_ld = noise_ld;
     return AAE_OK;
@@ -1526,7 +1528,14 @@ int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld) 
 // enc.lin1 and its bookkeeping only, and keeps running beside the step)
 int aae_join_output_layer(aae_handle h, void* stream) {
     if (!h) return fail(AAE_EINVAL, "handle is NULL");
-    if (h->opt_pending) { HIPCHK(hipStreamWaitEvent(S(stream), h->ev_opt, 0)); h->opt_pending = h->pf_pending = false; }
+    // (only the optimiser launch is settled here.  A prefetch enqueued BEHIND it - an item slice's, pf_after_opt - is not
+    //  covered by ev_opt and stays pending for the next step's join_deferred; one enqueued in front of it - aae_step's -
+    //  is covered by the later record of the in-order side stream)
+    if (h->opt_pending) {
+        HIPCHK(hipStreamWaitEvent(S(stream), h->ev_opt, 0));
+        h->opt_pending = false;
+        if (!h->pf_after_opt) h->pf_pending = false;
+    }
     return AAE_OK;
 }
 
@@ -1853,7 +1862,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
-    // row blocks of the fused output layer: one launch covers at most 112 rows; larger batches (cfg.reserved[4]) run as
+    // row blocks of the fused output layer: one launch covers at most 112 rows; larger batches (cfg.blocked_output) run as
     // nblk launches of the split form over equal row blocks
     const int nblk = m->have_batch ? row_blocks(m) : 1;
     const int Bb = (B + nblk - 1) / nblk;                        // rows per block (the last one may be shorter)
@@ -2188,7 +2197,7 @@ int aae_decoder_step(aae_handle m, const aae_batch* batch, const float* zin_dev,
 // VAE.partial_fit (vae.py:147-186): loss = mean BCE + KL sum (vae.py:132-145), one Adam over all five Linears
 int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, const float* eps_dev, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
-    if (!m->vae) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (!m->vae) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.model_kind = 3)");
     if (!m->use_chain) return fail(AAE_ESTATE, "VAE mode needs the layer-chain kernels");
     if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
     if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
@@ -2217,7 +2226,7 @@ int aae_vae_step(aae_handle m, const aae_batch* batch, const float* cond_dev, co
 int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev, const float* eps_dev, float* out_dev,
                     int64_t out_ld, void* stream) {
     if (!m || !out_dev) return fail(AAE_EINVAL, "handle/out is NULL");
-    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.model_kind = 3)");
     if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
     if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
     if (out_ld < m->N || (out_ld & 3) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
@@ -2243,7 +2252,7 @@ int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev,
 //   aae_vae_encoder_backward  reparametrize' + KL gradient -> [fc21; fc22] -> fc1, their updates
 int aae_vae_encode(aae_handle m, const aae_batch* batch, const float* eps_dev, float* z_out_dev, int32_t train, void* stream) {
     if (!m) return fail(AAE_EINVAL, "handle is NULL");
-    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.reserved[2] = 3)");
+    if (!m->vae || !m->use_chain) return fail(AAE_ESTATE, "model was not created in VAE mode (cfg.model_kind = 3)");
     if (m->cfg.rng_mode == AAE_RNG_INJECT && !eps_dev) return fail(AAE_EINVAL, "rng_mode inject needs eps_dev");
     TRY(set_batch(m, batch));
     remember_inject(m, nullptr, true);
@@ -2480,22 +2489,7 @@ int aae_first_layer_update(aae_handle m, const float* ga1_dev, int64_t ld, int32
         return fail(AAE_EINVAL, "aae_first_layer_update: blocks need ga1_dev and block_stride >= rows_per_block * ld");
     hipStream_t s = S(stream);
     const float* ga1 = ga1_dev ? ga1_dev : m->gb3.p;
-    // rows of an item slice are short (a few entries each, a rare long one): 1/8 of the workgroups the longest row
-    // would fill in one pass, each looping over its share of the entries
-    const int ny = std::max(2, std::min(m->chunks * 4, (m->chunks + 1) / 2));
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3(m->rows, ny), dim3(256), 0, s, m->bv, ga1, m->ldh, m->h, m->rscale,
-                       m->Gr[P_W1T].p, m->ldw1, 0, (int)rows_per_block, (size_t)block_stride);
-    LAUNCHCHK("enc_scatter (slice)");
-    const int set = which == O_GEN ? 1 : 0;
-    {
-        ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-        const int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
-        hipLaunchKernelGGL(w1_sparse_adam_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->P[P_W1T].p,
-                           m->M[set][P_W1T].p, m->V[set][P_W1T].p, m->Gr[P_W1T].p, m->ldw1, m->h, m->sc + which,
-                           m->tsync, m->step_ctr, (which == O_GEN || m->ae_only) ? 1 : 0);
-        LAUNCHCHK("w1_sparse_adam (slice)");
-    }
-    return AAE_OK;
+    return launch_w1_items(m, ga1, (int)rows_per_block, (size_t)block_stride, which, s);
 }
 
 // disc_step (aae.py:713-732)
@@ -2753,14 +2747,14 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
     if (!m || !hdr_dev || !vals_dev) return fail(AAE_EINVAL, "NULL argument");
     if (m->cfg.grad_mode != AAE_GRAD_EXPORT) return fail(AAE_ESTATE, "aae_w1_import needs grad_mode=export");
     if (which != O_ENC && which != O_GEN) return fail(AAE_EINVAL, "which must be enc_optim (0) or gen_optim (2)");
-    if (n_peers < 1 || n_peers > std::max(1, m->cfg.reserved[1])) return fail(AAE_EINVAL, "n_peers exceeds cfg.reserved[1]");
+    if (n_peers < 1 || n_peers > std::max(1, m->cfg.dp_world)) return fail(AAE_EINVAL, "n_peers exceeds cfg.dp_world");
     hipStream_t s = S(stream);
     hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, s, m->stamp, m->ucount);
     const size_t nsmall = enc_small_floats(m);
     const char* small0 = reinterpret_cast<const char*>(vals_dev + (size_t)cap * m->h);
     if (n_peers > 1 && m->pslot && !getenv("AAE_W1_SERIAL")) {
         // every peer in one launch each: slot map + union list, rank-ordered row sums, rank-ordered small-layer sums
-        const int W = m->cfg.reserved[1];
+        const int W = m->cfg.dp_world;
         hipLaunchKernelGGL(w1_map_kernel, dim3(std::max(1, std::min((cap + 255) / 256, 64)), n_peers), dim3(256), 0, s,
                            reinterpret_cast<const char*>(hdr_dev), (long long)peer_stride_bytes, W, m->pslot, m->ptag,
                            m->mark, m->stamp, m->ulist, m->ucount);
@@ -2792,7 +2786,7 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
         TRY(aae_apply_updates(m, which, stream));      // b1, W2, W3 (W1T is skipped there: sparse path below)
     }
     const int set = which == O_GEN ? 1 : 0;
-    const int grid = std::min(m->cfg.max_nnz * std::max(1, m->cfg.reserved[1]), 8192);
+    const int grid = std::min(m->cfg.max_nnz * std::max(1, m->cfg.dp_world), 8192);
     if (m->cfg.optimizer == AAE_OPT_ADAM) {
         hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, s, m->ulist, m->ucount, m->N, m->tsync,
                            m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,

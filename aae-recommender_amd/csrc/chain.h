@@ -612,13 +612,12 @@ struct DwJob {
     int tile0;                                                     // first linear tile id of this job
     int tiles_n;                                                   // tiles along N
 };
-// The first encoder layer's backward shares the launch: its row-sparse weight-gradient scatter (one workgroup per
-// (document, entry chunk)) and its bias column sums + optimiser (one workgroup per 64 columns) depend on the same
-// chain outputs as the dense jobs and on nothing else.
+// The first encoder layer's bias shares the launch: its column sums + optimiser (one workgroup per 64 columns) depend on
+// the same chain outputs as the dense jobs and on nothing else.  (The layer's row-sparse weight gradient + optimiser is
+// a launch of its own behind this one: w1_update.h.)
 struct W1Job {
-    int enabled; BatchView bv; const float* ga1; int ld, h, rows;
-    const float* rscale; float* gW1T; int ldw; int ny;            // scatter: blocks [blk0, blk0 + rows * ny)
-    float* bp; float* bm; float* bv1; float* bgrad; const OptScalars* sc;   // bias: blocks behind the scatter's
+    int enabled; const float* ga1; int ld, h, rows;
+    float* bp; float* bm; float* bv1; float* bgrad; const OptScalars* sc;   // blocks [blk0, blk0 + ncol)
     int blk0, ncol;
 };
 struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; };
@@ -628,9 +627,7 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
     if (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0) {          // (uniform) first-layer workgroups
         const W1Job& w = grp.w1;
-        const int id = blockIdx.x - w.blk0;
-        if (id < w.rows * w.ny) enc_scatter_body(w.bv, w.ga1, w.ld, w.h, w.rscale, w.gW1T, w.ldw, 0, id / w.ny, id % w.ny, w.ny);
-        else colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id - w.rows * w.ny, smem);
+        colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, (int)blockIdx.x - w.blk0, smem);
         return;
     }
     int j = 0;

@@ -122,80 +122,6 @@ __global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// K9: backward of the sparse first layer.  gW1T[idx_e, :] += (v_e * s_b) * ga1[b, :].
-// grid (docs, chunks): a workgroup takes 16-entry chunks of its document, one wave per entry;
-// each atomic wave-instruction adds 256 contiguous bytes (the shape the memory-side float
-// atomics run at full rate for).  zero != 0: store zeros instead (resets the touched rows after
-// the optimiser consumed them).
-// ---------------------------------------------------------------------------------------
-// rpb > 0: ga1 comes in blocks of rpb rows, bstride floats apart (the ranks' packets of an all-gather, read where they landed)
-__device__ __forceinline__ void enc_scatter_body(const BatchView& bv, const float* __restrict__ ga1, int ld, int h,
-                                                 const float* __restrict__ rscale, float* __restrict__ gW1T, int ldw,
-                                                 int zero, int b, int by, int ny, int rpb = 0, size_t bstride = 0) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* grow = rpb > 0 ? ga1 + (size_t)(b / rpb) * bstride + (size_t)(b % rpb) * ld : ga1 + (size_t)b * ld;
-    const int dc = bv.doc(b);
-    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
-    const float s = zero ? 0.f : rscale[b];
-    for (int64_t e0 = lo + 4 * (int64_t)by; e0 < hi; e0 += 4 * (int64_t)ny) {
-        const int64_t e = e0 + wave;
-        if (e >= hi) break;
-        const int idx = bv.indices[e];
-        const float x = bv.values[e] * s;
-        float* dst = gW1T + (size_t)idx * ldw;
-        for (int c = lane; c < h; c += 64) {
-            if (zero) dst[c] = 0.f;
-            else atomicAdd(dst + c, x * grow[c]);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void enc_scatter_kernel(BatchView bv, const float* __restrict__ ga1, int ld,
-                                                          int h, const float* __restrict__ rscale,
-                                                          float* __restrict__ gW1T, int ldw, int zero, int rpb = 0,
-                                                          size_t bstride = 0) {
-    enc_scatter_body(bv, ga1, ld, h, rscale, gW1T, ldw, zero, blockIdx.x, blockIdx.y, gridDim.y, rpb, bstride);
-}
-
-// The same gradient in a FIXED summation order (cfg.reserved[6] = 1): one workgroup per distinct item of the batch walks
-// the documents in batch order, finds the item in each row by bisection (rows of a canonical CSR matrix are sorted) and
-// sums its contributions in that order - no float atomics, so two runs of a training loop agree bit for bit.  (With the
-// atomics a swapped pair of adds moves a weight by an ulp; the adversarial dynamics turn that into 4e-5 .. 1e-4 in the
-// predictions 40-120 steps later: 3-5 % of the runs of the 120-step parity recipe.)  B x U bisections: for tests and
-// debugging, not for speed.
-__global__ __launch_bounds__(256) void w1_grad_ordered_kernel(BatchView bv, const int* __restrict__ ulist,
-                                                              const int* __restrict__ ucount, const float* __restrict__ ga1,
-                                                              int ld, int h, const float* __restrict__ rscale,
-                                                              float* __restrict__ gW1T, int ldw) {
-    const int n = *ucount;
-    for (int u = blockIdx.x; u < n; u += gridDim.x) {
-        const int item = ulist[u];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};            // columns tid, tid + 256, ... (h <= 1024)
-        for (int b = 0; b < bv.n_rows; ++b) {
-            const int dc = bv.doc(b);
-            int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
-            while (lo < hi) {                           // first entry with index >= item
-                const int64_t mid = (lo + hi) >> 1;
-                if (bv.indices[mid] < item) lo = mid + 1; else hi = mid;
-            }
-            if (lo < bv.indptr[dc + 1] && bv.indices[lo] == item) {
-                const float x = bv.values[lo] * rscale[b];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = threadIdx.x + 256 * k;
-                    if (c < h) acc[k] += x * ga1[(size_t)b * ld + c];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = threadIdx.x + 256 * k;
-            if (c < h) gW1T[(size_t)item * ldw + c] = acc[k];
-        }
-    }
-}
-
 // bias gradient of the first encoder layer for 64 columns, 256 threads (4 waves stride the rows), then its
 // optimiser update or export: the body of colsum_adam_kernel for use inside the grouped update launch
 __device__ __forceinline__ void colsum_adam_body(const float* __restrict__ ga, int rows, int h, int ld, float* p,

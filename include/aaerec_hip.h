@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AAE_ABI_VERSION 1
+#define AAE_ABI_VERSION 2
 
 /* error codes */
 #define AAE_OK 0
@@ -50,6 +50,14 @@ enum { AAE_RNG_INJECT = 0,   /* caller supplies them (parity tests, reference-RN
        AAE_RNG_DEVICE = 1 }; /* counter-based generator inside the kernels */
 /* prior for AAE_RNG_DEVICE: PRIOR_SAMPLERS, aaerec/aae.py:90-94 */
 enum { AAE_PRIOR_GAUSS = 0, AAE_PRIOR_CATEGORICAL = 1, AAE_PRIOR_BERNOULLI = 2 };
+/* which model of the reference the handle trains (cfg.model_kind) */
+enum { AAE_MODEL_AAE = 0,    /* AdversarialAutoEncoder, aae.py:587-870 */
+       AAE_MODEL_AE = 1,     /* plain AutoEncoder (aae.py:221-458): the step ends after the encoder backward,
+                                aae_disc_step / aae_gen_step are errors */
+       AAE_MODEL_VAE = 3 };  /* VAE (vae.py:47-266): see aae_vae_step */
+/* arithmetic of the GEMM-shaped products (cfg.dtype) */
+enum { AAE_DTYPE_F32 = 0,    /* fp32 throughout (the reference's precision) */
+       AAE_DTYPE_BF16 = 1 }; /* bf16 matrix-core inputs, fp32 accumulation, fp32 master weights and Adam (config C2) */
 /* what happens to gradients */
 enum { AAE_GRAD_FUSED = 0,   /* optimiser update fused into the weight-gradient kernels */
        AAE_GRAD_EXPORT = 1 };/* gradients are materialised (data-parallel: all-reduce, then
@@ -77,15 +85,16 @@ typedef struct aae_config {
     float prior_scale;        /* used when has_prior_scale != 0 (aae.py:717-718) */
     int32_t has_prior_scale;
     uint64_t seed;            /* device rng */
-    int32_t reserved[8];      /* must be zero, except [4] = 1: row-blocked fused output layer for batches > 112 rows
-                               * (DESIGN.md 7.3), [5] = 1: room for aae_set_input_noise; [6] = 1: the sparse first layer's weight
-                               * gradient in a fixed summation order instead of float atomics (bit-reproducible runs; for tests
-                               * and debugging: B x distinct-items bisections per step); [0] = 1: keep the decoder output layer on the unfused
-                                 three-kernel path (A/B measurements); [1] = number of data-parallel
-                                 peers whose packed rows aae_w1_import may receive (0 = 1); [2] = 1:
-                                 plain AutoEncoder (reference aae.py:221-458): the step ends after the
-                                 encoder backward, aae_disc_step / aae_gen_step are errors; [2] = 3: VAE
-                                 (reference vae.py:47-266): see aae_vae_step */
+    /* build-time knobs of the model (named fields since ABI version 2; they travelled in reserved[0..6] before) */
+    int32_t unfused_decoder;  /* 1: keep the decoder output layer on the three-kernel path (A/B measurements, tests) */
+    int32_t dp_world;         /* AAE_GRAD_EXPORT: number of data-parallel peers whose packed rows aae_w1_import may
+                               * receive (0 = 1) */
+    int32_t model_kind;       /* AAE_MODEL_*: which of the reference's models the handle trains */
+    int32_t dtype;            /* AAE_DTYPE_*: arithmetic of the matrix-core products (master weights / Adam stay fp32) */
+    int32_t blocked_output;   /* 1: batches beyond 112 rows run the fused output layer over row blocks */
+    int32_t dense_noise;      /* 1: room for aae_set_input_noise (DenoisingAutoEncoder corrupt='gauss'; needs
+                               * model_kind = AAE_MODEL_AE, fp32, fused optimiser) */
+    int32_t reserved[2];      /* must be zero */
 } aae_config;
 
 typedef struct aae_model* aae_handle;
@@ -93,7 +102,9 @@ typedef struct aae_model* aae_handle;
 /* A batch = `n_rows` rows picked out of a CSR matrix that is already resident in HBM
  * (replaces X_shuf[start:end].toarray() + torch.FloatTensor(X).cuda(), aae.py:823,751-754).
  * rows_dev == NULL means rows row_start .. row_start+n_rows-1.  Column indices must be unique
- * within a row and values in [0,1] (the reference's BCE raises otherwise). */
+ * within a row (canonical CSR, as scipy's tocsr() / sum_duplicates() produce: a repeated (row, item) pair counts
+ * once in the BCE target and in the first layer's weight gradient) and values in [0,1] (the reference's BCE raises
+ * otherwise). */
 typedef struct aae_batch {
     const int64_t* indptr_dev;
     const int32_t* indices_dev;
@@ -221,7 +232,7 @@ int aae_disc_gen(aae_handle h, const aae_rng_inject* inject, void* stream);
 int aae_decoder_step(aae_handle h, const aae_batch* batch, const float* zin_dev, int64_t zin_ld,
                      const aae_rng_inject* inject, float* dzin_out_dev, void* stream);
 /* VAE.partial_fit / VAE.predict, vae.py:147-186, 229-266.  The model must have been created with
- * cfg.reserved[2] = 3: ENC_W1T/B1 = fc1, ENC_W3 = [fc21; fc22] (2 * n_code rows: mu, then logvar), DEC_V1 = fc3,
+ * cfg.model_kind = AAE_MODEL_VAE: ENC_W1T/B1 = fc1, ENC_W3 = [fc21; fc22] (2 * n_code rows: mu, then logvar), DEC_V1 = fc3,
  * DEC_V3 = fc4; ENC_W2 / DEC_V2 / the discriminator are unused; cfg.gen_lr is the single learning rate and
  * cfg.dropout must be (0, 0).  loss = mean BCE (losses[0]) + KL sum (losses[1]), vae.py:132-145.
  *   cond_dev  constant concatenated condition block [rows][cond_inc] or NULL
@@ -374,7 +385,7 @@ int aae_apply_updates(aae_handle h, int which, void* stream);
  * caller hands the n_peers packets (peer p at byte offset p * peer_stride_bytes from both base
  * pointers) to aae_w1_import, which sums them in peer order, brings the union of rows up to date
  * and runs the optimiser `which` (0 enc_optim after the ae phases, 2 gen_optim after gen_step) on
- * them.  cfg.reserved[1] must hold the number of peers. */
+ * them.  cfg.dp_world must hold the number of peers. */
 int aae_w1_export(aae_handle h, int32_t* hdr_dev, float* vals_dev, int32_t cap, void* stream);
 /* packet layout for `cap` rows: hdr_words int32 words of header, then cap * n_hidden floats of
  * rows, then the encoder's small-layer gradients (b1, W2, W3), which aae_w1_import also sums and
@@ -425,7 +436,7 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
  * with gauss_noise = batch + randn(batch.size()) * noise_factor - the encoder of the NEXT step-opening call reads the
  * DENSE batch plus noise_dev [rows][noise_ld >= n_items] (already scaled) on all n_items columns, L1-normalised over all
  * of them (aae.py:132-133); its first layer runs as a dense product, its weight gradient as a dense product with the
- * optimiser on every row of ENC_W1T.  The BCE target stays the clean batch.  Needs cfg.reserved[5] = 1 (room for the
+ * optimiser on every row of ENC_W1T.  The BCE target stays the clean batch.  Needs cfg.dense_noise = 1 (room for the
  * dense input; plain autoencoder, fp32, fused optimiser); noise_dev must stay valid until the step has run. */
 int aae_set_input_noise(aae_handle h, const float* noise_dev, int64_t noise_ld);
 int aae_join(aae_handle h, void* stream);
@@ -437,8 +448,13 @@ int aae_join_output_layer(aae_handle h, void* stream);
  * its distinct items and the replay of the deferred zero-gradient Adam steps on their enc.lin1 rows (what
  * torch.optim.Adam did eagerly in enc_optim.step() / gen_optim.step(), aae.py:706,742) - runs on the handle's side
  * stream while the step before it executes, instead of opening the next step.  A hint, not a promise: a next step on
- * any other batch (other pointers / row window) ignores it and does the work itself; the row-id buffer `rows_dev`
- * must keep its contents until that step ran.  grad_mode = fused only (otherwise accepted and ignored). */
+ * any other batch (other pointers / row window) ignores it and does the work itself.
+ * HARD PRECONDITION: the step recognises the named batch by its pointers and row window, not by content - between this
+ * call and the step that runs the batch, the CSR arrays and the row-id buffer `rows_dev` it names must neither be
+ * rewritten in place nor freed and re-allocated (a refilled buffer at the same address would be taken for the batch whose
+ * item list was built ahead: rows missing from that list get no update).  A caller that recycles batch buffers does
+ * not hint.
+ * grad_mode = fused only (otherwise accepted and ignored). */
 int aae_prefetch_batch(aae_handle h, const aae_batch* next);
 int aae_set_split(aae_handle h, int32_t workgroups);
 

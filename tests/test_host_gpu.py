@@ -34,8 +34,8 @@ def test_fit_predict_tracks_reference_with_reference_rng():
     torch.manual_seed(seed)
     np.random.seed(seed)
     m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=3, batch_size=100, gen_lr=0.01, reg_lr=0.001,
-                               verbose=False, rng_mode="reference", deterministic=True)     # (bit-reproducible: see
-    m.fit(Xtr)                                                                               #  test_ranking_metrics_...)
+                               verbose=False, rng_mode="reference")
+    m.fit(Xtr)
     pred = m.predict(Xin[:40])
     assert pred.dtype == np.float32 and pred.shape == z["pred_short"].shape
     # north star: reconstructions within 1e-4 (fp32)
@@ -49,7 +49,7 @@ def _c1_mrr(seed, rng_mode):
     torch.manual_seed(seed)
     np.random.seed(seed)
     m = AdversarialAutoEncoder(n_hidden=50, n_code=50, n_epochs=100, batch_size=100, gen_lr=0.01, reg_lr=0.001,
-                               verbose=False, rng_mode=rng_mode, deterministic=True)     # (reproducible outcomes per seed)
+                               verbose=False, rng_mode=rng_mode)
     m.fit(Xtr)
     pred = remove_non_missing(m.predict(Xin), Xin, copy=True)
     return METRICS["mrr@10"](Yout.toarray(), pred)[0]
@@ -1027,28 +1027,27 @@ def test_ranking_metrics_identical_at_the_short_horizon():
     steps) of fit() with the reference's random draws replayed: the predictions for 200 test docs agree to 1e-4, and
     MRR@10 / MAP@10 / P@5 computed from them are IDENTICAL to the ones computed from the reference's own predictions
     (every top-10 list ranks its relevant item the same).
-    The run uses deterministic=True (cfg.reserved[6]: the sparse first layer's weight gradient summed in a fixed order):
-    it is then bit-reproducible (60 of 60 runs: max |diff| 1.0416e-5).  With the production float atomics a swapped pair
-    of adds moves one weight by an ulp, and 40-120 adversarial steps later that is 4e-5 (5 % of runs) or 1.09e-4 (3 %) in
-    the predictions (tools/debug/flake_hunt.py: the runs leave the majority at ONE step, by 1e-6) - the recipe's own
-    sensitivity, which the second half bounds at 5e-4."""
+    The path is the production path: since r3 the sparse first layer's weight gradient is a per-item sum in row order
+    (csrc/w1_update.h), no float atomics anywhere in the parameter path, so two runs of the same seeds agree bit for bit -
+    asserted below.  (r1/r2 scattered with float atomics: a swapped pair of adds moved one weight by an ulp, and 40-120
+    adversarial steps later that was 4e-5 (5 % of runs) or 1.09e-4 (3 %) in the predictions.)"""
     from aaerec.evaluation import remove_non_missing, METRICS
     import aaerec.aae  # noqa: F401  (its import seeds torch, as the reference's does, aae.py:27: import BEFORE seeding)
     z, Xtr, Xin, Yout = _big()
     seed = int(z["short_seed"])
     torch.manual_seed(seed)
     np.random.seed(seed)
-    m = _big_model(3, "reference", deterministic=True)
+    m = _big_model(3, "reference")
     m.fit(Xtr)
     n = z["pred_short"].shape[0]
     pred = m.predict(Xin[:n])
     np.testing.assert_allclose(pred, z["pred_short"], atol=1e-4)
-    # the production path (float atomics in the first layer's scatter): the same run, within the recipe's sensitivity
+    # the same run again: bit for bit the same predictions (no scheduling-dependent summation order in the parameter path)
     torch.manual_seed(seed)
     np.random.seed(seed)
     m2 = _big_model(3, "reference")
     m2.fit(Xtr)
-    np.testing.assert_allclose(m2.predict(Xin[:n]), z["pred_short"], atol=5e-4)     # (observed modes over 220 runs: 1.04e-5, 4.1e-5, 1.05e-4, 1.09e-4)
+    assert np.array_equal(m2.predict(Xin[:n]), pred)
     Y = Yout[:n].toarray()
     ours, ref = remove_non_missing(pred, Xin[:n], copy=True), remove_non_missing(z["pred_short"], Xin[:n], copy=True)
     for name in ("mrr@10", "map@10", "p@5"):
@@ -1068,20 +1067,16 @@ def test_mrr_parity_at_10k_test_docs():
       (b) the production device generator, 16 seeds: the mean over the converged runs lies within 2.5 standard errors
           of the reference's mean (s.e. of the difference ~0.007), the medians within 0.015;
       (c) bf16 mode (config C2's arithmetic), 8 seeds: the same bands;
-      (d) the production scatter (float atomics in the first layer's weight gradient), 16 seeds: robust statistics only.
-    (a)-(c) run with deterministic=True (cfg.reserved[6]): 4 800 adversarial steps amplify an ulp - a swapped pair of
-    atomic adds - into another trajectory, and a fragile initialisation (host seed 10: the reference's own lowest run) then
-    lands anywhere between 0.35 and 0.55 from one run of this library to the next (tools/debug/mrr_replay_det.py; with the
-    fixed summation order every run of a seed is the same run: 0.5400 / 0.5144 / 0.5431).  The r2 suite had these bands
-    on the atomic path: one failure in six runs of this test on its own."""
+    Every run of a seed is the same run (the parameter path has no float atomics since r3: host seeds 0 / 3 / 10 replay to
+    0.5400 / 0.5144 / 0.5431 each time); r2's atomic scatter let the fragile seed 10 land between 0.35 and 0.55."""
     import aaerec.aae  # noqa: F401  (import before seeding: the module seeds torch at import, as the reference's does)
     z, Xtr, Xin, Yout = _big()
     ref = z["ref_mrr10"]
 
-    def run(host_seed, rng_mode, deterministic=True, **kw):
+    def run(host_seed, rng_mode, **kw):
         torch.manual_seed(host_seed)
         np.random.seed(host_seed)
-        m = _big_model(120, rng_mode, deterministic=deterministic, **kw)
+        m = _big_model(120, rng_mode, **kw)
         m.fit(Xtr)
         return _mrr10(m.predict(Xin), Xin, Yout)
     same = {s: run(s, "reference") for s in (0, 3, 10)}
@@ -1089,8 +1084,8 @@ def test_mrr_parity_at_10k_test_docs():
     sd = float(ref.std(ddof=1))
     for s, v in same.items():
         # inside the reference's spread - or next to the reference's OWN outcome for this seed where that one is itself in
-        # the tail (seed 10: the reference's lowest run, 0.447; replays of it ended at 0.548 and at 0.426 in r2 - the
-        # first-layer scatter's atomics make even two runs of this library differ in the last bits)
+        # the tail (seed 10: the reference's lowest run, 0.447; replays of it ended at 0.548 and at 0.426 in r2, when the
+        # first-layer scatter's float atomics made two runs of this library differ in the last bits)
         assert abs(v - ref.mean()) < 4 * sd or abs(v - float(ref[s])) < 2 * sd, (s, v, float(ref[s]), float(ref.mean()), sd)
     # The recipe has a failure mode: for some initialisations the adversarial game wrecks the autoencoder for most prior
     # streams (host seed 15: the REFERENCE itself drops to MRR@10 0.09 when its z_real draws come from another generator,
@@ -1108,8 +1103,3 @@ def test_mrr_parity_at_10k_test_docs():
         assert abs(np.median(vals) - np.median(ref)) < 0.015, (np.median(vals), np.median(ref))
     summary("device generator", [run(s, "device", seed=1000 + s) for s in range(16)])
     summary("bf16 mode", [run(s, "device", seed=2000 + s, dtype="bf16") for s in range(8)])
-    # (d) the production path: the same 16 device seeds through the atomic scatter - the runs that collapse differ from
-    # launch to launch, so only the bulk is asserted
-    prod = np.asarray([run(s, "device", deterministic=False, seed=1000 + s) for s in range(16)])
-    print("MRR@10, production scatter:", np.round(prod, 4).tolist(), "median", round(float(np.median(prod)), 4))
-    assert (prod > 0.4).sum() >= 12 and abs(np.median(prod) - np.median(ref)) < 0.03, prod
