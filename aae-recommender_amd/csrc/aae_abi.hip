@@ -30,6 +30,7 @@
 #include "kernels.h"
 #include "dec_fused.h"
 #include "dec_fused_bf16.h"
+#include "dec_crit_x3.h"
 #include "chain.h"
 #include "chain4.h"
 #include "cond_embed.h"
@@ -135,6 +136,8 @@ struct aae_model {
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
+    bool split_any = false;        // AAE_SPLIT_ANY at creation: the split form of the output layer at any size (tests: small fixtures through the critical / deferred kernels)
+    bool x3_ok = false;            // dec_crit_x3.h: the critical launch's fp32 products on the bf16 matrix cores (3-term split)
     bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
     bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
     bool blocked_ok; Ten Gacc;   // cfg.blocked_output: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
@@ -832,11 +835,13 @@ int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int
     a.gout = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_W1T].p : nullptr;
     a.sc = m->sc + which; a.tsync = m->tsync; a.step_ctr = m->step_ctr;
     a.mark_synced = (which == O_GEN || m->ae_only) ? 1 : 0;
-    const size_t lds = w1_items_lds_bytes(m->rows);
-    if (lds > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
+    // one wavefront per item; 4 waves per workgroup while their row lists fit 64 KB of LDS, else 1
+    const size_t wave_bytes = sizeof(int) * w1_items_wave_words(m->rows);
+    const int nwave = 4 * wave_bytes <= 64 * 1024 ? 4 : 1;
+    if ((size_t)nwave * wave_bytes > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
     ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-    const int grid = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
-    hipLaunchKernelGGL(w1_item_update_kernel, dim3(grid), dim3(256), lds, s, a);
+    const int items = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+    hipLaunchKernelGGL(w1_item_update_kernel, dim3((items + nwave - 1) / nwave), dim3(64 * nwave), nwave * wave_bytes, s, a);
     LAUNCHCHK("w1_item_update");
     return AAE_OK;
 }
@@ -1254,6 +1259,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->bf16 = cfg->dtype == 1;
     m->blocked_ok = cfg->blocked_output == 1;
     m->blocked_any = getenv("AAE_BLOCKED_ANY") != nullptr;
+    m->split_any = getenv("AAE_SPLIT_ANY") != nullptr;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->model_kind == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
@@ -1297,7 +1303,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         }
     }
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)w1_items_lds_bytes(16384)) == hipSuccess;
+                                        (int)(sizeof(int) * w1_items_wave_words(16384))) == hipSuccess;
     (void)hipGetLastError();
     m->grad_scale = 1.f;
     m->rng_row0 = 0; m->rng_global = 0;
@@ -1352,6 +1358,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         m->split_ok = ok;
+        static const bool no_x3 = getenv("AAE_NO_X3") != nullptr;
+        m->x3_ok = ok && !no_x3
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
     }
     hipStream_t s = S(stream);
@@ -1900,7 +1911,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // below ~2 tiles per CU the two event hops cost more than the optimiser pass they hide (C1, N = 1 k: 0.173 -> 0.184
         // ms/step), and beyond ~32 M parameters the deferred launch on half the CUs outlasts the rest of the step and the
         // next step waits for it (one rank's C5 share, 442 M parameters: 3.5 -> 4.8 ms/step) - both take the single launch.
-        const bool split_fits = nblk > 1 || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
+        const bool split_fits = nblk > 1 || m->split_any || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
         if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && !want_ts && (fa.dbg_skip & ~256) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
@@ -1939,6 +1950,13 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                } else if (m->x3_ok) {
+                    const uint32_t lds3 = (uint32_t)dec_crit_x3_lds_bytes(m->fused_nb);
+                    switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_crit_x3_kernel<13>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    }
                 } else switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;

@@ -1,0 +1,353 @@
+// Critical launch of the fused decoder output layer (dec_fused.h, MODE kDecCrit: logits, BCE, dL/d(hidden), the stored
+// dL/dlogits tiles) with its fp32 products EMULATED on the bf16 matrix cores.
+//
+// gfx950 has no TF32 and its fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate.  Every fp32 operand
+// x is therefore split, on its way into LDS / registers, into three bf16 terms x = x1 + x2 + x3 (round to nearest even,
+// each residual is exact in fp32: 8 + 8 + 8 significand bits cover fp32's 24), and a product of two operands becomes
+// the six leading cross terms
+//     a * b  ~  a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1        (dropped: a2 b3 + a3 b2 + a3 b3 < 2^-23 |a b|)
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 instructions of 16 cycles per 32 k against 8 of 32 cycles - 2.7x
+// the fp32 matrix rate at fp32-level error (every bf16 x bf16 product is exact in fp32; what differs from the fp32 MFMA is
+// the summation order and the dropped 2^-24-relative terms - both below the fp32 rounding of the sum itself).
+// dtype stays f32: master weights, Adam, the BCE epilogue and all accumulators are fp32, and the reference's fixtures hold
+// at unchanged tolerances.
+//
+// Per tile of 32 items, one persistent 1024-thread workgroup per CU:
+//   S0     V3a tile (fp32 registers, requested one tile ahead) -> three bf16 images v3K[t][n][k] (k-contiguous rows);
+//          the tile's CSR entries (non-zero BCE targets) -> tgt[b][n]
+//   GEMM1  logits[b][n] = dh2 * V3a^T.  dh2 lives in REGISTERS for the whole kernel, already split, as the A fragments of
+//          the wave's row block (wave = (row block, k half): 48 VGPRs) - no LDS image of it (three of them would be 156
+//          KB) and no LDS traffic for half of GEMM1's operands; B fragments = one conflict-free 16-byte LDS read per term
+//   BCE    every thread two adjacent cells: the halves of the k split are added, zero-target form or - where tgt names a
+//          target - the reference's exact form; dL/dlogit -> the stored tile in HBM (fp32 [B][32], what the deferred
+//          optimiser launch reads) and, split, -> gK[t][b][n]; loss
+//   GEMM3  dA2[b][c] += G * V3a.  A fragments from gK; the B operand wants k = item contiguous per column c, i.e. the
+//          TRANSPOSE of the v3K rows: read with ds_read_b64_tr_b16 (gfx950's transposing LDS read) from the same images -
+//          no second, transposed image and none of the 2-byte scatter writes it would need
+// 4 LDS-only barriers per tile.
+#pragma once
+#include "dec_fused_bf16.h"
+
+namespace aae {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// (a, b) -> three packed bf16 pairs with a = a1 + a2 + a3, b = b1 + b2 + b3 exactly (low half = a)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = bf16_pack(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = bf16_pack(ra, rb);
+    p3 = bf16_pack(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xFFFF0000u));
+}
+
+// the six leading cross terms of (a1 + a2 + a3) (b1 + b2 + b3), smallest first
+__device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+
+// Row stride (dwords) of a k-contiguous bf16 image with kc 32-wide k-steps, read with ONE ds_read_b128 per fragment (8
+// consecutive k per lane): 16 kc + 8 = a stride of 32 bytes mod 64.  ds_read_b128 is serviced in four groups of 16 lanes
+// (MI355X_MICROARCH.md, LDS), each holding every fragment row fr once - half of them with the group's k-eighth fk, half with
+// fk ^ 1 -, and with stride / 16 = 2 mod 4 the rows of the first half fall on the even 16-byte slots of the 256-byte bank
+// row and those of the second on the odd ones: conflict-free.  (Two ds_read_b64 per fragment get fused by hipcc into
+// ds_read2_b64, which runs at half the rate.)
+__host__ __device__ constexpr int x3_stride(int kc) { return 16 * kc + 8; }
+// one 16x16x32 fragment: row `row`, k = 32 kc + 8 fk + {0..7}
+__device__ __forceinline__ bf16x8 x3_frag(const unsigned* img, int row, int S, int kc, int fk) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(img + row * S + 16 * kc + 4 * fk));
+}
+constexpr int kXRS = 33;       // row stride (floats) of the raw-logit halves [b][n]
+constexpr int kXT = 32;        // row stride (floats) of the target tile [b][n]
+
+constexpr int kXRegSteps = 3;  // k-steps of a wave's dh2 fragments kept in registers (12 VGPRs each); further ones live in LDS
+inline size_t dec_crit_x3_lds_bytes(int NB) {
+    const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1), S3 = x3_stride(1);
+    const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kXRS + (size_t)3 * kGR * S3 + (size_t)kGR * kXT + 64 +
+                            (size_t)lsteps * kMB * 3 * 64 * 4);
+}
+
+template <int NB>   // NB = ceil((h + 1) / 16) column blocks
+__global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
+    constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
+    constexpr int NKS = (KC1 + 1) / 2;         // ... per k half
+    constexpr int NKR = NKS > kXRegSteps ? kXRegSteps : NKS;   // ... of them in registers; the others' fragments in LDS, a private
+    constexpr int NKL = NKS - NKR;             // [step][term][lane] block per wave (12 VGPRs per step cost a spill at 128 -
+                                               // and a scratch reload waits for the V3a prefetch in flight; an LDS read does not)
+    constexpr int S1 = x3_stride(KC1), S3 = x3_stride(1);
+    static_assert(NB <= kNW && 2 * kMB <= kNW, "one column block / one (row block, k half) per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* v3K = reinterpret_cast<unsigned*>(lds);          // [3][32][S1]  V3a tile, k = hidden column
+    float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1); // [2][kGR][kXRS] the two k halves of the logits (fp32)
+    unsigned* gK = reinterpret_cast<unsigned*>(raw + 2 * kGR * kXRS);   // [3][kGR][S3] dL/dlogits, k = item
+    float* tgt = reinterpret_cast<float*>(gK + 3 * kGR * S3);  // [kGR][kXT]   non-zero BCE targets of the tile (else 0)
+    float* red = tgt + kGR * kXT;                              // [64]
+    u32x4_t* dAl = reinterpret_cast<u32x4_t*>(red + 64);        // [kMB][NKL][3][64] spilled-by-design dh2 fragments (k half 0 only)
+
+    // row blocks of one launch (item slices of the data-parallel scheme, dec_fused.h): this workgroup's block and tiles
+    const int nblk = a.nblk > 1 ? a.nblk : 1;
+    const int blk = nblk > 1 ? (int)blockIdx.x % nblk : 0, wgi = nblk > 1 ? (int)blockIdx.x / nblk : (int)blockIdx.x;
+    const int wgs = nblk > 1 ? (int)gridDim.x / nblk : (int)gridDim.x;
+    if (nblk > 1 && wgi >= wgs) return;
+    const int erow0 = nblk > 1 ? blk * a.Bb : a.erow0;
+    const int B = nblk > 1 ? min(a.Bb, a.B - erow0) : a.B;
+    const float* dh2_blk = nblk > 1 ? a.dh2 + (size_t)erow0 * a.ldh : a.dh2;
+    float* slabs_blk = nblk > 1 ? a.slabs + (size_t)erow0 * a.ld_slab : a.slabs;
+    float* Gt_blk = nblk > 1 ? a.Gt + (size_t)blk * ((a.N + kTI - 1) / kTI) * a.Bb * kTI : a.Gt;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ldv = a.ldv, N = a.N;
+    const int ntiles = (N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;                       // float4 slots per thread of a tile span (tile_f4 <= 2048)
+
+    // ---- once per workgroup: zero the images (k padding of v3K, rows >= B of gK, the target tile)
+    for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kXRS + 3 * kGR * S3 + kGR * kXT; i += kNT) v3K[i] = 0u;
+
+    // ---- dh2 -> split A fragments in registers.  GEMM1: wave w < 14 = (row block w % 7, k half w / 7) takes the k-steps
+    // kc = kh, kh + 2, ...; lane (fr, fk) of a fragment holds row 16 mb + fr, k = 32 kc + 8 fk + {0..7}
+    const bool g1 = wave < 2 * kMB;
+    const int mb1 = wave % kMB, kh = wave / kMB;
+    bf16x8 dA[NKR][3];
+    {
+        const int row = 16 * mb1 + fr;
+        const float* src = dh2_blk + (size_t)min(row, B - 1) * a.ldh;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            const int k0 = 32 * (kh + 2 * j) + 8 * fk;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+            if (g1 && row < B && k0 < a.ldh) x = *reinterpret_cast<const float4*>(src + k0);
+            if (g1 && row < B && k0 + 4 < a.ldh) y = *reinterpret_cast<const float4*>(src + k0 + 4);
+            unsigned p[3][4];
+            split3_pair(x.x, x.y, p[0][0], p[1][0], p[2][0]);
+            split3_pair(x.z, x.w, p[0][1], p[1][1], p[2][1]);
+            split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2]);
+            split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
+                if (j < NKR) dA[j < NKR ? j : 0][t] = __builtin_bit_cast(bf16x8, v);
+                else if (g1 && kh == 0) dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane] = v;
+            }
+        }
+    }
+    const int nks = (KC1 - kh + 1) / 2;         // k-steps this wave really has (the rest of dA is zero and never used)
+
+    // GEMM3: wave w < NB owns column block w for every row block
+    const bool own = wave < NB;
+    const int cb = min(wave, NB - 1);
+    f32x4 acc3[kMB];
+#pragma unroll
+    for (int q = 0; q < kMB; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float loss = 0.f;
+
+    // ---- the parameter stream: tensor base in a buffer descriptor (scalar registers), the tile's byte offset in a scalar
+    // register, this thread's slot offset in ONE vector register (+ an immediate); reads beyond the tensor return zero
+    // (the dispatcher keeps fused layers below 2 GB)
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto load_span = [&](int tile, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+    };
+    float4 vreg[NV];
+    int tile = wgi;
+    const int stride = wgs;
+    const int last_e = max(a.te.start[ntiles] - 1, 0);
+    int ozr;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(ozr));
+    auto load_range = [&](int t, int& lo, int& hi) {       // (vector loads: a scalar load would sit in lgkmcnt, see dec_fused.h)
+        const int tc = min(t, ntiles - 1) + ozr;
+        lo = a.te.start[tc]; hi = a.te.start[tc + 1];
+        if (t >= ntiles) hi = lo;
+    };
+    int ce0 = 0, ce1 = 0, ne0 = 0, ne1 = 0, fe0 = 0, fe1 = 0;
+    int ent_bn = 0; float ent_v = 0.f;          // this thread's entry of the NEXT tile: (doc << 5) | item-in-tile, value
+    auto load_entry = [&](int lo) {
+        const int e = min(lo + tid, last_e);
+        ent_bn = (a.te.eb[e] << 5) | a.te.en[e]; ent_v = a.te.ev[e];
+    };
+    if (tile < ntiles) {
+        load_span(tile, vreg);
+        load_range(tile, ne0, ne1);
+        load_range(tile + stride, fe0, fe1);
+        load_entry(ne0);
+    }
+    int s_rc[NV];                               // this thread's slots of a tile span: item row * 64 + float4 column
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+    }
+    const int g_f4 = B * (kTI / 4);             // float4 per stored dL/dlogits tile
+    const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
+    const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(Gt_blk, 0, gbytes, 0x00020000);
+    typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
+    int iter = 0;
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[11] = wall_clock64();
+    auto stamp = [&](int k) { if (a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
+    __syncthreads();
+
+    for (; tile < ntiles; tile += stride, ++iter) {
+        const int i0 = tile * kTI;
+        // A zero the compiler cannot see through: the LDS operand addresses of the phases are built from it, so they are
+        // recomputed per tile (a few VALU) instead of being hoisted out of the tile loop and held in registers across
+        // every phase - at 128 VGPRs that hoisting spilled, and a scratch reload waits for every older global load in
+        // flight (the next tile's V3a prefetch)
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int frz = fr + oz, fkz = fk + oz;
+        stamp(0);
+        lds_barrier();                          // the previous tile's readers of v3K (GEMM3) are done
+        // ---- S0: this tile's V3a -> the three bf16 images; its CSR entries -> tgt; request the next stage
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (tid + kNT * j < tile_f4) {
+                float4 p = vreg[j];
+                if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned q0[3], q1[3];
+                split3_pair(p.x, p.y, q0[0], q0[1], q0[2]);
+                split3_pair(p.z, p.w, q1[0], q1[1], q1[2]);
+                unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
+            }
+        }
+        ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
+        {
+            const int rb = (ent_bn >> 5) - erow0;       // (row-blocked launches: entries of other row blocks are not ours)
+            if (tid < ce1 - ce0 && (unsigned)rb < (unsigned)B) tgt[rb * kXT + (ent_bn & 31)] = ent_v;
+            for (int e = ce0 + kNT + tid; e < ce1; e += kNT) {      // tiles with more than 1024 entries (tiny vocabularies)
+                const int r2 = a.te.eb[e] - erow0;
+                if ((unsigned)r2 < (unsigned)B) tgt[r2 * kXT + a.te.en[e]] = a.te.ev[e];
+            }
+        }
+        load_span(tile + stride, vreg);         // (beyond the last tile: zeros, never used)
+        load_range(tile + 2 * stride, fe0, fe1);
+        load_entry(ne0);
+        lds_barrier();
+        stamp(1);
+
+        // ---- GEMM1: logits of the wave's row block x both item halves over its k-steps -> its half's raw tile
+        if (g1) {
+            float* rw = raw + kh * (kGR * kXRS) + (16 * mb1 + 4 * fkz) * kXRS + frz;    // C map: row = 4 fk + r, col = fr
+#pragma unroll
+            for (int nb2 = 0; nb2 < 2; ++nb2) {         // (one item half at a time: 12 fragment registers live, not 24)
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NKS; ++j)
+                    if (j < nks) {
+                        bf16x8 bb[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
+                        if (j < NKR) c = mfma_x3(dA[j < NKR ? j : 0], bb, c);
+                        else {
+                            bf16x8 al[3];
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane + oz]);
+                            c = mfma_x3(al, bb, c);
+                        }
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
+            }
+        }
+        lds_barrier();
+        stamp(2);
+
+        // ---- BCE: thread -> cells (b, n2), (b, n2 + 1) of pair id tid + 1024 j; the stored tile, the split G images, loss
+#pragma unroll
+        for (int j = 0; j < (kGR * (kTI / 2) + kNT - 1) / kNT; ++j) {
+            const int pid = tid + oz + kNT * j, b = pid >> 4, n2 = (pid & 15) * 2;
+            if (b < B) {
+                const float l0 = raw[b * kXRS + n2] + raw[kGR * kXRS + b * kXRS + n2];
+                const float l1 = raw[b * kXRS + n2 + 1] + raw[kGR * kXRS + b * kXRS + n2 + 1];
+                const float2 tt = *reinterpret_cast<const float2*>(tgt + b * kXT + n2);
+                float gA, lA, gB, lB;
+                if (tt.x != 0.f) bce_elem(l0, tt.x, a.gscale, gA, lA); else bce_elem_t0(l0, a.gscale, gA, lA);
+                if (tt.y != 0.f) bce_elem(l1, tt.y, a.gscale, gB, lB); else bce_elem_t0(l1, a.gscale, gB, lB);
+                if (tt.x != 0.f || tt.y != 0.f) *reinterpret_cast<float2*>(tgt + b * kXT + n2) = make_float2(0.f, 0.f);
+                if (i0 + n2 >= N) { gA = 0.f; lA = 0.f; }
+                if (i0 + n2 + 1 >= N) { gB = 0.f; lB = 0.f; }
+                loss += lA + lB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fu32x2, make_float2(gA, gB)), rGt, (unsigned)pid * 8u,
+                                                      (unsigned)tile * (unsigned)g_f4 * 16u, 0);
+                unsigned q[3];
+                split3_pair(gA, gB, q[0], q[1], q[2]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
+            }
+        }
+        lds_barrier();
+        stamp(3);
+
+        // ---- GEMM3: dA2[b][c] += sum_n G[b][n] V3a[n][c] for the wave's column block, every row block.  k-order of a
+        // fragment (both operands): element j = item 8 fk + j - what x3_frag reads from the gK rows; the B operand's fragment is
+        // the transpose of 2 x (4 items x 16 columns) of the v3K rows: ds_read_b64_tr_b16, lane 4 q + p of a 16-lane group
+        // names row q, columns 4 p .. 4 p + 3 of its block
+        if (own) {
+            bf16x8 vt[3];
+            {
+                const int lz = lane + oz, q = (lz >> 2) & 3, p = lz & 3;
+                const unsigned* base = v3K + (8 * fkz + q) * S1 + 8 * cb + 2 * p;        // (16 cb + 4 p) bf16 = 8 cb + 2 p dwords
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1)));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1) + 4 * S1));
+                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    vt[t] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kMB; ++q) {     // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
+                bf16x8 ga[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ga[t] = x3_frag(gK + t * (kGR * S3), 16 * q + frz, S3, 0, fkz);
+                acc3[q] = mfma_x3(ga, vt, acc3[q]);
+            }
+        }
+        stamp(4);
+        stamp(5);
+        stamp(6);
+    }
+    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
+
+    // ---- dA2 partial of this workgroup -> its slab; loss partial
+    float* slab = slabs_blk + (size_t)wgi * a.slab_stride;
+    if (own) {
+#pragma unroll
+        for (int q = 0; q < kMB; ++q) {
+            const int rb = q * 16 + fk * 4, cc = cb * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rb + r < B && cc < a.ld_slab) slab[(size_t)(rb + r) * a.ld_slab + cc] = acc3[q][r];
+        }
+    }
+    loss = wave_sum(loss);
+    __syncthreads();
+    if (lane == 0) red[wave] = loss;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < kNW; ++w) s += red[w];
+        a.partials[blockIdx.x] = s;
+        if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
+    }
+}
+
+}  // namespace aae

@@ -17,7 +17,8 @@ scaling): the global batch of N * B rows is sharded over the ranks by Adversaria
 Rank 0 prints ONE JSON line.  `roofline` is for the kernel that takes the most time in the step, from hipEvent
 pairs recorded around its launches inside the timed region; `cpu_baseline` is the PyTorch-CPU dense port of the
 reference step (oracle/dense_torch_port.py) timed on this box's host cores over a bounded sample of the same
-workload (N = 1 only); `extra.b512` is the MFMA-bound batch-512 variant of the same configuration (N = 1, f32).
+workload (N = 1 only); `extra.b512` is the MFMA-bound batch-512 variant of the same configuration (N = 1, f32),
+`extra.c2_bf16` BASELINE.json's configs[1] (|items| = 47 000, hidden 100, bf16 matrix-core inputs) through the same loop.
 """
 import argparse
 import contextlib
@@ -76,7 +77,11 @@ def parse():
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start one child per GPU (this process has not touched the GPU and
-    never will), wait for them, relay rank 0's JSON line.  Children get the torch.distributed.run environment."""
+    never will), watch ALL of them, relay rank 0's JSON line.  Children get the torch.distributed.run environment.  The
+    library is built once here, before the ranks start (a hipcc subprocess, no GPU call): N ranks racing to write
+    libaaerec_hip.so was one way for a rank other than 0 to die at start-up and leave rank 0 in the rendezvous."""
+    from aaerec import _build
+    _build.build(verbose=False)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -85,17 +90,42 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout carries the result line; the other ranks' output goes to stderr (their diagnostics stay visible)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode(errors="replace")
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        # a rank died: the others would wait for it in a collective for ever - stop them (our own children, by handle)
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}; stopping the other ranks", file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = (buf[0] if buf else b"").decode(errors="replace")
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     for ln in out.splitlines():
         if not ln.startswith("{"):
             print(ln, file=sys.stderr)
-    if lines:
+    if lines and failed is None:
         print(lines[-1], flush=True)
-    rc = max((abs(r) for r in rcs), default=0)
+    rc = abs(failed[1]) if failed is not None else max((abs(r) for r in rcs), default=0)
     sys.exit(rc if rc or lines else 1)
 
 
@@ -358,6 +388,37 @@ def main():
             extra["b512"] = dict(docs_per_s=round(k2 * 512 / d2, 1), ms_per_step=round(d2 / k2 * 1e3, 4), steps=k2,
                                  kernels=ks2)
             del m2, it2
+        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc:
+            # BASELINE.json configs[1] (C2, RCV1-scale: |items| = 47 000, hidden 100, bf16 matrix-core inputs) next to the
+            # headline config, so that the driver's line carries it: the same fit() loop at the reference's batch 100
+            a3 = argparse.Namespace(**vars(a))
+            a3.hidden, a3.items = 100, 47000
+            m3 = make_model(a3, B, None, dtype="bf16")
+            X3 = throughput_corpus(n_batches * B, a3.items, median_len=a.median_len, seed=2345)
+            with contextlib.redirect_stdout(sys.stderr):
+                it3 = m3.fit_steps(X3)
+                next(it3)
+            for _ in range(a.warmup):
+                next(it3)
+            m3.hip.profile_enable(True, kernels=K_OUT)
+            d3 = [timed_steps(it3, a.steps, barrier)]
+            m3.hip.profile_enable(False)
+            for _ in range(2):
+                d3.append(timed_steps(it3, a.steps, barrier))
+            km3 = kernel_models(a3.items, a3.hidden, B, X3.nnz / n_batches, c)
+            ks3 = {}
+            for kid in K_OUT:
+                ms, n = m3.hip.profile_read(kid)
+                if n:
+                    avg_s = ms / n * 1e-3
+                    ks3[NAMES[kid]] = dict(avg_us=round(avg_s * 1e6, 2), GBps=round(km3[NAMES[kid]]["bytes"] / avg_s / 1e9, 1),
+                                           frac_hbm=round(km3[NAMES[kid]]["bytes"] / avg_s / 1e9 / HBM_PEAK_GBS, 4))
+            dm = float(np.median(d3))
+            extra["c2_bf16"] = dict(workload=f"C2 RCV1-scale synthetic Bags: |items|={a3.items}, hidden={a3.hidden}, code={c}, bf16 MFMA "
+                                             f"inputs / fp32 accumulate, master weights and Adam, batch={B}, through fit()",
+                                    docs_per_s=round(a.steps * B / dm, 1), ms_per_step=round(dm / a.steps * 1e3, 4), steps=a.steps,
+                                    dtype="bf16", kernels=ks3)
+            del m3, it3
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -397,8 +458,15 @@ def main():
     if rank == 0:
         cfg_name = ("C2 RCV1-scale" if a.dtype == "bf16" else "C4 EconBiz-scale + 300-d title condition" if a.cond_inc
                     else "C3 PubMed-scale")
+        cfg_id = ("C3" if (N, h, a.dtype, a.cond_inc) == (100000, 200, "f32", 0) else
+                  "C2" if (N, h, a.dtype, a.cond_inc) == (47000, 100, "bf16", 0) else
+                  "C4" if a.cond_inc else "custom")
+        kitems = f"{N // 1000}k" if N % 1000 == 0 else str(N)
         out = {
-            "metric": "train docs/sec at |items|=100k h=200",
+            # (BASELINE.json's metric names the headline shape; any other shape names its own so that two lines are never
+            #  compared across configurations)
+            "metric": f"train docs/sec at |items|={kitems} h={h}" + ("" if a.dtype == "f32" else f" {a.dtype}"),
+            "config_id": cfg_id,
             "value": round(docs_per_s, 1), "unit": "docs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

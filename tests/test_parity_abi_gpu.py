@@ -75,6 +75,18 @@ def test_step_matches_reference(name):
     np.testing.assert_allclose(out, fx.z["predict.out"], atol=TOL_RECON)
 
 
+@pytest.mark.parametrize("name", ["step_headline", "step_masks", "step_wide", "step_ragged", "step_cond_concat", "step_sgd",
+                                  "step_lrs", "step_selu", "step_nonorm"])
+def test_step_matches_reference_through_the_split_output_layer(name, monkeypatch):
+    """The same replay with the output layer in the form the benchmark's shapes take (AAE_SPLIT_ANY lifts the size rule
+    that keeps small layers on the single launch): the CRITICAL launch with its fp32 products emulated on the bf16 matrix
+    cores (csrc/dec_crit_x3.h: three bf16 terms per operand, six cross products, fp32 accumulation - 16, 7-block and
+    13-block widths, ragged / empty rows, a condition block, SGD) and the DEFERRED optimiser launch on the side stream -
+    against the reference's recorded losses, parameters and Adam moments at the SAME tolerances as the fp32 kernels."""
+    monkeypatch.setenv("AAE_SPLIT_ANY", "1")
+    test_step_matches_reference(name)
+
+
 def test_plain_autoencoder_matches_reference():
     """cfg.reserved[2] = 1: the reference's non-adversarial AutoEncoder (aae.py:221-458) - only the
     reconstruction step runs; fixture generated from the reference's AutoEncoder class."""

@@ -689,6 +689,64 @@ def gen_e2e_c1_big(ref_aae, n_seeds=16):
                         recipe=np.asarray(json.dumps(dict(kw, n_epochs=120, dropout=[0., 0.]))))
 
 
+def gen_e2e_c3(ref_aae, n_epochs=6, out_name="e2e_c3.npz"):
+    """The ranking check at config C3's SHAPE (SURVEY 8d "scale the same recipe for the C3 MRR check"):
+    |items| = 100 000, hidden 200, code 50, batch 100 - the benchmark's layer sizes (3 125 item tiles in the output layer,
+    13-block layer chains) - on a prototype-structured corpus small enough for the reference to train on the build
+    container's CPU in about a minute: 200 prototype sets of 10 items drawn from the 100 000, 2 000 training docs (6-9
+    items of one prototype each), 200 test docs with one item hidden, n_epochs x 20 steps (6 epochs = 120 steps: the horizon up to which a replayed fp32 trajectory stays within 1e-4) at gen_lr 0.01 without dropout
+    (every draw is then the weight initialisation, the epoch permutations and z_real: replayed by rng_mode='reference').
+    The [200, 100 000] prediction matrix stays here (80 MB); the fixture holds what the reference's evaluation makes of it -
+    evaluation.remove_non_missing + argtopk (evaluation.py:183-199, 20-58): the 12 best items per test doc with their
+    scaled scores, MRR@10 / MAP@10 / P@5 - plus the raw sigmoid outputs at 32 probe items per doc."""
+    import aaerec.evaluation as ev
+    rng = np.random.RandomState(31337)
+    N, n_proto, n_train, n_test = 100000, 200, 2000, 200
+    protos = [rng.choice(N, size=10, replace=False) for _ in range(n_proto)]
+    docs = []
+    for _ in range(n_train + n_test):
+        p = protos[rng.randint(n_proto)]
+        k = rng.randint(6, 10)
+        docs.append(sorted(rng.choice(p, size=k, replace=False).tolist()))
+    train, test = docs[:n_train], docs[n_train:]
+    test_in, test_out = [], []
+    for d in test:
+        j = rng.randint(len(d))
+        test_out.append([d[j]])
+        test_in.append(d[:j] + d[j + 1:])
+
+    def csr(rows):
+        i0 = [b for b, r in enumerate(rows) for _ in r]
+        i1 = [i for r in rows for i in r]
+        return sp.coo_matrix((np.ones(len(i0)), (i0, i1)), shape=(len(rows), N)).tocsr()
+
+    Xtr, Xin, Yout = csr(train), csr(test_in), csr(test_out)
+    kw = dict(n_hidden=200, n_code=50, batch_size=100, gen_lr=0.01, reg_lr=0.001, dropout=(0., 0.), verbose=False)
+    seed = 11
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    import time
+    t0 = time.time()
+    m = ref_aae.AdversarialAutoEncoder(n_epochs=n_epochs, **kw)
+    m.fit(Xtr)
+    raw = m.predict(Xin).astype(np.float32)
+    print("e2e_c3: reference fit + predict", round(time.time() - t0, 1), "s", flush=True)
+    pred = ev.remove_non_missing(raw, Xin, copy=True)
+    Y = Yout.toarray()
+    metrics = {name: [float(v) for v in ev.METRICS[name](Y, pred)] for name in ("mrr@10", "map@10", "p@5")}
+    print("e2e_c3 reference metrics", metrics, flush=True)
+    top_idx = np.asarray(ev.argtopk(pred, 12)[1])
+    top_val = np.take_along_axis(pred, top_idx, axis=1).astype(np.float32)
+    probe = np.stack([np.concatenate([Yout[i].indices[:1], rng.choice(N, size=31, replace=False)]) for i in range(n_test)]).astype(np.int32)
+    probe_raw = np.take_along_axis(raw, probe, axis=1).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, out_name), seed=np.asarray(seed), N=np.asarray(N), n_epochs=np.asarray(n_epochs),
+                        train_indptr=Xtr.indptr, train_indices=Xtr.indices, in_indptr=Xin.indptr, in_indices=Xin.indices,
+                        out_indptr=Yout.indptr, out_indices=Yout.indices, top_idx=top_idx.astype(np.int32), top_val=top_val,
+                        probe=probe, probe_raw=probe_raw, metrics=np.asarray(json.dumps(metrics)),
+                        row_min=raw.min(1).astype(np.float32), row_max=raw.max(1).astype(np.float32),
+                        recipe=np.asarray(json.dumps(dict(kw, n_epochs=n_epochs, dropout=[0., 0.]))))
+
+
 def gen_dae():
     """The reference's DenoisingAutoEncoder (dae.py:144-314), corrupt='zeros' (its default): the batch tensor is
     thinned IN PLACE by zeros_noise (dae.py:48-52), so encoder input and BCE target are both the thinned batch.
@@ -1042,6 +1100,11 @@ def main():
         gen_e2e_c1(ref_aae)
     if want("e2e_big"):
         gen_e2e_c1_big(ref_aae)
+    if "e2e_c3" in which:       # (only on request: a minute or two of CPU at |items| = 100 000)
+        gen_e2e_c3(ref_aae)
+    for w in which:             # e2e_c3:<epochs> -> a scratch fixture at another horizon (debugging; not committed)
+        if w.startswith("e2e_c3:"):
+            gen_e2e_c3(ref_aae, n_epochs=int(w.split(":")[1]), out_name="tmp_e2e_c3_{}.npz".format(w.split(":")[1]))
 
 
 if __name__ == "__main__":
