@@ -104,7 +104,8 @@ struct aae_model {
     float* bce_partials; int bce_partials_cap;
     float* fix_partials;
     float* rscale;           // [R] 1/L1 of the rows of the running batch
-    bool w1_merged;          // the first-layer scatter + bias update of this phase rode in the grouped dW launch
+    bool w1_merged;          // the first layer's bias update of this phase rode in the grouped dW launch
+    bool w1_items_merged;    // ... and so did its row-sparse weight gradient + optimiser (w1_update.h)
     bool buckets_valid;      // the per-tile entry buckets (tstart/teb/ten/tev) describe the running batch
     // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
     bool lazy;
@@ -533,6 +534,8 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
 }
 
 int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s);
+W1Items w1_items_args(aae_model* m, const float* ga1, int rpb, size_t bstride, int which);
+int ensure_buckets(aae_model* m, hipStream_t s);
 
 // Encoder backward from dL/dz (gz [rows][ldgz]) + optimiser `which` (O_ENC or O_GEN) on all
 // encoder parameters.  z [rows][ldzz] is the encoder output of the matching forward.
@@ -735,17 +738,30 @@ struct DwBuilder {
     }
     // the first encoder layer's bias gradient + update of optimiser `which` ride along (the row-sparse weight gradient +
     // optimiser follow as a launch of their own: encoder_first_layer_update(..., merged = true))
-    void add_first_layer(aae_model* m, const float* ga1, int which) {
+    int add_first_layer(aae_model* m, const float* ga1, int which, hipStream_t s) {
         const int set = (which == O_GEN) ? 1 : 0;
         W1Job& w = g.w1;
         w.enabled = 1; w.ga1 = ga1; w.ld = m->ldh; w.h = m->h; w.rows = m->rows;
         w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
         w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
         w.ncol = (m->h + 63) / 64;
+        // the row-sparse weight gradient + optimiser of the layer rides along while its per-wave row lists fit the kernel's
+        // static LDS (batches up to ~750 rows); not for the dense noisy input (a dense product follows) or an external
+        // first layer (the rows live with their item slices)
+        static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
+        w.nitem = 0;
+        m->w1_items_merged = false;
+        if (!no_merge && !m->dense_step && !m->ext_first && 4 * sizeof(int) * w1_items_wave_words(m->rows) <= kDwSmemBytes) {
+            TRY(ensure_buckets(m, s));
+            w.items = w1_items_args(m, ga1, 0, 0, which);
+            w.nitem = (std::min(m->cfg.max_nnz, std::max(256, m->rows * 32)) + 3) / 4;
+            m->w1_items_merged = true;
+        }
+        return AAE_OK;
     }
     int launch(hipStream_t s) {
         int blocks = tiles;
-        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol; }
+        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
         return AAE_OK;
@@ -823,8 +839,7 @@ int ensure_buckets(aae_model* m, hipStream_t s) {
 
 // The sparse first layer's weight gradient over the running batch and optimiser `which` on the touched rows (or the
 // gradient rows -> AAE_T_GRAD + ENC_W1T in export mode), in a fixed summation order (w1_update.h)
-int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s) {
-    TRY(ensure_buckets(m, s));
+W1Items w1_items_args(aae_model* m, const float* ga1, int rpb, size_t bstride, int which) {
     const int set = (which == O_GEN) ? 1 : 0;
     W1Items a;
     a.ulist = m->ulist; a.ucount = m->ucount;
@@ -835,6 +850,11 @@ int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int
     a.gout = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_W1T].p : nullptr;
     a.sc = m->sc + which; a.tsync = m->tsync; a.step_ctr = m->step_ctr;
     a.mark_synced = (which == O_GEN || m->ae_only) ? 1 : 0;
+    return a;
+}
+int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s) {
+    TRY(ensure_buckets(m, s));
+    const W1Items a = w1_items_args(m, ga1, rpb, bstride, which);
     // one wavefront per item; 4 waves per workgroup while their row lists fit 64 KB of LDS, else 1
     const size_t wave_bytes = sizeof(int) * w1_items_wave_words(m->rows);
     const int nwave = 4 * wave_bytes <= 64 * 1024 ? 4 : 1;
@@ -971,6 +991,7 @@ int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStr
                            m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
         LAUNCHCHK("colsum_adam");
     }
+    if (merged && m->w1_items_merged) { m->w1_items_merged = false; return AAE_OK; }      // (rode in the grouped dW launch)
     // (export mode: the gradient rows -> AAE_T_GRAD + ENC_W1T; aae_w1_export / exchange / aae_w1_import follow)
     return launch_w1_items(m, ga1, 0, 0, which, s);
 }
@@ -1222,7 +1243,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     DwBuilder dw;
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
-    dw.add_first_layer(m, ga1_ptr(m), O_GEN);
+    TRY(dw.add_first_layer(m, ga1_ptr(m), O_GEN, s));
     TRY(dw.launch(s));
     if (m->ext_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
     return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
@@ -1912,7 +1933,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // ms/step), and beyond ~32 M parameters the deferred launch on half the CUs outlasts the rest of the step and the
         // next step waits for it (one rank's C5 share, 442 M parameters: 3.5 -> 4.8 ms/step) - both take the single launch.
         const bool split_fits = nblk > 1 || m->split_any || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
-        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && !want_ts && (fa.dbg_skip & ~256) == 0) {
+        // (AAE_DEC_TS: the timeline of the single launch - or, AAE_DEC_TS=x3, of the split form's critical launch dec_crit_x3.h)
+        static const bool ts_x3 = want_ts && strcmp(getenv("AAE_DEC_TS"), "x3") == 0;
+        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || (ts_x3 && m->x3_ok && !m->bf16)) && (fa.dbg_skip & ~256) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3
@@ -2031,6 +2054,12 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             unsigned long long t[128];
             hipStreamSynchronize(s);
             hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+            if (m->last_out_split)
+                fprintf(stderr, "[dec_crit_x3 tile 5] barrier=%.2f S0=%.2f GEMM1=%.2f BCE=%.2f GEMM3=%.2f | wg 0: prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
+                        (t[14] - t[0]) * 0.01, (t[1] - t[14]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
+                        (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
+                        (t[12] - t[7]) * 0.01);
+            else {
             if (m->bf16)
                 for (int k = 0; k < 5; ++k) {
                     fprintf(stderr, "[dec_fused_bf16 arrivals at barrier %d, us after the unit's start]", k);
@@ -2045,6 +2074,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             fprintf(stderr, "[dec_fused wg 0] prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
                     (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
                     (t[12] - t[7]) * 0.01);
+            }
         }
         // 256+ slabs -> 16 partial slabs (stored behind the per-workgroup ones) -> sum + act'/dropout; the same
         // launch reduces the per-workgroup loss partials
@@ -2151,7 +2181,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         DwBuilder dw;
         dw.add(m, m->gb0.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
         dw.add(m, m->gmulv.p, (int)m->gmulv.ld, m->eh1.p, m->ldh, B, P_W3, O_ENC);
-        dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+        TRY(dw.add_first_layer(m, m->gb3.p, O_ENC, s)); m->w1_merged = true;
         TRY(dw.launch(s));
         m->phase = 2;
         return AAE_OK;
@@ -2167,7 +2197,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         if (enc_too) {
             dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
             dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
-            dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+            TRY(dw.add_first_layer(m, m->gb3.p, O_ENC, s)); m->w1_merged = true;
             m->enc_bwd_done = true;
         }
         TRY(dw.launch(s));
@@ -2312,7 +2342,7 @@ int aae_vae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, v
     TRY(chain_vae_backward_enc(m, dz_dev, (int)dz_ld, s));
     DwBuilder dw;
     dw.add(m, m->gmulv.p, (int)m->gmulv.ld, m->eh1.p, m->ldh, B, P_W3, O_ENC);
-    dw.add_first_layer(m, m->gb3.p, O_ENC); m->w1_merged = true;
+    TRY(dw.add_first_layer(m, m->gb3.p, O_ENC, s)); m->w1_merged = true;
     TRY(dw.launch(s));
     TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
     m->phase = 0; m->vae_cut = false;
@@ -2329,7 +2359,7 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
             DwBuilder dw;
             dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, m->rows, P_W3, O_ENC);
             dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, m->rows, P_W2, O_ENC);
-            dw.add_first_layer(m, ga1_ptr(m), O_ENC); m->w1_merged = true;
+            TRY(dw.add_first_layer(m, ga1_ptr(m), O_ENC, s)); m->w1_merged = true;
             TRY(dw.launch(s));
         }
         if (!m->ext_first) TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
@@ -2406,7 +2436,7 @@ int aae_ae_backward(aae_handle m, const float* dA2_dev, int64_t dA2_ld, void* st
     dw.add(m, m->gb1.p, m->ldh, m->zc.p, m->ldc, B, P_V1, O_DEC);
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_ENC);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_ENC);
-    dw.add_first_layer(m, ga1_ptr(m), O_ENC); m->w1_merged = true;      // (external first layer: its bias blocks only)
+    TRY(dw.add_first_layer(m, ga1_ptr(m), O_ENC, s)); m->w1_merged = true;      // (external first layer: its bias blocks only)
     TRY(dw.launch(s));
     m->enc_bwd_done = true;
     m->phase = 2;

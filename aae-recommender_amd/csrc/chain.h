@@ -14,6 +14,7 @@
 #include "gemm_f32.h"
 #include "kernels.h"
 #include "buckets.h"
+#include "w1_update.h"
 
 namespace aae {
 
@@ -612,22 +613,29 @@ struct DwJob {
     int tile0;                                                     // first linear tile id of this job
     int tiles_n;                                                   // tiles along N
 };
-// The first encoder layer's bias shares the launch: its column sums + optimiser (one workgroup per 64 columns) depend on
-// the same chain outputs as the dense jobs and on nothing else.  (The layer's row-sparse weight gradient + optimiser is
-// a launch of its own behind this one: w1_update.h.)
+// The first encoder layer shares the launch: its bias' column sums + optimiser (one workgroup per 64 columns) and its
+// row-sparse weight gradient + optimiser over the batch's distinct items (w1_update.h: one wavefront per item) depend on
+// the same chain outputs as the dense jobs and on nothing else - as launches of their own behind this one they were 8-24 us
+// of the step's critical path, twice per step.
 struct W1Job {
     int enabled; const float* ga1; int ld, h, rows;
     float* bp; float* bm; float* bv1; float* bgrad; const OptScalars* sc;   // blocks [blk0, blk0 + ncol)
     int blk0, ncol;
+    int nitem;            // > 0: blocks [blk0 + ncol, blk0 + ncol + nitem) run the item update (else a launch of its own follows)
+    W1Items items;
 };
 struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; };
+constexpr int kDwSmemBytes = 2 * 64 * (32 + 16) * 4;       // static LDS of grouped_dw_kernel (2 * BK * LDT floats)
 
 __global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
     constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
+    static_assert(sizeof(float) * 2 * BK * LDT == kDwSmemBytes, "kDwSmemBytes");
     if (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0) {          // (uniform) first-layer workgroups
         const W1Job& w = grp.w1;
-        colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, (int)blockIdx.x - w.blk0, smem);
+        const int id = (int)blockIdx.x - w.blk0;
+        if (id < w.ncol) colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem);
+        else w1_item_update_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
         return;
     }
     int j = 0;

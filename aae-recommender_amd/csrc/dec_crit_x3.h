@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         const int frz = fr + oz, fkz = fk + oz;
         stamp(0);
         lds_barrier();                          // the previous tile's readers of v3K (GEMM3) are done
+        stamp(14);
         // ---- S0: this tile's V3a -> the three bf16 images; its CSR entries -> tgt; request the next stage
 #pragma unroll
         for (int j = 0; j < NV; ++j) {

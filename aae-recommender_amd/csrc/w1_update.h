@@ -45,8 +45,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
-    extern __shared__ unsigned w1_lds[];
+// vblock / vgrid: this workgroup's index among the workgroups that share the item list (the kernel below, or the first-layer
+// workgroups of the grouped weight-gradient launch, chain.h)
+__device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* w1_lds, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int nw = (a.rows + 31) >> 5;
     unsigned* bm = w1_lds + (size_t)wave * w1_items_wave_words(a.rows);   // [nw]   bit b: row b holds the item
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
     OptScalars s;
     if (upd) s = *a.sc;
     const int c0 = 4 * lane;                               // this lane's columns of a 256-column chunk
-    for (int u = blockIdx.x * nwave + wave; u < cnt; u += gridDim.x * nwave) {
+    for (int u = vblock * nwave + wave; u < cnt; u += vgrid * nwave) {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
@@ -113,13 +114,25 @@ __global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
             const int c = cb + c0;
             const int cc = min(c, a.ld - 4);               // (lanes beyond the row: clamped, never stored)
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = 0; i < n; ++i) {
-                const int r = rl[i];
-                const float x = xl[i] * a.rscale[r];
-                const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
-                                              : a.ga1 + (size_t)r * a.ld;
-                const float4 g = *reinterpret_cast<const float4*>(grow + cc);
-                acc.x += x * g.x; acc.y += x * g.y; acc.z += x * g.z; acc.w += x * g.w;
+            // kU rows at a time: their loads are independent and travel together (a popular item sits in most of the batch's
+            // rows - one dependent L2 round trip per row was the kernel's critical path), the adds stay in row order
+            constexpr int kU = 16;
+            for (int i0 = 0; i0 < n; i0 += kU) {
+                float4 g[kU]; float x[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    const int i = min(i0 + j, n - 1);
+                    const int r = rl[i];
+                    x[j] = (i0 + j < n ? xl[i] : 0.f) * a.rscale[r];  // (beyond the list: the last row again, times zero; the row
+                                                                      //  scale travels with the row itself: one round trip)
+                    const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
+                                                  : a.ga1 + (size_t)r * a.ld;
+                    g[j] = *reinterpret_cast<const float4*>(grow + cc);
+                }
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    acc.x += x[j] * g[j].x; acc.y += x[j] * g[j].y; acc.z += x[j] * g[j].z; acc.w += x[j] * g[j].w;
+                }
             }
             const size_t o = (size_t)item * a.ldw + min(c, a.ldw - 4);
             if (cb > 0 && upd) {
@@ -140,6 +153,11 @@ __global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
         if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
         wave_lds_sync();                                   // the lists are rebuilt for the next item
     }
+}
+
+__global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
+    extern __shared__ unsigned w1_lds_dyn[];
+    w1_item_update_body(a, w1_lds_dyn, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace aae

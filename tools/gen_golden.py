@@ -689,13 +689,16 @@ def gen_e2e_c1_big(ref_aae, n_seeds=16):
                         recipe=np.asarray(json.dumps(dict(kw, n_epochs=120, dropout=[0., 0.]))))
 
 
-def gen_e2e_c3(ref_aae, n_epochs=6, out_name="e2e_c3.npz"):
+def gen_e2e_c3(ref_aae, n_epochs=3, out_name="e2e_c3.npz", gen_lr=0.001):
     """The ranking check at config C3's SHAPE (SURVEY 8d "scale the same recipe for the C3 MRR check"):
     |items| = 100 000, hidden 200, code 50, batch 100 - the benchmark's layer sizes (3 125 item tiles in the output layer,
     13-block layer chains) - on a prototype-structured corpus small enough for the reference to train on the build
     container's CPU in about a minute: 200 prototype sets of 10 items drawn from the 100 000, 2 000 training docs (6-9
-    items of one prototype each), 200 test docs with one item hidden, n_epochs x 20 steps (6 epochs = 120 steps: the horizon up to which a replayed fp32 trajectory stays within 1e-4) at gen_lr 0.01 without dropout
-    (every draw is then the weight initialisation, the epoch permutations and z_real: replayed by rng_mode='reference').
+    items of one prototype each), 200 test docs with one item hidden, n_epochs x 20 steps at the reference's default
+    learning rates without dropout (every draw is then the weight initialisation, the epoch permutations and z_real:
+    replayed by rng_mode='reference').  (gen_lr = 0.01, the C1 recipe's rate, is no use at this width: 200 weights per
+    logit moving by 0.01 per step drive every sigmoid to exactly 0 within the first epoch - the reference's own MRR@10 is
+    0.0 after 1, 2 and 3 epochs - and the recovery out of that saturated state is decided by rounding.)
     The [200, 100 000] prediction matrix stays here (80 MB); the fixture holds what the reference's evaluation makes of it -
     evaluation.remove_non_missing + argtopk (evaluation.py:183-199, 20-58): the 12 best items per test doc with their
     scaled scores, MRR@10 / MAP@10 / P@5 - plus the raw sigmoid outputs at 32 probe items per doc."""
@@ -721,7 +724,7 @@ def gen_e2e_c3(ref_aae, n_epochs=6, out_name="e2e_c3.npz"):
         return sp.coo_matrix((np.ones(len(i0)), (i0, i1)), shape=(len(rows), N)).tocsr()
 
     Xtr, Xin, Yout = csr(train), csr(test_in), csr(test_out)
-    kw = dict(n_hidden=200, n_code=50, batch_size=100, gen_lr=0.01, reg_lr=0.001, dropout=(0., 0.), verbose=False)
+    kw = dict(n_hidden=200, n_code=50, batch_size=100, gen_lr=gen_lr, reg_lr=0.001, dropout=(0., 0.), verbose=False)
     seed = 11
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -1104,7 +1107,8 @@ def main():
         gen_e2e_c3(ref_aae)
     for w in which:             # e2e_c3:<epochs> -> a scratch fixture at another horizon (debugging; not committed)
         if w.startswith("e2e_c3:"):
-            gen_e2e_c3(ref_aae, n_epochs=int(w.split(":")[1]), out_name="tmp_e2e_c3_{}.npz".format(w.split(":")[1]))
+            f = w.split(":")
+            gen_e2e_c3(ref_aae, n_epochs=int(f[1]), out_name="tmp_e2e_c3_{}.npz".format(f[1]), gen_lr=float(f[2]) if len(f) > 2 else 0.01)
 
 
 if __name__ == "__main__":
