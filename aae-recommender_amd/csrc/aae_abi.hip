@@ -1330,7 +1330,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->rng_row0 = 0; m->rng_global = 0;
     m->Gt = m->G.p;
     m->split_ok = false; m->opt_pending = false; m->side = nullptr; m->ev_crit = m->ev_opt = nullptr;
-    m->split_wgs = std::max(1, m->n_cu / 2);
+    // workgroups of the deferred optimiser launch.  r2: half the CUs (it had 50 us of slack then); since the critical launch
+    // runs on the bf16 matrix cores (r3, 116 -> 84 us) the NEXT step waited for this launch - measured at C3, batch 100
+    // (AAE_SPLIT_WGS sweep, ms/step): 112 0.306 | 128 0.291 | 144 0.274 | 160 0.274 | 176 0.284 | 192 0.285 | 224 0.312:
+    // 5/8 of the CUs (beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains)
+    m->split_wgs = std::max(1, (m->n_cu * 5) / 8);
     { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
     m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->ev_head = m->ev_pf = nullptr;
     bool side_ok = false;
