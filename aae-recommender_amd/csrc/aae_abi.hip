@@ -1330,10 +1330,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->rng_row0 = 0; m->rng_global = 0;
     m->Gt = m->G.p;
     m->split_ok = false; m->opt_pending = false; m->side = nullptr; m->ev_crit = m->ev_opt = nullptr;
-    // workgroups of the deferred optimiser launch.  r2: half the CUs (it had 50 us of slack then); since the critical launch
-    // runs on the bf16 matrix cores (r3, 116 -> 84 us) the NEXT step waited for this launch - measured at C3, batch 100
-    // (AAE_SPLIT_WGS sweep, ms/step): 112 0.306 | 128 0.291 | 144 0.274 | 160 0.274 | 176 0.284 | 192 0.285 | 224 0.312:
-    // 5/8 of the CUs (beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains)
+    // workgroups of the deferred optimiser launch.  r2: half the CUs (it had 50 us of slack then).  Since the critical launch
+    // runs on the bf16 matrix cores (r3, 116 -> 84 us) the NEXT step waits for this launch; measured at C3, batch 100
+    // (AAE_SPLIT_WGS sweep, ms/step), with the fp32 deferred kernel: 112 0.306 | 128 0.291 | 144 0.274 | 160 0.274 | 176 0.284
+    // | 192 0.285 | 224 0.312; with the bf16-emulated one (dec_opt_x3_kernel: 160 -> 138 us on 128 workgroups): 112 0.279 |
+    // 128 0.273 | 144 0.276 | 160 0.278 | 176 0.286.  Half the CUs again (set below once x3_ok is known; 5/8 without it):
+    // beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains.
     m->split_wgs = std::max(1, (m->n_cu * 5) / 8);
     { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
     m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->ev_head = m->ev_pf = nullptr;
@@ -1389,6 +1391,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
+        if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) m->split_wgs = std::max(1, m->n_cu / 2);
     }
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);
@@ -1996,6 +1999,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             // nblk > 1 and at most kOBT tiles per workgroup on the chip: the deferred half of every block in ONE launch
             // (dec_opt_blocks_kernel), else one launch per block with the dV3 partial going through Gacc
             static const bool no_obk = getenv("AAE_NO_OPT_BLOCKS") != nullptr;
+            static const bool no_opt_x3 = getenv("AAE_NO_OPT_X3") != nullptr;
             const bool one_opt = nblk > 1 && !m->bf16 && !no_obk && ntiles <= kOBT * m->n_cu &&
                                  dec_opt_blocks_lds_bytes(Bb) <= 160 * 1024;
             if (one_opt) {
@@ -2021,6 +2025,14 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                } else if (r == 0 && nblk == 1 && m->x3_ok && !no_opt_x3) {
+                    // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
+                    const uint32_t lds3 = (uint32_t)dec_opt_x3_lds_bytes();
+                    switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_opt_x3_kernel<13>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    }
                 } else if (r == 0) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 if ((unsigned)r2 < (unsigned)B) tgt[r2 * kXT + a.te.en[e]] = a.te.ev[e];
             }
         }
-        load_span(tile + stride, vreg);         // (beyond the last tile: zeros, never used)
+        load_span(min(tile + stride, ntiles - 1), vreg);
         load_range(tile + 2 * stride, fe0, fe1);
         load_entry(ne0);
         lds_barrier();
@@ -348,6 +348,181 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         for (int w = 0; w < kNW; ++w) s += red[w];
         a.partials[blockIdx.x] = s;
         if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
+    }
+}
+
+}  // namespace aae
+
+namespace aae {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The DEFERRED launch of the split output layer (dec_fused.h MODE kDecOpt: dV3 = G^T dh2 from the stored dL/dlogits tiles,
+// then dec_optim on the tile) with the same 3-term bf16 emulation of its fp32 product.  Since r3 the next step waits for
+// this launch (the critical launch got 30 % shorter), and a third of a tile's time was the fp32 matrix pipe (26 blocks x
+// 28 v_mfma_f32_16x16x4_f32) fed by k-strided 4-byte LDS reads of a 95 KB dh2 image.  Here:
+//   dh2 (k = batch row, column c) lives in REGISTERS, split, as the B fragments of the wave's column block for the whole
+//        kernel (4 k-steps x 3 terms = 48 VGPRs; no LDS image of it);
+//   G   (the tile's stored dL/dlogits, fp32 [B][32]) -> three bf16 images gB[t][b][n]; the A operand G^T[n][k = b] is their
+//        transpose: ds_read_b64_tr_b16;
+//   dV3 tile -> os [32][kSO] (fp32) -> the optimiser exactly as in dec_fused.h (S5), V3a / m / v streamed non-temporally,
+//        V3a kept in registers between its load and its update (no LDS copy).
+// Waves 0..9 own a column block for both item halves, waves 10..15 one (column block, item half) each of blocks 10..12.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kXGS = 20;       // row stride (dwords) of a G image row: 32 bf16 + pad
+
+inline size_t dec_opt_x3_lds_bytes() { return sizeof(float) * ((size_t)3 * 128 * kXGS + (size_t)kTI * kSO + 64); }
+
+template <int NB>
+__global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
+    constexpr int KR = 4;                       // 32-wide k-steps over the (<= 112 -> 128) batch rows
+    static_assert(NB <= 13, "column blocks 10..12 are the ones split over two waves");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* gB = reinterpret_cast<unsigned*>(lds);            // [3][128][kXGS]  G tile, rows = batch rows (>= B: zero)
+    float* os = reinterpret_cast<float*>(gB + 3 * 128 * kXGS);  // [32][kSO]       dV3a tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int B = a.B, ldv = a.ldv, N = a.N;
+    const int ntiles = (N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;
+    const OptScalars sc = *a.sc;
+    const bool do_adam = a.gradV3 == nullptr;
+    typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+
+    for (int i = tid; i < 3 * 128 * kXGS; i += kNT) gB[i] = 0u;
+
+    // ownership: (column block, item halves)
+    int cb, nb_lo, nb_hi;
+    if (wave < 10) { cb = wave; nb_lo = 0; nb_hi = 2; }
+    else { cb = 10 + ((wave - 10) >> 1); nb_lo = (wave - 10) & 1; nb_hi = nb_lo + 1; }
+    const bool live = cb < NB;
+    cb = min(cb, NB - 1);
+    // dh2 -> split B fragments: lane (fr, fk) holds column 16 cb + fr, k = batch rows 32 kc + 8 fk + {0..7}
+    bf16x8 dB[KR][3];
+    {
+        const int c = min(16 * cb + fr, a.ldh - 1);
+#pragma unroll
+        for (int kc = 0; kc < KR; ++kc) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = 32 * kc + 8 * fk + j;
+                x[j] = (b < B && 16 * cb + fr < a.ldh) ? a.dh2[(size_t)b * a.ldh + c] : 0.f;
+            }
+            unsigned p[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
+                dB[kc][t] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+    }
+
+    // the streams: tensor bases in buffer descriptors, tile offset scalar, slot offset in one vector register
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
+    const int g_f4 = B * (kTI / 4);             // float4 per stored tile (<= 1024: B <= 128)
+    const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
+    const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(a.Gt, 0, gbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 2));
+    };
+    auto ldg = [&](int tile) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rGt, tid < g_f4 ? lane_off : 0x80000000u, (unsigned)tile * (unsigned)g_f4 * 16u, 2));
+    };
+    int s_rc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+    }
+    float4 p_cur[NV], p_nxt[NV], mreg[NV], sreg[NV], g_nxt;
+    int tile = blockIdx.x;
+    const int stride = gridDim.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) p_nxt[j] = ld4(rP, tile, j);
+        g_nxt = ldg(tile);
+    }
+    __syncthreads();
+
+    for (; tile < ntiles; tile += stride) {
+        const int i0 = tile * kTI;
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int lz = lane + oz;
+        lds_barrier();                          // the previous tile's readers of gB / os are done
+        // ---- S0: the stored dL/dlogits tile -> split images; rotate the pipeline, request the next stage
+        if (tid < g_f4) {
+            unsigned q0[3], q1[3];
+            split3_pair(g_nxt.x, g_nxt.y, q0[0], q0[1], q0[2]);
+            split3_pair(g_nxt.z, g_nxt.w, q1[0], q1[1], q1[2]);
+            unsigned* d = gB + (tid >> 3) * kXGS + (tid & 7) * 2;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (128 * kXGS)) = make_uint2(q0[t], q1[t]);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) p_cur[j] = p_nxt[j];
+        g_nxt = ldg(min(tile + stride, ntiles - 1));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) p_nxt[j] = ld4(rP, min(tile + stride, ntiles - 1), j);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { mreg[j] = ld4(rM, tile, j); sreg[j] = ld4(rV, tile, j); }
+        lds_barrier();
+
+        // ---- GEMM2: dV3a[n][c] = sum_b G[b][n] dh2[b][c].  A = G^T: the transpose of 2 x (4 rows b x 16 columns n) of a
+        // G image per fragment (ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group names row q, columns 4 p .. 4 p + 3)
+        if (live) {
+            const int tq = (lz >> 2) & 3, tp = lz & 3, g = lz >> 4;
+            for (int nb2 = nb_lo; nb2 < nb_hi; ++nb2) {
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const unsigned* base = gB + (8 * g + tq) * kXGS + 8 * nb2 + 2 * tp;      // (16 nb2 + 4 p) bf16 = 8 nb2 + 2 p dwords
+#pragma unroll
+                for (int kc = 0; kc < KR; ++kc) {
+                    bf16x8 ga[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const unsigned* pb = base + t * (128 * kXGS) + 32 * kc * kXGS;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb));
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 4 * kXGS));
+                        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        ga[t] = __builtin_bit_cast(bf16x8, v);
+                    }
+                    c = mfma_x3(ga, dB[kc], c);
+                }
+                // C map: row = item 16 nb2 + 4 fk + r, column = 16 cb + fr
+#pragma unroll
+                for (int r = 0; r < 4; ++r) os[(16 * nb2 + 4 * fk + r) * kSO + 16 * cb + fr] = c[r];
+            }
+        }
+        lds_barrier();                          // os complete
+
+        // ---- S5: optimiser on the tile (or gradient export), as dec_fused.h: every store issued on every path, a lane
+        // without a cell gets an offset beyond the descriptor
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool valid = tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < N;
+            const float4 g = *reinterpret_cast<const float4*>(os + (s_rc[j] >> 6) * kSO + (s_rc[j] & 63) * 4);
+            const unsigned so = (unsigned)tile * tile_bytes;
+            const unsigned vo = valid ? lane_off + (unsigned)(kNT * 16 * j) : 0x80000000u;
+            float4 p = p_cur[j], mm = mreg[j], vv = sreg[j];
+            adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
+            adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
+            const float4 out = do_adam ? p : g;
+            const unsigned vo2 = (do_adam && !sc.is_sgd) ? vo : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, out), do_adam ? rP : rG, vo, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, 2);
+        }
     }
 }
 
