@@ -138,6 +138,7 @@ struct aae_model {
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
     bool split_any = false;        // AAE_SPLIT_ANY at creation: the split form of the output layer at any size (tests: small fixtures through the critical / deferred kernels)
+    bool x3_gemm = false;          // gemm_f32.h gemm_x3_kernel: the streaming GEMMs (batches beyond the fused output layer, predict) likewise
     bool x3_ok = false;            // dec_crit_x3.h: the critical launch's fp32 products on the bf16 matrix cores (3-term split)
     bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
     bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
@@ -416,9 +417,11 @@ inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n +
 // GEMM wrappers (see gemm_f32.h for operand forms)
 // ------------------------------------------------------------------------------------------
 // Y[rows][out] = epi( X[rows][in+1] * Wa[out][in+1]^T )
-// bf: bf16 matrix-core inputs (cfg.dtype); every forward and dX product of a Linear layer takes them
+// bf: arithmetic of the product (gemm_f32.h: kGemmF32 / kGemmBf16 - cfg.dtype, every forward and dX product of a Linear layer
+// takes it - / kGemmX3: fp32 emulated on the bf16 matrix cores, the vocabulary-wide streaming GEMMs only)
+static inline int gmode(const aae_model* m) { return m->bf16 ? kGemmBf16 : m->x3_gemm ? kGemmX3 : kGemmF32; }
 template <class Epi>
-int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s, bool bf = false) {
+int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi, hipStream_t s, int bf = 0) {
     GemmShape g{X, Wa.p, rows, (int)Wa.rows, (int)Wa.cols, ldx, (int)Wa.ld, r4((int)Wa.cols) + 16};
     g.k_per_split = ((int)Wa.cols + 63) / 64 * 64;
     if (Wa.rows > 4096) (void)launch_gemm_mode<0, 1, true>(bf, g, epi, 1, s);   // vocabulary-wide: streaming regime
@@ -428,7 +431,7 @@ int linear_fwd(const float* X, int ldx, int rows, const Ten& Wa, const Epi& epi,
 }
 // dX[rows][n_in] = epi( Gd[rows][out] * Wa[out][0:n_in] )
 template <class Epi>
-int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s, bool bf = false) {
+int linear_dx(const float* Gd, int ldg, int rows, const Ten& Wa, int n_in, const Epi& epi, hipStream_t s, int bf = 0) {
     GemmShape g{Gd, Wa.p, rows, n_in, (int)Wa.rows, ldg, (int)Wa.ld, 0};
     g.k_per_split = ((int)Wa.rows + 63) / 64 * 64;
     (void)launch_gemm_mode<0, 0, false>(bf, g, epi, 1, s);
@@ -444,7 +447,7 @@ int linear_dw(aae_model* m, const float* Gd, int ldg, int rows, const float* X, 
     const bool big = W.rows > 4096;
     // bf16 mode: of the weight gradients only the decoder output layer's is a bf16 product (the hidden layers' and the
     // sparse first layer's stay fp32: they are launch-latency, not matrix-pipe, bound)
-    const bool bf = m->bf16 && pid == P_V3;
+    const int bf = pid == P_V3 ? gmode(m) : kGemmF32;
     if (m->cfg.grad_mode == AAE_GRAD_EXPORT) {
         EpiStore e; e.out = m->Gr[pid].p; e.ld = (int)W.ld;
         if (big) (void)launch_gemm_mode<1, 0, true>(bf, g, e, 1, s); else (void)launch_gemm_mode<1, 0, false>(bf, g, e, 1, s);
@@ -522,9 +525,9 @@ int encoder_forward(aae_model* m, bool train, const uint8_t* mk1, const uint8_t*
     }
     EpiDropAct e2; e2.out = m->eh2.p; e2.ld = m->ldh; e2.act = m->cfg.activation; e2.d = d2; e2.seed = m->cfg.seed;
     e2.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->eh1.p, m->ldh, B, m->P[P_W2], e2, s, m->bf16));
+    TRY(linear_fwd(m->eh1.p, m->ldh, B, m->P[P_W2], e2, s, gmode(m)));
     EpiStore e3; e3.out = z_dst; e3.ld = ldz_dst;
-    TRY(linear_fwd(m->eh2.p, m->ldh, B, m->P[P_W3], e3, s, m->bf16));
+    TRY(linear_fwd(m->eh2.p, m->ldh, B, m->P[P_W3], e3, s, gmode(m)));
     if (m->cfg.enc_final != AAE_FINAL_LINEAR) {
         hipLaunchKernelGGL(final_act_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, z_dst, B, m->c, ldz_dst,
                            m->cfg.enc_final, (float*)nullptr, 0);
@@ -554,12 +557,12 @@ int encoder_backward(aae_model* m, const float* gz, int ldgz, const float* z, in
     // lin3: dX first (needs the old weights), then dW + update
     EpiActBwd b2; b2.out = m->gb0.p; b2.ld = m->ldh; b2.y = m->eh2.p; b2.ldy = m->ldh; b2.act = m->cfg.activation;
     b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
-    TRY(linear_dx(ga3, ldga3, B, m->P[P_W3], h, b2, s, m->bf16));
+    TRY(linear_dx(ga3, ldga3, B, m->P[P_W3], h, b2, s, gmode(m)));
     TRY(linear_dw(m, ga3, ldga3, B, m->eh2.p, m->ldh, P_W3, which, s));
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->eh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
-    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s, m->bf16));
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_W2], h, b1, s, gmode(m)));
     TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->eh1.p, m->ldh, P_W2, which, s));
     // lin1: bias column sum + its optimiser, then the row-sparse weight gradient + optimiser (w1_update.h)
     const int set = (which == O_GEN) ? 1 : 0;
@@ -579,9 +582,9 @@ int disc_forward(aae_model* m, int rows, const uint8_t* m1a, const uint8_t* m1b,
     DropSpec d2 = make_drop(m, 1, true, m2a, m2b, split, h, sid2);
     EpiDropAct e1; e1.out = m->xh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
     e1.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->zin.p, m->ldz, rows, m->P[P_D1], e1, s, m->bf16));
+    TRY(linear_fwd(m->zin.p, m->ldz, rows, m->P[P_D1], e1, s, gmode(m)));
     EpiDropAct e2 = e1; e2.out = m->xh2.p; e2.d = d2;
-    TRY(linear_fwd(m->xh1.p, m->ldh, rows, m->P[P_D2], e2, s, m->bf16));
+    TRY(linear_fwd(m->xh1.p, m->ldh, rows, m->P[P_D2], e2, s, gmode(m)));
     EpiSigmoid e3; e3.out = m->dout.p; e3.ld = 4;
     TRY(linear_fwd(m->xh2.p, m->ldh, rows, m->P[P_D3], e3, s));
     return AAE_OK;
@@ -602,9 +605,9 @@ int decoder_hidden_forward(aae_model* m, bool train, const uint8_t* mk1, const u
     DropSpec d2 = make_drop(m, 1, train, mk2, nullptr, rows, m->h, 3);
     EpiDropAct e1; e1.out = m->dh1.p; e1.ld = m->ldh; e1.act = m->cfg.activation; e1.d = d1; e1.seed = m->cfg.seed;
     e1.step_ctr = m->step_ctr;
-    TRY(linear_fwd(m->zc.p, m->ldc, rows, m->P[P_V1], e1, s, m->bf16));
+    TRY(linear_fwd(m->zc.p, m->ldc, rows, m->P[P_V1], e1, s, gmode(m)));
     EpiDropAct e2 = e1; e2.out = m->dh2.p; e2.d = d2;
-    TRY(linear_fwd(m->dh1.p, m->ldh, rows, m->P[P_V2], e2, s, m->bf16));
+    TRY(linear_fwd(m->dh1.p, m->ldh, rows, m->P[P_V2], e2, s, gmode(m)));
     return AAE_OK;
 }
 
@@ -1281,6 +1284,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->blocked_ok = cfg->blocked_output == 1;
     m->blocked_any = getenv("AAE_BLOCKED_ANY") != nullptr;
     m->split_any = getenv("AAE_SPLIT_ANY") != nullptr;
+    m->x3_gemm = !m->bf16 && getenv("AAE_NO_GEMM_X3") == nullptr;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->model_kind == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
@@ -1837,7 +1841,7 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
         splits = (N + kps - 1) / kps;
         GemmShape g{m->Xn.p, m->P[P_W1T].p, B, h, N, m->ldn, m->ldw1, kps};
         EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
-        (void)launch_gemm_mode<0, 0, true>(false, g, e, splits, s);
+        (void)launch_gemm_mode<0, 0, true>(gmode(m), g, e, splits, s);
         LAUNCHCHK("dense first layer");
         DropSpec d1 = make_drop(m, 0, true, m->inj.masks_dev[0], nullptr, B, h, 0);
         hipLaunchKernelGGL(slab_reduce_fwd_kernel, dim3(grid1d((size_t)B * h)), dim3(256), 0, s, m->slabs.p, splits,
@@ -2129,7 +2133,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         EpiBce e; e.G = m->G.p; e.ldg = m->ldn; e.gscale = gscale; e.partials = m->bce_partials;
         {
             ProfScope ps(m, AAE_K_DEC_BCE_FWD, s);
-            TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s, m->bf16));
+            TRY(linear_fwd(m->dh2.p, m->ldh, B, m->P[P_V3], e, s, gmode(m)));
         }
         hipLaunchKernelGGL(bce_fixup_kernel, dim3(B, m->chunks), dim3(256), 0, s, m->bv, m->dh2.p, m->ldh, m->P[P_V3].p, m->ldh,
                            h + 1, m->G.p, m->ldn, gscale, m->fix_partials);
@@ -2147,7 +2151,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         EpiSlab e; e.out = m->slabs.p; e.ld = m->ldh; e.slab_stride = (size_t)m->R * m->ldh;
         {
             ProfScope ps(m, AAE_K_DEC_DA2, s);
-            (void)launch_gemm_mode<0, 0, true>(m->bf16, g, e, splits, s);
+            (void)launch_gemm_mode<0, 0, true>(gmode(m), g, e, splits, s);
         }
         LAUNCHCHK("dA2 gemm");
         if (m->only_output_layer) {
@@ -2223,11 +2227,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // lin2
     EpiActBwd b1; b1.out = m->gb1.p; b1.ld = m->ldh; b1.y = m->dh1.p; b1.ldy = m->ldh; b1.act = m->cfg.activation;
     b1.d = d1; b1.seed = m->cfg.seed; b1.step_ctr = m->step_ctr;
-    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_V2], h, b1, s, m->bf16));
+    TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_V2], h, b1, s, gmode(m)));
     TRY(linear_dw(m, m->gb0.p, m->ldh, B, m->dh1.p, m->ldh, P_V2, O_DEC, s));
     // lin1
     EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
-    TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_V1], cp, ez, s, m->bf16));
+    TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_V1], cp, ez, s, gmode(m)));
     TRY(linear_dw(m, m->gb1.p, m->ldh, B, m->zc.p, m->ldc, P_V1, O_DEC, s));
     if (dzc_out) {
         hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d((size_t)B * cp)), dim3(256), 0, s, m->gzc.p, m->ldc, dzc_out, cp,
@@ -2302,7 +2306,7 @@ int aae_vae_predict(aae_handle m, const aae_batch* batch, const float* cond_dev,
     TRY(gather_first_layer(m, false, nullptr, 0, s));
     TRY(chain_vae_forward(m, cond_dev, eps_dev, m->rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
-    TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s, m->bf16));
+    TRY(linear_fwd(m->dh2.p, m->ldh, m->rows, m->P[P_V3], e, s, gmode(m)));
     m->phase = 0;
     return AAE_OK;
 }
@@ -2596,7 +2600,7 @@ int aae_disc_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
         TRY(linear_dx(m->ga3.p, 4, 2 * B, m->P[P_D3], h, b2, s));
         TRY(linear_dw(m, m->ga3.p, 4, 2 * B, m->xh2.p, m->ldh, P_D3, O_DISC, s));
         EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
-        TRY(linear_dx(m->gb0.p, m->ldh, 2 * B, m->P[P_D2], h, b1, s, m->bf16));
+        TRY(linear_dx(m->gb0.p, m->ldh, 2 * B, m->P[P_D2], h, b1, s, gmode(m)));
         TRY(linear_dw(m, m->gb0.p, m->ldh, 2 * B, m->xh1.p, m->ldh, P_D2, O_DISC, s));
         TRY(linear_dw(m, m->gb1.p, m->ldh, 2 * B, m->zin.p, m->ldz, P_D1, O_DISC, s));
     }
@@ -2632,9 +2636,9 @@ int aae_gen_step(aae_handle m, const aae_rng_inject* inj, void* stream) {
         b2.d = d2; b2.seed = m->cfg.seed; b2.step_ctr = m->step_ctr;
         TRY(linear_dx(m->ga3.p, 4, B, m->P[P_D3], h, b2, s));
         EpiActBwd b1 = b2; b1.out = m->gb1.p; b1.y = m->xh1.p; b1.d = d1;
-        TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_D2], h, b1, s, m->bf16));
+        TRY(linear_dx(m->gb0.p, m->ldh, B, m->P[P_D2], h, b1, s, gmode(m)));
         EpiStore ez; ez.out = m->gzc.p; ez.ld = m->ldc;
-        TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_D1], cc, ez, s, m->bf16));
+        TRY(linear_dx(m->gb1.p, m->ldh, B, m->P[P_D1], cc, ez, s, gmode(m)));
     }
     TRY(encoder_backward(m, m->gzc.p, m->ldc, m->zsave.p, m->ldz, I.masks_dev[8], I.masks_dev[9], 8, 9, O_GEN, s));
     m->phase = 0;
@@ -2715,7 +2719,7 @@ int aae_decode(aae_handle m, const float* zc_dev, int64_t zc_ld, int32_t n_rows,
     else if (m->use_chain) TRY(chain_dec_hidden(m, false, n_rows, s));
     else TRY(decoder_hidden_forward(m, false, nullptr, nullptr, n_rows, s));
     EpiSigmoid e; e.out = out_dev; e.ld = (int)out_ld;
-    TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s, m->bf16));
+    TRY(linear_fwd(m->dh2.p, m->ldh, n_rows, m->P[P_V3], e, s, gmode(m)));
     return AAE_OK;
 }
 

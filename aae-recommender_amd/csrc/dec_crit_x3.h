@@ -32,24 +32,9 @@ namespace aae {
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-// (a, b) -> three packed bf16 pairs with a = a1 + a2 + a3, b = b1 + b2 + b3 exactly (low half = a)
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = bf16_pack(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
-    p2 = bf16_pack(ra, rb);
-    p3 = bf16_pack(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xFFFF0000u));
-}
-
-// the six leading cross terms of (a1 + a2 + a3) (b1 + b2 + b3), smallest first
-__device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
-    return c;
-}
+// the 3-term split of a pair of fp32 values and the six-term product: gemm_f32.h (x3_split_pair, x3_mfma)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) { x3_split_pair(a, b, p1, p2, p3); }
+__device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) { return x3_mfma(a, b, c); }
 
 // Row stride (dwords) of a k-contiguous bf16 image with kc 32-wide k-steps, read with ONE ds_read_b128 per fragment (8
 // consecutive k per lane): 16 kc + 8 = a stride of 32 bytes mod 64.  ds_read_b128 is serviced in four groups of 16 lanes

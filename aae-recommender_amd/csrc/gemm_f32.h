@@ -364,6 +364,182 @@ struct EpiAdam : EpiNoState {
     }
 };
 
+// -----------------------------------------------------------------------------------------------------------------
+// The streaming GEMMs with their fp32 products EMULATED on the bf16 matrix cores (r3; the idea and its error analysis:
+// dec_crit_x3.h).  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, so every operand element is split ONCE, on its way
+// from the staging registers into LDS, into three bf16 terms x = x1 + x2 + x3 (exact), the LDS images hold the terms, and
+// a 16x16x32 product is the six leading cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 2.7x the fp32
+// matrix rate at fp32-level error, dtype stays f32.  Same tiling (64x64 per 256-thread workgroup, 2x2 waves x 2x2 blocks),
+// same split-K, same epilogues as gemm_f32_kernel; slabs are 32 deep.
+//   k-contiguous operand (AT = 0 / BT = 1): image [row][32 k] per term, a fragment = one 16-byte read (8 consecutive k);
+//   m/n-contiguous operand (AT = 1 / BT = 0): image [32 k][64 rows] per term as it arrives (no 2-byte scatter), a
+//       fragment = the TRANSPOSE of 2 x (4 k x 16 rows): ds_read_b64_tr_b16.
+// -----------------------------------------------------------------------------------------------------------------
+typedef short gemm_s16x4 __attribute__((ext_vector_type(4)));
+typedef short gemm_s16x8 __attribute__((ext_vector_type(8)));
+// (a, b) -> three packed bf16 pairs with a = a1 + a2 + a3, b = b1 + b2 + b3 exactly (low half = a)
+__device__ __forceinline__ void x3_split_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = gemm_pack_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = gemm_pack_bf16(ra, rb);
+    p3 = gemm_pack_bf16(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xFFFF0000u));
+}
+// the six leading cross terms of (a1 + a2 + a3) (b1 + b2 + b3), smallest first
+__device__ __forceinline__ f32x4 x3_mfma(const gemm_bf16x8 (&a)[3], const gemm_bf16x8 (&b)[3], f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+
+template <int AT, int BT, class Epi>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmShape g, Epi epi) {
+    constexpr int TS = 64, BK = 32;
+    constexpr int SK = 24;                          // dwords per row of a [row][32 k] image: 64 bytes + 32 (a stride of 32 mod 64
+                                                    // bytes keeps the 16-byte fragment reads conflict-free, dec_crit_x3.h)
+    constexpr int SM = 36;                          // dwords per row of a [k][64 rows] image: 128 bytes + 16
+    constexpr int IA = AT == 0 ? TS * SK : BK * SM, IB = BT == 1 ? TS * SK : BK * SM;      // dwords per term image
+    constexpr int LDC = TS + 4;
+    constexpr int NV = TS * BK / 1024;              // float4 per thread and operand per slab (2)
+    constexpr int kSmem = (3 * (IA + IB) > TS * LDC) ? 3 * (IA + IB) : TS * LDC;
+    __shared__ __attribute__((aligned(16))) unsigned smem[kSmem];
+    unsigned* As = smem;
+    unsigned* Bs = smem + 3 * IA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (TS / 2), wn = (wave & 1) * (TS / 2);
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[NV], rb[NV];
+    // (as gemm_f32_kernel: every load unconditional from a clamped address, masked when written to LDS one slab later)
+    auto load_kc = [&](const float* P, int ld, int r0, int rmax, int k0, float4* r) {
+        const int kmax4 = ((kend + 3) & ~3) - 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            const int row = min(r0 + f / (BK / 4), rmax - 1), k = min(k0 + (f % (BK / 4)) * 4, kmax4);
+            r[j] = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+        }
+    };
+    auto load_mc = [&](const float* P, int ld, int c0, int cmax, int k0, float4* r) {
+        const int cmax4 = ((cmax + 3) & ~3) - 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            const int k = min(k0 + f / (TS / 4), kend - 1), cidx = min(c0 + (f % (TS / 4)) * 4, cmax4);
+            r[j] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + cidx);
+        }
+    };
+    auto put3 = [&](unsigned* T, int I, int off, float4 v) {       // 4 consecutive elements -> 8 bytes of each term image
+        unsigned q0[3], q1[3];
+        x3_split_pair(v.x, v.y, q0[0], q0[1], q0[2]);
+        x3_split_pair(v.z, v.w, q1[0], q1[1], q1[2]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(T + t * I + off) = make_uint2(q0[t], q1[t]);
+    };
+    auto store_kc = [&](unsigned* T, int I, const float4* r, int r0, int rmax, int k0) {      // image [row][k]
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+            const bool ok = r0 + row < rmax;
+            const int k = k0 + kq;
+            float4 v;
+            v.x = (ok && k < kend) ? r[j].x : 0.f; v.y = (ok && k + 1 < kend) ? r[j].y : 0.f;
+            v.z = (ok && k + 2 < kend) ? r[j].z : 0.f; v.w = (ok && k + 3 < kend) ? r[j].w : 0.f;
+            put3(T, I, row * SK + (kq >> 1), v);
+        }
+    };
+    auto store_mc = [&](unsigned* T, int I, const float4* r, int c0, int cmax, int k0) {      // image [k][row]
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = tid + 256 * j;
+            const int kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
+            const bool ok = k0 + kr < kend;
+            const int cidx = c0 + cq;
+            float4 v;
+            v.x = (ok && cidx < cmax) ? r[j].x : 0.f; v.y = (ok && cidx + 1 < cmax) ? r[j].y : 0.f;
+            v.z = (ok && cidx + 2 < cmax) ? r[j].z : 0.f; v.w = (ok && cidx + 3 < cmax) ? r[j].w : 0.f;
+            put3(T, I, kr * SM + (cq >> 1), v);
+        }
+    };
+    auto load_tiles = [&](int k0) {
+        if (AT == 0) load_kc(g.A, g.lda, m0, g.M, k0, ra); else load_mc(g.A, g.lda, m0, g.M, k0, ra);
+        if (BT == 1) load_kc(g.B, g.ldb, n0, g.N, k0, rb); else load_mc(g.B, g.ldb, n0, g.N, k0, rb);
+    };
+    // fragment of tile rows [r0, r0 + 16): lane (fr, fk) <- row r0 + fr, k = 8 fk + {0..7}
+    const int fr = lane & 15, fk = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    auto frag_kc = [&](const unsigned* T, int r0) {
+        return __builtin_bit_cast(gemm_bf16x8, *reinterpret_cast<const gemm_u32x4*>(T + (r0 + fr) * SK + 4 * fk));
+    };
+    auto frag_mc = [&](const unsigned* T, int r0) {
+        const unsigned* pb = T + (8 * fk + tq) * SM + (r0 >> 1) + 2 * tp;
+        const gemm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gemm_s16x4 __attribute__((address_space(3)))*)(pb));
+        const gemm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gemm_s16x4 __attribute__((address_space(3)))*)(pb + 4 * SM));
+        const gemm_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(gemm_bf16x8, v);
+    };
+
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            if (AT == 0) store_kc(As, IA, ra, m0, g.M, k0); else store_mc(As, IA, ra, m0, g.M, k0);
+            if (BT == 1) store_kc(Bs, IB, rb, n0, g.N, k0); else store_mc(Bs, IB, rb, n0, g.N, k0);
+            __syncthreads();
+            if (k0 + BK < kend) load_tiles(k0 + BK);
+            gemm_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    a[i][t] = AT == 0 ? frag_kc(As + t * IA, wm + 16 * i) : frag_mc(As + t * IA, wm + 16 * i);
+                    b[i][t] = BT == 1 ? frag_kc(Bs + t * IB, wn + 16 * i) : frag_mc(Bs + t * IB, wn + 16 * i);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = x3_mfma(a[i], b[j], acc[i][j]);
+            __syncthreads();
+        }
+    }
+
+    // accumulators -> LDS image -> epilogue, exactly as gemm_f32_kernel
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm + i * 16 + (lane >> 4) * 4 + r) * LDC + wn + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    typename Epi::State st;
+    epi.begin(st);
+    constexpr int RPP = 1024 / TS;
+#pragma unroll
+    for (int p = 0; p < TS / RPP; ++p) {
+        int row = p * RPP + tid / (TS / 4), col = (tid % (TS / 4)) * 4;
+        int gm = m0 + row, gn = n0 + col;
+        if (gm < g.M && gn < g.N) {
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
+            epi.apply(st, gm, gn, g.N, v, (int)blockIdx.z);
+        }
+    }
+    __syncthreads();
+    epi.finish(st, reinterpret_cast<float*>(smem), (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+}
+
 template <int AT, int BT, int BK, int TS, class Epi, bool BF = false>
 inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
     dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS, splits);
@@ -371,8 +547,17 @@ inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hi
     return hipGetLastError();
 }
 // the streaming (vocabulary-wide) / small-layer variants in either arithmetic: bf16 = true takes 32-deep slabs
+// mode: 0 = fp32 matrix pipe, 1 = bf16 inputs (config C2), 2 = fp32 emulated on the bf16 matrix cores (gemm_x3_kernel; the
+// streaming GEMMs only - the small layers are latency-, not matrix-pipe-, bound)
+enum { kGemmF32 = 0, kGemmBf16 = 1, kGemmX3 = 2 };
 template <int AT, int BT, bool BIG, class Epi>
-inline hipError_t launch_gemm_mode(bool bf16, const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
+inline hipError_t launch_gemm_mode(int mode, const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
+    const bool bf16 = mode == kGemmBf16;
+    if (BIG && mode == kGemmX3) {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
+        hipLaunchKernelGGL((gemm_x3_kernel<AT, BT, Epi>), grid, dim3(256), 0, s, g, epi);
+        return hipGetLastError();
+    }
     if (BIG) return bf16 ? launch_gemm<AT, BT, 32, 64, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 16, 64, Epi>(g, epi, splits, s);
     return bf16 ? launch_gemm<AT, BT, 64, 32, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 64, 32, Epi>(g, epi, splits, s);
 }
