@@ -71,6 +71,16 @@ class AaeRngInject(C.Structure):
     _fields_ = [("masks_dev", C.c_void_p * 12), ("z_real_dev", C.c_void_p)]
 
 
+_COLL_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+_COLL_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class AaeCollectives(C.Structure):
+    """aae_collectives (include/aaerec_hip.h): the collectives aae_dp_step calls at its exchange points."""
+    _fields_ = [("ctx", C.c_void_p), ("all_gather", _COLL_AG), ("reduce_scatter", _COLL_AG), ("all_reduce", _COLL_AR),
+                ("world", C.c_int32), ("rank", C.c_int32)]
+
+
 class AaeTensor(C.Structure):
     _fields_ = [("byte_offset", C.c_size_t), ("rows", C.c_int64), ("cols", C.c_int64), ("ld", C.c_int64)]
 
@@ -139,6 +149,13 @@ _PROTOS = {
     "aae_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "aae_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aae_join_output_layer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aae_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "aae_rccl_init": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(AaeCollectives)]),
+    "aae_rccl_destroy": (C.c_int, [C.POINTER(AaeCollectives)]),
+    "aae_dp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AaeCollectives), C.POINTER(AaeBatch), C.POINTER(AaeBatch),
+                              C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_memcpy_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aae_echo_collectives": (C.c_int, [C.c_int32, C.POINTER(AaeCollectives)]),
     "aae_set_input_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -733,6 +750,29 @@ class HipAAE:
         with self._on_device():
             _check(self.lib.aae_apply_gathered(self.handle, int(which_a), int(which_b), _ptr(packets), int(peer_stride),
                                                int(n_peers), int(span_offset), self._stream()))
+
+    def dp_step(self, slice_model, coll, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None,
+                next_global=None, cond=None, masks=None, z_real=None):
+        """One data-parallel partial_fit as ONE library call (aae_dp_step): this replica's documents + the global batch in
+        the slice model's corpus; every kernel and every collective of the step is enqueued by the library on this
+        handle's stream.  coll: an AaeCollectives table (parallel.rccl_collectives / parallel.python_collectives).
+        next_global = (row_start, rows) of the NEXT global batch in slice_csr: named ahead to the slice model."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        g = slice_model._batch(slice_csr, g_row_start, global_rows, g_rows)
+        nxt = None
+        if next_global is not None:
+            nxt = slice_model._batch(slice_csr, next_global[0], global_rows, next_global[1])
+            slice_model._pf_keep = (slice_csr, next_global[1])
+        inj = self._inject(masks, z_real)
+        slice_model._keep = []
+        if cond is not None:
+            cond = upload(cond, self.device, torch.float32).contiguous()
+            self._keep.append(cond)
+        self._keep.append((g_rows, rows))
+        with self._on_device():
+            _check(self.lib.aae_dp_step(self.handle, slice_model.handle, C.byref(coll), C.byref(b), C.byref(g),
+                                        C.byref(nxt) if nxt is not None else None, _ptr(cond),
+                                        C.byref(inj) if inj else None, self._stream()))
 
     def a1_rows(self, n_rows):
         """[n_rows, ld] view of the first layer's pre-activations."""

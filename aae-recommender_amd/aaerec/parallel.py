@@ -323,6 +323,34 @@ class VocabParallelAAE(DataParallelAAE):
         self._view_cache = {}
         if self.shard_first:
             model.set_first_layer_external(True)
+        # the step as one library call (aae_dp_step) when both models are library handles: RCCL collectives on a
+        # communicator the library creates (backend nccl), or - any other torch.distributed-like object: the host-staged
+        # gloo wrapper of the one-GPU tests, single-process stand-ins - Python callbacks.  AAE_DP_PYTHON=1 keeps the
+        # phase-by-phase Python driver (_step_both_sharded), which is also what CPU stand-in models run.
+        self._native = self._native_keep = None
+        import os
+        if self.shard_first and hasattr(model, "dp_step") and hasattr(slice_model, "handle") and os.environ.get("AAE_DP_PYTHON") is None:
+            if str(dist.get_backend(group)).lower() == "nccl":
+                self._native = rccl_collectives(model, dist, group)
+            elif str(dist.get_backend(group)).lower() == "echo":     # (tools/vocab_rank_time.py: device-side stand-ins)
+                import ctypes as C
+                from . import _hip
+                self._native = _hip.AaeCollectives()
+                _hip._check(model.lib.aae_echo_collectives(self.world, C.byref(self._native)))
+            else:
+                self._native, self._native_keep = python_collectives(model, dist, group)
+
+    def _native_stats(self, n_rows, global_rows):
+        """(collectives, payload bytes this rank contributes) of one native step: the seven exchanges of DESIGN.md 5.0"""
+        m = self.model
+        ld = m.ga1_rows(1).stride(0)
+        blk = n_rows * ld * 4
+        pk_ae = m.ga1_packet(n_rows, True)[0].numel() * 4
+        pk_gen = m.ga1_packet(n_rows, False)[0].numel() * 4
+        disc = sum(t.numel() for t in m.grad_buckets(O_DISC)) * 4
+        if getattr(m, "ae_only", False):
+            return (4, 2 * global_rows * ld * 4 + blk + pk_ae)
+        return (7, 3 * global_rows * ld * 4 + blk + pk_ae + pk_gen + disc)
 
     def step(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None, cond=None,
              masks=None, z_real=None):
@@ -334,6 +362,13 @@ class VocabParallelAAE(DataParallelAAE):
         self._coll = [0, 0]
         m.set_grad_scale(n_rows / float(global_rows))
         self._set_rng_rows(n_rows, global_rows)
+        if self.shard_first and self._native is not None:
+            # the whole step - kernels and collectives - enqueued by ONE library call (aae_dp_step, csrc/dp_step.h)
+            m.dp_step(sl, self._native, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=rows, g_rows=g_rows,
+                      cond=cond, masks=masks, z_real=z_real)
+            self._gathered = False
+            self._coll_last = self._native_stats(n_rows, global_rows)
+            return None
         if self.shard_first:
             return self._step_both_sharded(csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows, g_rows, cond,
                                            masks, z_real)
@@ -542,6 +577,84 @@ class VocabParallelAAE(DataParallelAAE):
         buf = part.to(self.model.device) if nccl else part
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
         return float(buf.item())
+
+
+def rccl_collectives(model, dist, group=None):
+    """An aae_collectives table (include/aaerec_hip.h) over an RCCL communicator the LIBRARY creates: rank 0 draws the
+    ncclUniqueId (aae_rccl_unique_id), torch.distributed carries its 128 bytes to the other ranks, every rank joins
+    (aae_rccl_init).  The communicator lives as long as the returned object."""
+    import ctypes as C
+    import torch
+    from . import _hip
+    lib = model.lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _hip._check(lib.aae_rccl_unique_id(buf))
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(model.device)
+    if world > 1:
+        dist.broadcast(t, src=0, group=group)
+    ident = bytes(t.cpu().numpy().tobytes())
+    tab = _hip.AaeCollectives()
+    with model._on_device():
+        _hip._check(lib.aae_rccl_init(C.create_string_buffer(ident, 128), world, rank, C.byref(tab)))
+    return tab
+
+
+def python_collectives(model, dist, group=None):
+    """The same table over any object with torch.distributed's collective interface (HostStagedCollectives, the
+    single-process stand-ins of the tools): the library calls back at the step's exchange points; operands are staged
+    through host memory (aae_memcpy_sync).  Functional, not fast - the production table is rccl_collectives.
+    Returns (table, keep-alive): the callbacks must outlive the table's users."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from . import _hip
+    lib = model.lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    raw = getattr(dist, "d", dist)                 # (HostStagedCollectives wraps the gloo module: CPU tensors go to it directly)
+
+    def fetch(ptr, count, stream):
+        host = np.empty(int(count), dtype=np.float32)
+        _hip._check(lib.aae_memcpy_sync(host.ctypes.data, ptr, host.nbytes, stream))
+        return torch.from_numpy(host)
+
+    def put(ptr, t, stream):
+        host = np.ascontiguousarray(t.numpy(), dtype=np.float32)
+        _hip._check(lib.aae_memcpy_sync(ptr, host.ctypes.data, host.nbytes, stream))
+
+    def guarded(fn):
+        def wrapped(*a):
+            try:
+                fn(*a)
+                return 0
+            except Exception as e:                 # (an exception must not unwind through the C frames)
+                import traceback
+                traceback.print_exc()
+                return -3
+        return wrapped
+
+    def all_gather(ctx, send, recv, count, stream):
+        x = fetch(send, count, stream)
+        out = torch.empty(world * int(count), dtype=torch.float32)
+        raw.all_gather_into_tensor(out, x)
+        put(recv, out, stream)
+
+    def reduce_scatter(ctx, send, recv, count, stream):
+        x = fetch(send, world * int(count), stream)
+        raw.all_reduce(x)
+        put(recv, x[rank * int(count):(rank + 1) * int(count)], stream)
+
+    def all_reduce(ctx, buf, count, stream):
+        x = fetch(buf, count, stream)
+        raw.all_reduce(x)
+        put(buf, x, stream)
+
+    cbs = (_hip._COLL_AG(guarded(all_gather)), _hip._COLL_AG(guarded(reduce_scatter)), _hip._COLL_AR(guarded(all_reduce)))
+    tab = _hip.AaeCollectives()
+    tab.ctx, tab.all_gather, tab.reduce_scatter, tab.all_reduce = None, cbs[0], cbs[1], cbs[2]
+    tab.world, tab.rank = world, rank
+    return tab, cbs
 
 
 class HostStagedCollectives:

@@ -138,6 +138,7 @@ struct aae_model {
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
     bool split_any = false;        // AAE_SPLIT_ANY at creation: the split form of the output layer at any size (tests: small fixtures through the critical / deferred kernels)
+    float* dp_scratch = nullptr; size_t dp_scratch_floats = 0;   // aae_dp_step: the ranks' gathered packets (hipMalloc, owned by the handle)
     bool x3_gemm = false;          // gemm_f32.h gemm_x3_kernel: the streaming GEMMs (batches beyond the fused output layer, predict) likewise
     bool x3_ok = false;            // dec_crit_x3.h: the critical launch's fp32 products on the bf16 matrix cores (3-term split)
     bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
@@ -748,16 +749,16 @@ struct DwBuilder {
         w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
         w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
         w.ncol = (m->h + 63) / 64;
-        // the row-sparse weight gradient + optimiser of the layer rides along while its per-wave row lists fit the kernel's
-        // static LDS (batches up to ~750 rows); not for the dense noisy input (a dense product follows) or an external
+        // the row-sparse weight gradient + optimiser of the layer rides along while its row lists fit the kernel's static LDS
+        // (batches up to ~2 500 rows); not for the dense noisy input (a dense product follows) or an external
         // first layer (the rows live with their item slices)
         static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
         w.nitem = 0;
         m->w1_items_merged = false;
-        if (!no_merge && !m->dense_step && !m->ext_first && 4 * sizeof(int) * w1_items_wave_words(m->rows) <= kDwSmemBytes) {
+        if (!no_merge && !m->dense_step && !m->ext_first && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
             TRY(ensure_buckets(m, s));
             w.items = w1_items_args(m, ga1, 0, 0, which);
-            w.nitem = (std::min(m->cfg.max_nnz, std::max(256, m->rows * 32)) + 3) / 4;
+            w.nitem = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
             m->w1_items_merged = true;
         }
         return AAE_OK;
@@ -858,13 +859,12 @@ W1Items w1_items_args(aae_model* m, const float* ga1, int rpb, size_t bstride, i
 int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s) {
     TRY(ensure_buckets(m, s));
     const W1Items a = w1_items_args(m, ga1, rpb, bstride, which);
-    // one wavefront per item; 4 waves per workgroup while their row lists fit 64 KB of LDS, else 1
-    const size_t wave_bytes = sizeof(int) * w1_items_wave_words(m->rows);
-    const int nwave = 4 * wave_bytes <= 64 * 1024 ? 4 : 1;
-    if ((size_t)nwave * wave_bytes > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
+    // one 256-thread workgroup per item
+    const size_t lds = sizeof(int) * w1_items_lds_words(m->rows);
+    if (lds > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
     ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
     const int items = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
-    hipLaunchKernelGGL(w1_item_update_kernel, dim3((items + nwave - 1) / nwave), dim3(64 * nwave), nwave * wave_bytes, s, a);
+    hipLaunchKernelGGL(w1_item_update_kernel, dim3(items), dim3(256), lds, s, a);
     LAUNCHCHK("w1_item_update");
     return AAE_OK;
 }
@@ -1328,7 +1328,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         }
     }
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(sizeof(int) * w1_items_wave_words(16384))) == hipSuccess;
+                                        (int)(sizeof(int) * w1_items_lds_words(16384))) == hipSuccess;
     (void)hipGetLastError();
     m->grad_scale = 1.f;
     m->rng_row0 = 0; m->rng_global = 0;
@@ -1425,6 +1425,7 @@ int aae_destroy(aae_handle h) {
         (void)hipStreamSynchronize(h->side);     // the arena is the caller's: nothing of ours may still write it
         (void)hipStreamDestroy(h->side);
     }
+    if (h->dp_scratch) (void)hipFree(h->dp_scratch);
     if (h->ev_crit) (void)hipEventDestroy(h->ev_crit);
     if (h->ev_opt) (void)hipEventDestroy(h->ev_opt);
     if (h->ev_head) (void)hipEventDestroy(h->ev_head);
@@ -2960,3 +2961,5 @@ int aae_apply_gathered(aae_handle m, int which_a, int which_b, const float* pack
 }
 
 }  // extern "C"
+
+#include "dp_step.h"

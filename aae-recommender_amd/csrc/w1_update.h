@@ -5,17 +5,19 @@
 //
 //   gW1T[item, :] = sum over the batch rows b that hold the item, IN ASCENDING ROW ORDER, of (v_be * s_b) * ga1[b, :]
 //
-// One WAVEFRONT per distinct item (grid-stride over the step's unique-item list; no workgroup barrier anywhere).  The
-// batch's entries come bucketed by 32-item tile (buckets.h - the counting sort the fused output layer needs anyway, built
-// off the critical path); the order INSIDE a bucket is whatever the sort's LDS atomics produced, so the wave first marks
-// its item's rows in an LDS bitmap, ranks them by prefix popcount and only then walks them: the summation order is a
-// function of the batch alone and two runs of a training loop agree bit for bit.  (r1/r2 scattered the products with
+// One WORKGROUP (4 waves) per distinct item (grid-stride over the step's unique-item list).  The batch's entries come
+// bucketed by 32-item tile (buckets.h - the counting sort the fused output layer needs anyway, built off the critical
+// path); the order INSIDE a bucket is whatever the sort's LDS atomics produced, so the workgroup first marks its item's
+// rows in an LDS bitmap, ranks them by prefix popcount and only then walks them: the summation order is a function of the
+// batch alone and two runs of a training loop agree bit for bit.  (r1/r2 scattered the products with
 // global_atomic_add_f32: a swapped pair of adds moves a weight by an ulp, and the adversarial dynamics turned that into
 // 4e-5 .. 1e-4 in the predictions 40-120 steps later in 3-12 % of the runs of the 120-step parity recipe.)
 // The optimiser runs on the sum in registers: the gradient rows never exist in HBM (fused mode), or are written once
-// (export mode: aae_w1_export packs them for the data-parallel exchange).  A lane owns 4 consecutive columns (one
-// 16-byte access per row); the row's parameter and moments are requested before the entry lists are read, so the kernel
-// is four dependent memory round trips deep: item id -> tile range (+ row state) -> entries -> dL/d(a1) rows.
+// (export mode: aae_w1_export packs them for the data-parallel exchange).  The row's parameter and moments are requested
+// before the entry lists are read, so the kernel is four dependent memory round trips deep: item id -> tile range (+ row
+// state) -> entries -> dL/d(a1) rows.  (Measured on the way, r3: one wavefront per item with its rows added one dependent
+// round trip at a time - 29 us per launch, the most popular item's rows being the critical path; 16 rows' loads in
+// flight at a time - 17 us at batch 100, but 43 us on an item slice that sees 800 rows; this form: see DESIGN.md.)
 //
 // Preconditions (aae_batch): column indices unique within a row - a repeated (row, item) pair collapses to one term.
 #pragma once
@@ -35,48 +37,50 @@ struct W1Items {
     const OptScalars* sc; int* tsync; const long long* step_ctr; int mark_synced;
 };
 
-// LDS words one wavefront needs for a batch of `rows` documents: bitmap + prefix + (row, value) list
-__host__ __device__ inline size_t w1_items_wave_words(int rows) { return 2 * (size_t)((rows + 31) >> 5) + 2 * (size_t)rows; }
+// LDS words one workgroup needs for a batch of `rows` documents: bitmap + prefix + (row, value) list + the waves' partial sums
+__host__ __device__ inline size_t w1_items_lds_words(int rows) { return 2 * (size_t)((rows + 31) >> 5) + 2 * (size_t)rows + 4 * 256 + 4; }
 
-// (LDS traffic of one wave: the hardware runs a wave's DS instructions in order; the fence keeps the compiler from moving
-//  a lane's read above another lane's write)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
+// One 256-thread workgroup per distinct item (grid-stride over the step's unique-item list).
 // vblock / vgrid: this workgroup's index among the workgroups that share the item list (the kernel below, or the first-layer
-// workgroups of the grouped weight-gradient launch, chain.h)
+// workgroups of the grouped weight-gradient launch, chain.h).
+//   rows of the item   marked in an LDS bitmap, ranked by prefix popcount -> (row, value) list in ascending row order;
+//   the sum            up to 16 rows: wave 0 adds them in row order.  More (a popular item sits in most of a batch's rows:
+//                      hundreds on an item slice that sees the global batch of 8 ranks): the list is cut into four
+//                      contiguous quarters, wave w adds its quarter in row order - 16 rows' loads in flight at a time -
+//                      and the four partial sums are added in wave order: still a function of the batch alone;
+//   the update         thread t owns column t of a 256-column chunk; its parameter and moments were requested before the
+//                      lists were built.
 __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* w1_lds, int vblock, int vgrid) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = (a.rows + 31) >> 5;
-    unsigned* bm = w1_lds + (size_t)wave * w1_items_wave_words(a.rows);   // [nw]   bit b: row b holds the item
-    int* pre = reinterpret_cast<int*>(bm + nw);                            // [nw]   rows below word w that hold it
-    int* rl = pre + nw;                                                    // [rows] its rows, ascending
-    float* xl = reinterpret_cast<float*>(rl + a.rows);                     // [rows] their values
+    unsigned* bm = w1_lds;                                 // [nw]   bit b: row b holds the item
+    int* pre = reinterpret_cast<int*>(bm + nw);            // [nw]   rows below word w that hold it
+    int* rl = pre + nw;                                    // [rows] its rows, ascending
+    float* xl = reinterpret_cast<float*>(rl + a.rows);     // [rows] their values
+    float* part = xl + a.rows;                             // [4][256] the waves' partial sums of a column chunk
+    int* s_n = reinterpret_cast<int*>(part + 4 * 256);
     const int cnt = *a.ucount;
     const bool upd = a.gout == nullptr;
     OptScalars s;
     if (upd) s = *a.sc;
-    const int c0 = 4 * lane;                               // this lane's columns of a 256-column chunk
-    for (int u = vblock * nwave + wave; u < cnt; u += vgrid * nwave) {
+    for (int u = vblock; u < cnt; u += vgrid) {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
-        // the row's state for the first 256 columns travels while the lists are built (clamped: lanes beyond h re-read the
-        // last float4 of the row and never store)
-        const size_t o0 = (size_t)item * a.ldw + min(c0, a.ldw - 4);
-        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pm = pw, pv = pw;
+        // this thread's column of the first chunk: its state travels while the lists are built
+        const size_t o0 = (size_t)item * a.ldw + min(tid, a.ldw - 1);
+        float pw = 0.f, pm = 0.f, pv = 0.f;
         if (upd) {
-            pw = *reinterpret_cast<const float4*>(a.W + o0);
-            if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o0); pv = *reinterpret_cast<const float4*>(a.V + o0); }
+            pw = a.W[o0];
+            if (!s.is_sgd) { pm = a.M[o0]; pv = a.V[o0]; }
         }
-        for (int i = lane; i < nw; i += 64) bm[i] = 0u;
-        wave_lds_sync();
-        // pass 1: mark the rows; a lane keeps its first match in registers (tiles beyond 64 entries: re-read in pass 2)
+        for (int i = tid; i < nw; i += 256) bm[i] = 0u;
+        __syncthreads();
+        // pass 1: mark the rows; a thread keeps its first match in registers (tiles beyond 256 entries: re-read in pass 2)
         int my_r = -1; float my_x = 0.f;
-        for (int base = e0; base < e1; base += 64) {
-            const int e = base + lane;
+        for (int base = e0; base < e1; base += 256) {
+            const int e = base + tid;
             const int ec = min(e, e1 - 1);
             const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
             if (e < e1 && en_e == it) {
@@ -84,24 +88,27 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
                 if (base == e0) { my_r = r; my_x = x; }
             }
         }
-        wave_lds_sync();
-        int n = 0;                                         // exclusive prefix of the words' popcounts
-        for (int base = 0; base < nw; base += 64) {
-            const int i = base + lane;
-            const int c = i < nw ? __popc(bm[i]) : 0;
-            int inc = c;
+        __syncthreads();
+        if (wave == 0) {                                   // exclusive prefix of the words' popcounts
+            int n = 0;
+            for (int base = 0; base < nw; base += 64) {
+                const int i = base + lane;
+                const int c = i < nw ? __popc(bm[i]) : 0;
+                int inc = c;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-            if (i < nw) pre[i] = n + inc - c;
-            n += __shfl(inc, 63, 64);
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+                if (i < nw) pre[i] = n + inc - c;
+                n += __shfl(inc, 63, 64);
+            }
+            if (lane == 0) *s_n = n;
         }
-        wave_lds_sync();
+        __syncthreads();
         if (my_r >= 0) {
             const int k = pre[my_r >> 5] + __popc(bm[my_r >> 5] & ((1u << (my_r & 31)) - 1u));
             rl[k] = my_r; xl[k] = my_x;
         }
-        for (int base = e0 + 64; base < e1; base += 64) {  // (hot tiles only)
-            const int e = base + lane;
+        for (int base = e0 + 256; base < e1; base += 256) {     // (hot tiles only)
+            const int e = base + tid;
             const int ec = min(e, e1 - 1);
             const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
             if (e < e1 && en_e == it) {
@@ -109,22 +116,24 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
                 rl[k] = r; xl[k] = x;
             }
         }
-        wave_lds_sync();
+        __syncthreads();
+        const int n = *s_n;
+        // this wave's share of the list
+        const int q = n <= 16 ? n : (n + 3) >> 2;
+        const int i_lo = min(wave * q, n), i_hi = min(i_lo + q, n);
         for (int cb = 0; cb < a.h; cb += 256) {            // 256-column chunks (one for n_hidden <= 256)
-            const int c = cb + c0;
-            const int cc = min(c, a.ld - 4);               // (lanes beyond the row: clamped, never stored)
+            const int c4 = cb + 4 * lane;                  // the accumulating lanes own 4 consecutive columns
+            const int cc = min(c4, a.ld - 4);              // (lanes beyond the row: clamped, masked below)
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            // kU rows at a time: their loads are independent and travel together (a popular item sits in most of the batch's
-            // rows - one dependent L2 round trip per row was the kernel's critical path), the adds stay in row order
-            constexpr int kU = 16;
-            for (int i0 = 0; i0 < n; i0 += kU) {
+            constexpr int kU = 16;                         // rows whose loads travel together; the adds stay in row order
+            for (int i0 = i_lo; i0 < i_hi; i0 += kU) {
                 float4 g[kU]; float x[kU];
 #pragma unroll
                 for (int j = 0; j < kU; ++j) {
-                    const int i = min(i0 + j, n - 1);
+                    const int i = min(i0 + j, i_hi - 1);
                     const int r = rl[i];
-                    x[j] = (i0 + j < n ? xl[i] : 0.f) * a.rscale[r];  // (beyond the list: the last row again, times zero; the row
-                                                                      //  scale travels with the row itself: one round trip)
+                    x[j] = (i0 + j < i_hi ? xl[i] : 0.f) * a.rscale[r];   // (beyond the share: its last row again, times zero; the
+                                                                          //  row scale travels with the row: one round trip)
                     const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
                                                   : a.ga1 + (size_t)r * a.ld;
                     g[j] = *reinterpret_cast<const float4*>(grow + cc);
@@ -134,24 +143,31 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
                     acc.x += x[j] * g[j].x; acc.y += x[j] * g[j].y; acc.z += x[j] * g[j].z; acc.w += x[j] * g[j].w;
                 }
             }
-            const size_t o = (size_t)item * a.ldw + min(c, a.ldw - 4);
+            // (columns h .. of a row are padding: a lane's float4 may straddle h - the pad columns get a zero gradient)
+            if (c4 >= a.h) acc.x = 0.f;
+            if (c4 + 1 >= a.h) acc.y = 0.f;
+            if (c4 + 2 >= a.h) acc.z = 0.f;
+            if (c4 + 3 >= a.h) acc.w = 0.f;
+            *reinterpret_cast<float4*>(part + wave * 256 + 4 * lane) = acc;
+            __syncthreads();
+            const int c = cb + tid;
+            const float g = ((part[tid] + part[256 + tid]) + part[512 + tid]) + part[768 + tid];      // wave order
+            const size_t o = (size_t)item * a.ldw + min(c, a.ldw - 1);
             if (cb > 0 && upd) {
-                pw = *reinterpret_cast<const float4*>(a.W + o);
-                if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o); pv = *reinterpret_cast<const float4*>(a.V + o); }
+                pw = a.W[o];
+                if (!s.is_sgd) { pm = a.M[o]; pv = a.V[o]; }
             }
-            if (c >= a.h) continue;
-            // (columns h .. ldw - 1 of a row are padding: a lane's float4 may straddle h - the pad columns get a zero gradient)
-            if (c + 1 >= a.h) acc.y = 0.f;
-            if (c + 2 >= a.h) acc.z = 0.f;
-            if (c + 3 >= a.h) acc.w = 0.f;
-            if (!upd) { *reinterpret_cast<float4*>(a.gout + o) = acc; continue; }
-            adam_update(pw.x, pm.x, pv.x, acc.x, s); adam_update(pw.y, pm.y, pv.y, acc.y, s);
-            adam_update(pw.z, pm.z, pv.z, acc.z, s); adam_update(pw.w, pm.w, pv.w, acc.w, s);
-            *reinterpret_cast<float4*>(a.W + o) = pw;
-            if (!s.is_sgd) { *reinterpret_cast<float4*>(a.M + o) = pm; *reinterpret_cast<float4*>(a.V + o) = pv; }
+            if (c < a.ldw) {
+                if (!upd) a.gout[o] = g;
+                else {
+                    adam_update(pw, pm, pv, g, s);
+                    a.W[o] = pw;
+                    if (!s.is_sgd) { a.M[o] = pm; a.V[o] = pv; }
+                }
+            }
+            __syncthreads();                               // part / the lists are rewritten next
         }
-        if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
-        wave_lds_sync();                                   // the lists are rebuilt for the next item
+        if (upd && a.mark_synced && tid == 0) a.tsync[item] = (int)*a.step_ctr;
     }
 }
 

@@ -400,6 +400,46 @@ int aae_w1_import(aae_handle h, const int32_t* hdr_dev, const float* vals_dev, i
 int aae_apply_updates_except(aae_handle h, int which, int skip_tensor_id, void* stream);
 int aae_apply_shard(aae_handle h, int tensor_id, int64_t row_begin, int64_t row_end,
                     const float* grad_shard_dev, int which, void* stream);
+/* ---- the data-parallel step as ONE call (r3; SURVEY 8b "aae_comm_init + entry points that enqueue kernels and RCCL calls") ----
+ * Scheme: both vocabulary-wide matrices sharded over the ranks (aae_first_layer_* / aae_output_layer_step above; DESIGN.md
+ * 5.0): per partial_fit the ranks exchange seven small blocks - reduce-scatter of the first layer's shares, all-gather of
+ * the decoder's last hidden activations, reduce-scatter of dL/d(hidden), all-gather of [dL/d(a1) | small-layer gradients]
+ * (twice: enc_optim, gen_optim), reduce-scatter for Enc_eval, all-reduce of the discriminator's gradients.  aae_dp_step
+ * enqueues ALL of it - kernels and collectives - on `stream`; no host work in between (driven phase by phase from Python
+ * the loop needed 0.35 ms of host time per step at 8 ranks against 0.33 ms of GPU work).
+ * The collectives come as a table of function pointers over device float buffers: count = floats PER RANK (all_gather:
+ * what each rank sends; reduce_scatter: what each rank receives, sums over the ranks; all_reduce: the whole buffer, in
+ * place); each enqueues on `stream` and returns 0 or a negative AAE_E* code.  aae_rccl_init fills the table with RCCL
+ * (xGMI) collectives on a communicator the library creates from a 128-byte ncclUniqueId (rank 0: aae_rccl_unique_id, then
+ * hand it to the other ranks by any means - torch.distributed.broadcast, MPI, a file); librccl.so is opened at run time.
+ * Any other table works as well (the tests use host-staged gloo collectives and single-process stand-ins).
+ *   replica            this rank's replica handle: grad_mode = AAE_GRAD_EXPORT, aae_set_first_layer_external(1)
+ *   slice              this rank's item-slice handle (fused optimiser, aae_set_doc_l1, aae_set_grad_scale(slice / all items))
+ *   local              this rank's documents (its share of the global batch) in the replica's corpus
+ *   global_slice       the GLOBAL batch, rank-major, in the slice's corpus (its items' columns); n_rows = world x local's
+ *   next_global_slice  the global batch of the NEXT step (aae_prefetch_batch on the slice handle) or NULL
+ *   cond_dev / inject  as aae_step */
+typedef struct aae_collectives {
+    void* ctx;
+    int (*all_gather)(void* ctx, const float* send_dev, float* recv_dev, int64_t count, void* stream);
+    int (*reduce_scatter)(void* ctx, const float* send_dev, float* recv_dev, int64_t count, void* stream);
+    int (*all_reduce)(void* ctx, float* buf_dev, int64_t count, void* stream);
+    int32_t world, rank;
+} aae_collectives;
+int aae_rccl_unique_id(char id_out[128]);
+int aae_rccl_init(const char id[128], int32_t world, int32_t rank, aae_collectives* out);
+int aae_rccl_destroy(aae_collectives* c);
+int aae_dp_step(aae_handle replica, aae_handle slice, const aae_collectives* coll, const aae_batch* local,
+                const aae_batch* global_slice, const aae_batch* next_global_slice, const float* cond_dev,
+                const aae_rng_inject* inject, void* stream);
+/* a single-process stand-in table (measurement aid: one rank's compute with every exchange replaced by device copies of the
+ * same shapes - all_gather = the operand repeated `world` times, reduce_scatter = its first chunk, all_reduce = identity;
+ * rank 0 of `world`) */
+int aae_echo_collectives(int32_t world, aae_collectives* out);
+/* blocking copy between any two buffers (host or device) behind `stream`: what a host-side collectives table needs to
+ * stage operands without a HIP binding of its own */
+int aae_memcpy_sync(void* dst, const void* src, size_t bytes, void* stream);
+
 /* scale applied to this rank's loss gradients (local_rows / global_rows) so that the
  * all-reduced sum equals the single-process mean over the global batch. */
 int aae_set_grad_scale(aae_handle h, float scale);

@@ -1164,3 +1164,57 @@ def test_c3_scale_ranking_matches_reference():
     ours = evaluate_topk(Yout, idx[:, :10], list(names))
     for name, (mean, std) in zip(names, ours):
         assert abs(mean - ref_metrics[name][0]) < 1e-12 and abs(std - ref_metrics[name][1]) < 1e-9, (name, mean, std, ref_metrics[name])
+
+
+def _rccl_world1_worker(rank, port, ret):
+    """One rank over REAL RCCL (backend nccl, world 1): fit() in dp_mode='vocab' takes the native step driver - aae_dp_step
+    with the collectives table aae_rccl_init builds on a communicator the library creates."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "aae-recommender_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import aaerec.aae  # noqa: F401
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1, device_id=torch.device("cuda", 0))
+    np.random.seed(5)
+    torch.manual_seed(5)
+    m = _dp_model(True, data_parallel=True, dp_mode="vocab")
+    m.fit(_dp_corpus())
+    ret["native"] = m._dp._native is not None and m._dp._native_keep is None       # (the RCCL table, not Python callbacks)
+    ret["state"] = m.hip.state_dict()
+    ret["pred"] = m.predict(_dp_corpus()[:33])
+    ret["stats"] = m._dp.comm_stats()
+    dist.destroy_process_group()
+
+
+def test_native_step_driver_over_rccl_on_one_rank():
+    """aae_dp_step over real RCCL collectives (world 1: the only multi-rank-capable transport a one-GPU box can run): the
+    whole both-sharded step - 7 collectives on a library-owned communicator and every kernel - is ONE library call per
+    partial_fit; parameters and predictions equal the plain single-process fit()."""
+    import torch.multiprocessing as mp
+    import aaerec.aae                               # noqa: F401
+    port = free_port()
+    with mp.get_context("spawn").Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_world1_worker, args=(port, ret), nprocs=1, join=True)
+        got = dict(ret)
+    assert got["native"]
+    assert got["stats"]["collectives"] == 7
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    one = _dp_model(True)
+    one.fit(X)
+    for k, w in one.hip.state_dict().items():
+        d = np.abs(got["state"][k] - w)
+        assert (d > 2e-4).sum() <= max(8, 0.01 * d.size) and d.max() < 0.02, f"{k}: {(d > 2e-4).sum()} off, max {d.max():.2e}"
+    np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=2e-3)
+
+
+def test_fit_on_two_ranks_through_the_python_step_driver(monkeypatch):
+    """The phase-by-phase Python driver of the both-sharded scheme (VocabParallelAAE._step_both_sharded: what the CPU
+    stand-ins of tests/test_parallel_gloo.py run, and what AAE_DP_PYTHON=1 selects on the GPU) on two ranks sharing the
+    GPU: same result as the default - the native aae_dp_step - checks against (test_fit_on_two_ranks_equals_...)."""
+    monkeypatch.setenv("AAE_DP_PYTHON", "1")
+    test_fit_on_two_ranks_equals_single_process("vocab", True)
