@@ -143,6 +143,7 @@ struct aae_model {
     bool x3_ok = false;            // dec_crit_x3.h: the critical launch's fp32 products on the bf16 matrix cores (3-term split)
     bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
     bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
+    Ten dh2f;                      // dec_opt_blocks_x3_kernel: the step's dh2 as split matrix-core fragments (dh2_frag_kernel)
     bool blocked_ok; Ten Gacc;   // cfg.blocked_output: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
@@ -152,6 +153,7 @@ struct aae_model {
     bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
     hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
     bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)
+    bool side_ordered = false;                             // ... or put its dV3 GEMM there: the side stream is in order behind that step's output layer
 };
 
 namespace {
@@ -283,6 +285,9 @@ size_t layout(aae_model* m, char* base, bool dry) {
     if (c.dense_noise == 1) m->Xn = a.mat(R, N, m->ldn);
     m->Gacc = Ten();
     if (c.blocked_output && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
+    m->dh2f = Ten();
+    if (c.blocked_output && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB && R <= kMaxRowBlocks * kRowBlock)
+        m->dh2f = a.mat((int64_t)((R + kXCH - 1) / kXCH) * 13 * (kXCH / 32) * 3, 256, 256);      // [chunk][column block][k-step][term] x 1 KB
     if (c.model_kind == 3) {
         m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
     }
@@ -800,8 +805,11 @@ static bool fused_decoder_applies(const aae_model* m) {
     // ~30 TFLOP/s) fits beside the rest of the step: 800 rows x 12.5 k items (an item slice at world 8) 0.40 against 0.46 ms
     // per step, 208 x 100 k 0.64 against 0.70; beyond ~32 M cells the next step waits for it and the three GEMMs win
     // (512 x 100 k: 1.48 against 1.12 ms; 512 x 275 k, a C5 slice: 3.7 against 2.7 ms).  AAE_BLOCKED_ANY lifts the cap (tests).
+    // r3: with both launches on the emulated product (dec_crit_x3.h: the deferred half of all blocks in ONE launch for any
+    // vocabulary, dec_opt_blocks_x3_kernel) the cap is gone: 512 x 100 k 0.77 ms/step against 0.93 on the three GEMMs.
     const bool blocked = !one && m->blocked_ok && !m->bf16 && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
-                         m->cfg.grad_mode == AAE_GRAD_FUSED && (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20));
+                         m->cfg.grad_mode == AAE_GRAD_FUSED &&
+                         (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr));
     return m->fused_ok && !m->force_unfused && (one || blocked) &&
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
@@ -1393,7 +1401,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->x3_ok = ok && !no_x3
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
         if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) m->split_wgs = std::max(1, m->n_cu / 2);
     }
@@ -1865,6 +1877,20 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     }
     if (m->lazy && !ahead) TRY(lazy_prepare(m, -1, false, s));
     m->dec_hidden_done = false; m->enc_bwd_done = false;
+    // Batches beyond one fused launch (112 rows): their tile buckets (the row-blocked output layer's entry lists and the first
+    // layer's per-item update read them; one wide launch, 47 us at 512 rows x 100 k items alone, 100 us beside a streaming
+    // GEMM) depend on the batch only - built on the side stream beside the list building, the gather and the forward
+    // chain, as aae_first_layer_forward does for the item slices, instead of in front of their first reader.  (Up to 112
+    // rows the builder rides in the step's first chain launch.)  The side stream is in order behind the previous step's
+    // deferred launch, which waited for that step's output layer - the alternate bucket set's last readers are older.
+    {
+        static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
+        if (bk_ahead && m->side && m->ev_bk && m->side_ordered && m->use_chain && m->rows > 16 * kMB && !m->buckets_valid) {
+            TRY(build_tile_buckets(m, m->side));
+            HIPCHK(hipEventRecord(m->ev_bk, m->side));
+            m->bk_pending = true;
+        }
+    }
     const bool pf = m->pf_armed && m->side && m->mark2 && m->lazy && m->use_chain;
     if (m->pf_armed && !pf) m->pf_armed = false;
     if (m->use_chain) {
@@ -1947,7 +1973,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         const bool split_fits = nblk > 1 || m->split_any || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
         // (AAE_DEC_TS: the timeline of the single launch - or, AAE_DEC_TS=x3, of the split form's critical launch dec_crit_x3.h)
         static const bool ts_x3 = want_ts && strcmp(getenv("AAE_DEC_TS"), "x3") == 0;
-        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || (ts_x3 && m->x3_ok && !m->bf16)) && (fa.dbg_skip & ~256) == 0) {
+        static const bool ts_obk = want_ts && strcmp(getenv("AAE_DEC_TS"), "obk") == 0;
+        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !m->bf16)) && (fa.dbg_skip & ~(256 | 0xF000)) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3
@@ -2007,7 +2034,52 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             static const bool no_opt_x3 = getenv("AAE_NO_OPT_X3") != nullptr;
             const bool one_opt = nblk > 1 && !m->bf16 && !no_obk && ntiles <= kOBT * m->n_cu &&
                                  dec_opt_blocks_lds_bytes(Bb) <= 160 * 1024;
-            if (one_opt) {
+            // (r3) the same on the emulated product, any vocabulary size: dec_opt_blocks_x3_kernel (dec_crit_x3.h)
+            static const bool no_obk_x3 = getenv("AAE_NO_OPT_BLOCKS_X3") != nullptr;
+            if (nblk > 1 && !m->bf16 && m->x3_ok && !no_opt_x3 && !no_obk_x3 && !no_obk && m->dh2f.p) {
+                DecFusedArgs b = fa;
+                b.nblk = nblk; b.Bb = Bb;
+                hipLaunchKernelGGL(dh2_frag_kernel, dim3((B + kXCH - 1) / kXCH, m->fused_nb), dim3(128), 0, m->side, m->dh2.p, m->ldh, B,
+                                   reinterpret_cast<u32x4_t*>(m->dh2f.p));
+                b.acc = m->dh2f.p;                      // (this kernel's reading of the field: the fragment image)
+                // tile groups of at most kXBT tiles, the same number (+-1 tile) for every workgroup and round
+                // (workgroups: 5/8 of the CUs - 512 rows x 100 k items 0.827 / 0.809 / 0.823 / 0.839 ms per step on 128 / 160 / 192 / 224;
+                //  half of them on an item slice of 12.5 k items x 800 rows: 0.382 / 0.379 / 0.400 / 0.387 ms of per-rank compute on 96 / 128 / 160 / 192)
+                static const int obk_env = getenv("AAE_OBK_WGS") ? atoi(getenv("AAE_OBK_WGS")) : 0;
+                const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : ntiles < 1024 ? m->n_cu / 2 : m->n_cu * 5 / 8), std::min(ntiles, m->n_cu)));
+                const int rounds = (ntiles + g3 * kXBT - 1) / (g3 * kXBT);
+                b.tpp = g3 * rounds;
+                const uint32_t lds3 = (uint32_t)dec_opt_blocks_x3_lds_bytes();
+                hipEvent_t start = nullptr, stop = nullptr;
+                (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
+                if (ts_obk && m->fused_nb == 13) {
+                    hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13, true>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b);
+                    hipStreamSynchronize(m->side);
+                    unsigned long long t[128];
+                    hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+                    for (int w = 0; w < 2; ++w) {
+                        fprintf(stderr, "[dec_opt_blocks_x3 wave %d, steps 8..15, us: products | split | to the next barrier;  spare wave: - | split | requests | wait for the slot | to the next barrier]", w ? 12 : 0);
+                        for (int q = 0; q < 8; ++q) {
+                            const unsigned long long* u = t + 64 * w + 4 * q;
+                            if (w == 0) fprintf(stderr, "  %.2f %.2f %.2f", (u[1] - u[0]) * 0.01, (u[2] - u[1]) * 0.01, q < 7 ? ((double)u[4] - (double)u[2]) * 0.01 : 0.0);
+                            else fprintf(stderr, "  %.2f %.2f %.2f %.2f", (u[1] - u[0]) * 0.01, (u[2] - u[1]) * 0.01, (u[3] - u[2]) * 0.01, q < 7 ? ((double)u[4] - (double)u[3]) * 0.01 : 0.0);
+                        }
+                        fprintf(stderr, "\n");
+                    }
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned long long* u = t + (k ? 96 : 32);
+                        fprintf(stderr, "[dec_opt_blocks_x3 step %d: every wave's arrival at the step's closing barrier, us after wave 0 finished its products]", k ? 12 : 9);
+                        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.2f", ((double)u[w] - (double)u[16]) * 0.01);
+                        fprintf(stderr, "\n");
+                    }
+                } else
+                switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<4>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<7>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                }
+                LAUNCHCHK("dec_opt_blocks_x3");
+            } else if (one_opt) {
                 DecFusedArgs b = fa;
                 b.nblk = nblk; b.Bb = Bb;
                 const int g3 = std::max(std::min(g2, ntiles), (ntiles + kOBT - 1) / kOBT);
@@ -2051,14 +2123,14 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             }
             TRY(side_done(m, m->ev_opt));
             m->opt_pending = true;
-            m->last_out_split = true;
+            m->last_out_split = true; m->side_ordered = true;
             // an item slice's next batch (named ahead): its distinct items and their deferred-Adam catch-up behind the
             // deferred launch on the same stream (ordered behind this step's head by ev_crit; rows of the running batch
             // are skipped there, the step's own updates bring them to the same step)
             if (m->only_output_layer && m->pf_armed && m->mark2 && m->lazy) TRY(launch_prefetch(m, false));
         } else
         {
-            m->last_out_split = false;
+            m->last_out_split = false; m->side_ordered = false;
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
             if (m->bf16) switch (m->fused_nb) {
                 case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
@@ -2075,7 +2147,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             unsigned long long t[128];
             hipStreamSynchronize(s);
             hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
-            if (m->last_out_split)
+            if (m->last_out_split && ts_obk) { /* printed at the launch */ }
+            else if (m->last_out_split)
                 fprintf(stderr, "[dec_crit_x3 tile 5] barrier=%.2f S0=%.2f GEMM1=%.2f BCE=%.2f GEMM3=%.2f | wg 0: prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
                         (t[14] - t[0]) * 0.01, (t[1] - t[14]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
                         (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
@@ -2181,7 +2254,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         }
         TRY(side_done(m, m->ev_opt));
         m->opt_pending = true;
+        m->side_ordered = true;
     } else {
+        m->side_ordered = false;
         ProfScope ps(m, AAE_K_DEC_DV3_ADAM, s);
         TRY(linear_dw(m, m->G.p, m->ldn, B, m->dh2.p, m->ldh, P_V3, O_DEC, s));
     }

@@ -511,4 +511,327 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The deferred half for ALL row blocks of a row-blocked step in one launch (dec_fused.h's dec_opt_blocks_kernel) on the
+// emulated product, for any vocabulary: dV3 = G^T dh2 over the WHOLE batch from the tiles the critical launch stored,
+// then dec_optim.  dh2 cannot stay resident (512 rows x 208 columns in three bf16 terms: 640 KB against a 512 KB register
+// file), so a workgroup takes a GROUP of up to kXBT consecutive tiles (256 items) per pass, keeps their dV3 in registers
+// (64 VGPRs of a column-block owner) while it walks the batch in chunks of 64 rows, and loads a chunk's dh2 fragments (24
+// VGPRs) once per (pass, chunk): the re-read costs 426 KB / kXBT per tile from L2 beside the tile's own 66 KB of
+// dL/dlogits and 154 KB of optimiser traffic.  The row blocks only shape the ADDRESS of a row's stored dL/dlogits (tile-major
+// per block, dec_fused.h); the k walk is over global rows, so a batch of 512 rows is 16 full k-steps, no padding per block.
+// Wave w < NB owns column block w for both item halves.  One LDS-only barrier per (chunk, tile) step: the step's G image
+// was split into the other buffer during the step before, its fp32 values requested two steps ahead.
+// a.tpp = number of tile groups G (a multiple of the grid): group g = tiles [g nt / G, (g + 1) nt / G), at most kXBT.
+// Summation order: rows in order (32-row k-steps), a function of the batch alone.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kXBT = 6;       // tiles per group: 48 accumulator VGPRs of a column-block owner (7: 17 spilled registers at 128, and a
+                               // scratch reload waits for every load in flight - the stream's prefetch)
+constexpr int kXCH = 64;       // batch rows per chunk
+constexpr int kXRowTab = 768;  // requester threads at most (16 - 4 waves)
+constexpr int kXRing = 6;      // steps of dL/dlogits rows in flight (LDS-DMA ring slots of 8 KB)
+
+// 16 bytes per lane global -> LDS without a register destination: lane l's bytes land at lds_dst + 16 l (lds_dst: wave-uniform
+// LDS byte address, through M0, which is the compiler's: saved and restored in the same statement).  hipcc does not count
+// this load: its completion is waited for by hand (s_waitcnt vmcnt(N), N = younger requests of the wave).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+inline size_t dec_opt_blocks_x3_lds_bytes() { return sizeof(float) * std::max((size_t)2 * 3 * 2 * kXCH * 8 + (size_t)kXRing * kXCH * kTI + 256 + 9 * kXRowTab, (size_t)kXBT * kTI * kSO); }
+
+// dh2 [B][ldh] -> the multipliers' B fragments, split, in the order they are read: [chunk][column block][k-step][term][lane]
+// x 16 bytes (lane (fr, fk) = column 16 cb + fr, rows 64 ch + 32 kc + 8 fk + {0..7}; beyond the batch / the row: zeros).
+// One launch per step in front of dec_opt_blocks_x3_kernel, on its stream: a multiplier then fetches a chunk's fragments
+// with six coalesced 16-byte loads instead of sixteen strided 4-byte ones plus the split, once per (group, chunk).
+__global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__ dh2, int ldh, int B, u32x4_t* __restrict__ out) {
+    const int ch = blockIdx.x, cb = blockIdx.y, nb = gridDim.y;
+    const int kc = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    const int c = 16 * cb + fr;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b = kXCH * ch + 32 * kc + 8 * fk + j;
+        x[j] = (b < B && c < ldh) ? dh2[(size_t)b * ldh + c] : 0.f;
+    }
+    unsigned p[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
+        out[((((size_t)ch * nb + cb) * (kXCH / 32) + kc) * 3 + t) * 64 + lane] = v;
+    }
+}
+
+template <int NB, bool TS = false>   // TS: debug timeline (AAE_DEC_TS=obk) of workgroup 0, steps 8 .. 15 of its first group, waves 0 and 12
+__global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) {
+    constexpr int KR = kXCH / 32;
+    // A term image of a step: [item half][row slot][8 dwords = 16 items], no padding.  ds_read_b64_tr_b16 is serviced in two
+    // groups of 32 lanes (MI355X_MICROARCH.md, LDS) which name the rows {8g + q, 8(g+1) + q : q < 4} x 4 column chunks of 8
+    // bytes: with rows 0-3 and 8-11 in eight CONSECUTIVE 32-byte slots the group covers the 64 banks exactly once.  Hence
+    // slot(row) = row with bits 2 and 3 swapped.  (The [row][20 dwords] images of dec_opt_x3_kernel put rows 3 and 11 of a
+    // group on banks that rows 0 and 8 occupy: 2-way conflicts on a quarter of the lanes, and this kernel's product phase is
+    // bound by exactly these reads - 312 per step.)
+    constexpr int IMG = 2 * kXCH * 8;           // dwords per term image
+    auto slot_of = [](int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); };
+    static_assert(NB <= kNW, "one column block per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* gB = reinterpret_cast<unsigned*>(lds);            // [2][3][64][kXGS]  a chunk's rows of one G tile (rows >= B: zero)
+    float* ring = lds + 2 * 3 * IMG;                            // [kXRing][64 rows][32] fp32 dL/dlogits rows as they arrive (LDS-DMA), + a dump KB
+    unsigned* rowtab = reinterpret_cast<unsigned*>(ring + kXRing * kXCH * kTI + 256);     // [3][kXRowTab]: the requesters' row addresses of a chunk
+    float* os = lds;                                            // [kXBT][32][kSO]   the group's dV3a tiles (over both, once the products are done)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ldv = a.ldv, N = a.N, B = a.B;
+    const int ntiles = (N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;
+    const OptScalars sc = *a.sc;
+    typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+    const int G = max(a.tpp, 1);
+    const int nch = (B + kXCH - 1) / kXCH;
+    const int cb = min(wave, NB - 1);
+
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 2));
+    };
+    // Roles: waves 0 .. NB-1 multiply (wave w = column block w, both item halves) and go from a step's barrier straight
+    // into their products.  The stored dL/dlogits rows of a step arrive by LDS-DMA (global_load_lds_dwordx4: no register
+    // destination, so kXRing steps are in flight with no prefetch register and no rotation - rotating prefetch registers
+    // made every step wait for the newest request, ~2 us of HBM latency under the optimiser traffic of the other workgroups)
+    // into a ring of fp32 slots, requested by the 16 - NB >= 3 spare waves, which do nothing else and know when a slot has
+    // landed (their vmcnt); the workgroup's barrier carries that to everybody.  Behind its products EVERY thread then splits
+    // one float2 of the next step's slot into the other image (1024 threads x 8 bytes = 64 rows x 32 items): measured
+    // alternatives - the split by the spare waves alone (3 float4 per thread: 1.0 us per step against 0.5 us of products),
+    // by half the workgroup in front of its products (0.6-0.8 us) - left the multipliers waiting.
+    constexpr int NL = (kNW - NB) * 64, NS = (kXCH * 8 + NL - 1) / NL;
+    static_assert(NB < kNW, "no spare wave left");
+    static_assert(kXCH * 8 * 2 == kNT, "one float4 of a slot per thread of the lower half");
+    const bool mult = wave < NB;
+    const int lt = tid - NB * 64;               // requesting thread
+    // stored dL/dlogits of global row b, tile t: block r = b / Bb holds [tile][Br][32] (dec_fused.h)
+    const float inv_bb = 1.0f / (float)a.Bb;
+    const size_t blk_floats = (size_t)ntiles * a.Bb * kTI;
+    auto g_row = [&](int b, int c4, unsigned& tile_stride) {           // address of (row b, tile 0, float4 c4) + its stride per tile
+        const int bc = min(b, B - 1);
+        const int r = (int)(((float)bc + 0.5f) * inv_bb);          // bc / Bb (exact: Bb <= 128, bc < 2^16)
+        const int Br = min(a.Bb, B - r * a.Bb);
+        tile_stride = (unsigned)Br * kTI;
+        return a.Gt + (size_t)r * blk_floats + (size_t)(bc - r * a.Bb) * kTI + (size_t)c4 * 4;
+    };
+    const unsigned ring_lds = (unsigned)reinterpret_cast<size_t>(ring);
+    const int lw = wave - NB;                   // loader wave: its request i of a step covers the float4s 64 (lw + (16 - NB) i) ..
+
+    for (int grp = blockIdx.x; grp < G; grp += gridDim.x) {
+        const int t0 = (int)(((long long)grp * ntiles) / G), nt = (int)(((long long)(grp + 1) * ntiles) / G) - t0;
+        if (nt <= 0) continue;
+        const int Q = nch * nt;                         // steps q = ch * nt + j
+        const bool stamp_wg = TS && a.ts && blockIdx.x == 0 && grp == (int)blockIdx.x && lane == 0;
+
+        // ---- the optimiser on the group's tiles (all threads, after the multipliers have put every dV3a tile of the group
+        // into os: no accumulator is alive beside it, so two tiles' parameters and moments are in flight behind the one
+        // being updated, and no barrier sits between the tiles)
+        auto optimiser = [&]() {
+            const bool on = !(a.dbg_skip & 0x2000);
+            int s_rc[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int fc = min(tid + kNT * u, tile_f4 - 1), row = fc / f4_per_row;
+                s_rc[u] = row * kSO + (fc - row * f4_per_row) * 4;
+            }
+            constexpr int D = 2;                        // register sets (the tile in hand + the next one in flight; 3: spills)
+            float4 pr[D][NV], mr[D][NV], vr[D][NV];
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d)
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int t = min(t0 + d, t0 + nt - 1);
+                    pr[d][u] = ld4(rP, t, u); mr[d][u] = ld4(rM, t, u); vr[d][u] = ld4(rV, t, u);
+                }
+#pragma unroll
+            for (int j = 0; j < kXBT; ++j) {
+                if (j >= nt) break;
+                const int tile = t0 + j, i0 = tile * kTI;
+                const int cur = j % D, nxt = (j + D - 1) % D;
+                if (on) {
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) {
+                        const int t = min(tile + D - 1, t0 + nt - 1);
+                        pr[nxt][u] = ld4(rP, t, u); mr[nxt][u] = ld4(rM, t, u); vr[nxt][u] = ld4(rV, t, u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int row = (tid + kNT * u) / f4_per_row;       // (only for the bound check below)
+                    const bool valid = tid + kNT * u < tile_f4 && i0 + row < N && on;
+                    const float4 g = *reinterpret_cast<const float4*>(os + j * (kTI * kSO) + s_rc[u]);
+                    const unsigned so = (unsigned)tile * tile_bytes;
+                    const unsigned vo = valid ? lane_off + (unsigned)(kNT * 16 * u) : 0x80000000u;
+                    float4 p = pr[cur][u], mm = mr[cur][u], vv = vr[cur][u];
+                    adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
+                    adam_update(p.z, mm.z, vv.z, g.z, sc); adam_update(p.w, mm.w, vv.w, g.w, sc);
+                    const unsigned vo2 = !sc.is_sgd ? vo : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, p), rP, vo, so, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, mm), rM, vo2, so, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fu32x4, vv), rV, vo2, so, 2);
+                }
+            }
+        };
+
+        lds_barrier();                                  // (the previous group's readers of os are done)
+        // step q = (chunk q / nt, tile index q % nt); beyond the last step: the last step again (the count of requests in
+        // flight is what the waits below rely on)
+        // step q = (chunk q / nt, tile index q % nt); beyond the last step: the last step again (the waits count requests)
+        // A requester keeps the addresses of its NS rows of the chunk being requested (tile 0) and their strides per tile in
+        // LDS words of its own, rewritten when the request stream enters a chunk: a request is then one 64-bit multiply-add
+        // (recomputed per request - a row's block, three 32-bit and two 64-bit multiplies - three requests took 0.8 us per
+        // step, more than the step's products; as registers they would be alive across the multipliers' accumulators).
+        auto request = [&](int q) {
+            const int qc = min(q, Q - 1), ch = qc / nt, jj = qc - ch * nt;
+            const unsigned slot = (unsigned)(q % kXRing) * (kXCH * kTI * 4u);
+            if (jj == 0 && q < Q) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int f = min(lt + NL * i, kXCH * 8 - 1);
+                    unsigned ts;
+                    const size_t p = reinterpret_cast<size_t>(g_row(kXCH * ch + (f >> 3), f & 7, ts));
+                    rowtab[(3 * i + 0) * kXRowTab + lt] = (unsigned)p;
+                    rowtab[(3 * i + 1) * kXRowTab + lt] = (unsigned)(p >> 32);
+                    rowtab[(3 * i + 2) * kXRowTab + lt] = ts;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int fb = 64 * (lw + (kNW - NB) * i);      // (uniform) beyond the chunk: a request into the dump KB, so that
+                const unsigned dst = fb < kXCH * 8 ? slot + (unsigned)fb * 16u : (unsigned)kXRing * (kXCH * kTI * 4u);   // every wave has NS per step
+                const size_t p = (size_t)rowtab[(3 * i + 0) * kXRowTab + lt] | ((size_t)rowtab[(3 * i + 1) * kXRowTab + lt] << 32);
+                const unsigned ts = rowtab[(3 * i + 2) * kXRowTab + lt];
+                if (!(a.dbg_skip & 0x8000)) glds16(reinterpret_cast<const float*>(p) + (size_t)(t0 + jj) * ts, __builtin_amdgcn_readfirstlane(ring_lds + dst));
+            }
+        };
+        // ring slot of step q (chunk ch) -> image q & 1 (rows beyond the batch: zeros), in two halves: the read is issued
+        // before the requester's own LDS reads and requests, so that a spare wave queues behind the multipliers' burst of
+        // fragment reads once per step, not twice
+        // ring slot of step q (chunk ch) -> image q & 1 (rows beyond the batch: zeros): by the LOWER half of the workgroup,
+        // one float4 per thread, behind its products.  On a SIMD the matrix pipe serves its four waves roughly in order
+        // (arrival at the step's closing barrier, us after wave 0's products: waves 0-3 0.1-0.2, 4-7 0.2-0.4, 8-11 0.4,
+        // wave 12 0.55 - SIMD 0 holds four multipliers, 96 MFMAs of 16 cycles per step): waves 0 .. 7 have the time, and
+        // nothing then stands between the last multiplier's last product and the barrier.
+        auto slot_read = [&](int q) { return *reinterpret_cast<const float4*>(ring + (q % kXRing) * (kXCH * kTI) + 4 * (tid & (kXCH * 8 - 1))); };
+        auto split_write = [&](int q, int ch, float4 g) {
+            const int f = tid & (kXCH * 8 - 1);
+            if ((f >> 3) >= B - kXCH * ch) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned q0[3], q1[3];
+            split3_pair(g.x, g.y, q0[0], q0[1], q0[2]);
+            split3_pair(g.z, g.w, q1[0], q1[1], q1[2]);
+            unsigned* d = gB + (q & 1) * 3 * IMG + ((f >> 2) & 1) * (kXCH * 8) + slot_of(f >> 3) * 8 + (f & 3) * 2;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * IMG) = make_uint2(q0[t], q1[t]);
+        };
+        const bool splitter = wave < kNW / 2;
+        if (!mult) {
+#pragma unroll
+            for (int d = 0; d < kXRing; ++d) request(d);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS * (kXRing - 2)) : "memory");      // steps 0 and 1 have landed
+        }
+        lds_barrier();
+        if (splitter) split_write(0, 0, slot_read(0));
+
+        f32x4 acc[kXBT][2];
+#pragma unroll
+        for (int j = 0; j < kXBT; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        int q = 0;
+        bf16x8 dB[KR][3];
+        for (int ch = 0; ch < nch; ++ch) {
+            // the chunk's dh2 fragments (dh2_frag_kernel's image)
+            if (mult && (ch == 0 || !(a.dbg_skip & 0x4000))) {
+                const u32x4_t* F = reinterpret_cast<const u32x4_t*>(a.acc) + (((size_t)ch * NB + cb) * KR * 3) * 64 + lane;
+#pragma unroll
+                for (int kc = 0; kc < KR; ++kc)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) dB[kc][t] = __builtin_bit_cast(bf16x8, F[(kc * 3 + t) * 64]);
+                // the fragments are waited for HERE: left to the compiler, the wait lands in front of their first use inside
+                // every step
+#pragma unroll
+                for (int kc = 0; kc < KR; ++kc)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4_t v = __builtin_bit_cast(u32x4_t, dB[kc][t]);
+                        asm volatile("" : "+v"(v));
+                        dB[kc][t] = __builtin_bit_cast(bf16x8, v);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < kXBT; ++j) {
+                if (j >= nt) break;                     // (uniform)
+                int oz;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+                const int lz = lane + oz;
+                lds_barrier();                          // image q is complete, slot q + 1 has landed, slot q is free
+                const bool stamp = stamp_wg && (wave == 0 || wave == NB) && q >= 8 && q < 16;
+                unsigned long long* tsq = a.ts + (wave ? 64 : 0) + (q - 8) * 4;
+                if (stamp) tsq[0] = wall_clock64();
+                if (mult && !(a.dbg_skip & 0x1000)) {
+                    const int tq = (lz >> 2) & 3, tp = lz & 3, g = lz >> 4;
+                    const unsigned* img = gB + (q & 1) * 3 * IMG;
+#pragma unroll
+                    for (int nb2 = 0; nb2 < 2; ++nb2) {
+                        f32x4 c = acc[j][nb2];
+                        // rows 32 kc + 8 g + 4 hi + tq -> slot tq | (g & 1) << 2 | hi << 3 | (g >> 1) << 4 | kc << 5
+                        const unsigned* base = img + nb2 * (kXCH * 8) + (tq | ((g & 1) << 2) | ((g >> 1) << 4)) * 8 + 2 * tp;
+#pragma unroll
+                        for (int kc = 0; kc < KR; ++kc) {
+                            bf16x8 ga[3];
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const unsigned* pb = base + t * IMG + 32 * kc * 8;
+                                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb));
+                                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 8 * 8));
+                                typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                ga[t] = __builtin_bit_cast(bf16x8, v);
+                            }
+                            c = mfma_x3(ga, dB[kc], c);
+                        }
+                        acc[j][nb2] = c;
+                    }
+                }
+                if (stamp) tsq[1] = wall_clock64();
+                if (splitter && q + 1 < Q) split_write(q + 1, j + 1 < nt ? ch : ch + 1, slot_read(q + 1));
+                if (!mult) request(q + kXRing);         // slot q is requested again
+                if (stamp) tsq[2] = wall_clock64();
+                if (!mult) {                            // step q + 2 will have landed at the next barrier
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS * (kXRing - 2)) : "memory");
+                    if (stamp) tsq[3] = wall_clock64();
+                }
+                if (TS && stamp_wg && (q == 9 || q == 12)) { a.ts[(q == 9 ? 32 : 96) + wave] = wall_clock64(); if (wave == 0) a.ts[(q == 9 ? 48 : 112)] = tsq[1]; }
+                ++q;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the ring's last requests have landed: os takes its place)
+        lds_barrier();                                  // every multiplier is done with the images
+        if (mult) {
+#pragma unroll
+            for (int j = 0; j < kXBT; ++j)
+#pragma unroll
+                for (int nb2 = 0; nb2 < 2; ++nb2)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) os[j * (kTI * kSO) + (16 * nb2 + 4 * fk + rr) * kSO + 16 * cb + fr] = acc[j][nb2][rr];
+        }
+        lds_barrier();
+        optimiser();
+    }
+}
+
 }  // namespace aae

@@ -13,6 +13,7 @@
 // as whole 256-byte row segments (float4 per lane) instead of the MFMA's 64-byte column
 // fragments.  blockIdx.z = split-K slice.
 #pragma once
+#include <cstdlib>
 #include "device_common.h"
 
 namespace aae {
@@ -22,7 +23,37 @@ struct GemmShape {
     int M, N, K;
     int lda, ldb;
     int k_per_split;   // multiple of 16; gridDim.z slices
+    // XCD-aware tile order of the streaming GEMMs (launch_gemm_mode fills these; gx == 0: plain 3-D grid).  The tiles that
+    // share the LARGE operand form a group - the m-tiles of one n-tile (forward: the V3 tile), the n-tiles of one m-tile
+    // (weight gradient: the dL/dlogits tile), all tiles of one split-K slice (dX: both) - and a group's members get
+    // consecutive slots of ONE XCD (workgroup L runs on XCD L % 8): the operand comes from HBM once and from that XCD's L2
+    // for the other members.  With the plain grid order a group's members sit on different XCDs, or thousands of
+    // workgroups apart, and the vocabulary-wide operand crossed the HBM bus 4-8 times (r3: 1.3 GB instead of 0.69 per
+    // dV3 launch at batch 512).
+    int gx = 0, gy = 0, gz = 0;
 };
+
+// this workgroup's tile: false = a padding workgroup of the remapped grid
+__device__ __forceinline__ bool gemm_tile_of_block(const GemmShape& g, int& bx, int& by, int& bz) {
+    if (g.gx == 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return true; }
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    int ngroups, gsz;
+    if (g.gz > 1) { ngroups = g.gz; gsz = g.gx * g.gy; }
+    else if (g.gx >= g.gy) { ngroups = g.gx; gsz = g.gy; }
+    else { ngroups = g.gy; gsz = g.gx; }
+    const int grp = (s / gsz) * 8 + xcd, mem = s % gsz;
+    if (grp >= ngroups) return false;
+    if (g.gz > 1) { bz = grp; bx = mem % g.gx; by = mem / g.gx; }
+    else if (g.gx >= g.gy) { bx = grp; by = mem; bz = 0; }
+    else { by = grp; bx = mem; bz = 0; }
+    return true;
+}
+inline unsigned gemm_remapped_grid(GemmShape& g, int gx, int gy, int gz) {
+    g.gx = gx; g.gy = gy; g.gz = gz;
+    const int ngroups = gz > 1 ? gz : (gx >= gy ? gx : gy);
+    const int gsz = gz > 1 ? gx * gy : (gx >= gy ? gy : gx);
+    return (unsigned)(8 * ((ngroups + 7) / 8) * gsz);
+}
 
 // TS = square tile edge per 256-thread workgroup (4 waves as 2x2, each wave (TS/2)^2):
 //   64 for the streaming GEMMs over the item vocabulary; 32 for the tiny layer GEMMs, where a
@@ -59,8 +90,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (TS / 2), wn = (wave & 1) * (TS / 2);
-    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    int bx, by, bz;
+    if (!gemm_tile_of_block(g, bx, by, bz)) return;
+    const int m0 = by * TS, n0 = bx * TS;
+    const int kbeg = bz * g.k_per_split;
+    const int ntx = g.gx ? g.gx : (int)gridDim.x, nty = g.gx ? g.gy : (int)gridDim.y;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     f32x4 acc[MI][MI];
@@ -198,11 +232,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
         int gm = m0 + row, gn = n0 + col;
         if (gm < g.M && gn < g.N) {
             float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
-            epi.apply(st, gm, gn, g.N, v, (int)blockIdx.z);
+            epi.apply(st, gm, gn, g.N, v, bz);
         }
     }
     __syncthreads();
-    epi.finish(st, smem, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+    epi.finish(st, smem, bx + ntx * (by + nty * bz));
 }
 
 // -----------------------------------------------------------------------------------------
@@ -411,8 +445,11 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmShape g, Epi epi) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (TS / 2), wn = (wave & 1) * (TS / 2);
-    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    int bx, by, bz;
+    if (!gemm_tile_of_block(g, bx, by, bz)) return;
+    const int m0 = by * TS, n0 = bx * TS;
+    const int kbeg = bz * g.k_per_split;
+    const int ntx = g.gx ? g.gx : (int)gridDim.x, nty = g.gx ? g.gy : (int)gridDim.y;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     f32x4 acc[2][2];
@@ -533,17 +570,19 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmShape g, Epi epi) {
         int gm = m0 + row, gn = n0 + col;
         if (gm < g.M && gn < g.N) {
             float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
-            epi.apply(st, gm, gn, g.N, v, (int)blockIdx.z);
+            epi.apply(st, gm, gn, g.N, v, bz);
         }
     }
     __syncthreads();
-    epi.finish(st, reinterpret_cast<float*>(smem), (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+    epi.finish(st, reinterpret_cast<float*>(smem), bx + ntx * (by + nty * bz));
 }
 
 template <int AT, int BT, int BK, int TS, class Epi, bool BF = false>
-inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
+inline hipError_t launch_gemm(const GemmShape& g, const Epi& epi, int splits, hipStream_t s, bool remap = false) {
+    GemmShape gg = g;
     dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS, splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, BK, TS, Epi, BF>), grid, dim3(256), 0, s, g, epi);
+    if (remap) grid = dim3(gemm_remapped_grid(gg, (int)grid.x, (int)grid.y, (int)grid.z));
+    hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, BK, TS, Epi, BF>), grid, dim3(256), 0, s, gg, epi);
     return hipGetLastError();
 }
 // the streaming (vocabulary-wide) / small-layer variants in either arithmetic: bf16 = true takes 32-deep slabs
@@ -553,12 +592,15 @@ enum { kGemmF32 = 0, kGemmBf16 = 1, kGemmX3 = 2 };
 template <int AT, int BT, bool BIG, class Epi>
 inline hipError_t launch_gemm_mode(int mode, const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
     const bool bf16 = mode == kGemmBf16;
+    static const bool remap = getenv("AAE_NO_GEMM_REMAP") == nullptr;
     if (BIG && mode == kGemmX3) {
+        GemmShape gg = g;
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
-        hipLaunchKernelGGL((gemm_x3_kernel<AT, BT, Epi>), grid, dim3(256), 0, s, g, epi);
+        if (remap) grid = dim3(gemm_remapped_grid(gg, (int)grid.x, (int)grid.y, (int)grid.z));
+        hipLaunchKernelGGL((gemm_x3_kernel<AT, BT, Epi>), grid, dim3(256), 0, s, gg, epi);
         return hipGetLastError();
     }
-    if (BIG) return bf16 ? launch_gemm<AT, BT, 32, 64, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 16, 64, Epi>(g, epi, splits, s);
+    if (BIG) return bf16 ? launch_gemm<AT, BT, 32, 64, Epi, true>(g, epi, splits, s, remap) : launch_gemm<AT, BT, 16, 64, Epi>(g, epi, splits, s, remap);
     return bf16 ? launch_gemm<AT, BT, 64, 32, Epi, true>(g, epi, splits, s) : launch_gemm<AT, BT, 64, 32, Epi>(g, epi, splits, s);
 }
 
