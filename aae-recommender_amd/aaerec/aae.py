@@ -224,10 +224,10 @@ class AdversarialAutoEncoder:
             grad_mode="export" if dist is not None else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
             unfused_decoder=self._unfused_decoder, dense_noise=getattr(self, "_dense_noise", False),
-            # batches of 113..256 rows: the output layer as row blocks of the fused kernel (one critical launch + the
-            # deferred optimiser half; 0.70 -> 0.64 ms/step at 208 rows); beyond that the deferred half outlasts the rest
-            # of the step and the three GEMMs win (1.12 vs 1.48 ms at 512 rows), DESIGN.md 7.3
-            blocked_output=16 * 7 < self.batch_size <= 256 and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
+            # batches of 113..1664 rows: the output layer as row blocks of the fused kernel (one critical launch for all
+            # blocks + one deferred optimiser launch, both on the bf16-emulated product: 0.70 -> 0.64 ms/step at 208 rows,
+            # 0.93 -> 0.78 at 512); beyond 16 blocks the library takes the three streaming GEMMs
+            blocked_output=16 * 7 < self.batch_size <= 16 * 104 and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
         self.hip.load_params(params)
         self.enc, self.dec, self.disc = (_NetView(self, n) for n in ("enc", "dec", "disc"))
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")

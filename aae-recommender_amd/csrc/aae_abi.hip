@@ -1883,9 +1883,10 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     // chain, as aae_first_layer_forward does for the item slices, instead of in front of their first reader.  (Up to 112
     // rows the builder rides in the step's first chain launch.)  The side stream is in order behind the previous step's
     // deferred launch, which waited for that step's output layer - the alternate bucket set's last readers are older.
+    // (Not on the three-GEMM path: there the side stream holds the previous step's dV3 GEMM for most of this step.)
     {
         static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
-        if (bk_ahead && m->side && m->ev_bk && m->side_ordered && m->use_chain && m->rows > 16 * kMB && !m->buckets_valid) {
+        if (bk_ahead && m->side && m->ev_bk && m->last_out_split && m->use_chain && m->rows > 16 * kMB && !m->buckets_valid && fused_decoder_applies(m)) {
             TRY(build_tile_buckets(m, m->side));
             HIPCHK(hipEventRecord(m->ev_bk, m->side));
             m->bk_pending = true;
