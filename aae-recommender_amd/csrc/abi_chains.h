@@ -1,0 +1,641 @@
+// The hidden stacks as layer-chain programs (chain.h / chain4.h), the grouped weight-gradient launches, tile buckets and the
+// first layer's per-item update, next-batch prefetch, VAE / discriminator / generator programs.
+// (one of the parts of aae_abi.hip's translation unit: included there in order, not on its own)
+#pragma once
+
+namespace {
+
+// ==========================================================================================
+// chain path (chain.h): the hidden stacks as row-blocked programs
+// ==========================================================================================
+ChainOp cop(int kind, int src, int dst, int N) {
+    ChainOp o; memset(&o, 0, sizeof(o));
+    o.kind = kind; o.src = src; o.dst = dst; o.N = N; o.one_col = -1; o.scale = 1.f; o.yslot = 0; o.fake_slot = -1;
+    return o;
+}
+ChainOp cop_load(const float* g, int ld, int dst, int N, int row0 = 0) {
+    ChainOp o = cop(COP_LOAD, 0, dst, N); o.W = g; o.ldw = ld; o.out_row0 = row0; return o;
+}
+ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int epi) {
+    ChainOp o = cop(kind, src, dst, N); o.W = W.p; o.ldw = (int)W.ld; o.K = K; o.epi = epi;
+    if (kind == COP_LINEAR_DX) { o.Wkn = W.p; o.ldkn = (int)W.ld; }      // already k-major
+    return o;
+}
+void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
+
+W4Copies w4_of(const aae_model* m, int pid) {
+    return W4Copies{m->PT[pid].p, m->D4[pid].p, (int)m->P[pid].rows, (int)m->P[pid].cols};
+}
+// where dL/d(a1) of the encoder backward goes: gb3, or (external first layer, export mode) the tail of ga1x
+float* ga1_ptr(const aae_model* m) {
+    return (m->ext_first && m->ga1x.p) ? m->ga1x.p + (size_t)(m->R - m->rows) * m->ldh : m->gb3.p;
+}
+// (re-)derive the k4-interleaved copies of a hidden layer after something other than the optimiser kernels wrote the weights
+void ensure_pt(aae_model* m, int pid, hipStream_t s) {
+    const Ten& T = m->PT[pid];
+    if (!T.p || m->pt_ok[pid]) return;
+    const Ten& W = m->P[pid];
+    hipLaunchKernelGGL(interleave4_kernel, dim3(grid1d((size_t)W.rows * ((W.cols + 3) / 4))), dim3(256), 0, s, W.p, (int)W.ld,
+                       w4_of(m, pid));
+    m->pt_ok[pid] = true;
+}
+
+// forward layer: dst[rows][N] = epi(src[rows][K] * W[N][K]^T), K = in + 1 (the bias input is the last column)
+ChainOp cop_fwd(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
+    ChainOp o = cop_linear(COP_LINEAR, src, dst, m->P[pid], K, N, epi);
+    if (m->PT[pid].p) { ensure_pt(m, pid, s); o.W4 = m->PT[pid].p; o.ns4 = (int)m->P[pid].rows; }
+    return o;
+}
+
+// dX of a hidden layer: dst[rows][N] = epi(src[rows][K] * W[K][0:N]).  chain4.h reads the D4 copy (k = output row) with
+// 16-byte loads, or the matrix itself (k-major for this product); chain.h walks the matrix.
+ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
+    ChainOp o = cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);       // (Wkn = the matrix itself: k-major for this product)
+    if (m->D4[pid].p) { ensure_pt(m, pid, s); o.W4 = m->D4[pid].p; o.ns4 = (int)m->P[pid].cols; }
+    return o;
+}
+
+struct ChainBuilder {
+    ChainProgram P;
+    ChainBuilder(const aae_model* m, int rows) {
+        memset(&P, 0, sizeof(P));
+        P.rows = rows; P.act = m->cfg.activation; P.seed = m->cfg.seed; P.step_ctr = m->step_ctr;
+        P.loss_out = m->losses; P.loss_slot = 3;
+        { const char* e = getenv("AAE_CHAIN_SKIP"); P.dbg = e ? atoi(e) : 0; }
+    }
+    ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
+};
+
+int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
+    if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
+    const int grid = (cb.P.rows + kCR - 1) / kCR + (cb.P.bk.enabled ? 1 : 0);
+    static const bool want_ts = getenv("AAE_CHAIN_TS") != nullptr;      // debug: per-op timeline of workgroup 0
+    static unsigned long long* ts_dev = nullptr;
+    if (want_ts) {
+        if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
+        cb.P.ts = ts_dev;
+    }
+    ProfScope ps(m, AAE_K_CHAIN, s);
+    // 4-row workgroups (chain4.h) whenever every linear op of the program has its k-major matrix (all but the VAE's)
+    bool four = m->use_chain4;
+    for (int i = 0; i < cb.P.nops && four; ++i)
+        if ((cb.P.ops[i].kind == COP_LINEAR || cb.P.ops[i].kind == COP_LINEAR_DX) && !cb.P.ops[i].Wkn && !cb.P.ops[i].W4) four = false;
+    for (int i = 0; i < cb.P.nops && four; ++i)
+        if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
+    for (int i = 0; i < cb.P.nops; ++i)
+        if (cb.P.ops[i].row_lo > 0 && !four) return fail(AAE_ESTATE, "a program prefix for the upper rows needs the 4-row chain kernel");
+    if (four) {
+        const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
+        if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+        else hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    } else if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    LAUNCHCHK("chain_kernel");
+    if (want_ts) {
+        unsigned long long h[32];
+        hipStreamSynchronize(s);
+        hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "DISC_HEAD", "PRIOR"};
+        fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
+        for (int i = 0; i < cb.P.nops; ++i)
+            fprintf(stderr, " %s(K%d,N%d%s%s)=%.2f", names[cb.P.ops[i].kind], cb.P.ops[i].K, cb.P.ops[i].N,
+                    cb.P.ops[i].out ? ",st" : "", cb.P.ops[i].out2 ? ",st2" : "", (h[i + 1] - h[i]) * 0.01);
+        fprintf(stderr, "\n");
+        if (cb.P.nops > 2)
+            fprintf(stderr, "   [op 2, wave 0 of workgroup 0] loads+mfma+partials=%.2f wait-barrier=%.2f epi-ctx=%.2f epilogue=%.2f barrier=%.2f (us)\n",
+                    (h[21] - h[20]) * 0.01, (h[22] - h[21]) * 0.01, (h[23] - h[22]) * 0.01, (h[24] - h[23]) * 0.01, (h[25] - h[24]) * 0.01);
+    }
+    return AAE_OK;
+}
+
+// up to 4 weight-gradient jobs in one launch
+struct DwBuilder {
+    DwGroup g; int tiles;
+    DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
+    void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
+        DwJob& J = g.jobs[g.njobs++];
+        const Ten& W = m->P[pid];
+        const int set = (which == O_GEN) ? 1 : 0;
+        J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
+        J.p = W.p; J.m = m->M[set][pid].p; J.v = m->V[set][pid].p; J.ld = (int)W.ld; J.sc = m->sc + which;
+        J.grad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[pid].p : nullptr;
+        J.w4 = w4_of(m, pid);                                  // (fused optimiser: the k4-interleaved copies follow p)
+        J.tile0 = tiles; J.tiles_n = (J.N + 31) / 32;
+        tiles += ((J.M + 31) / 32) * J.tiles_n;
+    }
+    // the first encoder layer's bias gradient + update of optimiser `which` ride along (the row-sparse weight gradient +
+    // optimiser follow as a launch of their own: encoder_first_layer_update(..., merged = true))
+    int add_first_layer(aae_model* m, const float* ga1, int which, hipStream_t s) {
+        const int set = (which == O_GEN) ? 1 : 0;
+        W1Job& w = g.w1;
+        w.enabled = 1; w.ga1 = ga1; w.ld = m->ldh; w.h = m->h; w.rows = m->rows;
+        w.bp = m->P[P_B1].p; w.bm = m->M[set][P_B1].p; w.bv1 = m->V[set][P_B1].p;
+        w.bgrad = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_B1].p : nullptr; w.sc = m->sc + which;
+        w.ncol = (m->h + 63) / 64;
+        // the row-sparse weight gradient + optimiser of the layer rides along while its row lists fit the kernel's static LDS
+        // (batches up to ~2 500 rows); not for the dense noisy input (a dense product follows) or an external
+        // first layer (the rows live with their item slices)
+        static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
+        w.nitem = 0;
+        m->w1_items_merged = false;
+        if (!no_merge && !m->dense_step && !m->ext_first && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
+            TRY(ensure_buckets(m, s));
+            w.items = w1_items_args(m, ga1, 0, 0, which);
+            w.nitem = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+            m->w1_items_merged = true;
+        }
+        return AAE_OK;
+    }
+    int launch(hipStream_t s) {
+        int blocks = tiles;
+        if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
+        hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
+        LAUNCHCHK("grouped_dw_kernel");
+        return AAE_OK;
+    }
+};
+
+// Encoder hidden stack from the gathered first layer (eh1 in global): lin2, lin3, output activation.
+// ops appended to `cb`; z ends in slot 2.
+void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_t* mk2, uint32_t sid2, int rows,
+                        float* eh2_out, hipStream_t s, const uint8_t* mk1 = nullptr, uint32_t sid1 = 0) {
+    const int h = m->h;
+    if (m->ext_first) {
+        // the first layer lives with the caller (aae_set_first_layer_external): a1 -> dropout -> activation here
+        cb.add(cop_load(m->a1.p, m->ldh, 3, h));
+        ChainOp& e1 = cb.add(cop(COP_DROPACT, 3, 0, h));
+        e1.d = make_drop(m, 0, train, mk1, nullptr, rows, h, sid1); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
+    } else {
+        ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    }
+    ChainOp& a = cb.add(cop_fwd(m, P_W2, 0, 1, h + 1, h, CEPI_DROPACT, s));
+    a.d = make_drop(m, 1, train, mk2, nullptr, rows, h, sid2); a.one_col = h;
+    if (eh2_out) cop_out(a, eh2_out, m->ldh);
+    cb.add(cop_fwd(m, P_W3, 1, 2, h + 1, m->c, CEPI_NONE, s));
+}
+
+// The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
+// as one extra workgroup (chain.h), off the critical path.
+static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m->rows + kRowBlock - 1) / kRowBlock; }
+static bool fused_decoder_applies(const aae_model* m) {
+    const bool one = m->rows <= 16 * kMB;
+    // The row-blocked form pays while its deferred half (2 * rows * N * (h + 1) flop of GEMM2 at the optimiser kernel's
+    // ~30 TFLOP/s) fits beside the rest of the step: 800 rows x 12.5 k items (an item slice at world 8) 0.40 against 0.46 ms
+    // per step, 208 x 100 k 0.64 against 0.70; beyond ~32 M cells the next step waits for it and the three GEMMs win
+    // (512 x 100 k: 1.48 against 1.12 ms; 512 x 275 k, a C5 slice: 3.7 against 2.7 ms).  AAE_BLOCKED_ANY lifts the cap (tests).
+    // r3: with both launches on the emulated product (dec_crit_x3.h: the deferred half of all blocks in ONE launch for any
+    // vocabulary, dec_opt_blocks_x3_kernel) the cap is gone: 512 x 100 k 0.77 ms/step against 0.93 on the three GEMMs.
+    const bool blocked = !one && m->blocked_ok && !m->bf16 && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
+                         m->cfg.grad_mode == AAE_GRAD_FUSED &&
+                         (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr));
+    return m->fused_ok && !m->force_unfused && (one || blocked) &&
+           ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
+           (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
+}
+// counting sort of the running batch's entries into the fused output layer's 32-item tiles (buckets.h / dec_fused.h)
+static void flip_bucket_set(aae_model* m) {
+    std::swap(m->tstart, m->tstart2); std::swap(m->teb, m->teb2); std::swap(m->ten, m->ten2); std::swap(m->tev, m->tev2);
+}
+int build_tile_buckets(aae_model* m, hipStream_t s) {
+    const int ntiles = (m->N + kTI - 1) / kTI, B = m->rows;
+    flip_bucket_set(m);
+    const size_t lds1 = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+    if (ntiles <= kBucketMaxTiles && B <= kBucketMaxDocs && (m->fused_ok || lds1 <= 48 * 1024)) {      // (fused_ok: the LDS limit of the kernel was raised)
+        hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds1, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
+    } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
+        // (the global batch of an item slice: one launch instead of four, 25 -> 9 us)
+        const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
+        hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
+    } else {
+        const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));
+        hipLaunchKernelGGL(zero_int_kernel, dim3(std::min(64, ntiles / 256 + 1)), dim3(256), 0, s, m->tcount, ntiles + 1);
+        hipLaunchKernelGGL(tile_hist_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tcount);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, m->tcount, m->tstart, ntiles);
+        hipLaunchKernelGGL(tile_fill_kernel, dim3(B, gy), dim3(256), 0, s, m->bv, m->tstart, m->tcount, m->teb, m->ten, m->tev);
+    }
+    LAUNCHCHK("tile buckets");
+    m->buckets_valid = true;
+    return AAE_OK;
+}
+// the tile buckets of the running batch exist and are visible to stream s (the first layer's update reads them, w1_update.h)
+int ensure_buckets(aae_model* m, hipStream_t s) {
+    if (m->bk_pending) {                // built on the side stream (aae_first_layer_forward)
+        HIPCHK(hipStreamWaitEvent(s, m->ev_bk, 0));
+        m->bk_pending = false;
+    }
+    if (!m->buckets_valid) TRY(build_tile_buckets(m, s));
+    return AAE_OK;
+}
+
+// The sparse first layer's weight gradient over the running batch and optimiser `which` on the touched rows (or the
+// gradient rows -> AAE_T_GRAD + ENC_W1T in export mode), in a fixed summation order (w1_update.h)
+W1Items w1_items_args(aae_model* m, const float* ga1, int rpb, size_t bstride, int which) {
+    const int set = (which == O_GEN) ? 1 : 0;
+    W1Items a;
+    a.ulist = m->ulist; a.ucount = m->ucount;
+    a.tstart = m->tstart; a.eb = m->teb; a.en = m->ten; a.ev = m->tev;
+    a.ga1 = ga1; a.ld = m->ldh; a.rpb = rpb; a.bstride = bstride;
+    a.rscale = m->rscale; a.rows = m->rows; a.h = m->h;
+    a.W = m->P[P_W1T].p; a.M = m->M[set][P_W1T].p; a.V = m->V[set][P_W1T].p; a.ldw = m->ldw1;
+    a.gout = m->cfg.grad_mode == AAE_GRAD_EXPORT ? m->Gr[P_W1T].p : nullptr;
+    a.sc = m->sc + which; a.tsync = m->tsync; a.step_ctr = m->step_ctr;
+    a.mark_synced = (which == O_GEN || m->ae_only) ? 1 : 0;
+    return a;
+}
+int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int which, hipStream_t s) {
+    TRY(ensure_buckets(m, s));
+    const W1Items a = w1_items_args(m, ga1, rpb, bstride, which);
+    // one 256-thread workgroup per item
+    const size_t lds = sizeof(int) * w1_items_lds_words(m->rows);
+    if (lds > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
+    ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
+    const int items = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+    hipLaunchKernelGGL(w1_item_update_kernel, dim3(items), dim3(256), lds, s, a);
+    LAUNCHCHK("w1_item_update");
+    return AAE_OK;
+}
+
+static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
+    const int ntiles = (m->N + kTI - 1) / kTI;
+    const size_t need = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+    if (m->buckets_valid || !fused_decoder_applies(m) || ntiles > kBucketMaxTiles || m->rows > kBucketMaxDocs ||
+        need > (size_t)kCSlots * kCR * kCL * sizeof(float) || getenv("AAE_NO_PIGGYBACK"))
+        return;
+    flip_bucket_set(m);
+    BucketJob& b = cb.P.bk;
+    b.bv = m->bv; b.ntiles = ntiles; b.tstart = m->tstart; b.eb = m->teb; b.en = m->ten; b.ev = m->tev; b.enabled = 1;
+    m->buckets_valid = true;
+}
+
+// ae forward after the gather: encoder tail (+ optionally the decoder's two hidden layers)
+int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* z_out, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    piggyback_buckets(m, cb);
+    chain_encoder_tail(m, cb, true, I.masks_dev[1], 1, B, m->eh2.p, s, I.masks_dev[0], 0);
+    // the encoder's output activation; the identity (gauss prior, aae.py:97-101) is no op of its own: its stores and
+    // bias-input column ride on the last linear layer
+    ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
+    f.aux = m->cfg.enc_final;
+    cop_out(f, m->zc.p, m->ldc); f.out2 = m->zsave.p; f.ldo2 = m->ldz;
+    if (z_out) { ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, z_out, c); }
+    if (with_dec) {
+        if (m->cfg.cond_inc > 0) {
+            ChainOp& cl = cb.add(cop_load(cond_dev, m->cfg.cond_inc, 2, m->cfg.cond_inc)); cl.dst_col0 = c; cl.one_col = cp;
+        } else {
+            f.one_col = cp;
+        }
+        ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
+        v1.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
+        ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 3, 4, h + 1, h, CEPI_DROPACT, s));
+        v2.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
+    }
+    m->dec_hidden_done = with_dec;
+    return launch_chain(m, cb, s);
+}
+
+// decoder hidden layers from zc (global): split API and predict
+int chain_dec_hidden(aae_model* m, bool train, int rows, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 0, cp)); l.one_col = cp;
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 0, 1, cp + 1, h, CEPI_DROPACT, s));
+    v1.d = make_drop(m, 0, train, I.masks_dev[2], nullptr, rows, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
+    ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 1, 2, h + 1, h, CEPI_DROPACT, s));
+    v2.d = make_drop(m, 1, train, I.masks_dev[3], nullptr, rows, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
+// decoder backward below the output layer (+ optionally the encoder backward) as one program.
+//   dec: sum of the 16 dA2 partial slabs -> act'/dropout -> V2 -> V1 -> gzc
+//   enc: dz (slot or external) -> output activation' -> W3 -> W2 -> ga1
+int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* part_slabs, size_t slab_stride,
+                      const float* gz_ext, int ld_gz, float* dzc_out, int which, hipStream_t s, int nslab = 16) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    if (dec_part) {
+        if (part_slabs) {
+            // sum of the dA2 partial slabs times act'(dh2) and the dropout scale in one op (dh2 read from global)
+            ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 2, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = nslab; ss.stride = slab_stride;
+            ss.epi = CEPI_ACTBWD; ss.aux_ptr = m->dh2.p; ss.aux_ld = m->ldh;
+            ss.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); cop_out(ss, m->gb0.p, m->ldh);
+        } else {
+            cb.add(cop_load(m->gb0.p, m->ldh, 2, h));      // unfused decoder path: gb0 already holds dL/da2
+        }
+        cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
+        ChainOp& x2 = cb.add(cop_dx(m, P_V2, 2, 4, h, h, CEPI_ACTBWD, s)); x2.yslot = 3;
+        x2.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); cop_out(x2, m->gb1.p, m->ldh);
+        ChainOp& x1 = cb.add(cop_dx(m, P_V1, 4, 5, h, cp, CEPI_NONE, s));
+        cop_out(x1, m->gzc.p, m->ldc);
+        if (dzc_out) { x1.out2 = dzc_out; x1.ldo2 = cp; }
+    }
+    if (enc_part) {
+        if (!dec_part || gz_ext) cb.add(cop_load(gz_ext ? gz_ext : m->gzc.p, gz_ext ? ld_gz : m->ldc, 5, c));
+        // the encoder's output activation backward; for the identity (gauss prior) with nothing concatenated the dX op
+        // that produced dL/dz stores it as the W3 weight-gradient operand itself and no op is needed
+        int sg = 7;
+        ChainOp* prod = (dec_part && !gz_ext && cb.P.nops) ? &cb.P.ops[cb.P.nops - 1] : nullptr;
+        if (m->cfg.enc_final == AAE_FINAL_LINEAR && prod && cp == c && !prod->out2) {
+            prod->out2 = m->ga3.p; prod->ldo2 = m->ldz; sg = 5;
+        } else {
+            if (m->cfg.enc_final != AAE_FINAL_LINEAR) cb.add(cop_load(m->zsave.p, m->ldz, 6, c));   // z: only the derivative of a softmax / sigmoid output needs it
+            ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
+            cop_out(fb, m->ga3.p, m->ldz);
+        }
+        cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
+        ChainOp& x3 = cb.add(cop_dx(m, P_W3, sg, 9, c, h, CEPI_ACTBWD, s)); x3.yslot = 8;
+        x3.d = make_drop(m, 1, true, I.masks_dev[which == O_GEN ? 9 : 1], nullptr, B, h, which == O_GEN ? 9 : 1);
+        cop_out(x3, m->gb2.p, m->ldh);
+        cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
+        ChainOp& x2 = cb.add(cop_dx(m, P_W2, 9, 1, h, h, CEPI_ACTBWD, s)); x2.yslot = 0;
+        x2.d = make_drop(m, 0, true, I.masks_dev[which == O_GEN ? 8 : 0], nullptr, B, h, which == O_GEN ? 8 : 0);
+        cop_out(x2, ga1_ptr(m), m->ldh);
+    }
+    return launch_chain(m, cb, s);
+}
+
+// first encoder layer's weight gradient (sparse scatter), bias gradient and their optimiser
+int encoder_first_layer_update(aae_model* m, const float* ga1, int which, hipStream_t s, bool merged = false) {
+    const int B = m->rows, h = m->h;
+    const int set = (which == O_GEN) ? 1 : 0;
+    const bool exportg = m->cfg.grad_mode == AAE_GRAD_EXPORT;
+    if (m->dense_step) {
+        // dW1T [N][h] = x^T [N][B] * dL/da1 [B][h] with the fused optimiser on EVERY row (torch.optim.Adam is dense), then
+        // all rows carry this step
+        if (!merged) {
+            hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
+                               m->M[set][P_B1].p, m->V[set][P_B1].p, (float*)nullptr, m->sc + which);
+            LAUNCHCHK("colsum_adam");
+        }
+        TRY(linear_dw(m, m->Xn.p, m->ldn, B, ga1, m->ldh, P_W1T, which, s));
+        hipLaunchKernelGGL(fill_tsync_kernel, dim3(grid1d((size_t)m->N)), dim3(256), 0, s, m->tsync, m->N, m->step_ctr);
+        LAUNCHCHK("fill_tsync");
+        return AAE_OK;
+    }
+    if (!merged) {
+        hipLaunchKernelGGL(colsum_adam_kernel, dim3((h + 63) / 64), dim3(1024), 0, s, ga1, B, h, m->ldh, m->P[P_B1].p,
+                           m->M[set][P_B1].p, m->V[set][P_B1].p, exportg ? m->Gr[P_B1].p : (float*)nullptr, m->sc + which);
+        LAUNCHCHK("colsum_adam");
+    }
+    if (merged && m->w1_items_merged) { m->w1_items_merged = false; return AAE_OK; }      // (rode in the grouped dW launch)
+    // (export mode: the gradient rows -> AAE_T_GRAD + ENC_W1T; aae_w1_export / exchange / aae_w1_import follow)
+    return launch_w1_items(m, ga1, 0, 0, which, s);
+}
+
+// done_ev: an event that rides on the launch's completion signal (the side stream's "the step has begun" mark)
+// head: tell the side stream that the main stream has passed this launch (ev_head rides on its completion signal)
+int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t sid1, hipStream_t s, bool head = false,
+                       bool open_step = false) {
+    const int B = m->rows, h = m->h;
+    DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
+    ProfScope ps(m, AAE_K_ENC_GATHER, s);
+    size_t shm = (size_t)16 * r4(h) * sizeof(float);
+    hipExtLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), (uint32_t)shm, s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
+                          (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
+                          m->a1.p, m->eh1.p, m->ldh, (int)m->cfg.activation, d1, (uint64_t)m->cfg.seed,
+                          (const long long*)m->step_ctr, m->rscale, m->doc_l1,
+                          // open_step: the step-opening bookkeeping rides in this launch (advance_step_body) and the
+                          // workgroups take the step number from the host (m->hstep == *step_ctr once the step is open)
+                          AdvanceJob{m->sc, m->step_ctr, m->lazy ? m->tab : nullptr, m->losses, open_step ? 1 : 0},
+                          (long long)(open_step ? m->hstep : -1));
+    LAUNCHCHK("enc_gather");
+    return AAE_OK;
+}
+
+static bool same_batch(const aae_batch& a, const aae_batch& b) {
+    return a.indptr_dev == b.indptr_dev && a.indices_dev == b.indices_dev && a.values_dev == b.values_dev &&
+           a.rows_dev == b.rows_dev && a.row_start == b.row_start && a.n_rows == b.n_rows;
+}
+
+// aae_prefetch_batch, second half: the hinted batch's unique-item list + deferred-Adam catch-up (through the RUNNING
+// step, whose scalars advance_step has published by the time ev_head fires) on the side stream, into the second list
+// set.  Rows of the running batch are skipped: the step's own updates bring them to the same step.
+int launch_prefetch(aae_model* m, bool wait_head = true) {
+    const aae_batch& b = m->pf_batch;
+    m->pf_armed = false;
+    m->pf_after_opt = !wait_head;
+    if (!m->side || !m->mark2 || !m->lazy) return AAE_OK;
+    BatchView bv; bv.indptr = b.indptr_dev; bv.indices = b.indices_dev; bv.values = b.values_dev;
+    bv.rows = b.rows_dev; bv.row_start = b.row_start; bv.n_rows = b.n_rows;
+    const int mr = b.max_row_nnz > 0 ? b.max_row_nnz : 1024;
+    const int chunks = std::max(1, std::min(64, (mr + 15) / 16));
+    const int gy = std::max(1, std::min(16, chunks / 16 + 1));
+    hipStream_t q = m->side;
+    if (wait_head) HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));      // (else: the caller enqueues behind work that is ordered behind the step's head)
+    hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
+    hipLaunchKernelGGL(uniq_items_kernel, dim3(b.n_rows, gy), dim3(256), 0, q, bv, m->mark2, m->stamp2, m->ulist2, m->ucount2);
+    if (m->cfg.optimizer == AAE_OPT_ADAM) {
+        const int grid = std::min(m->cfg.max_nnz, std::max(256, b.n_rows * 32));
+        hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, q, m->ulist2, m->ucount2, m->N, m->tsync,
+                           m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,
+                           m->ldw1, m->h, m->tab, m->step_ctr, 0, m->mark, m->stamp);
+    }
+    LAUNCHCHK("prefetch (unique items + catch-up of the next batch)");
+    TRY(side_done(m, m->ev_pf));
+    m->pf_pending = true;
+    m->pf_built = true; m->pf_step = m->hstep + 1; m->pf_built_batch = b;
+    return AAE_OK;
+}
+
+// ---- VAE (reference vae.py:47-266) -----------------------------------------------------------
+// forward: eh1 (the gather's act(fc1 x)) -> [mu | logvar] = [fc21; fc22] eh1 -> z = mu + eps * exp(logvar/2)
+// -> (constant condition block) -> dh2 = act(fc3 z): the input of the vocabulary-wide output layer fc4
+int chain_vae_forward(aae_model* m, const float* cond_dev, const float* eps_dev, int rows, hipStream_t s) {
+    const int h = m->h, c = m->c, cp = m->cp;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    ChainOp& ml = cb.add(cop_fwd(m, P_W3, 0, 1, h + 1, 2 * c, CEPI_NONE, s));
+    cop_out(ml, m->mulv.p, (int)m->mulv.ld);
+    ChainOp& rp = cb.add(cop(COP_REPARAM, 1, 2, c));
+    rp.W = eps_dev; rp.ldw = c; rp.aux = 12; rp.aux_ptr = m->veps.p; rp.aux_ld = (int)m->veps.ld;
+    if (m->cfg.cond_inc > 0) {
+        ChainOp& cl = cb.add(cop_load(cond_dev, m->cfg.cond_inc, 2, m->cfg.cond_inc)); cl.dst_col0 = c; cl.one_col = cp;
+    } else {
+        rp.one_col = cp;
+    }
+    ChainOp& st = cb.add(cop(COP_STORE, 2, 2, cp)); cop_out(st, m->zc.p, m->ldc);
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
+    v1.one_col = h; cop_out(v1, m->dh2.p, m->ldh);        // no dropout in the VAE: DropSpec stays disabled
+    return launch_chain(m, cb, s);
+}
+
+// the two halves of chain_vae_forward for a caller that imposes its conditions between them (aae_vae_encode / the
+// decoder half inside aae_vae_decode_backward and aae_decode)
+int chain_vae_encode(aae_model* m, const float* eps_dev, float* z_out, int rows, hipStream_t s) {
+    const int h = m->h, c = m->c;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->eh1.p, m->ldh, 0, h)); l.one_col = h;
+    ChainOp& ml = cb.add(cop_fwd(m, P_W3, 0, 1, h + 1, 2 * c, CEPI_NONE, s));
+    cop_out(ml, m->mulv.p, (int)m->mulv.ld);
+    ChainOp& rp = cb.add(cop(COP_REPARAM, 1, 2, c));
+    rp.W = eps_dev; rp.ldw = c; rp.aux = 12; rp.aux_ptr = m->veps.p; rp.aux_ld = (int)m->veps.ld;
+    ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, m->zc.p, m->ldc);
+    if (z_out) { st.out2 = z_out; st.ldo2 = c; }
+    return launch_chain(m, cb, s);
+}
+int chain_vae_dec_hidden(aae_model* m, int rows, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    ChainBuilder cb(m, rows);
+    ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 2, cp)); l.one_col = cp;
+    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
+    v1.one_col = h; cop_out(v1, m->dh2.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+// ... and of chain_vae_backward: down to dL/d(decoder input) (-> gzc and the caller), then from dL/dz on
+int chain_vae_backward_dec(aae_model* m, const float* part_slabs, size_t slab_stride, float* dzc_out, hipStream_t s) {
+    const int B = m->rows, h = m->h, cp = m->cp;
+    ChainBuilder cb(m, B);
+    if (part_slabs) {
+        ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+        cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
+        ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1; cop_out(ab, m->gb0.p, m->ldh);
+    } else {
+        cb.add(cop_load(m->gb0.p, m->ldh, 2, h));
+    }
+    ChainOp& dzc = cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    cop_out(dzc, m->gzc.p, m->ldc);
+    if (dzc_out) { dzc.out2 = dzc_out; dzc.ldo2 = cp; }
+    return launch_chain(m, cb, s);
+}
+int chain_vae_backward_enc(aae_model* m, const float* dz_dev, int ld_dz, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 1;                                   // KL sum -> losses[1]
+    cb.add(cop_load(dz_dev, ld_dz, 3, c));
+    cb.add(cop_load(m->mulv.p, (int)m->mulv.ld, 4, 2 * c));
+    ChainOp& rb = cb.add(cop(COP_REPARAM_BWD, 3, 5, 2 * c)); rb.yslot = 4; rb.scale = m->grad_scale;
+    rb.aux_ptr = m->veps.p; rb.aux_ld = (int)m->veps.ld; cop_out(rb, m->gmulv.p, (int)m->gmulv.ld);
+    cb.add(cop_load(m->eh1.p, m->ldh, 6, h));
+    ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 5, 7, m->P[P_W3], 2 * c, h, CEPI_ACTBWD)); x1.yslot = 6;
+    cop_out(x1, m->gb3.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
+// backward below the output layer: dL/d(dh2) -> fc3 -> dz -> (dmu, dlogvar) incl. the KL term -> [fc21; fc22] -> ga1
+int chain_vae_backward(aae_model* m, const float* part_slabs, size_t slab_stride, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c, cp = m->cp;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 1;                                   // KL sum -> losses[1]
+    if (part_slabs) {
+        ChainOp& ss = cb.add(cop(COP_SLABSUM, 0, 0, h)); ss.W = part_slabs; ss.ldw = m->ldh; ss.aux = 16; ss.stride = slab_stride;
+        cb.add(cop_load(m->dh2.p, m->ldh, 1, h));
+        ChainOp& ab = cb.add(cop(COP_ACTBWD, 0, 2, h)); ab.yslot = 1; cop_out(ab, m->gb0.p, m->ldh);
+    } else {
+        cb.add(cop_load(m->gb0.p, m->ldh, 2, h));         // unfused decoder path: gb0 already holds dL/d(pre-activation)
+    }
+    ChainOp& dzc = cb.add(cop_linear(COP_LINEAR_DX, 2, 3, m->P[P_V1], h, cp, CEPI_NONE));
+    if (cp > c) cop_out(dzc, m->gzc.p, m->ldc);          // dL/d(decoder input): its condition columns train a device-native CategoricalCondition
+    cb.add(cop_load(m->mulv.p, (int)m->mulv.ld, 4, 2 * c));
+    ChainOp& rb = cb.add(cop(COP_REPARAM_BWD, 3, 5, 2 * c)); rb.yslot = 4; rb.scale = m->grad_scale;
+    rb.aux_ptr = m->veps.p; rb.aux_ld = (int)m->veps.ld; cop_out(rb, m->gmulv.p, (int)m->gmulv.ld);
+    cb.add(cop_load(m->eh1.p, m->ldh, 6, h));
+    ChainOp& x1 = cb.add(cop_linear(COP_LINEAR_DX, 5, 7, m->P[P_W3], 2 * c, h, CEPI_ACTBWD)); x1.yslot = 6;
+    cop_out(x1, m->gb3.p, m->ldh);
+    return launch_chain(m, cb, s);
+}
+
+// disc_step on the chain path
+int chain_disc_step(aae_model* m, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    const aae_rng_inject& I = m->inj;
+    if (!m->ext_first) TRY(gather_first_layer(m, false, nullptr, 0, s));     // (external: the caller refreshed AAE_T_ACT_A1)
+    // Enc_eval is row-local like the discriminator program behind it: with 4-row workgroups and a batch that is a
+    // multiple of 4 it runs as a PREFIX of that program in the workgroups of the z_fake rows (ChainOp::row_lo), z_fake
+    // handed over in a slot - one launch (and its ~4.5 us floor) less per step
+    static const bool merge_ok = getenv("AAE_NO_DISC_MERGE") == nullptr;
+    bool merged = merge_ok && m->use_chain4 && B % kR4 == 0 && !m->vae;
+    for (int pid : {P_W2, P_W3, P_D1, P_D2}) merged = merged && m->PT[pid].p != nullptr;
+    if (!merged) {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)
+        ChainBuilder cb(m, B);
+        chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
+        ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? cb.P.ops[cb.P.nops - 1] : cb.add(cop(COP_FINAL_FWD, 2, 2, c));
+        f.aux = m->cfg.enc_final; cop_out(f, m->zin.p, m->ldz, B);
+        TRY(launch_chain(m, cb, s));
+    }
+    {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
+        ChainBuilder cb(m, 2 * B);
+        cb.P.loss_slot = 1;
+        if (merged) {
+            chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
+            if (m->cfg.enc_final != AAE_FINAL_LINEAR) { ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final; }
+            for (int i = 0; i < cb.P.nops; ++i) {
+                ChainOp& o = cb.P.ops[i];
+                o.row_lo = B;                               // program row r >= B = document r - B
+                if (o.kind == COP_LOAD || o.out) o.out_row0 = -B;
+            }
+        }
+        // rows [0, B): z_real drawn (or injected) right here; rows [B, 2B): z_fake of the program above
+        ChainOp& l = cb.add(cop(COP_PRIOR, 0, 0, c)); l.one_col = c;
+        l.W = m->zin.p; l.ldw = m->ldz; l.row_split = B; l.aux = m->cfg.prior;
+        l.scale = m->cfg.has_prior_scale ? m->cfg.prior_scale : 1.0f;
+        l.grow0 = m->rng_row0;
+        l.aux_ptr = m->cfg.rng_mode == AAE_RNG_DEVICE ? nullptr : const_cast<float*>(I.z_real_dev); l.aux_ld = c;
+        cop_out(l, m->zin.p, m->ldz);                      // the weight-gradient GEMM of D1 reads all 2B rows
+        if (merged) l.fake_slot = 2;                       // (z_fake sits in slot 2 of the workgroup that just computed it)
+        ChainOp& d1 = cb.add(cop_fwd(m, P_D1, 0, 1, c + 1, h, CEPI_DROPACT, s));
+        d1.d = make_drop(m, 0, true, I.masks_dev[4], I.masks_dev[6], B, h, 4); d1.one_col = h; cop_out(d1, m->xh1.p, m->ldh);
+        ChainOp& d2 = cb.add(cop_fwd(m, P_D2, 1, 2, h + 1, h, CEPI_DROPACT, s));
+        d2.d = make_drop(m, 1, true, I.masks_dev[5], I.masks_dev[7], B, h, 5); d2.one_col = h; cop_out(d2, m->xh2.p, m->ldh);
+        // D3 (h -> 1) + sigmoid + adversarial loss + its dX in one op
+        ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 2, 5, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 2; x3.d = d2.d;
+        x3.aux = 0; x3.row_split = B; x3.scale = m->grad_scale; x3.aux_ptr = m->ga3.p; x3.aux_ld = 4;
+        cop_out(x3, m->gb0.p, m->ldh);
+        ChainOp& x2 = cb.add(cop_dx(m, P_D2, 5, 6, h, h, CEPI_ACTBWD, s)); x2.yslot = 1; x2.d = d1.d;
+        cop_out(x2, m->gb1.p, m->ldh);
+        TRY(launch_chain(m, cb, s));
+    }
+    DwBuilder dw;
+    dw.add(m, m->ga3.p, 4, m->xh2.p, m->ldh, 2 * B, P_D3, O_DISC);
+    dw.add(m, m->gb0.p, m->ldh, m->xh1.p, m->ldh, 2 * B, P_D2, O_DISC);
+    dw.add(m, m->gb1.p, m->ldh, m->zin.p, m->ldz, 2 * B, P_D1, O_DISC);
+    return dw.launch(s);
+}
+
+// gen_step on the chain path: everything between the shared gather and the weight gradients is
+// row-local and runs as ONE program
+int chain_gen_step(aae_model* m, hipStream_t s) {
+    const int B = m->rows, h = m->h, c = m->c;
+    const aae_rng_inject& I = m->inj;
+    ChainBuilder cb(m, B);
+    cb.P.loss_slot = 2;
+    cb.add(cop_load(m->a1.p, m->ldh, 0, h));
+    ChainOp& e1 = cb.add(cop(COP_DROPACT, 0, 1, h));
+    e1.d = make_drop(m, 0, true, I.masks_dev[8], nullptr, B, h, 8); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
+    ChainOp& e2 = cb.add(cop_fwd(m, P_W2, 1, 2, h + 1, h, CEPI_DROPACT, s));
+    e2.d = make_drop(m, 1, true, I.masks_dev[9], nullptr, B, h, 9); e2.one_col = h; cop_out(e2, m->eh2.p, m->ldh);
+    ChainOp& l3 = cb.add(cop_fwd(m, P_W3, 2, 3, h + 1, c, CEPI_NONE, s));
+    ChainOp& f = m->cfg.enc_final == AAE_FINAL_LINEAR ? l3 : cb.add(cop(COP_FINAL_FWD, 3, 3, c));
+    f.aux = m->cfg.enc_final; f.one_col = c;
+    ChainOp& d1 = cb.add(cop_fwd(m, P_D1, 3, 4, c + 1, h, CEPI_DROPACT, s));
+    d1.d = make_drop(m, 0, true, I.masks_dev[10], nullptr, B, h, 10); d1.one_col = h;
+    ChainOp& d2 = cb.add(cop_fwd(m, P_D2, 4, 5, h + 1, h, CEPI_DROPACT, s));
+    d2.d = make_drop(m, 1, true, I.masks_dev[11], nullptr, B, h, 11); d2.one_col = h;
+    ChainOp& x3 = cb.add(cop_linear(COP_DISC_HEAD, 5, 8, m->P[P_D3], h + 1, h, CEPI_ACTBWD)); x3.yslot = 5; x3.d = d2.d;
+    x3.aux = 1; x3.row_split = B; x3.scale = m->grad_scale;
+    ChainOp& x2 = cb.add(cop_dx(m, P_D2, 8, 9, h, h, CEPI_ACTBWD, s)); x2.yslot = 4; x2.d = d1.d;
+    ChainOp& dz = cb.add(cop_dx(m, P_D1, 9, 0, h, c, CEPI_NONE, s));    // dL/dz
+    int sg = 6;
+    if (m->cfg.enc_final == AAE_FINAL_LINEAR) {        // identity output activation: dL/dz is dL/da3 already
+        cop_out(dz, m->ga3.p, m->ldz); sg = 0;
+    } else {
+        ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 0, 6, c)); fb.yslot = 3; fb.aux = m->cfg.enc_final;
+        cop_out(fb, m->ga3.p, m->ldz);
+    }
+    ChainOp& w3 = cb.add(cop_dx(m, P_W3, sg, 7, c, h, CEPI_ACTBWD, s)); w3.yslot = 2; w3.d = e2.d;
+    cop_out(w3, m->gb2.p, m->ldh);
+    ChainOp& w2 = cb.add(cop_dx(m, P_W2, 7, 8, h, h, CEPI_ACTBWD, s)); w2.yslot = 1; w2.d = e1.d;
+    cop_out(w2, ga1_ptr(m), m->ldh);
+    TRY(launch_chain(m, cb, s));
+    DwBuilder dw;
+    dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
+    dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
+    TRY(dw.add_first_layer(m, ga1_ptr(m), O_GEN, s));
+    TRY(dw.launch(s));
+    if (m->ext_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
+    return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
+}
+
+}  // namespace

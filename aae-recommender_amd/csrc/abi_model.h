@@ -1,0 +1,388 @@
+// The handle: error reporting, tensors and the arena layout of an aae_model (reference aaerec/aae.py:782-804), config
+// validation, stream / profiling / join helpers, dropout specs.
+// (one of the parts of aae_abi.hip's translation unit: included there in order, not on its own)
+#pragma once
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(AAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define LAUNCHCHK(what)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) return fail(AAE_EHIP, std::string(what) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != AAE_OK) return rc_; } while (0)
+
+namespace {
+
+inline int r4(int x) { return (x + 3) & ~3; }
+
+struct Ten {
+    float* p = nullptr; size_t off = 0; int64_t rows = 0, cols = 0, ld = 0;
+    size_t floats() const { return (size_t)rows * ld; }
+};
+
+enum { P_W1T = 0, P_B1, P_W2, P_W3, P_V1, P_V2, P_V3, P_D1, P_D2, P_D3, NP };
+enum { O_ENC = 0, O_DEC = 1, O_GEN = 2, O_DISC = 3 };
+
+}  // namespace
+
+struct aae_model {
+    aae_config cfg;
+    char* base; size_t bytes;
+    int N, h, c, cp, R, R2;
+    int ldh, ldw1, ldc, ldz, ldn;
+    bool alpha_mode;
+    float grad_scale;
+    int rng_row0, rng_global;   // device rng: this rank's rows are [rng_row0, rng_row0 + rows) of a global batch of rng_global (0: local)
+    // parameters, two Adam-state sets (index 0: the owning optimiser, 1: gen_optim for enc),
+    // gradients (all in export mode, gW1T always)
+    Ten P[NP], M[2][NP], V[2][NP], Gr[NP];
+    // transposed copies [in + 1][out] of the hidden layers' augmented weights: chain.h's dX ops read rows [0, in) with
+    // the forward layers' access pattern, chain4.h's forward layers read all of it (n contiguous).  Kept in step by the fused / grouped optimiser kernels;
+    // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
+    Ten PT[NP]; Ten D4[NP]; bool pt_ok[NP];      // PT = the F4 copy, D4 = the dX copy (device_common.h W4Copies)
+    // activations
+    Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
+    Ten ga1x;                // export mode: see aae_create
+    bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
+    const float* doc_l1;     // aae_set_doc_l1: L1 norms of the complete documents (a handle that holds an item slice of them)
+    bool ext_first;          // aae_set_first_layer_external: AAE_T_ACT_A1 comes from the caller, dL/d(a1) goes back to it
+    bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
+    bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
+    bool bf16;               // cfg.dtype = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)
+    bool vae_bwd;            // aae_vae_step is running: aae_ae_decode_backward continues with the VAE's backward
+    bool vae_cut;            // ... cut at the condition boundary (aae_vae_encode / _decode_backward / _encoder_backward)
+    Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
+    bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
+    bool use_chain4;         // ... with 4 rows per workgroup (chain4.h) where a program allows it
+    bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
+    bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
+    bool enc_bwd_done;
+    int max_slabs;
+    float* bce_partials; int bce_partials_cap;
+    float* fix_partials;
+    float* rscale;           // [R] 1/L1 of the rows of the running batch
+    bool w1_merged;          // the first layer's bias update of this phase rode in the grouped dW launch
+    bool w1_items_merged;    // ... and so did its row-sparse weight gradient + optimiser (w1_update.h)
+    bool buckets_valid;      // the per-tile entry buckets (tstart/teb/ten/tev) describe the running batch
+    // lazy Adam on W1T (kernels.h): per-row sync step, unique-row scratch, per-step scalar table
+    bool lazy;
+    // fused decoder output layer (dec_fused.h): tile-bucketed batch entries, eligibility
+    int n_cu; bool fused_ok; int fused_nb; bool force_unfused;
+    int* tcount; int* tstart; int* teb; int* ten; float* tev;
+    // second set of the bucket arrays: every build goes to the set the previous batch is NOT in, so a build on the side
+    // stream (aae_first_layer_forward) never races the previous step's last reader on the caller's stream (the first
+    // layer's gen_optim update, w1_update.h)
+    int* tstart2; int* teb2; int* ten2; float* tev2;
+    int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
+    int* pslot; int* ptag;   // data parallel, peers > 1: [N][peers] slot of an item's row in each peer's packet / its stamp
+    int chunks;              // grid.y of the per-entry kernels for the running batch
+    float* losses;
+    OptScalars* sc;          // [4]
+    long long* step_ctr;
+    // state of the running step
+    BatchView bv; bool have_batch; int rows; int phase;
+    aae_rng_inject inj;      // randomness of the running step (inject mode)
+    // optional per-kernel timing (hipEvent pairs on the launch stream)
+    bool prof_on; unsigned prof_mask;   // bit k: time kernel id k
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* prof_ev;   // [AAE_K_N]
+    size_t prof_used[AAE_K_N];
+    // split form of the fused decoder output layer (dec_fused.h, kDecCrit / kDecOpt): the optimiser launch of a step
+    // runs on `side` behind the rest of the step; ev_crit = the critical launch is done (the side stream waits for it),
+    // ev_opt = the optimiser launch is done (join_deferred() makes a caller's stream wait for it)
+    bool split_ok; int split_wgs; bool opt_pending;
+    hipStream_t side; hipEvent_t ev_crit, ev_opt;
+    float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
+    Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
+    bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
+    bool split_any = false;        // AAE_SPLIT_ANY at creation: the split form of the output layer at any size (tests: small fixtures through the critical / deferred kernels)
+    float* dp_scratch = nullptr; size_t dp_scratch_floats = 0;   // aae_dp_step: the ranks' gathered packets (hipMalloc, owned by the handle)
+    bool x3_gemm = false;          // gemm_f32.h gemm_x3_kernel: the streaming GEMMs (batches beyond the fused output layer, predict) likewise
+    bool x3_ok = false;            // dec_crit_x3.h: the critical launch's fp32 products on the bf16 matrix cores (3-term split)
+    bool w1_big_lds = false;       // w1_item_update_kernel may take more than 64 KB of LDS (batches beyond ~7 k rows)
+    bool blocked_any = false;      // AAE_BLOCKED_ANY at creation: the row-blocked output layer at any size (tests)
+    Ten dh2f;                      // dec_opt_blocks_x3_kernel: the step's dh2 as split matrix-core fragments (dh2_frag_kernel)
+    bool blocked_ok; Ten Gacc;   // cfg.blocked_output: batches beyond 112 rows as row-blocked launches of the split form; dV3 partial
+    // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
+    // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
+    int* mark2; int* ulist2; int* ucount2; int* stamp2;
+    aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
+    bool pf_pending; hipEvent_t ev_head, ev_pf;
+    bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
+    hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
+    bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)
+    bool side_ordered = false;                             // ... or put its dV3 GEMM there: the side stream is in order behind that step's output layer
+};
+
+namespace {
+
+struct Arena {
+    char* base; size_t off = 0; bool dry;
+    float* take(size_t nfloats, size_t* off_out) {
+        off = (off + 255) & ~(size_t)255;
+        size_t o = off; off += nfloats * sizeof(float);
+        if (off_out) *off_out = o;
+        return dry ? nullptr : reinterpret_cast<float*>(base + o);
+    }
+    // pad_rows: extra rows behind the tensor that stay zero for the life of the arena (the layer-chain
+    // kernel reads whole 4-row k-steps of a weight matrix without clamping the row index)
+    Ten mat(int64_t rows, int64_t cols, int64_t ld, int64_t pad_rows = 0) {
+        Ten t; t.rows = rows; t.cols = cols; t.ld = ld;
+        t.p = take((size_t)(rows + pad_rows) * ld, &t.off);
+        return t;
+    }
+};
+
+// row-blocked fused output layer: at most kMaxRowBlocks launches of at most kRowBlock rows each
+constexpr int kRowBlock = 104, kMaxRowBlocks = 16;
+
+// layer widths the fused decoder output-layer kernel (dec_fused.h) is instantiated for
+inline bool fused_width_ok(int h, int ldh) {
+    return (h + 1 + 15) / 16 <= 13 && ldh <= 256 && (ldh % 4) == 0 && ldh <= kSD - 2;
+}
+
+int validate(const aae_config* c) {
+    if (!c) return fail(AAE_EINVAL, "cfg is NULL");
+    if (c->abi_version != AAE_ABI_VERSION) return fail(AAE_EINVAL, "abi_version mismatch");
+    if (c->n_items < 1 || c->n_hidden < 1 || c->n_code < 1 || c->cond_inc < 0)
+        return fail(AAE_EINVAL, "n_items/n_hidden/n_code must be positive");
+    if (c->n_hidden > 4096) return fail(AAE_EINVAL, "n_hidden > 4096 not supported");
+    if (c->max_batch < 1 || c->max_nnz < 1) return fail(AAE_EINVAL, "max_batch/max_nnz must be positive");
+    if (c->max_batch > 16384) return fail(AAE_EINVAL, "max_batch > 16384 not supported");
+    if (c->activation < 0 || c->activation > AAE_ACT_LEAKYRELU) return fail(AAE_EINVAL, "unknown activation");
+    if (c->enc_final < 0 || c->enc_final > AAE_FINAL_SIGMOID) return fail(AAE_EINVAL, "unknown enc_final");
+    if (c->optimizer != AAE_OPT_ADAM && c->optimizer != AAE_OPT_SGD) return fail(AAE_EINVAL, "unknown optimizer");
+    if (c->rng_mode != AAE_RNG_INJECT && c->rng_mode != AAE_RNG_DEVICE) return fail(AAE_EINVAL, "unknown rng_mode");
+    if (c->grad_mode != AAE_GRAD_FUSED && c->grad_mode != AAE_GRAD_EXPORT) return fail(AAE_EINVAL, "unknown grad_mode");
+    if (!(c->dropout1 >= 0.f && c->dropout1 < 1.f && c->dropout2 >= 0.f && c->dropout2 < 1.f))
+        return fail(AAE_EINVAL, "dropout must be in [0,1)");
+    if (c->reserved[0] || c->reserved[1]) return fail(AAE_EINVAL, "reserved fields must be zero");
+    if (c->dense_noise != 0 && c->dense_noise != 1) return fail(AAE_EINVAL, "dense_noise must be 0 or 1 (dense noisy encoder input)");
+    if (c->dense_noise == 1 && (c->model_kind != 1 || c->grad_mode != AAE_GRAD_FUSED || c->dtype != 0))
+        return fail(AAE_EINVAL, "dense_noise = 1 (dense noisy encoder input) needs the plain autoencoder (model_kind = 1), fp32, fused optimiser");
+    if (c->blocked_output != 0 && c->blocked_output != 1) return fail(AAE_EINVAL, "blocked_output must be 0 or 1 (row-blocked fused output layer)");
+    if (c->dtype != 0 && c->dtype != 1) return fail(AAE_EINVAL, "dtype must be 0 (fp32) or 1 (bf16 matrix-core inputs)");
+    if (c->dtype == 1 && c->model_kind == 3) return fail(AAE_EINVAL, "bf16 arithmetic is not available in VAE mode");
+    if (c->model_kind < 0 || c->model_kind > 3 || c->model_kind == 2)
+        return fail(AAE_EINVAL, "model_kind must be 0 (AAE), 1 (plain autoencoder) or 3 (VAE)");
+    if (c->model_kind == 3 && (c->n_hidden + 1 > 208 || c->n_code + c->cond_inc + 1 > 208 || 2 * c->n_code > 208))
+        return fail(AAE_EINVAL, "VAE mode needs n_hidden <= 207, n_code + cond_inc <= 207, 2 * n_code <= 208");
+    if (c->dp_world < 0 || c->dp_world > 64) return fail(AAE_EINVAL, "dp_world (data-parallel world size) out of range");
+    if (c->unfused_decoder != 0 && c->unfused_decoder != 1) return fail(AAE_EINVAL, "unfused_decoder must be 0 or 1");
+    return AAE_OK;
+}
+
+// lays the model out; with dry=true only measures
+size_t layout(aae_model* m, char* base, bool dry) {
+    const aae_config& c = m->cfg;
+    m->N = c.n_items; m->h = c.n_hidden; m->c = c.n_code; m->cp = c.n_code + c.cond_inc;
+    m->R = c.max_batch; m->R2 = 2 * c.max_batch;
+    m->ldh = r4(m->h + 1); m->ldw1 = r4(m->h); m->ldc = r4(m->cp + 1); m->ldz = r4(m->c + 1); m->ldn = r4(m->N);
+    Arena a{base, 0, dry};
+    const int N = m->N, h = m->h, cc = m->c, cp = m->cp;
+    m->P[P_W1T] = a.mat(N, h, m->ldw1);
+    m->P[P_B1] = a.mat(1, h, m->ldw1);
+    m->P[P_W2] = a.mat(h, h + 1, m->ldh, 16);
+    m->P[P_W3] = a.mat(c.model_kind == 3 ? 2 * cc : cc, h + 1, m->ldh, 16);   // VAE: [fc21; fc22]
+    m->P[P_V1] = a.mat(h, cp + 1, m->ldc, 16);
+    m->P[P_V2] = a.mat(h, h + 1, m->ldh, 16);
+    m->P[P_V3] = a.mat(N, h + 1, m->ldh, 2 * kTI);  // (+ two tiles of padding rows: dec_fused_bf16.h reads whole tiles unclamped and parks the stores of lanes without a cell there)
+    m->P[P_D1] = a.mat(h, cc + 1, m->ldz, 16);
+    m->P[P_D2] = a.mat(h, h + 1, m->ldh, 16);
+    m->P[P_D3] = a.mat(1, h + 1, m->ldh, 16);
+    for (int i = 0; i < NP; ++i) {
+        m->M[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
+        m->V[0][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
+    }
+    for (int i = P_W1T; i <= P_W3; ++i) {
+        m->M[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+        m->V[1][i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld);
+    }
+    m->Gr[P_W1T] = a.mat(N, h, m->ldw1);
+    // export mode: dL/d(a1) of a replica with an external first layer, RIGHT-aligned in a buffer that ends where the small
+    // layers' gradient span begins - [its rows | b1, W2, W3, V1, V2 gradients] is then one contiguous packet for the
+    // all-gather of the both-sharded scheme (no packing launch)
+    if (c.grad_mode == AAE_GRAD_EXPORT) m->ga1x = a.mat(m->R, h + 1, m->ldh);
+    if (c.grad_mode == AAE_GRAD_EXPORT)
+        for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
+    for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
+    if (h + 1 <= 208 && cp + 1 <= 208 && c.model_kind != 3)          // layer-chain models (not the VAE's programs)
+        for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
+        {
+            const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;
+            m->PT[pid] = a.mat((Nc + 3) / 4, 4 * M, 4 * M, 1);      // F4 [(in + 1 + 3) / 4][out][4]: k = input column (the bias is k = in)
+            m->D4[pid] = a.mat((M + 3) / 4, 4 * Nc, 4 * Nc, 1);     // D4 [(out + 3) / 4][in + 1][4]: k = output row
+        }
+    const int R = m->R, R2 = m->R2;
+    m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);
+    m->zc = a.mat(R, cp + 1, m->ldc);
+    m->dh1 = a.mat(R, h + 1, m->ldh); m->dh2 = a.mat(R, h + 1, m->ldh);
+    m->G = a.mat(R, N, m->ldn, (32 * (int64_t)R + m->ldn - 1) / m->ldn + 1 + (c.blocked_output ? kMaxRowBlocks : 0));   // (+ room for the tile-major form [ceil(N/32)][R][32] of dec_fused.h's split launches)
+    // split-K slabs for dA2 = G * V3: enough slices to put >= ~512 workgroups on the chip
+    {
+        int tiles = ((R + 63) / 64) * ((h + 63) / 64);
+        m->max_slabs = std::max(1, std::min(128, 2048 / tiles));
+        // the fused decoder kernel writes one dA2 slab per workgroup (<= 304 CUs assumed for sizing) of at most
+        // 16 * kMB rows: a model with a larger max_batch still takes it for its short (tail) batches
+        int64_t slab_rows = (int64_t)m->max_slabs * R;
+        if (fused_width_ok(h, m->ldh)) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * std::min(R, 16 * kMB));
+        // row-blocked form: every workgroup's slab spans the whole batch (each launch fills its rows)
+        if (fused_width_ok(h, m->ldh) && c.blocked_output && R <= kMaxRowBlocks * kRowBlock) slab_rows = std::max(slab_rows, (int64_t)(304 + 16) * R);
+        m->slabs = a.mat(slab_rows, h, m->ldh);
+    }
+    m->gb0 = a.mat(R2, h + 1, m->ldh); m->gb1 = a.mat(R2, h + 1, m->ldh);
+    m->gb2 = a.mat(R2, h + 1, m->ldh); m->gb3 = a.mat(R2, h + 1, m->ldh);
+    m->gzc = a.mat(R, cp + 1, m->ldc);
+    m->ga3 = a.mat(R2, cc + 1, m->ldz);
+    m->zin = a.mat(R2, cc + 1, m->ldz);
+    m->xh1 = a.mat(R2, h + 1, m->ldh); m->xh2 = a.mat(R2, h + 1, m->ldh);
+    m->dout = a.mat(R2, 1, 4);
+    m->zsave = a.mat(R, cc, m->ldz);
+    m->da2 = a.mat(R, h + 1, m->ldh);
+    m->Xn = Ten();
+    if (c.dense_noise == 1) m->Xn = a.mat(R, N, m->ldn);
+    m->Gacc = Ten();
+    if (c.blocked_output && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB) m->Gacc = a.mat(N, h + 1, m->ldh, 2 * kTI);
+    m->dh2f = Ten();
+    if (c.blocked_output && c.grad_mode == AAE_GRAD_FUSED && R > 16 * kMB && R <= kMaxRowBlocks * kRowBlock)
+        m->dh2f = a.mat((int64_t)((R + kXCH - 1) / kXCH) * 13 * (kXCH / 32) * 3, 256, 256);      // [chunk][column block][k-step][term] x 1 KB
+    if (c.model_kind == 3) {
+        m->mulv = a.mat(R, 2 * cc, r4(2 * cc)); m->gmulv = a.mat(R, 2 * cc, r4(2 * cc)); m->veps = a.mat(R, cc, r4(cc));
+    }
+    m->bce_partials_cap = std::max(512 * (c.blocked_output ? kMaxRowBlocks : 1), ((N + 31) / 32) * ((R + 31) / 32));
+    m->bce_partials = a.take(m->bce_partials_cap, nullptr);
+    m->fix_partials = a.take((size_t)R * 64, nullptr);
+    m->rscale = a.take(R, nullptr);
+    m->tsync = reinterpret_cast<int*>(a.take(N, nullptr));
+    m->mark = reinterpret_cast<int*>(a.take(N, nullptr));
+    m->ulist = reinterpret_cast<int*>(a.take((size_t)c.max_nnz * (size_t)std::max(1, c.dp_world), nullptr));
+    m->pslot = m->ptag = nullptr;
+    if (c.grad_mode == AAE_GRAD_EXPORT && c.dp_world > 1) {
+        m->pslot = reinterpret_cast<int*>(a.take((size_t)N * c.dp_world, nullptr));
+        m->ptag = reinterpret_cast<int*>(a.take((size_t)N * c.dp_world, nullptr));
+    }
+    m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
+    m->stamp = m->ucount ? m->ucount + 1 : nullptr;
+    m->mark2 = m->ulist2 = m->ucount2 = m->stamp2 = nullptr;
+    if (c.grad_mode == AAE_GRAD_FUSED) {      // second list set for aae_prefetch_batch (single-process training only)
+        m->mark2 = reinterpret_cast<int*>(a.take(N, nullptr));
+        m->ulist2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ucount2 = reinterpret_cast<int*>(a.take(4, nullptr));
+        m->stamp2 = m->ucount2 ? m->ucount2 + 1 : nullptr;
+    }
+    m->tab = reinterpret_cast<LazyTab*>(a.take((size_t)kLazyTabCap * 4, nullptr));
+    {
+        const size_t nt = (size_t)(N + kTI - 1) / kTI + 1;
+        m->tcount = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->tstart = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->teb = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ten = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->tev = a.take((size_t)c.max_nnz, nullptr);
+        m->tstart2 = reinterpret_cast<int*>(a.take(nt, nullptr));
+        m->teb2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->ten2 = reinterpret_cast<int*>(a.take((size_t)c.max_nnz, nullptr));
+        m->tev2 = a.take((size_t)c.max_nnz, nullptr);
+    }
+    m->losses = a.take(4, nullptr);
+    m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
+    m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
+    return (a.off + 255) & ~(size_t)255;
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// scoped hipEvent pair around one kernel launch when profiling is enabled
+struct ProfScope {
+    aae_model* m; int k; hipStream_t s; bool on;
+    ProfScope(aae_model* m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_), on(m_->prof_on && ((m_->prof_mask >> k_) & 1)) {
+        if (!on) return;
+        auto& v = m->prof_ev[k];
+        if (m->prof_used[k] == v.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            v.emplace_back(a, b);
+        }
+        (void)hipEventRecord(v[m->prof_used[k]].first, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(m->prof_ev[k][m->prof_used[k]].second, s);
+        m->prof_used[k]++;
+    }
+};
+
+// A timing pair for a launch through hipExtLaunchKernelGGL (the events ride on the kernel's own start / completion
+// signals: no marker packets on the stream); false when kernel id k is not being timed
+bool prof_pair(aae_model* m, int k, hipEvent_t* a, hipEvent_t* b) {
+    if (!(m->prof_on && ((m->prof_mask >> k) & 1))) return false;
+    auto& v = m->prof_ev[k];
+    if (m->prof_used[k] == v.size()) {
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        v.emplace_back(x, y);
+    }
+    *a = v[m->prof_used[k]].first; *b = v[m->prof_used[k]].second;
+    m->prof_used[k]++;
+    return true;
+}
+
+// The previous step's deferred optimiser launch (dec_fused.h kDecOpt on m->side) writes DEC_V3 and its moments and
+// reads dh2 / the G scratch / the decoder's step scalars: everything that touches those waits for it here.
+int join_deferred(aae_model* m, hipStream_t s) {
+    // (one side stream, in order: the later record covers the earlier - the prefetch is enqueued in front of the deferred
+    //  launch by aae_step's path and behind it by an item slice's, so both marks are waited for when both are pending)
+    if (m->opt_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
+    if (m->pf_pending && (!m->opt_pending || m->pf_after_opt)) HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0));
+    m->opt_pending = m->pf_pending = false;
+    return AAE_OK;
+}
+// behind work enqueued on the side stream: what join_deferred waits for
+int side_done(aae_model* m, hipEvent_t ev) {
+    HIPCHK(hipEventRecord(ev, m->side));
+    return AAE_OK;
+}
+// ... for the entry points without a stream (host-synchronous state import / export)
+int join_host(aae_model* m) {
+    if (!m->opt_pending && !m->pf_pending) return AAE_OK;
+    HIPCHK(hipStreamSynchronize(m->side));
+    m->opt_pending = m->pf_pending = false;
+    return AAE_OK;
+}
+
+DropSpec make_drop(const aae_model* m, int layer, bool train, const uint8_t* ma, const uint8_t* mb, int split,
+                   int width, uint32_t stream_id) {
+    DropSpec d; memset(&d, 0, sizeof(d));
+    float p = layer == 0 ? m->cfg.dropout1 : m->cfg.dropout2;
+    d.enabled = (train && p > 0.f) ? 1 : 0;
+    if (!d.enabled) return d;
+    d.mask_a = ma; d.mask_b = mb; d.split_row = split; d.width = width;
+    d.device_rng = m->cfg.rng_mode == AAE_RNG_DEVICE;
+    d.goff_a = m->rng_row0;
+    d.goff_b = m->rng_row0 + (m->rng_global > 0 ? m->rng_global - split : 0);
+    d.keep_threshold = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
+    d.stream_id = stream_id;
+    if (m->alpha_mode) {
+        const double alpha = 1.7580993408473766;
+        double a = 1.0 / sqrt((alpha * alpha * p + 1.0) * (1.0 - p));
+        d.mul_keep = (float)a;
+        d.add_keep = (float)(alpha * a * p);
+        d.add_drop = (float)(-alpha * a) + (float)(alpha * a * p);
+    } else {
+        d.mul_keep = 1.0f / (1.0f - p);
+        d.add_keep = 0.f; d.add_drop = 0.f;
+    }
+    if (!d.device_rng && !ma && !mb) d.enabled = 0;   // inject mode without masks: identity
+    return d;
+}
+
+inline int grid1d(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 2048); }
+
+
+}  // namespace
