@@ -166,7 +166,7 @@ def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, monkeypatc
     from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
     from tools.synth import throughput_corpus
     h, c = 200, 50
-    monkeypatch.setenv("AAE_BLOCKED_ANY", "1")       # (the library keeps the three GEMMs beyond 32 M cells: 275 000 x 512, a C5 slice, is tested all the same)
+    monkeypatch.setenv("AAE_BLOCKED_ANY", "1")       # (r2: the library kept the three GEMMs beyond 32 M cells; since r3 the row-blocked form covers 275 000 x 512, a C5 slice, by itself)
     rng = np.random.default_rng(Ns + B)
     k = 1.0 / np.sqrt(h)
     full = {"dec.lin3.weight": ((rng.random((Ns, h)) * 2 - 1) * k).astype(np.float32),
@@ -195,13 +195,13 @@ def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, monkeypatc
         assert _maxdiff(a, b) <= tol + 1e-4 * float(np.abs(b).max()), (tid, _maxdiff(a, b))
 
 
-@pytest.mark.parametrize("N,B", [(6000, 150), (40000, 224)])
+@pytest.mark.parametrize("N,B", [(6000, 150), (40000, 224), (100000, 512)])
 def test_row_blocked_full_steps_equal_the_three_kernel_steps(N, B):
     """Whole training steps (aae_step: ae + disc + gen) on ONE handle with 113..256-row batches - what
     AdversarialAutoEncoder creates for such batch sizes (blocked_output: the output layer as one critical launch for the
-    row blocks + the deferred optimiser launch(es); 6 000 items: dec_opt_blocks_kernel, 40 000: one launch per block) -
-    against the same steps on the three-kernel output layer: losses and every parameter after 3 steps, short batches
-    in between included."""
+    row blocks + ONE deferred optimiser launch for any vocabulary, dec_opt_blocks_x3_kernel; 100 000 x 512 is bench.py's
+    extra.b512: four passes of <= 6 tiles per workgroup) - against the same steps on the three-kernel output layer: losses
+    and every parameter after 3 steps, short batches in between included."""
     from aaerec._hip import HipAAE, DeviceCSR
     from tools.synth import init_params, throughput_corpus
     h, c = 200, 50
