@@ -606,20 +606,25 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 2));
     };
-    // Roles: waves 0 .. NB-1 multiply (wave w = column block w, both item halves) and go from a step's barrier straight
-    // into their products.  The stored dL/dlogits rows of a step arrive by LDS-DMA (global_load_lds_dwordx4: no register
+    // Roles: waves 0 .. NB multiply (wave w = column block w, both item halves - the last block's halves on two waves,
+    // below) and go from a step's barrier straight into their products.  The stored dL/dlogits rows of a step arrive by LDS-DMA (global_load_lds_dwordx4: no register
     // destination, so kXRing steps are in flight with no prefetch register and no rotation - rotating prefetch registers
     // made every step wait for the newest request, ~2 us of HBM latency under the optimiser traffic of the other workgroups)
-    // into a ring of fp32 slots, requested by the 16 - NB >= 3 spare waves, which do nothing else and know when a slot has
+    // into a ring of fp32 slots, requested by the 15 - NB >= 2 spare waves, which do nothing else and know when a slot has
     // landed (their vmcnt); the workgroup's barrier carries that to everybody.  Behind its products EVERY thread then splits
     // one float2 of the next step's slot into the other image (1024 threads x 8 bytes = 64 rows x 32 items): measured
     // alternatives - the split by the spare waves alone (3 float4 per thread: 1.0 us per step against 0.5 us of products),
     // by half the workgroup in front of its products (0.6-0.8 us) - left the multipliers waiting.
-    constexpr int NL = (kNW - NB) * 64, NS = (kXCH * 8 + NL - 1) / NL;
-    static_assert(NB < kNW, "no spare wave left");
+    // The LAST column block's two item halves go to two waves (NB - 1 and NB): with one owner per column block a SIMD that
+    // holds four of 13 owners (waves w, w + 4, w + 8, w + 12 share a SIMD) has 8 of the 26 (column block, half) units and
+    // sets the step's length; this way the SIMDs hold 7 / 7 / 6 / 6.  NM multipliers, the rest request.
+    constexpr int NM = NB + 1;
+    constexpr int NL = (kNW - NM) * 64, NS = (kXCH * 8 + NL - 1) / NL;
+    static_assert(NM < kNW, "no spare wave left");
     static_assert(kXCH * 8 * 2 == kNT, "one float4 of a slot per thread of the lower half");
-    const bool mult = wave < NB;
-    const int lt = tid - NB * 64;               // requesting thread
+    const bool mult = wave < NM;
+    const int nb_lo = wave == NB ? 1 : 0, nb_hi = wave == NB - 1 ? 1 : 2;       // this multiplier's item halves
+    const int lt = tid - NM * 64;               // requesting thread
     // stored dL/dlogits of global row b, tile t: block r = b / Bb holds [tile][Br][32] (dec_fused.h)
     const float inv_bb = 1.0f / (float)a.Bb;
     const size_t blk_floats = (size_t)ntiles * a.Bb * kTI;
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
         return a.Gt + (size_t)r * blk_floats + (size_t)(bc - r * a.Bb) * kTI + (size_t)c4 * 4;
     };
     const unsigned ring_lds = (unsigned)reinterpret_cast<size_t>(ring);
-    const int lw = wave - NB;                   // loader wave: its request i of a step covers the float4s 64 (lw + (16 - NB) i) ..
+    const int lw = wave - NM;                   // requesting wave: its request i of a step covers the float4s 64 (lw + (16 - NM) i) ..
 
     for (int grp = blockIdx.x; grp < G; grp += gridDim.x) {
         const int t0 = (int)(((long long)grp * ntiles) / G), nt = (int)(((long long)(grp + 1) * ntiles) / G) - t0;
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
             }
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const int fb = 64 * (lw + (kNW - NB) * i);      // (uniform) beyond the chunk: a request into the dump KB, so that
+                const int fb = 64 * (lw + (kNW - NM) * i);      // (uniform) beyond the chunk: a request into the dump KB, so that
                 const unsigned dst = fb < kXCH * 8 ? slot + (unsigned)fb * 16u : (unsigned)kXRing * (kXCH * kTI * 4u);   // every wave has NS per step
                 const size_t p = (size_t)rowtab[(3 * i + 0) * kXRowTab + lt] | ((size_t)rowtab[(3 * i + 1) * kXRowTab + lt] << 32);
                 const unsigned ts = rowtab[(3 * i + 2) * kXRowTab + lt];
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
                 asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
                 const int lz = lane + oz;
                 lds_barrier();                          // image q is complete, slot q + 1 has landed, slot q is free
-                const bool stamp = stamp_wg && (wave == 0 || wave == NB) && q >= 8 && q < 16;
+                const bool stamp = stamp_wg && (wave == 0 || wave == NM) && q >= 8 && q < 16;
                 unsigned long long* tsq = a.ts + (wave ? 64 : 0) + (q - 8) * 4;
                 if (stamp) tsq[0] = wall_clock64();
                 if (mult && !(a.dbg_skip & 0x1000)) {
@@ -787,6 +792,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
                     const unsigned* img = gB + (q & 1) * 3 * IMG;
 #pragma unroll
                     for (int nb2 = 0; nb2 < 2; ++nb2) {
+                        if (nb2 < nb_lo || nb2 >= nb_hi) continue;      // (uniform)
                         f32x4 c = acc[j][nb2];
                         // rows 32 kc + 8 g + 4 hi + tq -> slot tq | (g & 1) << 2 | hi << 3 | (g >> 1) << 4 | kc << 5
                         const unsigned* base = img + nb2 * (kXCH * 8) + (tq | ((g & 1) << 2) | ((g >> 1) << 4)) * 8 + 2 * tp;
@@ -826,8 +832,10 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
             for (int j = 0; j < kXBT; ++j)
 #pragma unroll
                 for (int nb2 = 0; nb2 < 2; ++nb2)
+                    if (nb2 >= nb_lo && nb2 < nb_hi) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) os[j * (kTI * kSO) + (16 * nb2 + 4 * fk + rr) * kSO + 16 * cb + fr] = acc[j][nb2][rr];
+                        for (int rr = 0; rr < 4; ++rr) os[j * (kTI * kSO) + (16 * nb2 + 4 * fk + rr) * kSO + 16 * cb + fr] = acc[j][nb2][rr];
+                    }
         }
         lds_barrier();
         optimiser();
