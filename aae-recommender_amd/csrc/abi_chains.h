@@ -72,7 +72,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     static const bool want_ts = getenv("AAE_CHAIN_TS") != nullptr;      // debug: per-op timeline of workgroup 0
     static unsigned long long* ts_dev = nullptr;
     if (want_ts) {
-        if (!ts_dev && hipMalloc(&ts_dev, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
+        if (!ts_dev && hipMalloc(&ts_dev, 128 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
         cb.P.ts = ts_dev;
     }
     ProfScope ps(m, AAE_K_CHAIN, s);
@@ -92,7 +92,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     LAUNCHCHK("chain_kernel");
     if (want_ts) {
-        unsigned long long h[32];
+        unsigned long long h[128];
         hipStreamSynchronize(s);
         hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
         static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "DISC_HEAD", "PRIOR"};
@@ -104,6 +104,15 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (cb.P.nops > 2)
             fprintf(stderr, "   [op 2, wave 0 of workgroup 0] loads+mfma+partials=%.2f wait-barrier=%.2f epi-ctx=%.2f epilogue=%.2f barrier=%.2f (us)\n",
                     (h[21] - h[20]) * 0.01, (h[22] - h[21]) * 0.01, (h[23] - h[22]) * 0.01, (h[24] - h[23]) * 0.01, (h[25] - h[24]) * 0.01);
+        if (cb.P.nops > 2 && four)
+            fprintf(stderr, "   [op 2: matrix phase %.2f us = %.0f shader clocks -> %.2f GHz]\n", (h[64 + 50] - h[64 + 48]) * 0.01,
+                    (double)(h[64 + 51] - h[64 + 49]), (double)(h[64 + 51] - h[64 + 49]) / ((h[64 + 50] - h[64 + 48]) * 10.0));
+        if (cb.P.nops > 2 && four)
+            for (int k = 0; k < 3; ++k) {
+                fprintf(stderr, "   [op 2, every wave, us after the op's start: %s]", k == 0 ? "loads issued" : k == 1 ? "first chunk multiplied" : "partial sums stored");
+                for (int w = 0; w < 16; ++w) fprintf(stderr, " %.2f", ((double)h[64 + 16 * k + w] - (double)h[64 + 48]) * 0.01);
+                fprintf(stderr, "\n");
+            }
     }
     return AAE_OK;
 }

@@ -105,16 +105,23 @@ struct EpiCtx {
 
 __device__ __forceinline__ EpiCtx chain_epi_ctx(int epi, const ChainOp& op, const ChainProgram& P, uint64_t key,
                                                 const float* slots) {
+    // ALL fields requested first, then pinned by two statements: one s_waitcnt for the batch.  (Pinned one by one - r1-r3 -
+    // every field was a scalar-load round trip of its own, ~200 clocks each from the kernel-argument segment:
+    // tools/debug/ubench/sload_latency.hip.)
     EpiCtx c;
-    c.epi = chain_pin(epi); c.act = chain_pin(P.act);
-    c.den = chain_pin(op.d.enabled); c.drng = chain_pin(op.d.device_rng);
-    c.split = chain_pin(op.d.split_row); c.width = chain_pin(op.d.width);
-    c.goa = chain_pin(op.d.goff_a); c.gob = chain_pin(op.d.goff_b);
-    c.thr = chain_pin(op.d.keep_threshold);
-    c.dkey = chain_pin(key ^ ((uint64_t)op.d.stream_id * 0xA0761D6478BD642Full));
-    c.mk = chain_pin(op.d.mul_keep); c.ak = chain_pin(op.d.add_keep); c.ad = chain_pin(op.d.add_drop);
-    c.ma = chain_pin(op.d.mask_a); c.mb = chain_pin(op.d.mask_b);
-    c.y = slots + chain_pin(op.yslot) * kCR * kCL;
+    c.epi = epi; c.act = P.act;
+    c.den = op.d.enabled; c.drng = op.d.device_rng;
+    c.split = op.d.split_row; c.width = op.d.width;
+    c.goa = op.d.goff_a; c.gob = op.d.goff_b;
+    c.thr = op.d.keep_threshold;
+    uint64_t sid = op.d.stream_id;
+    c.mk = op.d.mul_keep; c.ak = op.d.add_keep; c.ad = op.d.add_drop;
+    c.ma = op.d.mask_a; c.mb = op.d.mask_b;
+    int ys = op.yslot;
+    asm volatile("" : "+s"(c.epi), "+s"(c.act), "+s"(c.den), "+s"(c.drng), "+s"(c.split), "+s"(c.width), "+s"(c.goa), "+s"(c.gob), "+s"(c.thr));
+    asm volatile("" : "+s"(sid), "+s"(c.mk), "+s"(c.ak), "+s"(c.ad), "+s"(c.ma), "+s"(c.mb), "+s"(ys));
+    c.dkey = key ^ (sid * 0xA0761D6478BD642Full);
+    c.y = slots + ys * kCR * kCL;
     return c;
 }
 

@@ -34,11 +34,15 @@ __device__ __forceinline__ float chain4_rb(float x) {       // nearest bf16 valu
 }
 
 // One layer's matrix work for this wave: MK = k-steps per wave (compile-time bound of the register arrays).
+// the scalars of a linear op, loaded from the op descriptor in one batch by the caller
+struct Lin4 { int N, K, ldkn, ns4; const float* W4; const float* Wkn; };
+
 template <int MK, bool BF>
-__device__ __forceinline__ void chain4_linear(const ChainOp& op, const float* src, float* part, int wave, int lane,
-                                              int cgp, int kper) {
+__device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, float* part, int wave, int lane,
+                                              int cgs, int kper, unsigned long long* wts = nullptr) {
     const int N = op.N, K = op.K, ld = op.ldkn;
-    const int cg = wave & (cgp - 1), ks = wave / cgp;
+    const int cgp = 1 << cgs;
+    const int cg = wave & (cgp - 1), ks = wave >> cgs;
     const int k0 = ks * kper;
     const int n = min(64 * cg + lane, N - 1);
     // all weight loads of the layer in flight before the first MFMA; row index clamped (the A operand is zero beyond K)
@@ -53,7 +57,11 @@ __device__ __forceinline__ void chain4_linear(const ChainOp& op, const float* sr
 #pragma unroll
         for (int j = 0; j < MK / 4; ++j) {
             const unsigned so = (unsigned)(min(kc0 + j, kcmax) * op.ns4) * 16u;
+#ifdef C4_NO_LOADS
+            const float4 t = make_float4(1.f + so, 2.f, 3.f, 4.f + vo);
+#else
             const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0));
+#endif
             w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
         }
     } else {
@@ -63,34 +71,63 @@ __device__ __forceinline__ void chain4_linear(const ChainOp& op, const float* sr
     }
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const float* a = src + (lane & 3) * kCL;
+    if (wts && lane == 0) wts[wave] = wall_clock64();                  // (debug, AAE_CHAIN_TS) every load of the wave is issued
+    // The A operand: one 16-byte LDS read per chunk of 4 k, from an always valid (clamped, wave-uniform) address, requested
+    // one chunk AHEAD of its products.  This wave's k range is [k0, klim): a chunk inside it needs no masking, the one klim
+    // falls into is masked by selects on scalar conditions, chunks beyond it are skipped - three scalar instructions per
+    // chunk in the common case.  (r1-r3 masked every element of every chunk against K, the slot row and the k-slice: ~20
+    // scalar + 4 vector instructions per chunk beside its 4 MFMAs, and read the chunk under a branch right in front of its
+    // first product - the matrix phase of a 201 -> 200 layer took 3.6 us where its loads, products and partial sums take
+    // 1.7 us in isolation: tools/debug/ubench/chain_stream.hip, chain_real.hip.)
+    const int klim = min(min(K, k0 + kper), kCL);
+#ifdef C4_NO_A
+    auto ldx = [&](int j) { return make_float4(1.f + j, 2.f, 3.f, 4.f + lane); };
+#else
+    auto ldx = [&](int j) { return *reinterpret_cast<const float4*>(a + min(k0 + 4 * j, kCL - 4)); };
+#endif
+    float4 xn = ldx(0);
 #pragma unroll
     for (int j = 0; j < MK / 4; ++j) {
+        if (wts && j == 1 && lane == 0) { asm volatile("s_nop 0" :: "v"(acc0[0])); wts[16 + wave] = wall_clock64(); }       // ... its first chunk has arrived and is multiplied
         const int kk = k0 + 4 * j;
-        float4 x = *reinterpret_cast<const float4*>(a + min(kk, kCL - 4));
-        if (kk > kCL - 4 || 4 * j >= kper) x = make_float4(0.f, 0.f, 0.f, 0.f);    // beyond the slot row / this wave's k-slice
-        if (kk + 0 >= K) x.x = 0.f;
-        if (kk + 1 >= K) x.y = 0.f;
-        if (kk + 2 >= K) x.z = 0.f;
-        if (kk + 3 >= K) x.w = 0.f;
+        float4 x = xn;
+        if (j + 1 < MK / 4) xn = ldx(j + 1);
+        if (kk >= klim) continue;                                       // (uniform)
+        if (kk + 4 > klim) {                                            // (uniform) the chunk klim falls into
+            x.y = kk + 1 < klim ? x.y : 0.f;
+            x.z = kk + 2 < klim ? x.z : 0.f;
+            x.w = 0.f;
+        }
         float w0 = w[4 * j], w1 = w[4 * j + 1], w2 = w[4 * j + 2], w3 = w[4 * j + 3];
         if (BF) {
             x.x = chain4_rb(x.x); x.y = chain4_rb(x.y); x.z = chain4_rb(x.z); x.w = chain4_rb(x.w);
             w0 = chain4_rb(w0); w1 = chain4_rb(w1); w2 = chain4_rb(w2); w3 = chain4_rb(w3);
         }
+#ifdef C4_NO_MFMA
+        acc0[0] += x.x * w0; acc1[0] += x.y * w1; acc0[1] += x.z * w2; acc1[1] += x.w * w3;
+#else
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, w0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, w1, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, w2, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, w3, acc1, 0, 0, 0);
+#endif
     }
     acc0 += acc1;
     // partial sums: part[ks][row][64 cg + lane], row stride 64 cgp
     float* pp = part + (size_t)ks * (4 * 64 * cgp) + 64 * cg + lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r) pp[r * 64 * cgp] = acc0[r];
+    if (wts && lane == 0) wts[32 + wave] = wall_clock64();             // ... its partial sums are in LDS
 }
 
+#ifdef C4_PROG_PTR
+template <bool BF>
+__global__ __launch_bounds__(kC4T) void chain4_kernel(const ChainProgram* __restrict__ Pp) {
+    const ChainProgram& P = *Pp;
+#else
 template <bool BF>
 __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
+#endif
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][4][kCL], then the partial-sum scratch
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
         tile_bucket_body(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
@@ -107,29 +144,58 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     for (int oi = 0; oi < P.nops; ++oi) {
         const ChainOp& op = P.ops[oi];
         if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[oi] = wall_clock64();
-        if (r0 < op.row_lo) continue;                  // (workgroup-uniform: an op of the upper rows' program prefix)
-        float* dst = slots + op.dst * kR4 * kCL;
-        const float* src = slots + op.src * kR4 * kCL;
-        const int kind = op.kind;
+        // The scalars every op needs, and a linear op's, requested together and pinned by ONE statement each: a single
+        // s_waitcnt for the batch.  hipcc treats descriptor fields (kernel-argument segment) as free to re-load at their
+        // use, each a dependent scalar-load round trip of ~200 clocks (tools/debug/ubench/sload_latency.hip) - ~20 of them
+        // per op, serialised, were most of the 4 us an op cost WITHOUT its weight loads and products
+        // (tools/debug/ubench/chain_real.hip, r3).
+        int kind = op.kind, src_i = op.src, dst_i = op.dst, row_lo = op.row_lo, one_col = op.one_col, opN = op.N, opK = op.K;
+        int ldo = op.ldo, ldo2 = op.ldo2, out_row0 = op.out_row0;
+        float* outp = op.out; float* out2p = op.out2;
+        Lin4 lin; lin.N = opN; lin.K = opK; lin.ldkn = op.ldkn; lin.ns4 = op.ns4; lin.W4 = op.W4; lin.Wkn = op.Wkn;
+        int epi_k = op.epi;
+        asm volatile("" : "+s"(kind), "+s"(src_i), "+s"(dst_i), "+s"(row_lo), "+s"(one_col), "+s"(opN), "+s"(opK), "+s"(ldo), "+s"(ldo2),
+                          "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k));
+        asm volatile("" : "+s"(lin.ldkn), "+s"(lin.ns4), "+s"(lin.W4), "+s"(lin.Wkn));
+        lin.N = opN; lin.K = opK;
+        if (r0 < row_lo) continue;                     // (workgroup-uniform: an op of the upper rows' program prefix)
+        float* dst = slots + dst_i * kR4 * kCL;
+        const float* src = slots + src_i * kR4 * kCL;
 
         if (kind == COP_LINEAR || kind == COP_LINEAR_DX) {
-            const int N = op.N, K = op.K;
+            const int N = opN, K = opK;
             const int CG = (N + 63) >> 6;
-            const int cgp = CG <= 1 ? 1 : CG <= 2 ? 2 : 4;                 // column groups, rounded to a power of two
-            const int KS = 16 / cgp;                                        // waves per column group: the k-split
-            const int kper = ((K + KS - 1) / KS + 3) & ~3;                  // k-steps per wave, a multiple of 4
+            const int cgs = CG <= 1 ? 0 : CG <= 2 ? 1 : 2, cgp = 1 << cgs;  // column groups, rounded to a power of two (shifts: a
+            const int KS = 16 >> cgs;                                       // runtime division is ~150 clocks of its own, three of them per op)
+            const int kper = (((K + KS - 1) >> (4 - cgs)) + 3) & ~3;        // k-steps per wave, a multiple of 4
+            unsigned long long* wts = (P.ts && blockIdx.x == 0 && oi == 2) ? P.ts + 64 : nullptr;
+            if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
             if ((wave & (cgp - 1)) < CG) {
-                if (kper <= 16) chain4_linear<16, BF>(op, src, part, wave, lane, cgp, kper);
-                else if (kper <= 28) chain4_linear<28, BF>(op, src, part, wave, lane, cgp, kper);
-                else chain4_linear<52, BF>(op, src, part, wave, lane, cgp, kper);
+                if (kper <= 16) chain4_linear<16, BF>(lin, src, part, wave, lane, cgs, kper, wts);
+                else if (kper <= 28) chain4_linear<28, BF>(lin, src, part, wave, lane, cgs, kper, wts);
+                else chain4_linear<52, BF>(lin, src, part, wave, lane, cgs, kper, wts);
             }
             chain_barrier();
-            const EpiCtx ec = chain_epi_ctx(op.epi, op, P, key, slots);
+            if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
+            const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
+            if (wts && tid == 0) wts[52] = wall_clock64();
             if (ecol < kCL) {
                 float v = 0.f;
                 if (ecol < N && erow < nrows) {
+                    // the k-slices' partial sums: every read of the cell in flight at once (a loop over KS waited for each
+                    // read before it asked for the next: 4-16 LDS round trips in a row), summed in slice order
                     const float* pp = part + erow * 64 * cgp + ecol;
-                    for (int ks = 0; ks < KS; ++ks) v += pp[(size_t)ks * (4 * 64 * cgp)];
+                    auto sum_slices = [&](auto n) {
+                        constexpr int NS = decltype(n)::value;
+                        float pv[NS];
+#pragma unroll
+                        for (int ks = 0; ks < NS; ++ks) pv[ks] = pp[(size_t)ks * (4 * 64 * cgp)];
+#pragma unroll
+                        for (int ks = 0; ks < NS; ++ks) v += pv[ks];
+                    };
+                    if (cgs == 2) sum_slices(std::integral_constant<int, 4>{});           // (KS = 16 >> cgs)
+                    else if (cgs == 1) sum_slices(std::integral_constant<int, 8>{});
+                    else sum_slices(std::integral_constant<int, 16>{});
                     // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
                     if (ec.epi == CEPI_ACTBWD) {
                         v *= act_grad_from_y(ec.act, (slots + op.yslot * kR4 * kCL)[erow * kCL + ecol]);
@@ -275,14 +341,16 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 }
             }
         }   // COP_STORE: only the stores below.  (COP_ADV / COP_REPARAM*: VAE programs stay on chain.h's kernel)
+        if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 53] = wall_clock64();
         chain_barrier();
-        if (op.one_col >= 0) {
-            if (tid < kR4) dst[tid * kCL + op.one_col] = tid < nrows ? 1.f : 0.f;
+        if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 54] = wall_clock64();
+        if (one_col >= 0) {
+            if (tid < kR4) dst[tid * kCL + one_col] = tid < nrows ? 1.f : 0.f;
             chain_barrier();
         }
-        if (erow < nrows && ecol < op.N) {
-            if (op.out) op.out[(size_t)(op.out_row0 + r0 + erow) * op.ldo + ecol] = dst[erow * kCL + ecol];
-            if (op.out2) op.out2[(size_t)(r0 + erow) * op.ldo2 + ecol] = dst[erow * kCL + ecol];
+        if (erow < nrows && ecol < opN) {
+            if (outp) outp[(size_t)(out_row0 + r0 + erow) * ldo + ecol] = dst[erow * kCL + ecol];
+            if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];
         }
     }
     if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[P.nops] = wall_clock64();
