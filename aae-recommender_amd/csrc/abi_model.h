@@ -217,8 +217,10 @@ size_t layout(aae_model* m, char* base, bool dry) {
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
         {
             const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;
-            m->PT[pid] = a.mat((Nc + 3) / 4, 4 * M, 4 * M, 1);      // F4 [(in + 1 + 3) / 4][out][4]: k = input column (the bias is k = in)
-            m->D4[pid] = a.mat((M + 3) / 4, 4 * Nc, 4 * Nc, 1);     // D4 [(out + 3) / 4][in + 1][4]: k = output row
+            // (+ kW4Pad zero rows behind each: a wave of the 4-row chain kernel reads whole runs of k-chunks unclamped,
+            //  chain4.h; the A operand is zero there)
+            m->PT[pid] = a.mat((Nc + 3) / 4, 4 * M, 4 * M, kW4Pad);      // F4 [(in + 1 + 3) / 4][out][4]: k = input column (the bias is k = in)
+            m->D4[pid] = a.mat((M + 3) / 4, 4 * Nc, 4 * Nc, kW4Pad);     // D4 [(out + 3) / 4][in + 1][4]: k = output row
         }
     const int R = m->R, R2 = m->R2;
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);

@@ -45,7 +45,45 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
     const int cg = wave & (cgp - 1), ks = wave >> cgs;
     const int k0 = ks * kper;
     const int n = min(64 * cg + lane, N - 1);
-    // all weight loads of the layer in flight before the first MFMA; row index clamped (the A operand is zero beyond K)
+    // ---- the common case, with as few SCALAR instructions as possible.  The CU has ONE scalar unit for its 16 waves: at
+    // ~300 scalar instructions per wave and op (r3 counters: SQ_INSTS_SALU) it alone was ~2 of an op's 3.8 us, every wave
+    // computing the same clamps, bounds and offsets.  When this wave's MK k-steps are all its own (kper == MK), lie inside
+    // the slot row, and the weight chunks it names exist (the matrix + its kW4Pad zero rows), nothing needs clamping or
+    // masking: the A operand beyond K is zero by construction (every writer of a slot zeroes columns >= N; the constant-1
+    // column is the last one a layer reads), the chunk offsets advance by one scalar add, the LDS reads take immediate
+    // offsets.
+    if (op.W4 && kper == MK && k0 + MK <= kCL && (k0 >> 2) + MK / 4 - 1 <= ((K - 1) >> 2) + kW4Pad) {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.W4), 0, 0x7FFFFFF0, 0x00020000);
+        const unsigned vo = (unsigned)n * 16u;
+        const unsigned st = (unsigned)op.ns4 * 16u;
+        unsigned so = (unsigned)(k0 >> 2) * st;
+        float4 wq[MK / 4];
+#pragma unroll
+        for (int j = 0; j < MK / 4; ++j) { wq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0)); so += st; }
+        if (wts && lane == 0) wts[wave] = wall_clock64();
+        const float4* a4 = reinterpret_cast<const float4*>(src + (lane & 3) * kCL + k0);
+        f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int j = 0; j < MK / 4; ++j) {
+            float4 x = a4[j];
+            float w0 = wq[j].x, w1 = wq[j].y, w2 = wq[j].z, w3 = wq[j].w;
+            if (BF) {
+                x.x = chain4_rb(x.x); x.y = chain4_rb(x.y); x.z = chain4_rb(x.z); x.w = chain4_rb(x.w);
+                w0 = chain4_rb(w0); w1 = chain4_rb(w1); w2 = chain4_rb(w2); w3 = chain4_rb(w3);
+            }
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, w0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, w1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, w2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, w3, c1, 0, 0, 0);
+        }
+        c0 += c1;
+        float* pq = part + (size_t)ks * (4 * 64 * cgp) + 64 * cg + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pq[r * 64 * cgp] = c0[r];
+        if (wts && lane == 0) wts[32 + wave] = wall_clock64();
+        return;
+    }
+    // ---- the general case: all weight loads of the layer in flight before the first MFMA; row index clamped
     float w[MK];
     if (op.W4) {
         // k4-interleaved copy: four consecutive k of this lane's column in one 16-byte load, a wave-instruction = 1 KB
@@ -116,7 +154,11 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
     // partial sums: part[ks][row][64 cg + lane], row stride 64 cgp
     float* pp = part + (size_t)ks * (4 * 64 * cgp) + 64 * cg + lane;
 #pragma unroll
+#ifndef C4_NO_PART
     for (int r = 0; r < 4; ++r) pp[r * 64 * cgp] = acc0[r];
+#else
+    if (acc0[0] == 12345.f) pp[0] = acc0[1];
+#endif
     if (wts && lane == 0) wts[32 + wave] = wall_clock64();             // ... its partial sums are in LDS
 }
 
@@ -179,7 +221,11 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
             const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
             if (wts && tid == 0) wts[52] = wall_clock64();
+#ifdef C4_NO_EPI
+            if (ecol < 0) {
+#else
             if (ecol < kCL) {
+#endif
                 float v = 0.f;
                 if (ecol < N && erow < nrows) {
                     // the k-slices' partial sums: every read of the cell in flight at once (a loop over KS waited for each
@@ -344,10 +390,12 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 53] = wall_clock64();
         chain_barrier();
         if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 54] = wall_clock64();
+#ifndef C4_NO_ONECOL
         if (one_col >= 0) {
             if (tid < kR4) dst[tid * kCL + one_col] = tid < nrows ? 1.f : 0.f;
             chain_barrier();
         }
+#endif
         if (erow < nrows && ecol < opN) {
             if (outp) outp[(size_t)(out_row0 + r0 + erow) * ldo + ecol] = dst[erow * kCL + ecol];
             if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];

@@ -153,6 +153,7 @@ namespace aae {
 // interleave4_kernel after any other writer.
 // ---------------------------------------------------------------------------------------------
 struct W4Copies { float* f4; float* d4; int M, N; };      // f4 == NULL: the layer has none
+constexpr int kW4Pad = 4;      // zero k-chunk rows behind a k4-interleaved copy (what an unclamped run of chunks may read)
 // element (o, i) of P just became v
 __device__ __forceinline__ void w4_put1(const W4Copies& c, int o, int i, float v) {
     c.f4[((size_t)(i >> 2) * c.M + o) * 4 + (i & 3)] = v;
