@@ -183,9 +183,13 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     const int nrows = min(kR4, P.rows - r0);
     const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
 
-    for (int oi = 0; oi < P.nops; ++oi) {
+    // (debug stamps, AAE_CHAIN_TS: workgroup 0 only; one pinned pointer, NULL in production)
+    unsigned long long* tsp = blockIdx.x == 0 ? P.ts : nullptr;
+    int nops = P.nops;
+    asm volatile("" : "+s"(tsp), "+s"(nops));
+    for (int oi = 0; oi < nops; ++oi) {
         const ChainOp& op = P.ops[oi];
-        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[oi] = wall_clock64();
+        if (tsp && tid == 0) tsp[oi] = wall_clock64();
         // The scalars every op needs, and a linear op's, requested together and pinned by ONE statement each: a single
         // s_waitcnt for the batch.  hipcc treats descriptor fields (kernel-argument segment) as free to re-load at their
         // use, each a dependent scalar-load round trip of ~200 clocks (tools/debug/ubench/sload_latency.hip) - ~20 of them
@@ -195,22 +199,32 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         int ldo = op.ldo, ldo2 = op.ldo2, out_row0 = op.out_row0;
         float* outp = op.out; float* out2p = op.out2;
         Lin4 lin; lin.N = opN; lin.K = opK; lin.ldkn = op.ldkn; lin.ns4 = op.ns4; lin.W4 = op.W4; lin.Wkn = op.Wkn;
-        int epi_k = op.epi;
+        int epi_k = op.epi, yslot_k = op.yslot;
         asm volatile("" : "+s"(kind), "+s"(src_i), "+s"(dst_i), "+s"(row_lo), "+s"(one_col), "+s"(opN), "+s"(opK), "+s"(ldo), "+s"(ldo2),
-                          "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k));
+                          "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k), "+s"(yslot_k));
         asm volatile("" : "+s"(lin.ldkn), "+s"(lin.ns4), "+s"(lin.W4), "+s"(lin.Wkn));
         lin.N = opN; lin.K = opK;
         if (r0 < row_lo) continue;                     // (workgroup-uniform: an op of the upper rows' program prefix)
         float* dst = slots + dst_i * kR4 * kCL;
         const float* src = slots + src_i * kR4 * kCL;
 
+        // the other kinds' scalars, the same way (one batch)
+        const float* qW = nullptr; float* qaux_ptr = nullptr; size_t qstride = 0;
+        int qldw = 0, qdst_col0 = 0, qaux = 0, qaux_ld = 0, qyslot = 0, qgrow0 = 0, qrow_split = 0, qfake_slot = -1;
+        float qscale = 0.f;
+        if (kind != COP_LINEAR && kind != COP_LINEAR_DX) {
+            qW = op.W; qaux_ptr = op.aux_ptr; qstride = op.stride; qldw = op.ldw; qdst_col0 = op.dst_col0; qaux = op.aux;
+            qaux_ld = op.aux_ld; qyslot = op.yslot; qgrow0 = op.grow0; qrow_split = op.row_split; qfake_slot = op.fake_slot; qscale = op.scale;
+            asm volatile("" : "+s"(qW), "+s"(qaux_ptr), "+s"(qstride), "+s"(qldw), "+s"(qdst_col0), "+s"(qaux), "+s"(qaux_ld), "+s"(qyslot),
+                              "+s"(qgrow0), "+s"(qrow_split), "+s"(qfake_slot), "+s"(qscale));
+        }
         if (kind == COP_LINEAR || kind == COP_LINEAR_DX) {
             const int N = opN, K = opK;
             const int CG = (N + 63) >> 6;
             const int cgs = CG <= 1 ? 0 : CG <= 2 ? 1 : 2, cgp = 1 << cgs;  // column groups, rounded to a power of two (shifts: a
             const int KS = 16 >> cgs;                                       // runtime division is ~150 clocks of its own, three of them per op)
             const int kper = (((K + KS - 1) >> (4 - cgs)) + 3) & ~3;        // k-steps per wave, a multiple of 4
-            unsigned long long* wts = (P.ts && blockIdx.x == 0 && oi == 2) ? P.ts + 64 : nullptr;
+            unsigned long long* wts = (tsp && oi == 2) ? tsp + 64 : nullptr;
             if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
             if ((wave & (cgp - 1)) < CG) {
                 if (kper <= 16) chain4_linear<16, BF>(lin, src, part, wave, lane, cgs, kper, wts);
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                     else sum_slices(std::integral_constant<int, 16>{});
                     // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
                     if (ec.epi == CEPI_ACTBWD) {
-                        v *= act_grad_from_y(ec.act, (slots + op.yslot * kR4 * kCL)[erow * kCL + ecol]);
+                        v *= act_grad_from_y(ec.act, (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
                     } else {
                         v = chain_epi(ec, r0 + erow, erow, ecol, v);
@@ -253,39 +267,39 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 dst[erow * kCL + ecol] = v;                                 // columns >= N read as zero for the next layer
             }
         } else if (kind == COP_LOAD) {
-            if (ecol + op.dst_col0 < kCL)
-                dst[erow * kCL + op.dst_col0 + ecol] =
-                    (erow < nrows && ecol < op.N) ? op.W[(size_t)(op.out_row0 + r0 + erow) * op.ldw + ecol] * op.scale : 0.f;
+            if (ecol + qdst_col0 < kCL)
+                dst[erow * kCL + qdst_col0 + ecol] =
+                    (erow < nrows && ecol < opN) ? qW[(size_t)(out_row0 + r0 + erow) * qldw + ecol] * qscale : 0.f;
         } else if (kind == COP_SLABSUM) {
-            // sum of op.aux (<= 16) partial slabs: every slab load of a thread is in flight at once
+            // sum of qaux (<= 16) partial slabs: every slab load of a thread is in flight at once
             if (ecol < kCL) {
-                const int rowc = min(erow, max(nrows, 1) - 1), cc = min(ecol, op.N - 1);
+                const int rowc = min(erow, max(nrows, 1) - 1), cc = min(ecol, opN - 1);
                 float v[16];
 #pragma unroll
                 for (int z = 0; z < 16; ++z)
-                    v[z] = op.W[(size_t)min(z, op.aux - 1) * op.stride + (size_t)(r0 + rowc) * op.ldw + cc];
+                    v[z] = qW[(size_t)min(z, qaux - 1) * qstride + (size_t)(r0 + rowc) * qldw + cc];
                 float acc = 0.f;
 #pragma unroll
                 for (int z = 0; z < 16; ++z)
-                    if (z < op.aux) acc += v[z];
-                if (op.epi == CEPI_ACTBWD) {
+                    if (z < qaux) acc += v[z];
+                if (epi_k == CEPI_ACTBWD) {
                     const EpiCtx sec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
-                    const float y = op.aux_ptr[(size_t)(r0 + rowc) * op.aux_ld + cc];
-                    const bool cell = erow < nrows && ecol < op.N;
+                    const float y = qaux_ptr[(size_t)(r0 + rowc) * qaux_ld + cc];
+                    const bool cell = erow < nrows && ecol < opN;
                     const float kp = (sec.den && cell) ? (chain_keep(sec, r0 + erow, ecol) ? sec.mk : 0.f) : 1.f;
                     acc *= act_grad_from_y(sec.act, y) * kp;
                 }
-                dst[erow * kCL + ecol] = (erow < nrows && ecol < op.N) ? acc : 0.f;
+                dst[erow * kCL + ecol] = (erow < nrows && ecol < opN) ? acc : 0.f;
             }
         } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
             const EpiCtx ec = chain_epi_ctx(kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD, op, P, key, slots);
             if (ecol < kCL) {
                 float v = 0.f;
-                if (erow < nrows && ecol < op.N) {
+                if (erow < nrows && ecol < opN) {
                     v = src[erow * kCL + ecol];
                     if (kind == COP_DROPACT) v = chain_epi(ec, r0 + erow, erow, ecol, v);
                     else {
-                        v *= act_grad_from_y(ec.act, (slots + op.yslot * kR4 * kCL)[erow * kCL + ecol]);
+                        v *= act_grad_from_y(ec.act, (slots + qyslot * kR4 * kCL)[erow * kCL + ecol]);
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
                     }
                 }
@@ -294,52 +308,52 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         } else if (kind == COP_FINAL_FWD) {
             if (wave < kR4) {                           // one wave per row; softmax / sigmoid / identity, in place on dst
                 float* zr = dst + wave * kCL;
-                if (op.aux == 1) {
+                if (qaux == 1) {
                     float mx = -INFINITY;
-                    for (int j = lane; j < op.N; j += 64) mx = fmaxf(mx, zr[j]);
+                    for (int j = lane; j < opN; j += 64) mx = fmaxf(mx, zr[j]);
                     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
                     float sum = 0.f;
-                    for (int j = lane; j < op.N; j += 64) sum += expf(zr[j] - mx);
+                    for (int j = lane; j < opN; j += 64) sum += expf(zr[j] - mx);
                     sum = wave_sum(sum);
-                    for (int j = lane; j < op.N; j += 64) zr[j] = expf(zr[j] - mx) / sum;
-                } else if (op.aux == 2) {
-                    for (int j = lane; j < op.N; j += 64) zr[j] = sigmoidf_(zr[j]);
+                    for (int j = lane; j < opN; j += 64) zr[j] = expf(zr[j] - mx) / sum;
+                } else if (qaux == 2) {
+                    for (int j = lane; j < opN; j += 64) zr[j] = sigmoidf_(zr[j]);
                 }
             }
         } else if (kind == COP_FINAL_BWD) {
             if (wave < kR4) {
-                const float* zr = slots + op.yslot * kR4 * kCL + wave * kCL;
+                const float* zr = slots + qyslot * kR4 * kCL + wave * kCL;
                 const float* gr = src + wave * kCL;
                 float* o = dst + wave * kCL;
-                if (op.aux == 1) {
+                if (qaux == 1) {
                     float dot = 0.f;
-                    for (int j = lane; j < op.N; j += 64) dot += gr[j] * zr[j];
+                    for (int j = lane; j < opN; j += 64) dot += gr[j] * zr[j];
                     dot = wave_sum(dot);
-                    for (int j = lane; j < op.N; j += 64) o[j] = zr[j] * (gr[j] - dot);
-                } else if (op.aux == 2) {
-                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j] * zr[j] * (1.f - zr[j]);
+                    for (int j = lane; j < opN; j += 64) o[j] = zr[j] * (gr[j] - dot);
+                } else if (qaux == 2) {
+                    for (int j = lane; j < opN; j += 64) o[j] = gr[j] * zr[j] * (1.f - zr[j]);
                 } else {
-                    for (int j = lane; j < op.N; j += 64) o[j] = gr[j];
+                    for (int j = lane; j < opN; j += 64) o[j] = gr[j];
                 }
-                for (int j = op.N + lane; j < kCL; j += 64) o[j] = 0.f;
+                for (int j = opN + lane; j < kCL; j += 64) o[j] = 0.f;
             }
         } else if (kind == COP_PRIOR) {
             if (ecol < kCL) {
-                const int grow = r0 + erow, n = op.N;
+                const int grow = r0 + erow, n = opN;
                 const uint64_t k = key ^ (100ull * 0xA0761D6478BD642Full);
                 float v = 0.f;
                 if (erow < nrows && ecol < n) {
-                    if (grow >= op.row_split) v = op.fake_slot >= 0 ? (slots + op.fake_slot * kR4 * kCL)[erow * kCL + ecol] : op.W[(size_t)grow * op.ldw + ecol];
-                    else if (op.aux_ptr) v = op.aux_ptr[(size_t)grow * op.aux_ld + ecol] * op.scale;
-                    else if (op.aux == 0) {          // gauss: Box-Muller on two words of the counter generator
-                        const uint32_t u1 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * ecol));
-                        const uint32_t u2 = hash_cell(k, (uint32_t)(grow + op.grow0), (uint32_t)(2 * ecol + 1));
+                    if (grow >= qrow_split) v = qfake_slot >= 0 ? (slots + qfake_slot * kR4 * kCL)[erow * kCL + ecol] : qW[(size_t)grow * qldw + ecol];
+                    else if (qaux_ptr) v = qaux_ptr[(size_t)grow * qaux_ld + ecol] * qscale;
+                    else if (qaux == 0) {          // gauss: Box-Muller on two words of the counter generator
+                        const uint32_t u1 = hash_cell(k, (uint32_t)(grow + qgrow0), (uint32_t)(2 * ecol));
+                        const uint32_t u2 = hash_cell(k, (uint32_t)(grow + qgrow0), (uint32_t)(2 * ecol + 1));
                         const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
                         const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
-                        v = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2) * op.scale;
-                    } else if (op.aux == 1) {        // categorical: one-hot of a uniform class per row
-                        const uint32_t u = hash_cell(k, (uint32_t)(grow + op.grow0), 0xFFFFFFFFu);
-                        v = ((int)(u % (uint32_t)n) == ecol) ? op.scale : 0.f;
+                        v = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2) * qscale;
+                    } else if (qaux == 1) {        // categorical: one-hot of a uniform class per row
+                        const uint32_t u = hash_cell(k, (uint32_t)(grow + qgrow0), 0xFFFFFFFFu);
+                        v = ((int)(u % (uint32_t)n) == ecol) ? qscale : 0.f;
                     }                                // bernoulli: the reference's randint(0, 1) is always 0 (aae.py:86-88)
                 }
                 dst[erow * kCL + ecol] = v;
@@ -349,30 +363,30 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             if (wave < kR4) {
                 const EpiCtx ec = chain_epi_ctx(CEPI_ACTBWD, op, P, key, slots);
                 const int lrow = wave, grow = r0 + lrow;
-                const int Kk = op.K, Nn = op.N;
+                const int Kk = opK, Nn = opN;
                 float wv[4], dot = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = lane + 64 * j;
-                    wv[j] = op.W[min(k, Kk - 1)];
+                    wv[j] = qW[min(k, Kk - 1)];
                     if (k < Kk) dot += src[lrow * kCL + k] * wv[j];
                 }
                 const float logit = wave_sum(dot);
                 float gv = 0.f;
                 if (lrow < nrows) {
                     const float dv = sigmoidf_(logit);
-                    const int Bsplit = op.row_split;
+                    const int Bsplit = qrow_split;
                     const float invB = 1.f / (float)Bsplit;
                     float l, gg;
-                    if (op.aux == 0 && grow >= Bsplit) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
+                    if (qaux == 0 && grow >= Bsplit) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
                     else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
-                    gv = gg * dv * (1.f - dv) * op.scale;
+                    gv = gg * dv * (1.f - dv) * qscale;
                     if (lane == 0) {
                         atomicAdd(P.loss_out + P.loss_slot, -l * invB);
-                        if (op.aux_ptr) op.aux_ptr[(size_t)grow * op.aux_ld] = gv;
+                        if (qaux_ptr) qaux_ptr[(size_t)grow * qaux_ld] = gv;
                     }
                 }
-                const float* ys = slots + op.yslot * kR4 * kCL;
+                const float* ys = slots + qyslot * kR4 * kCL;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = lane + 64 * j;
@@ -387,9 +401,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 }
             }
         }   // COP_STORE: only the stores below.  (COP_ADV / COP_REPARAM*: VAE programs stay on chain.h's kernel)
-        if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 53] = wall_clock64();
+        if (tsp && oi == 2 && tid == 0) tsp[64 + 53] = wall_clock64();
         chain_barrier();
-        if (P.ts && blockIdx.x == 0 && oi == 2 && tid == 0) P.ts[64 + 54] = wall_clock64();
+        if (tsp && oi == 2 && tid == 0) tsp[64 + 54] = wall_clock64();
 #ifndef C4_NO_ONECOL
         if (one_col >= 0) {
             if (tid < kR4) dst[tid * kCL + one_col] = tid < nrows ? 1.f : 0.f;
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];
         }
     }
-    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[P.nops] = wall_clock64();
+    if (tsp && tid == 0) tsp[nops] = wall_clock64();
 }
 
 }  // namespace aae
