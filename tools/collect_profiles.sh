@@ -20,4 +20,5 @@ echo "[collect] pmc write"; bash tools/pmc_pass.sh write WRITE_SIZE
 echo "[collect] pmc mfma"; bash tools/pmc_pass.sh mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
 echo "[collect] pmc mfma (bf16 ops: the r3 output-layer kernels multiply on the bf16 matrix cores)"; bash tools/pmc_pass.sh mfma_bf16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES
 echo "[collect] pmc lds"; bash tools/pmc_pass.sh lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
+echo "[collect] pmc scalar / vector instruction counts (r3: the CU's one scalar unit serves its 16 waves)"; bash tools/pmc_pass.sh insts SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES
 echo "[collect] done"
