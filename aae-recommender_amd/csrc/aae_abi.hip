@@ -98,6 +98,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         m->force_unfused = cfg->unfused_decoder == 1;   // debugging / A-B switch: unfused_decoder = 1 keeps the 3-kernel path
         if (m->fused_ok) {
@@ -182,6 +184,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess

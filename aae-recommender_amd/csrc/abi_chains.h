@@ -86,7 +86,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (cb.P.ops[i].row_lo > 0 && !four) return fail(AAE_ESTATE, "a program prefix for the upper rows needs the 4-row chain kernel");
     if (four) {
         const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
-        if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+        if (want_ts && !m->bf16) hipLaunchKernelGGL((chain4_kernel<false, true>), dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+        else if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
         else hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     } else if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);

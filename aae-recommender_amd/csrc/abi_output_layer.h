@@ -105,7 +105,10 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_crit_x3_kernel<13>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    default:
+                        if (b.ts) hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b);
+                        else hipExtLaunchKernelGGL((dec_crit_x3_kernel<13>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b);
+                        break;
                     }
                 } else switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;

@@ -37,9 +37,10 @@ __device__ __forceinline__ float chain4_rb(float x) {       // nearest bf16 valu
 // the scalars of a linear op, loaded from the op descriptor in one batch by the caller
 struct Lin4 { int N, K, ldkn, ns4; const float* W4; const float* Wkn; };
 
-template <int MK, bool BF>
+template <int MK, bool BF, bool TS = false>
 __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, float* part, int wave, int lane,
-                                              int cgs, int kper, unsigned long long* wts = nullptr) {
+                                              int cgs, int kper, unsigned long long* wts_ = nullptr) {
+    unsigned long long* wts = TS ? wts_ : nullptr;
     const int N = op.N, K = op.K, ld = op.ldkn;
     const int cgp = 1 << cgs;
     const int cg = wave & (cgp - 1), ks = wave >> cgs;
@@ -59,7 +60,14 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
         unsigned so = (unsigned)(k0 >> 2) * st;
         float4 wq[MK / 4];
 #pragma unroll
+#ifdef C4_NO_LOADS
+        for (int j = 0; j < MK / 4; ++j) { wq[j] = make_float4(1.f + so, 2.f, 3.f, 4.f + vo); so += st; }
+#else
         for (int j = 0; j < MK / 4; ++j) { wq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0)); so += st; }
+#endif
+#ifdef C4_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (wts && lane == 0) wts[wave] = wall_clock64();
         const float4* a4 = reinterpret_cast<const float4*>(src + (lane & 3) * kCL + k0);
         f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
@@ -162,14 +170,11 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
     if (wts && lane == 0) wts[32 + wave] = wall_clock64();             // ... its partial sums are in LDS
 }
 
-#ifdef C4_PROG_PTR
-template <bool BF>
-__global__ __launch_bounds__(kC4T) void chain4_kernel(const ChainProgram* __restrict__ Pp) {
-    const ChainProgram& P = *Pp;
-#else
-template <bool BF>
+// TS: the debug build with in-kernel stamps (AAE_CHAIN_TS).  The production build carries none: a stamp site between a layer's
+// weight loads and its products is a (flat) store the compiler orders with s_waitcnt vmcnt(0) - every product then waited for
+// ALL of the wave's loads instead of its own chunk's - and each site costs every wave scalar instructions.
+template <bool BF, bool TS = false>
 __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
-#endif
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][4][kCL], then the partial-sum scratch
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
         tile_bucket_body(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
@@ -184,12 +189,12 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
 
     // (debug stamps, AAE_CHAIN_TS: workgroup 0 only; one pinned pointer, NULL in production)
-    unsigned long long* tsp = blockIdx.x == 0 ? P.ts : nullptr;
+    unsigned long long* tsp = (TS && blockIdx.x == 0) ? P.ts : nullptr;
     int nops = P.nops;
     asm volatile("" : "+s"(tsp), "+s"(nops));
     for (int oi = 0; oi < nops; ++oi) {
         const ChainOp& op = P.ops[oi];
-        if (tsp && tid == 0) tsp[oi] = wall_clock64();
+        if (TS && tsp && tid == 0) tsp[oi] = wall_clock64();
         // The scalars every op needs, and a linear op's, requested together and pinned by ONE statement each: a single
         // s_waitcnt for the batch.  hipcc treats descriptor fields (kernel-argument segment) as free to re-load at their
         // use, each a dependent scalar-load round trip of ~200 clocks (tools/debug/ubench/sload_latency.hip) - ~20 of them
@@ -224,12 +229,12 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             const int cgs = CG <= 1 ? 0 : CG <= 2 ? 1 : 2, cgp = 1 << cgs;  // column groups, rounded to a power of two (shifts: a
             const int KS = 16 >> cgs;                                       // runtime division is ~150 clocks of its own, three of them per op)
             const int kper = (((K + KS - 1) >> (4 - cgs)) + 3) & ~3;        // k-steps per wave, a multiple of 4
-            unsigned long long* wts = (tsp && oi == 2) ? tsp + 64 : nullptr;
+            unsigned long long* wts = (TS && tsp && oi == 2) ? tsp + 64 : nullptr;
             if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
             if ((wave & (cgp - 1)) < CG) {
-                if (kper <= 16) chain4_linear<16, BF>(lin, src, part, wave, lane, cgs, kper, wts);
-                else if (kper <= 28) chain4_linear<28, BF>(lin, src, part, wave, lane, cgs, kper, wts);
-                else chain4_linear<52, BF>(lin, src, part, wave, lane, cgs, kper, wts);
+                if (kper <= 16) chain4_linear<16, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                else if (kper <= 28) chain4_linear<28, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                else chain4_linear<52, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
             }
             chain_barrier();
             if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
@@ -401,9 +406,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 }
             }
         }   // COP_STORE: only the stores below.  (COP_ADV / COP_REPARAM*: VAE programs stay on chain.h's kernel)
-        if (tsp && oi == 2 && tid == 0) tsp[64 + 53] = wall_clock64();
+        if (TS && tsp && oi == 2 && tid == 0) tsp[64 + 53] = wall_clock64();
         chain_barrier();
-        if (tsp && oi == 2 && tid == 0) tsp[64 + 54] = wall_clock64();
+        if (TS && tsp && oi == 2 && tid == 0) tsp[64 + 54] = wall_clock64();
 #ifndef C4_NO_ONECOL
         if (one_col >= 0) {
             if (tid < kR4) dst[tid * kCL + one_col] = tid < nrows ? 1.f : 0.f;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];
         }
     }
-    if (tsp && tid == 0) tsp[nops] = wall_clock64();
+    if (TS && tsp && tid == 0) tsp[nops] = wall_clock64();
 }
 
 }  // namespace aae

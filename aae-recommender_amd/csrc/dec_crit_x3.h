@@ -58,7 +58,10 @@ inline size_t dec_crit_x3_lds_bytes(int NB) {
                             (size_t)lsteps * kMB * 3 * 64 * 4);
 }
 
-template <int NB>   // NB = ceil((h + 1) / 16) column blocks
+// TS: the debug build with in-kernel stamps (AAE_DEC_TS=x3).  The production build carries none: every stamp site is a lane
+// test + two exec-mask instructions + a branch in all 16 waves, eight of them per tile - a quarter of the tile loop's ~100 scalar
+// instructions per wave, on a CU whose one scalar unit serves all its waves.
+template <int NB, bool TS = false>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
     constexpr int NKS = (KC1 + 1) / 2;         // ... per k half
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     float* Gt_blk = nblk > 1 ? a.Gt + (size_t)blk * ((a.N + kTI - 1) / kTI) * a.Bb * kTI : a.Gt;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
+    if (TS && a.ts && blockIdx.x == 0 && tid == 0) a.ts[10] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     const int ldv = a.ldv, N = a.N;
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(Gt_blk, 0, gbytes, 0x00020000);
     typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
     int iter = 0;
-    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[11] = wall_clock64();
-    auto stamp = [&](int k) { if (a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
+    if (TS && a.ts && blockIdx.x == 0 && tid == 0) a.ts[11] = wall_clock64();
+    auto stamp = [&](int k) { if (TS && a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
     __syncthreads();
 
     for (; tile < ntiles; tile += stride, ++iter) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         stamp(5);
         stamp(6);
     }
-    if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
+    if (TS && a.ts && blockIdx.x == 0 && tid == 0) a.ts[7] = wall_clock64();
 
     // ---- dA2 partial of this workgroup -> its slab; loss partial
     float* slab = slabs_blk + (size_t)wgi * a.slab_stride;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         float s = 0.f;
         for (int w = 0; w < kNW; ++w) s += red[w];
         a.partials[blockIdx.x] = s;
-        if (a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
+        if (TS && a.ts && blockIdx.x == 0) { a.ts[12] = wall_clock64(); a.ts[13] = (unsigned long long)iter; }
     }
 }
 

@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
     }
     const int grid = (rows + 3) / 4;
     hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define C4K(...) do { if (want_ts) hipLaunchKernelGGL((chain4_kernel<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((chain4_kernel<false>), __VA_ARGS__); } while (0)
     const size_t lds = kCSlots * kCR * kCL * sizeof(float);
 #ifdef C4_PROG_PTR
     ChainProgram* Pd; hipMalloc(&Pd, sizeof(P)); hipMemcpy(Pd, &P, sizeof(P), hipMemcpyHostToDevice);
@@ -40,11 +42,11 @@ int main(int argc, char** argv) {
 #else
 #define PARG P
 #endif
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid), dim3(1024), lds, 0, PARG);
+    for (int i = 0; i < 5; ++i) C4K(dim3(grid), dim3(1024), lds, 0, PARG);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid), dim3(1024), lds, 0, PARG);
+    for (int i = 0; i < 100; ++i) C4K(dim3(grid), dim3(1024), lds, 0, PARG);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[128]; hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
