@@ -22,16 +22,16 @@ constexpr int kBucketMaxTiles = 32 * 1024;   // LDS: (tiles + 1 + docs + 1 + 102
 // MAXD: documents the instance can take (kBucketMaxDocs, or kBucketWideDocs = 1024 for the global batch an item slice of
 // the vocabulary-sharded scheme sees: 8 ranks x 100 documents)
 constexpr int kBucketWideDocs = 1024;
-template <int MAXD = kBucketMaxDocs>
+template <int MAXD = kBucketMaxDocs, int NT = 1024>     // NT = threads of the calling workgroup (>= MAXD)
 __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles, int* __restrict__ tstart,
                                                  int* __restrict__ eb, int* __restrict__ en, float* __restrict__ ev,
                                                  int* bk_lds) {
     int* cnt = bk_lds;                               // [ntiles + 1]  histogram, then fill cursor
     int* dbeg = cnt + ntiles + 1;                    // [docs + 1]    first flat entry of each document
-    int* part = dbeg + MAXD + 1;                     // [1024]        scan scratch
+    int* part = dbeg + MAXD + 1;                     // [NT]          scan scratch
     __shared__ long long dlo[MAXD];                  // CSR offset of each document's first entry
     const int t = threadIdx.x, docs = bv.n_rows;
-    for (int i = t; i <= ntiles; i += 1024) cnt[i] = 0;
+    for (int i = t; i <= ntiles; i += NT) cnt[i] = 0;
     int len = 0;
     if (t < docs) {
         const int dc = bv.doc(t);
@@ -58,19 +58,19 @@ __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles
         return lo;
     };
     // pass 1: histogram over the tiles
-    for (int f = t; f < total; f += 1024) {
+    for (int f = t; f < total; f += NT) {
         const int d = doc_of(f);
         atomicAdd(&cnt[bv.indices[dlo[d] + (f - dbeg[d])] / kTI], 1);
     }
     __syncthreads();
     // exclusive scan of the tile counters -> tstart (global) and the fill cursors (LDS)
-    const int per = (ntiles + 1023) / 1024;
+    const int per = (ntiles + NT - 1) / NT;
     const int lo = min(t * per, ntiles), hi = min(ntiles, lo + per);
     int sum = 0;
     for (int i = lo; i < hi; ++i) sum += cnt[i];
     part[t] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < NT; o <<= 1) {
         const int v = t >= o ? part[t - o] : 0;
         __syncthreads();
         part[t] += v;
@@ -83,10 +83,10 @@ __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles
         cnt[i] = run;
         run += c;
     }
-    if (t == 1023) tstart[ntiles] = part[1023];
+    if (t == NT - 1) tstart[ntiles] = part[NT - 1];
     __syncthreads();
     // pass 2: fill
-    for (int f = t; f < total; f += 1024) {
+    for (int f = t; f < total; f += NT) {
         const int d = doc_of(f);
         const long long e = dlo[d] + (f - dbeg[d]);
         const int idx = bv.indices[e], tile = idx / kTI;

@@ -26,7 +26,14 @@
 namespace aae {
 
 constexpr int kR4 = 4;          // rows per workgroup
-constexpr int kC4T = 1024;      // threads
+#ifndef C4_WAVES
+#define C4_WAVES 16
+#endif
+constexpr int kC4W = C4_WAVES;              // waves per workgroup: 16, or 8 (every thread then owns two cells of the element-wise work)
+constexpr int kC4WS = kC4W == 16 ? 4 : 3;   // log2
+constexpr int kC4T = 64 * kC4W; // threads
+constexpr int kC4E = 1024 / kC4T;           // cells per thread in element-wise work (4 rows x 256 columns)
+constexpr int kC4ER = kC4T / 256;           // rows a pass of the workgroup's threads covers
 constexpr int kC4Part = 4096;   // floats of the k-split partial-sum scratch: [16 / cgp][4][64 cgp]
 
 __device__ __forceinline__ float chain4_rb(float x) {       // nearest bf16 value, as fp32
@@ -177,13 +184,13 @@ template <bool BF, bool TS = false>
 __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][4][kCL], then the partial-sum scratch
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
-        tile_bucket_body(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
+        tile_bucket_body<kBucketMaxDocs, kC4T>(P.bk.bv, P.bk.ntiles, P.bk.tstart, P.bk.eb, P.bk.en, P.bk.ev, reinterpret_cast<int*>(slots));
         return;
     }
     float* part = slots + kCSlots * kR4 * kCL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int erow = tid >> 8, ecol = tid & 255;       // element-wise work: one cell per thread
+    const int erow0 = tid >> 8, ecol = tid & 255;      // element-wise work: cell (erow0 + kC4ER e, ecol), e < kC4E
     const int r0 = blockIdx.x * kR4;
     const int nrows = min(kR4, P.rows - r0);
     const uint64_t key = rng_key(P.seed, (uint64_t)*P.step_ctr, 0);
@@ -227,24 +234,30 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             const int N = opN, K = opK;
             const int CG = (N + 63) >> 6;
             const int cgs = CG <= 1 ? 0 : CG <= 2 ? 1 : 2, cgp = 1 << cgs;  // column groups, rounded to a power of two (shifts: a
-            const int KS = 16 >> cgs;                                       // runtime division is ~150 clocks of its own, three of them per op)
-            const int kper = (((K + KS - 1) >> (4 - cgs)) + 3) & ~3;        // k-steps per wave, a multiple of 4
+            const int KS = kC4W >> cgs;                                     // runtime division is ~150 clocks of its own, three of them per op)
+            const int kper = (((K + KS - 1) >> (kC4WS - cgs)) + 3) & ~3;    // k-steps per wave, a multiple of 4
             unsigned long long* wts = (TS && tsp && oi == 2) ? tsp + 64 : nullptr;
             if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
             if ((wave & (cgp - 1)) < CG) {
                 if (kper <= 16) chain4_linear<16, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
                 else if (kper <= 28) chain4_linear<28, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
-                else chain4_linear<52, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                else if (kper <= 52) chain4_linear<52, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                else if (kC4W == 8) {       // (8 waves: two k-slices of a 200-wide layer - 100 or 104 k-steps per wave)
+                    if (kper == 100) chain4_linear<100, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                    else chain4_linear<104, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
+                }
             }
             chain_barrier();
             if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
             const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
             if (wts && tid == 0) wts[52] = wall_clock64();
 #ifdef C4_NO_EPI
-            if (ecol < 0) {
+            if (ecol < 0)
 #else
-            if (ecol < kCL) {
+            if (ecol < kCL)
 #endif
+            for (int eh = 0; eh < kC4E; ++eh) {
+                const int erow = erow0 + kC4ER * eh;
                 float v = 0.f;
                 if (ecol < N && erow < nrows) {
                     // the k-slices' partial sums: every read of the cell in flight at once (a loop over KS waited for each
@@ -258,9 +271,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
 #pragma unroll
                         for (int ks = 0; ks < NS; ++ks) v += pv[ks];
                     };
-                    if (cgs == 2) sum_slices(std::integral_constant<int, 4>{});           // (KS = 16 >> cgs)
-                    else if (cgs == 1) sum_slices(std::integral_constant<int, 8>{});
-                    else sum_slices(std::integral_constant<int, 16>{});
+                    if (cgs == 2) sum_slices(std::integral_constant<int, kC4W / 4>{});    // (KS = waves >> cgs)
+                    else if (cgs == 1) sum_slices(std::integral_constant<int, kC4W / 2>{});
+                    else sum_slices(std::integral_constant<int, kC4W>{});
                     // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
                     if (ec.epi == CEPI_ACTBWD) {
                         v *= act_grad_from_y(ec.act, (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);
@@ -273,11 +286,16 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             }
         } else if (kind == COP_LOAD) {
             if (ecol + qdst_col0 < kCL)
-                dst[erow * kCL + qdst_col0 + ecol] =
-                    (erow < nrows && ecol < opN) ? qW[(size_t)(out_row0 + r0 + erow) * qldw + ecol] * qscale : 0.f;
+                for (int eh = 0; eh < kC4E; ++eh) {
+                    const int erow = erow0 + kC4ER * eh;
+                    dst[erow * kCL + qdst_col0 + ecol] =
+                        (erow < nrows && ecol < opN) ? qW[(size_t)(out_row0 + r0 + erow) * qldw + ecol] * qscale : 0.f;
+                }
         } else if (kind == COP_SLABSUM) {
             // sum of qaux (<= 16) partial slabs: every slab load of a thread is in flight at once
-            if (ecol < kCL) {
+            if (ecol < kCL)
+            for (int eh = 0; eh < kC4E; ++eh) {
+                const int erow = erow0 + kC4ER * eh;
                 const int rowc = min(erow, max(nrows, 1) - 1), cc = min(ecol, opN - 1);
                 float v[16];
 #pragma unroll
@@ -298,7 +316,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             }
         } else if (kind == COP_DROPACT || kind == COP_ACTBWD) {
             const EpiCtx ec = chain_epi_ctx(kind == COP_DROPACT ? CEPI_DROPACT : CEPI_ACTBWD, op, P, key, slots);
-            if (ecol < kCL) {
+            if (ecol < kCL)
+            for (int eh = 0; eh < kC4E; ++eh) {
+                const int erow = erow0 + kC4ER * eh;
                 float v = 0.f;
                 if (erow < nrows && ecol < opN) {
                     v = src[erow * kCL + ecol];
@@ -343,7 +363,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 for (int j = opN + lane; j < kCL; j += 64) o[j] = 0.f;
             }
         } else if (kind == COP_PRIOR) {
-            if (ecol < kCL) {
+            if (ecol < kCL)
+            for (int eh = 0; eh < kC4E; ++eh) {
+                const int erow = erow0 + kC4ER * eh;
                 const int grow = r0 + erow, n = opN;
                 const uint64_t k = key ^ (100ull * 0xA0761D6478BD642Full);
                 float v = 0.f;
@@ -415,9 +437,12 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             chain_barrier();
         }
 #endif
-        if (erow < nrows && ecol < opN) {
-            if (outp) outp[(size_t)(out_row0 + r0 + erow) * ldo + ecol] = dst[erow * kCL + ecol];
-            if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];
+        for (int eh = 0; eh < kC4E; ++eh) {
+            const int erow = erow0 + kC4ER * eh;
+            if (erow < nrows && ecol < opN) {
+                if (outp) outp[(size_t)(out_row0 + r0 + erow) * ldo + ecol] = dst[erow * kCL + ecol];
+                if (out2p) out2p[(size_t)(r0 + erow) * ldo2 + ecol] = dst[erow * kCL + ecol];
+            }
         }
     }
     if (TS && tsp && tid == 0) tsp[nops] = wall_clock64();

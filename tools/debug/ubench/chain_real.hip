@@ -42,11 +42,11 @@ int main(int argc, char** argv) {
 #else
 #define PARG P
 #endif
-    for (int i = 0; i < 5; ++i) C4K(dim3(grid), dim3(1024), lds, 0, PARG);
+    for (int i = 0; i < 5; ++i) C4K(dim3(grid), dim3(kC4T), lds, 0, PARG);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 100; ++i) C4K(dim3(grid), dim3(1024), lds, 0, PARG);
+    for (int i = 0; i < 100; ++i) C4K(dim3(grid), dim3(kC4T), lds, 0, PARG);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[128]; hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
