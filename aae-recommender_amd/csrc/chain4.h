@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             asm volatile("" : "+s"(qW), "+s"(qaux_ptr), "+s"(qstride), "+s"(qldw), "+s"(qdst_col0), "+s"(qaux), "+s"(qaux_ld), "+s"(qyslot),
                               "+s"(qgrow0), "+s"(qrow_split), "+s"(qfake_slot), "+s"(qscale));
         }
+        bool one_done = false;                         // the constant-1 column was written by the op's own cell loop
         if (kind == COP_LINEAR || kind == COP_LINEAR_DX) {
             const int N = opN, K = opK;
             const int CG = (N + 63) >> 6;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                     else chain4_linear<104, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
                 }
             }
+            one_done = true;
             chain_barrier();
             if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
             const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
@@ -282,15 +284,18 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                         v = chain_epi(ec, r0 + erow, erow, ecol, v);
                     }
                 }
-                dst[erow * kCL + ecol] = v;                                 // columns >= N read as zero for the next layer
+                // (columns >= N read as zero for the next layer; the constant-1 column of an augmented layer input rides here
+                //  instead of in a write + barrier of its own behind every op)
+                dst[erow * kCL + ecol] = ecol == one_col ? (erow < nrows ? 1.f : 0.f) : v;
             }
         } else if (kind == COP_LOAD) {
             if (ecol + qdst_col0 < kCL)
                 for (int eh = 0; eh < kC4E; ++eh) {
                     const int erow = erow0 + kC4ER * eh;
-                    dst[erow * kCL + qdst_col0 + ecol] =
-                        (erow < nrows && ecol < opN) ? qW[(size_t)(out_row0 + r0 + erow) * qldw + ecol] * qscale : 0.f;
+                    const float lv = (erow < nrows && ecol < opN) ? qW[(size_t)(out_row0 + r0 + erow) * qldw + ecol] * qscale : 0.f;
+                    dst[erow * kCL + qdst_col0 + ecol] = qdst_col0 + ecol == one_col ? (erow < nrows ? 1.f : 0.f) : lv;
                 }
+            one_done = true;
         } else if (kind == COP_SLABSUM) {
             // sum of qaux (<= 16) partial slabs: every slab load of a thread is in flight at once
             if (ecol < kCL)
@@ -328,8 +333,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
                     }
                 }
-                dst[erow * kCL + ecol] = v;
+                dst[erow * kCL + ecol] = ecol == one_col ? (erow < nrows ? 1.f : 0.f) : v;
             }
+            one_done = true;
         } else if (kind == COP_FINAL_FWD) {
             if (wave < kR4) {                           // one wave per row; softmax / sigmoid / identity, in place on dst
                 float* zr = dst + wave * kCL;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         chain_barrier();
         if (TS && tsp && oi == 2 && tid == 0) tsp[64 + 54] = wall_clock64();
 #ifndef C4_NO_ONECOL
-        if (one_col >= 0) {
+        if (one_col >= 0 && !one_done) {
             if (tid < kR4) dst[tid * kCL + one_col] = tid < nrows ? 1.f : 0.f;
             chain_barrier();
         }
