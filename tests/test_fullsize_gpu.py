@@ -156,8 +156,9 @@ def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_defe
     np.testing.assert_allclose(split.predict(csr, 0, B).cpu().numpy(), single.predict(csr, 0, B).cpu().numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("Ns,B", [(12500, 105), (12500, 800), (25000, 512), (4587, 1000), (50000, 200), (275000, 512)])
-def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, monkeypatch):
+@pytest.mark.parametrize("Ns,B,h", [(12500, 105, 200), (12500, 800, 200), (25000, 512, 200), (4587, 1000, 200), (50000, 200, 200), (275000, 512, 200),
+                                    (6000, 300, 50), (9000, 230, 100), (40000, 512, 100), (3000, 130, 61)])
+def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, h, monkeypatch):
     """Batches beyond one fused launch (112 rows) on a model created with blocked_output=True - what the item slices of the
     vocabulary-sharded scheme run at every world size > 1 (slice x the global batch, aae_output_layer_step): one critical
     launch per row block of <= 104 rows, the deferred launches accumulating dV3 over the blocks before ONE optimiser pass.
@@ -165,7 +166,7 @@ def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, monkeypatc
     above): dL/d(dh2), loss, parameters and both moments after two consecutive steps."""
     from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
     from tools.synth import throughput_corpus
-    h, c = 200, 50
+    c = 50        # (h = 50 / 61 / 100: the 4- and 7-column-block instantiations of both launches, 12 / 9 spare waves in the deferred one)
     monkeypatch.setenv("AAE_BLOCKED_ANY", "1")       # (r2: the library kept the three GEMMs beyond 32 M cells; since r3 the row-blocked form covers 275 000 x 512, a C5 slice, by itself)
     rng = np.random.default_rng(Ns + B)
     k = 1.0 / np.sqrt(h)
