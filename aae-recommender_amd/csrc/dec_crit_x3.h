@@ -98,6 +98,43 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
     constexpr int NV = 2;                       // float4 slots per thread of a tile span (tile_f4 <= 2048)
 
+    // ---- the parameter stream, FIRST: the first tile's parameters and entries travel (an HBM round trip, ~2 us) while the
+    // workgroup zeroes its images and splits its dh2 fragments below.
+    // The stream: tensor base in a buffer descriptor (scalar registers), the tile's byte offset in a scalar
+    // register, this thread's slot offset in ONE vector register (+ an immediate); reads beyond the tensor return zero
+    // (the dispatcher keeps fused layers below 2 GB)
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto load_span = [&](int tile, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+    };
+    float4 vreg[NV];
+    int tile = wgi;
+    const int stride = wgs;
+    const int last_e = max(a.te.start[ntiles] - 1, 0);
+    int ozr;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(ozr));
+    auto load_range = [&](int t, int& lo, int& hi) {       // (vector loads: a scalar load would sit in lgkmcnt, see dec_fused.h)
+        const int tc = min(t, ntiles - 1) + ozr;
+        lo = a.te.start[tc]; hi = a.te.start[tc + 1];
+        if (t >= ntiles) hi = lo;
+    };
+    int ce0 = 0, ce1 = 0, ne0 = 0, ne1 = 0, fe0 = 0, fe1 = 0;
+    int ent_bn = 0; float ent_v = 0.f;          // this thread's entry of the NEXT tile: (doc << 5) | item-in-tile, value
+    auto load_entry = [&](int lo) {
+        const int e = min(lo + tid, last_e);
+        ent_bn = (a.te.eb[e] << 5) | a.te.en[e]; ent_v = a.te.ev[e];
+    };
+    if (tile < ntiles) {
+        load_span(tile, vreg);
+        load_range(tile, ne0, ne1);
+        load_range(tile + stride, fe0, fe1);
+        load_entry(ne0);
+    }
     // ---- once per workgroup: zero the images (k padding of v3K, rows >= B of gK, the target tile)
     for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kXRS + 3 * kGR * S3 + kGR * kXT; i += kNT) v3K[i] = 0u;
 
@@ -138,41 +175,6 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     for (int q = 0; q < kMB; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float loss = 0.f;
 
-    // ---- the parameter stream: tensor base in a buffer descriptor (scalar registers), the tile's byte offset in a scalar
-    // register, this thread's slot offset in ONE vector register (+ an immediate); reads beyond the tensor return zero
-    // (the dispatcher keeps fused layers below 2 GB)
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
-    const unsigned lane_off = (unsigned)tid * 16u;
-    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    auto load_span = [&](int tile, float4* r) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
-    };
-    float4 vreg[NV];
-    int tile = wgi;
-    const int stride = wgs;
-    const int last_e = max(a.te.start[ntiles] - 1, 0);
-    int ozr;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(ozr));
-    auto load_range = [&](int t, int& lo, int& hi) {       // (vector loads: a scalar load would sit in lgkmcnt, see dec_fused.h)
-        const int tc = min(t, ntiles - 1) + ozr;
-        lo = a.te.start[tc]; hi = a.te.start[tc + 1];
-        if (t >= ntiles) hi = lo;
-    };
-    int ce0 = 0, ce1 = 0, ne0 = 0, ne1 = 0, fe0 = 0, fe1 = 0;
-    int ent_bn = 0; float ent_v = 0.f;          // this thread's entry of the NEXT tile: (doc << 5) | item-in-tile, value
-    auto load_entry = [&](int lo) {
-        const int e = min(lo + tid, last_e);
-        ent_bn = (a.te.eb[e] << 5) | a.te.en[e]; ent_v = a.te.ev[e];
-    };
-    if (tile < ntiles) {
-        load_span(tile, vreg);
-        load_range(tile, ne0, ne1);
-        load_range(tile + stride, fe0, fe1);
-        load_entry(ne0);
-    }
     int s_rc[NV];                               // this thread's slots of a tile span: item row * 64 + float4 column
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
