@@ -40,10 +40,11 @@ __device__ __forceinline__ float chain4_rb(float x) {       // nearest bf16 valu
     return __builtin_bit_cast(float, gemm_pack_bf16(x, 0.f) << 16);
 }
 
-// One layer's matrix work for this wave: MK = k-steps per wave (compile-time bound of the register arrays).
 // the scalars of a linear op, loaded from the op descriptor in one batch by the caller
 struct Lin4 { int N, K, ldkn, ns4; const float* W4; const float* Wkn; };
 
+// One layer's matrix work for this wave: MK = k-steps per wave (compile-time bound of the register arrays).
+// (-DC4_NO_LOADS / C4_NO_MFMA / C4_NO_A / C4_NO_PART / C4_NO_EPI / C4_NO_ONECOL: timing-only ablations, tools/debug/ubench/README.md)
 template <int MK, bool BF, bool TS = false>
 __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, float* part, int wave, int lane,
                                               int cgs, int kper, unsigned long long* wts_ = nullptr) {
@@ -71,9 +72,6 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
         for (int j = 0; j < MK / 4; ++j) { wq[j] = make_float4(1.f + so, 2.f, 3.f, 4.f + vo); so += st; }
 #else
         for (int j = 0; j < MK / 4; ++j) { wq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0)); so += st; }
-#endif
-#ifdef C4_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
 #endif
         if (wts && lane == 0) wts[wave] = wall_clock64();
         const float4* a4 = reinterpret_cast<const float4*>(src + (lane & 3) * kCL + k0);
