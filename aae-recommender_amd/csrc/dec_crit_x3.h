@@ -266,10 +266,16 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 const float l0 = raw[b * kXRS + n2] + raw[kGR * kXRS + b * kXRS + n2];
                 const float l1 = raw[b * kXRS + n2 + 1] + raw[kGR * kXRS + b * kXRS + n2 + 1];
                 const float2 tt = *reinterpret_cast<const float2*>(tgt + b * kXT + n2);
+                // the zero-target form for both cells; the pair of a target (2 400 of 10 M cells) takes ONE branch afterwards
+                // (three lane-dependent branches per pair cost every wave ~10 scalar instructions per tile more)
                 float gA, lA, gB, lB;
-                if (tt.x != 0.f) bce_elem(l0, tt.x, a.gscale, gA, lA); else bce_elem_t0(l0, a.gscale, gA, lA);
-                if (tt.y != 0.f) bce_elem(l1, tt.y, a.gscale, gB, lB); else bce_elem_t0(l1, a.gscale, gB, lB);
-                if (tt.x != 0.f || tt.y != 0.f) *reinterpret_cast<float2*>(tgt + b * kXT + n2) = make_float2(0.f, 0.f);
+                bce_elem_t0(l0, a.gscale, gA, lA);
+                bce_elem_t0(l1, a.gscale, gB, lB);
+                if (tt.x != 0.f || tt.y != 0.f) {
+                    if (tt.x != 0.f) bce_elem(l0, tt.x, a.gscale, gA, lA);
+                    if (tt.y != 0.f) bce_elem(l1, tt.y, a.gscale, gB, lB);
+                    *reinterpret_cast<float2*>(tgt + b * kXT + n2) = make_float2(0.f, 0.f);
+                }
                 if (i0 + n2 >= N) { gA = 0.f; lA = 0.f; }
                 if (i0 + n2 + 1 >= N) { gB = 0.f; lB = 0.f; }
                 loss += lA + lB;
