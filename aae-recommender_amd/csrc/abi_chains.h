@@ -119,7 +119,9 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
 }
 
 // up to 4 weight-gradient jobs in one launch
+int launch_w1_hot(aae_model* m, hipStream_t s);
 struct DwBuilder {
+    aae_model* mh = nullptr;       // set by add_first_layer: the wave form's hot list is worked off behind the launch
     DwGroup g; int tiles;
     DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
     void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
@@ -148,11 +150,22 @@ struct DwBuilder {
         static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
         w.nitem = 0;
         m->w1_items_merged = false;
+        w.wave_form = 0;
         if (!no_merge && !m->dense_step && !m->ext_first && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
             TRY(ensure_buckets(m, s));
             w.items = w1_items_args(m, ga1, 0, 0, which);
             w.nitem = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
             m->w1_items_merged = true;
+            // wide batches (beyond one fused launch): one wave per item, the head items through the hot list behind the launch
+            static const bool no_wave = getenv("AAE_NO_W1_WAVE") != nullptr;
+            if (!no_wave && m->rows > 16 * kMB && m->hot_list) {
+                w.wave_form = 1;
+                w.nitem = (w.nitem + 3) / 4;
+                const int set = m->hot_flip; m->hot_flip ^= 1;
+                w.hot = m->hot_list + (size_t)set * m->hot_cap; w.hot_count = m->hot_count + set; w.hot_zero = m->hot_count + (set ^ 1);
+                m->w1_hot_pending = true; m->w1_hot_set = set; m->w1_hot_which = which; m->w1_hot_ga1 = ga1;
+                mh = m;
+            }
         }
         return AAE_OK;
     }
@@ -161,9 +174,22 @@ struct DwBuilder {
         if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
+        if (mh) TRY(launch_w1_hot(mh, s));
         return AAE_OK;
     }
 };
+
+// the head items a wave-form first-layer update left on its hot list: the workgroup form over that list (w1_update.h)
+int launch_w1_hot(aae_model* m, hipStream_t s) {
+    if (!m->w1_hot_pending) return AAE_OK;
+    m->w1_hot_pending = false;
+    W1Items a = w1_items_args(m, m->w1_hot_ga1, 0, 0, m->w1_hot_which);
+    a.ulist = m->hot_list + (size_t)m->w1_hot_set * m->hot_cap; a.ucount = m->hot_count + m->w1_hot_set;
+    const size_t lds = sizeof(int) * w1_items_lds_words(m->rows);
+    hipLaunchKernelGGL(w1_item_update_kernel, dim3(std::min(m->hot_cap, 256)), dim3(256), lds, s, a);
+    LAUNCHCHK("w1_item_update (hot list)");
+    return AAE_OK;
+}
 
 // Encoder hidden stack from the gathered first layer (eh1 in global): lin2, lin3, output activation.
 // ops appended to `cb`; z ends in slot 2.

@@ -82,6 +82,8 @@ struct aae_model {
     // layer's gen_optim update, w1_update.h)
     int* tstart2; int* teb2; int* ten2; float* tev2;
     int* tsync; int* mark; int* ulist; int* ucount; int* stamp; LazyTab* tab;
+    int* hot_list = nullptr; int* hot_count = nullptr; int hot_cap = 0, hot_flip = 0;      // (w1_update.h, the wave form's head items)
+    bool w1_hot_pending = false; int w1_hot_set = 0, w1_hot_which = 0; const float* w1_hot_ga1 = nullptr;
     int* pslot; int* ptag;   // data parallel, peers > 1: [N][peers] slot of an item's row in each peer's packet / its stamp
     int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
@@ -272,6 +274,11 @@ size_t layout(aae_model* m, char* base, bool dry) {
     }
     m->ucount = reinterpret_cast<int*>(a.take(4, nullptr));
     m->stamp = m->ucount ? m->ucount + 1 : nullptr;
+    // wide batches: the head items of the first layer's one-wave-per-item update (w1_update.h): two alternating lists + counters
+    m->hot_cap = (int)std::max<int64_t>(256, c.max_nnz / kW1WaveRows + 64);
+    m->hot_list = reinterpret_cast<int*>(a.take((size_t)2 * m->hot_cap, nullptr));
+    m->hot_count = reinterpret_cast<int*>(a.take(4, nullptr));
+    m->hot_flip = 0;
     m->mark2 = m->ulist2 = m->ucount2 = m->stamp2 = nullptr;
     if (c.grad_mode == AAE_GRAD_FUSED) {      // second list set for aae_prefetch_batch (single-process training only)
         m->mark2 = reinterpret_cast<int*>(a.take(N, nullptr));

@@ -171,6 +171,118 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same update with one WAVE per item, for WIDE batches (beyond one fused launch's 112 rows: batch 512 on one GPU,
+// the global batch of an item slice).  A batch of 512 documents has ~7 000 distinct items, nearly all of them in one or two
+// rows: with a 4-wave workgroup each, a CU holds 8 items at a time and the launch ran in ~9 rounds of a latency chain four
+// memory round trips deep (75-98 us beside the deferred output-layer launch, r3).  A wave needs no barrier and no partial
+// sums: lane l owns the columns 4 l .. 4 l + 3 of a 256-column chunk for the sum AND for the optimiser (float4 state), and
+// a CU holds 32 items.  The rows of the item are collected from its tile's entries (lanes = entries, ballot + prefix
+// popcount), ranked by row (every listed row compared with every other: n <= kW1WaveRows) and added in ascending row order
+// - the summation order is a function of the batch alone, as in the workgroup form.  An item with more rows than
+// kW1WaveRows (a handful of head items of the Zipf vocabulary: the one item in every row would be 512 dependent-ish
+// loads for ONE wave) goes to the HOT list instead, which a launch of the workgroup form (w1_item_update_kernel with
+// ulist / ucount = the hot list) works off behind this one.
+// LDS: 4 x kW1WaveRows words per wave.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kW1WaveRows = 48;
+__host__ __device__ inline size_t w1_wave_lds_words(int waves) { return (size_t)waves * 4 * kW1WaveRows; }
+
+__device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restrict__ hot, int* __restrict__ hot_count,
+                                                  unsigned* lds, int vwave, int vwaves) {
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6);
+    int* rl = reinterpret_cast<int*>(lds) + wv * 4 * kW1WaveRows;      // rows as found
+    float* xl = reinterpret_cast<float*>(rl + kW1WaveRows);             // their values
+    int* rs = reinterpret_cast<int*>(xl + kW1WaveRows);                 // rows, ascending
+    float* xs = reinterpret_cast<float*>(rs + kW1WaveRows);             // their values x row scale
+    const int cnt = *a.ucount;
+    const bool upd = a.gout == nullptr;
+    OptScalars s;
+    if (upd) s = *a.sc;
+    for (int u = vwave; u < cnt; u += vwaves) {
+        const int item = a.ulist[u];
+        const int tile = item / kTI, it = item - tile * kTI;
+        const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
+        // the first column chunk's state travels while the rows are collected
+        const int c4 = 4 * lane;
+        const size_t o0 = (size_t)item * a.ldw + min(c4, a.ldw - 4);
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pm = pw, pv = pw;
+        if (upd) {
+            pw = *reinterpret_cast<const float4*>(a.W + o0);
+            if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o0); pv = *reinterpret_cast<const float4*>(a.V + o0); }
+        }
+        int n = 0;
+        for (int base = e0; base < e1; base += 64) {
+            const int e = base + lane, ec = min(e, e1 - 1);
+            const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
+            const bool hit = e < e1 && en_e == it;
+            const unsigned long long bal = __ballot(hit);
+            const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && k < kW1WaveRows) { rl[k] = r; xl[k] = x; }
+            n += __popcll(bal);
+        }
+        if (n > kW1WaveRows) {                          // a head item: the workgroup form takes it
+            if (lane == 0) hot[atomicAdd(hot_count, 1)] = item;
+            continue;
+        }
+        // rank by row (distinct rows: the batch's CSR is canonical) -> ascending lists
+        if (lane < n) {
+            const int r = rl[lane];
+            int k = 0;
+            for (int j = 0; j < n; ++j) k += rl[j] < r ? 1 : 0;
+            rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
+        }
+        // (one wave: its LDS writes are in order before its reads - no barrier)
+        for (int cb = 0; cb < a.h; cb += 256) {
+            const int cc = min(cb + c4, a.ld - 4);      // (lanes beyond the row: clamped, masked below)
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int kU = 8;                       // rows whose loads travel together; the adds stay in row order
+            for (int i0 = 0; i0 < n; i0 += kU) {
+                float4 g[kU]; float x[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    const int i = min(i0 + j, n - 1);
+                    const int r = rs[i];
+                    x[j] = i0 + j < n ? xs[i] : 0.f;
+                    const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
+                                                  : a.ga1 + (size_t)r * a.ld;
+                    g[j] = *reinterpret_cast<const float4*>(grow + cc);
+                }
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    acc.x += x[j] * g[j].x; acc.y += x[j] * g[j].y; acc.z += x[j] * g[j].z; acc.w += x[j] * g[j].w;
+                }
+            }
+            const int c = cb + c4;
+            if (c >= a.h) acc.x = 0.f;                  // (columns h .. of a row are padding: a zero gradient)
+            if (c + 1 >= a.h) acc.y = 0.f;
+            if (c + 2 >= a.h) acc.z = 0.f;
+            if (c + 3 >= a.h) acc.w = 0.f;
+            const size_t o = (size_t)item * a.ldw + min(c, a.ldw - 4);
+            if (cb > 0 && upd) {
+                pw = *reinterpret_cast<const float4*>(a.W + o);
+                if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o); pv = *reinterpret_cast<const float4*>(a.V + o); }
+            }
+            if (c < a.ldw) {
+                if (!upd) *reinterpret_cast<float4*>(a.gout + o) = acc;
+                else {
+                    adam_update(pw.x, pm.x, pv.x, acc.x, s); adam_update(pw.y, pm.y, pv.y, acc.y, s);
+                    adam_update(pw.z, pm.z, pv.z, acc.z, s); adam_update(pw.w, pm.w, pv.w, acc.w, s);
+                    *reinterpret_cast<float4*>(a.W + o) = pw;
+                    if (!s.is_sgd) { *reinterpret_cast<float4*>(a.M + o) = pm; *reinterpret_cast<float4*>(a.V + o) = pv; }
+                }
+            }
+        }
+        if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
+    }
+}
+
+// (hot / hot_count: this launch's list; other_count: the list of the NEXT use, zeroed here - the two alternate)
+__global__ __launch_bounds__(256) void w1_item_wave_kernel(W1Items a, int* hot, int* hot_count) {
+    extern __shared__ unsigned w1w_lds_dyn[];
+    w1_item_wave_body(a, hot, hot_count, w1w_lds_dyn, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), (int)gridDim.x * 4);
+}
+
 __global__ __launch_bounds__(256) void w1_item_update_kernel(W1Items a) {
     extern __shared__ unsigned w1_lds_dyn[];
     w1_item_update_body(a, w1_lds_dyn, (int)blockIdx.x, (int)gridDim.x);
