@@ -1,0 +1,6 @@
+for w in 96 112 128 144; do for i in 1 2; do
+  export AAE_SPLIT_WGS=$w
+  python bench.py --no-cpu --no-extra 2>/dev/null | tail -1 | python -c "
+import json,sys,os
+d=json.loads(sys.stdin.read()); print(os.environ['AAE_SPLIT_WGS'], d['value'], d['ms_per_step'], d['roofline']['avg_us'])"
+done; done
