@@ -331,7 +331,22 @@ class VocabParallelAAE(DataParallelAAE):
         import os
         if self.shard_first and hasattr(model, "dp_step") and hasattr(slice_model, "handle") and os.environ.get("AAE_DP_PYTHON") is None:
             if str(dist.get_backend(group)).lower() == "nccl":
-                self._native = rccl_collectives(model, dist, group)
+                # every rank must take the same driver: the ranks agree on whether the library's communicator came up, and
+                # if it did not on any of them, all keep the phase-by-phase driver over torch.distributed (RCCL as well)
+                err = None
+                try:
+                    self._native = rccl_collectives(model, dist, group)
+                except Exception as e:              # noqa: BLE001 - reported below, on every rank
+                    err = e
+                import torch
+                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=model.device)
+                if self.world > 1:
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    import sys
+                    print("aaerec: the library's RCCL communicator is not available on every rank (%s); "
+                          "using the phase-by-phase driver over torch.distributed" % (err,), file=sys.stderr, flush=True)
+                    self._native = None
             elif str(dist.get_backend(group)).lower() == "echo":     # (tools/vocab_rank_time.py: device-side stand-ins)
                 import ctypes as C
                 from . import _hip
