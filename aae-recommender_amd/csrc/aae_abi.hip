@@ -190,7 +190,20 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
-        if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) m->split_wgs = std::max(1, m->n_cu / 2);
+        if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
+            // Workgroups of the deferred launch (batches of one fused launch).  It has to end before the step does (the next
+            // step opens behind it), and every CU it holds is one the step's own launches share with it: wide enough to take
+            // ~80 us - every shape's step has that much work left behind the critical launch - and never more than 9/16 of
+            // the chip.  A tile of 32 items costs a workgroup 3.3 us + 13 ns per hidden unit (measured: 5.9 us at 200, 4.6 us
+            // at 100).  tools/debug/sweep_split_wgs*.sh, r3: C3 (3125 tiles, 200) 128 -> 0.2652-0.2733 ms/step, 144 ->
+            // 0.2651-0.2655, 160 -> 0.2683, 176 -> 0.282; C2 (1469 tiles, 100) 64 -> 0.1806, 80 -> 0.1710, 96 -> 0.1721,
+            // 128 -> 0.177, 160 -> 0.185.
+            const int ntiles = (m->N + 31) / 32;
+            const double t_tile = 3.3 + 0.0131 * m->h;
+            int w = (int)(ntiles * t_tile / 82.0 / 8.0 + 0.5) * 8;
+            w = std::max(w, std::min(ntiles, 64));
+            m->split_wgs = std::max(1, std::min(w, m->n_cu * 9 / 16));
+        }
     }
     hipStream_t s = S(stream);
     hipError_t e = hipMemsetAsync(arena_dev, 0, need, s);

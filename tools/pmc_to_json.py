@@ -7,7 +7,7 @@ import ast, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 N, h, B = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (100000, 200, 100)
-NAMES = [("dec_crit_x3_kernel<13>", "dec_crit"), ("dec_opt_x3_kernel<13>", "dec_opt"),
+NAMES = [("dec_crit_x3_kernel<13", "dec_crit"), ("dec_opt_x3_kernel<13", "dec_opt"),
          ("dec_fused_kernel<13, 1>", "dec_crit"), ("dec_fused_kernel<13, 2>", "dec_opt"), ("dec_fused_kernel<13>", "dec_fused"),
          ("dec_fused_kernel<13, 0>", "dec_fused"), ("enc_gather_kernel", "enc_gather"), ("w1_sparse_adam_kernel", "enc_w1_adam"),
          ("chain4_kernel", "chain"), ("w1_catchup_kernel", "w1_catchup"), ("grouped_dw_kernel", "grouped_dw")]
