@@ -471,7 +471,8 @@ int aae_profile_read(aae_handle h, int kernel_id, double* total_ms, int64_t* lau
  * its own arena views (aae_tensor_info) calls aae_join first: it makes `stream` wait for the deferred launch (a
  * no-op when none is pending).  aae_sync includes it.  aae_set_split(h, 0) turns the split form off (one launch,
  * everything on the caller's stream: needed to capture a step into a hipGraph without joining), n > 0 sets the number
- * of workgroups of the deferred launch (default: 5/8 of the CUs). */
+ * of workgroups of the deferred launch (default: by shape - enough for the launch to take ~80 us, at most 9/16 of the
+ * CUs in fp32, 5/8 with bf16 inputs). */
 /* DenoisingAutoEncoder(corrupt='gauss'), reference dae.py:40-45 and 191: `self.enc(self.corrupt(batch, noise_factor))`
  * with gauss_noise = batch + randn(batch.size()) * noise_factor - the encoder of the NEXT step-opening call reads the
  * DENSE batch plus noise_dev [rows][noise_ld >= n_items] (already scaled) on all n_items columns, L1-normalised over all
