@@ -134,10 +134,15 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                                    reinterpret_cast<u32x4_t*>(m->dh2f.p));
                 b.acc = m->dh2f.p;                      // (this kernel's reading of the field: the fragment image)
                 // tile groups of at most kXBT tiles, the same number (+-1 tile) for every workgroup and round
-                // (workgroups: 5/8 of the CUs - 512 rows x 100 k items 0.827 / 0.809 / 0.823 / 0.839 ms per step on 128 / 160 / 192 / 224;
-                //  half of them on an item slice of 12.5 k items x 800 rows: 0.382 / 0.379 / 0.400 / 0.387 ms of per-rank compute on 96 / 128 / 160 / 192)
+                // Workgroups: one per ~16 tiles, between half and three quarters of the CUs (tools/debug/sweep_obk_wgs*.sh, late r3,
+                // ms per step): 100 k items x 512 rows 0.774 / 0.725 / 0.710 / 0.703 / 0.690 / 0.755 / 0.749 on 128 / 144 / 160 /
+                // 176 / 192 / 208 / 224; x 256 rows 0.506 / 0.468 / 0.443 / 0.506 on 128 / 160 / 192 / 208; x 1024 rows 1.260 /
+                // 1.245 / 1.356 on 160 / 192 / 208; 47 k items x 500 rows 0.388 / 0.372 / 0.369 / 0.381 / 0.378 on 96 / 112 / 128 /
+                // 144 / 160; an item slice of 12.5 k items x 800 rows 0.382 / 0.379 / 0.400 / 0.387 ms of per-rank compute on
+                // 96 / 128 / 160 / 192.  (Beyond 3/4 of the chip the step's own launches lose more than this one gains.)
                 static const int obk_env = getenv("AAE_OBK_WGS") ? atoi(getenv("AAE_OBK_WGS")) : 0;
-                const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : ntiles < 1024 ? m->n_cu / 2 : m->n_cu * 5 / 8), std::min(ntiles, m->n_cu)));
+                const int by_tiles = std::max(m->n_cu / 2, std::min(m->n_cu * 3 / 4, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
+                const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : by_tiles), std::min(ntiles, m->n_cu)));
                 const int rounds = (ntiles + g3 * kXBT - 1) / (g3 * kXBT);
                 b.tpp = g3 * rounds;
                 const uint32_t lds3 = (uint32_t)dec_opt_blocks_x3_lds_bytes();
