@@ -86,7 +86,7 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     // (Not on the three-GEMM path: there the side stream holds the previous step's dV3 GEMM for most of this step.)
     {
         static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
-        if (bk_ahead && m->side && m->ev_bk && m->last_out_split && m->use_chain && m->rows > 16 * kMB && !m->buckets_valid && fused_decoder_applies(m)) {
+        if (bk_ahead && m->side && m->ev_bk && m->last_out_split && m->rows > 16 * kMB && !m->buckets_valid && fused_decoder_applies(m)) {
             TRY(build_tile_buckets(m, m->side));
             HIPCHK(hipEventRecord(m->ev_bk, m->side));
             m->bk_pending = true;

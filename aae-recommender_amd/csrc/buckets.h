@@ -57,10 +57,22 @@ __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (dbeg[mid] <= f) lo = mid; else hi = mid - 1; }
         return lo;
     };
+    // Both passes take U entries per thread and round: their document searches (LDS) and their index / value loads are in
+    // flight together - one entry per round was a dependent chain of a search and a global round trip per entry, 84 us for
+    // 1000 documents x 4.6 k items in one workgroup (r3, C4's shape).
+    constexpr int U = MAXD > 16 * kMB ? 8 : 2;
     // pass 1: histogram over the tiles
-    for (int f = t; f < total; f += NT) {
-        const int d = doc_of(f);
-        atomicAdd(&cnt[bv.indices[dlo[d] + (f - dbeg[d])] / kTI], 1);
+    for (int f0 = t; f0 < total; f0 += NT * U) {
+        int idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = min(f0 + u * NT, total - 1);
+            const int d = doc_of(f);
+            idx[u] = bv.indices[dlo[d] + (f - dbeg[d])];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (f0 + u * NT < total) atomicAdd(&cnt[idx[u] / kTI], 1);
     }
     __syncthreads();
     // exclusive scan of the tile counters -> tstart (global) and the fill cursors (LDS)
@@ -86,12 +98,23 @@ __device__ __forceinline__ void tile_bucket_body(const BatchView& bv, int ntiles
     if (t == NT - 1) tstart[ntiles] = part[NT - 1];
     __syncthreads();
     // pass 2: fill
-    for (int f = t; f < total; f += NT) {
-        const int d = doc_of(f);
-        const long long e = dlo[d] + (f - dbeg[d]);
-        const int idx = bv.indices[e], tile = idx / kTI;
-        const int pos = atomicAdd(&cnt[tile], 1);
-        eb[pos] = d; en[pos] = idx - tile * kTI; ev[pos] = bv.values[e];
+    for (int f0 = t; f0 < total; f0 += NT * U) {
+        int idx[U], dd[U];
+        float val[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = min(f0 + u * NT, total - 1);
+            const int d = doc_of(f);
+            const long long e = dlo[d] + (f - dbeg[d]);
+            dd[u] = d; idx[u] = bv.indices[e]; val[u] = bv.values[e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (f0 + u * NT < total) {
+                const int tile = idx[u] / kTI;
+                const int pos = atomicAdd(&cnt[tile], 1);
+                eb[pos] = dd[u]; en[pos] = idx[u] - tile * kTI; ev[pos] = val[u];
+            }
     }
 }
 
