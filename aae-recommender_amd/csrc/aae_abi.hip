@@ -86,7 +86,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         const int nb = (m->h + 1 + 15) / 16;
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
         m->fused_ok = m->fused_nb != 0 && fused_width_ok(m->h, m->ldh);       // (the arena's slab area is sized by the same test)
-        m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= 208) && getenv("AAE_NO_CHAIN") == nullptr;
+        // (a decoder input [z | condition | 1] of up to 2 x 208 columns: two k-parts on the 4-row kernel; the VAE's programs keep 208)
+        m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= (cfg->model_kind == 3 || getenv("AAE_NO_WIDE_CHAIN") ? 208 : 2 * 208)) && getenv("AAE_NO_CHAIN") == nullptr;
         if (m->use_chain && (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess ||
@@ -101,6 +102,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
+        if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
         m->force_unfused = cfg->unfused_decoder == 1;   // debugging / A-B switch: unfused_decoder = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;

@@ -55,6 +55,13 @@ ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, h
     return o;
 }
 
+struct ChainBuilder;
+constexpr int kCWide = 208;        // columns of a slot row a layer may read (chain.h: kCL = 212)
+// The decoder's first layer reads [z | condition | 1] - wider than a slot row when the condition is (C4: 50 + 300 + 1).
+// Such a layer runs as two ops (4-row kernel): input columns [0, 208) from one slot, the rest from a second one, the second op
+// adding to the first one's products before the epilogue (ChainOp::acc_in); its dX as two ops over the input columns.
+inline bool wide_dec_in(const aae_model* m) { return m->cp + 1 > kCWide; }
+
 struct ChainBuilder {
     ChainProgram P;
     ChainBuilder(const aae_model* m, int rows) {
@@ -65,6 +72,36 @@ struct ChainBuilder {
     }
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
 };
+
+// forward of dec.lin1: srcA holds input columns [0, 208) (all of them when the input fits), srcB the rest with the constant 1
+// last; returns the op that carries the epilogue (dropout, activation, stores)
+ChainOp& add_dec_in_fwd(ChainBuilder& cb, aae_model* m, int srcA, int srcB, int dst, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    if (!wide_dec_in(m)) return cb.add(cop_fwd(m, P_V1, srcA, dst, cp + 1, h, CEPI_DROPACT, s));
+    cb.add(cop_fwd(m, P_V1, srcA, dst, kCWide, h, CEPI_NONE, s));
+    ChainOp b = cop_fwd(m, P_V1, srcB, dst, cp + 1 - kCWide, h, CEPI_DROPACT, s);
+    b.W += kCWide;
+    if (b.W4) b.W4 += (size_t)(kCWide / 4) * b.ns4 * 4;          // (F4: chunk stride = outputs x 4 floats)
+    b.acc_in = 1;
+    return cb.add(b);
+}
+// dX of dec.lin1 -> gzc (+ dzc_out): the columns beyond 208 into slot dstB first, then columns [0, 208) (dL/dz among them)
+// into dstA; returns that last op
+ChainOp& add_dec_in_dx(ChainBuilder& cb, aae_model* m, int src, int dstA, int dstB, float* dzc_out, hipStream_t s) {
+    const int h = m->h, cp = m->cp;
+    if (wide_dec_in(m)) {
+        ChainOp b = cop_dx(m, P_V1, src, dstB, h, cp - kCWide, CEPI_NONE, s);
+        b.W += kCWide; b.Wkn += kCWide;
+        if (b.W4) b.W4 += (size_t)kCWide * 4;                     // (D4: [k chunk][input column][4])
+        cop_out(b, m->gzc.p + kCWide, m->ldc);
+        if (dzc_out) { b.out2 = dzc_out + kCWide; b.ldo2 = cp; }
+        cb.add(b);
+    }
+    ChainOp& a = cb.add(cop_dx(m, P_V1, src, dstA, h, std::min(cp, kCWide), CEPI_NONE, s));
+    cop_out(a, m->gzc.p, m->ldc);
+    if (dzc_out) { a.out2 = dzc_out; a.ldo2 = cp; }
+    return a;
+}
 
 int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
@@ -83,7 +120,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     for (int i = 0; i < cb.P.nops && four; ++i)
         if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
     for (int i = 0; i < cb.P.nops; ++i)
-        if (cb.P.ops[i].row_lo > 0 && !four) return fail(AAE_ESTATE, "a program prefix for the upper rows needs the 4-row chain kernel");
+        if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in) && !four)
+            return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
     if (four) {
         const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
         if (want_ts && !m->bf16) hipLaunchKernelGGL((chain4_kernel<false, true>), dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
@@ -317,12 +355,17 @@ int chain_ae_forward(aae_model* m, bool with_dec, const float* cond_dev, float* 
     cop_out(f, m->zc.p, m->ldc); f.out2 = m->zsave.p; f.ldo2 = m->ldz;
     if (z_out) { ChainOp& st = cb.add(cop(COP_STORE, 2, 2, c)); cop_out(st, z_out, c); }
     if (with_dec) {
-        if (m->cfg.cond_inc > 0) {
+        if (wide_dec_in(m)) {
+            // the condition's first columns behind z in slot 2 (208 columns in all), the others + the constant 1 in slot 5
+            const int nA = kCWide - c, ci = m->cfg.cond_inc;
+            ChainOp& ca = cb.add(cop_load(cond_dev, ci, 2, nA)); ca.dst_col0 = c;
+            ChainOp& cl = cb.add(cop_load(cond_dev + nA, ci, 5, ci - nA)); cl.one_col = cp - kCWide;
+        } else if (m->cfg.cond_inc > 0) {
             ChainOp& cl = cb.add(cop_load(cond_dev, m->cfg.cond_inc, 2, m->cfg.cond_inc)); cl.dst_col0 = c; cl.one_col = cp;
         } else {
             f.one_col = cp;
         }
-        ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 2, 3, cp + 1, h, CEPI_DROPACT, s));
+        ChainOp& v1 = add_dec_in_fwd(cb, m, 2, 5, 3, s);
         v1.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
         ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 3, 4, h + 1, h, CEPI_DROPACT, s));
         v2.d = make_drop(m, 1, true, I.masks_dev[3], nullptr, B, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
@@ -336,8 +379,13 @@ int chain_dec_hidden(aae_model* m, bool train, int rows, hipStream_t s) {
     const int h = m->h, cp = m->cp;
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, rows);
-    ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 0, cp)); l.one_col = cp;
-    ChainOp& v1 = cb.add(cop_fwd(m, P_V1, 0, 1, cp + 1, h, CEPI_DROPACT, s));
+    if (wide_dec_in(m)) {
+        cb.add(cop_load(m->zc.p, m->ldc, 0, kCWide));
+        ChainOp& lb = cb.add(cop_load(m->zc.p + kCWide, m->ldc, 3, cp - kCWide)); lb.one_col = cp - kCWide;
+    } else {
+        ChainOp& l = cb.add(cop_load(m->zc.p, m->ldc, 0, cp)); l.one_col = cp;
+    }
+    ChainOp& v1 = add_dec_in_fwd(cb, m, 0, 3, 1, s);
     v1.d = make_drop(m, 0, train, I.masks_dev[2], nullptr, rows, h, 2); v1.one_col = h; cop_out(v1, m->dh1.p, m->ldh);
     ChainOp& v2 = cb.add(cop_fwd(m, P_V2, 1, 2, h + 1, h, CEPI_DROPACT, s));
     v2.d = make_drop(m, 1, train, I.masks_dev[3], nullptr, rows, h, 3); v2.one_col = h; cop_out(v2, m->dh2.p, m->ldh);
@@ -364,9 +412,7 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
         cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
         ChainOp& x2 = cb.add(cop_dx(m, P_V2, 2, 4, h, h, CEPI_ACTBWD, s)); x2.yslot = 3;
         x2.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); cop_out(x2, m->gb1.p, m->ldh);
-        ChainOp& x1 = cb.add(cop_dx(m, P_V1, 4, 5, h, cp, CEPI_NONE, s));
-        cop_out(x1, m->gzc.p, m->ldc);
-        if (dzc_out) { x1.out2 = dzc_out; x1.ldo2 = cp; }
+        add_dec_in_dx(cb, m, 4, 5, 3, dzc_out, s);        // (slot 3 - dh1, the y of the op above - is free again)
     }
     if (enc_part) {
         if (!dec_part || gz_ext) cb.add(cop_load(gz_ext ? gz_ext : m->gzc.p, gz_ext ? ld_gz : m->ldc, 5, c));

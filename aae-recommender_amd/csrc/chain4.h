@@ -209,9 +209,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         int ldo = op.ldo, ldo2 = op.ldo2, out_row0 = op.out_row0;
         float* outp = op.out; float* out2p = op.out2;
         Lin4 lin; lin.N = opN; lin.K = opK; lin.ldkn = op.ldkn; lin.ns4 = op.ns4; lin.W4 = op.W4; lin.Wkn = op.Wkn;
-        int epi_k = op.epi, yslot_k = op.yslot;
+        int epi_k = op.epi, yslot_k = op.yslot, acc_in = op.acc_in;
         asm volatile("" : "+s"(kind), "+s"(src_i), "+s"(dst_i), "+s"(row_lo), "+s"(one_col), "+s"(opN), "+s"(opK), "+s"(ldo), "+s"(ldo2),
-                          "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k), "+s"(yslot_k));
+                          "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k), "+s"(yslot_k), "+s"(acc_in));
         asm volatile("" : "+s"(lin.ldkn), "+s"(lin.ns4), "+s"(lin.W4), "+s"(lin.Wkn));
         lin.N = opN; lin.K = opK;
         if (r0 < row_lo) continue;                     // (workgroup-uniform: an op of the upper rows' program prefix)
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                     if (cgs == 2) sum_slices(std::integral_constant<int, kC4W / 4>{});    // (KS = waves >> cgs)
                     else if (cgs == 1) sum_slices(std::integral_constant<int, kC4W / 2>{});
                     else sum_slices(std::integral_constant<int, kC4W>{});
+                    if (acc_in) v += dst[erow * kCL + ecol];          // (uniform) the layer's earlier k-part: this thread's own cell
                     // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
                     if (ec.epi == CEPI_ACTBWD) {
                         v *= act_grad_from_y(ec.act, (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);

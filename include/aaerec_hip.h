@@ -267,7 +267,7 @@ int aae_vae_encoder_backward(aae_handle h, const float* dz_dev, int64_t dz_ld, v
  *   aae_ae_backward        decoder hidden backward + encoder backward + their updates / exported gradients from
  *                          dA2_dev (NULL = this handle's ACT_DA2), leading dimension = ACT_DH2's
  * followed by aae_disc_step / aae_gen_step as in the replicated scheme.  aae_ae_forward / aae_ae_backward: layer-chain models only
- * (n_hidden, n_code + cond_inc <= 207); the slice handle may be any size. */
+ * (n_hidden <= 207, n_code + cond_inc <= 415); the slice handle may be any size. */
 int aae_ae_forward(aae_handle h, const aae_batch* batch, const float* cond_dev, const aae_rng_inject* inject, void* stream);
 int aae_output_layer_step(aae_handle h, const aae_batch* batch, void* stream);
 int aae_ae_backward(aae_handle h, const float* dA2_dev, int64_t dA2_ld, void* stream);

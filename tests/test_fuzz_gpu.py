@@ -33,6 +33,8 @@ def _config(seed, tiny=False):
         cfg["N"] = min(cfg["N"], 1200)
     cfg["long_rows"] = bool(r.random() < 0.15)       # documents with hundreds of items (per-row chunking, >1024 entries per tile)
     cfg["window"] = bool(r.random() < 0.3)           # the batch is a permutation window into a larger resident corpus
+    if not tiny and r.random() < 0.2:         # a condition that makes the decoder's input wider than a chain slot (two k-parts)
+        cfg["inc"] = int(r.integers(208 - cfg["c"], 415 - cfg["c"]))
     return cfg, r
 
 
@@ -49,11 +51,33 @@ def _close_enough(got, want, tol, dmax, tag):
 @pytest.mark.parametrize("tiny", [False, True])
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_configuration_matches_oracle(seed, tiny):
+    cfg, r = _config(seed, tiny)           # tiny: degenerate sizes (one hidden unit, a code of one, two items, one document)
+    _check_configuration(cfg, r, seed)
+
+
+# A decoder input [z | condition | 1] wider than a row of the layer-chain kernel's LDS slots (208 columns): dec.lin1 runs as
+# two k-parts, its dX as two column parts (csrc/abi_chains.h: add_dec_in_fwd / add_dec_in_dx).  C4's shape (code 50 +
+# 300-d condition), the narrowest wide input (209 columns: the second part is the bias column alone), the widest (416),
+# a part boundary inside the condition / right behind z, a batch beyond one fused launch.
+WIDE = [dict(N=300, h=40, c=50, B=37, inc=300), dict(N=120, h=200, c=10, B=100, inc=198), dict(N=500, h=64, c=100, B=64, inc=315),
+        dict(N=257, h=207, c=207, B=5, inc=33), dict(N=900, h=100, c=50, B=150, inc=300), dict(N=64, h=7, c=2, B=3, inc=206)]
+
+
+@pytest.mark.parametrize("cut", [False, True])
+@pytest.mark.parametrize("case", range(len(WIDE)))
+def test_condition_wider_than_a_chain_slot_matches_oracle(case, cut):
+    r = np.random.default_rng(7000 + case)
+    cfg = dict(**WIDE[case], act=ACTS[case % len(ACTS)], prior=["gauss", "categorical", "gauss"][case % 3],
+               opt=["adam", "adam", "sgd"][case % 3], drop=bool(case % 2 == 0), norm=bool(case % 3), scale=0.0, cut=cut,
+               long_rows=False, window=bool(case % 2), predict=True)
+    _check_configuration(cfg, r, 7000 + case)
+
+
+def _check_configuration(cfg, r, seed):
     import torch
     from aaerec._hip import HipAAE, DeviceCSR
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
-    cfg, r = _config(seed, tiny)           # tiny: degenerate sizes (one hidden unit, a code of one, two items, one document)
     N, h, c, B, inc = cfg["N"], cfg["h"], cfg["c"], cfg["B"], cfg["inc"]
     params = init_params(N, h, c, cond_inc=inc, seed=seed)
     p = (0.2, 0.3) if cfg["drop"] else (0.0, 0.0)
@@ -111,6 +135,11 @@ def test_random_configuration_matches_oracle(seed, tiny):
     # more than 3 lr.
     for k, w in ora.p.items():
         _close_enough(got[k], w, 5e-5, 3 * max(lr), f"{cfg} {k}")
+    if cfg.get("predict"):                     # the last batch's reconstructions with the trained weights (no dropout)
+        out = dev.predict(csr, 0, Bs, cond=cdev) if sel is None else None
+        if out is not None:
+            want = ora.predict(ip, idx, val, [cond] if inc else None)
+            np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-4, err_msg=f"{cfg} predict")
 
 
 def _batch(r, N, Bs, B, max_len=12):
