@@ -194,9 +194,13 @@ struct DwBuilder {
             w.items = w1_items_args(m, ga1, 0, 0, which);
             w.nitem = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
             m->w1_items_merged = true;
-            // wide batches (beyond one fused launch): one wave per item, the head items through the hot list behind the launch
+            // wide batches (beyond one fused launch) over a large vocabulary: one wave per item, the head items through the hot
+            // list behind the launch.  With few items per row of the batch (N < 40 rows) most items sit in many rows and the
+            // workgroup form stays ahead (tools/debug/c4_w1_ab.sh, ms/step wave | workgroup form: 1000 rows x 4.6 k items
+            // 0.459 | 0.413, 10 k 0.501 | 0.465, 20 k 0.575 | 0.553, 40 k 0.723 | 0.728; 512 rows x 4.6 k 0.304 | 0.282,
+            // 10 k 0.329 | 0.314, 20 k 0.362 | 0.363).
             static const bool no_wave = getenv("AAE_NO_W1_WAVE") != nullptr;
-            if (!no_wave && m->rows > 16 * kMB && m->hot_list) {
+            if (!no_wave && m->rows > 16 * kMB && m->hot_list && (int64_t)m->N >= 40ll * m->rows) {
                 w.wave_form = 1;
                 w.nitem = (w.nitem + 3) / 4;
                 const int set = m->hot_flip; m->hot_flip ^= 1;
