@@ -638,7 +638,7 @@ struct W1Job {
 struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; };
 constexpr int kDwSmemBytes = 2 * 64 * (32 + 16) * 4;       // static LDS of grouped_dw_kernel (2 * BK * LDT floats)
 
-__global__ __launch_bounds__(256) void grouped_dw_kernel(DwGroup grp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
     constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
     static_assert(sizeof(float) * 2 * BK * LDT == kDwSmemBytes, "kDwSmemBytes");
