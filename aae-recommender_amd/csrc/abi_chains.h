@@ -73,6 +73,14 @@ struct ChainBuilder {
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
 };
 
+// y of an ACTBWD epilogue that a kernel before this one left in global memory: the 4-row kernel reads it from there (the cells
+// of a thread requested before the op's products: no op, no barrier, no slot); the 16-row kernel gets it loaded into `slot`
+void set_y(ChainBuilder& cb, aae_model* m, ChainOp& op, const float* y, int ld, int slot) {
+    op.yslot = slot;
+    if (m->use_chain4) { op.y_glb = y; op.y_ld = ld; }
+}
+bool y_needs_load(const aae_model* m) { return !m->use_chain4; }
+
 // forward of dec.lin1: srcA holds input columns [0, 208) (all of them when the input fits), srcB the rest with the constant 1
 // last; returns the op that carries the epilogue (dropout, activation, stores)
 ChainOp& add_dec_in_fwd(ChainBuilder& cb, aae_model* m, int srcA, int srcB, int dst, hipStream_t s) {
@@ -120,7 +128,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     for (int i = 0; i < cb.P.nops && four; ++i)
         if (cb.P.ops[i].kind == COP_ADV || cb.P.ops[i].kind == COP_REPARAM || cb.P.ops[i].kind == COP_REPARAM_BWD) four = false;
     for (int i = 0; i < cb.P.nops; ++i)
-        if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in) && !four)
+        if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in || cb.P.ops[i].y_glb) && !four)
             return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
     if (four) {
         const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
@@ -413,8 +421,8 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
         } else {
             cb.add(cop_load(m->gb0.p, m->ldh, 2, h));      // unfused decoder path: gb0 already holds dL/da2
         }
-        cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
-        ChainOp& x2 = cb.add(cop_dx(m, P_V2, 2, 4, h, h, CEPI_ACTBWD, s)); x2.yslot = 3;
+        if (y_needs_load(m)) cb.add(cop_load(m->dh1.p, m->ldh, 3, h));
+        ChainOp& x2 = cb.add(cop_dx(m, P_V2, 2, 4, h, h, CEPI_ACTBWD, s)); set_y(cb, m, x2, m->dh1.p, m->ldh, 3);
         x2.d = make_drop(m, 0, true, I.masks_dev[2], nullptr, B, h, 2); cop_out(x2, m->gb1.p, m->ldh);
         add_dec_in_dx(cb, m, 4, 5, 3, dzc_out, s);        // (slot 3 - dh1, the y of the op above - is free again)
     }
@@ -431,12 +439,12 @@ int chain_ae_backward(aae_model* m, bool dec_part, bool enc_part, const float* p
             ChainOp& fb = cb.add(cop(COP_FINAL_BWD, 5, 7, c)); fb.yslot = 6; fb.aux = m->cfg.enc_final;
             cop_out(fb, m->ga3.p, m->ldz);
         }
-        cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
-        ChainOp& x3 = cb.add(cop_dx(m, P_W3, sg, 9, c, h, CEPI_ACTBWD, s)); x3.yslot = 8;
+        if (y_needs_load(m)) cb.add(cop_load(m->eh2.p, m->ldh, 8, h));
+        ChainOp& x3 = cb.add(cop_dx(m, P_W3, sg, 9, c, h, CEPI_ACTBWD, s)); set_y(cb, m, x3, m->eh2.p, m->ldh, 8);
         x3.d = make_drop(m, 1, true, I.masks_dev[which == O_GEN ? 9 : 1], nullptr, B, h, which == O_GEN ? 9 : 1);
         cop_out(x3, m->gb2.p, m->ldh);
-        cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
-        ChainOp& x2 = cb.add(cop_dx(m, P_W2, 9, 1, h, h, CEPI_ACTBWD, s)); x2.yslot = 0;
+        if (y_needs_load(m)) cb.add(cop_load(m->eh1.p, m->ldh, 0, h));
+        ChainOp& x2 = cb.add(cop_dx(m, P_W2, 9, 1, h, h, CEPI_ACTBWD, s)); set_y(cb, m, x2, m->eh1.p, m->ldh, 0);
         x2.d = make_drop(m, 0, true, I.masks_dev[which == O_GEN ? 8 : 0], nullptr, B, h, which == O_GEN ? 8 : 0);
         cop_out(x2, ga1_ptr(m), m->ldh);
     }

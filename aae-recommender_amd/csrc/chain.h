@@ -71,6 +71,8 @@ struct ChainOp {
     int row_lo;                         // chain4.h: the op runs only in workgroups whose first row is >= row_lo (a program prefix
                                         // for the upper rows: Enc_eval in front of the discriminator program, aae_abi.hip)
     int fake_slot;                      // COP_PRIOR, chain4.h: >= 0: rows >= row_split come from this slot instead of from W
+    const float* y_glb; int y_ld;       // chain4.h, a linear op with the ACTBWD epilogue: y read from global memory [rows][y_ld] (requested
+                                        // before the op's products) instead of from a slot that an op of its own loaded
     int acc_in;                         // COP_LINEAR, chain4.h: 1 = the products are added to what dst holds before the epilogue (the
                                         // second k-part of a layer whose input is wider than a slot: the decoder's [z | condition | 1])
 };

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
         int epi_k = op.epi, yslot_k = op.yslot, acc_in = op.acc_in;
         asm volatile("" : "+s"(kind), "+s"(src_i), "+s"(dst_i), "+s"(row_lo), "+s"(one_col), "+s"(opN), "+s"(opK), "+s"(ldo), "+s"(ldo2),
                           "+s"(out_row0), "+s"(outp), "+s"(out2p), "+s"(epi_k), "+s"(yslot_k), "+s"(acc_in));
-        asm volatile("" : "+s"(lin.ldkn), "+s"(lin.ns4), "+s"(lin.W4), "+s"(lin.Wkn));
+        const float* ygp = op.y_glb; int yld = op.y_ld;
+        asm volatile("" : "+s"(lin.ldkn), "+s"(lin.ns4), "+s"(lin.W4), "+s"(lin.Wkn), "+s"(ygp), "+s"(yld));
         lin.N = opN; lin.K = opK;
         if (r0 < row_lo) continue;                     // (workgroup-uniform: an op of the upper rows' program prefix)
         float* dst = slots + dst_i * kR4 * kCL;
@@ -237,6 +238,16 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             const int kper = (((K + KS - 1) >> (kC4WS - cgs)) + 3) & ~3;    // k-steps per wave, a multiple of 4
             unsigned long long* wts = (TS && tsp && oi == 2) ? tsp + 64 : nullptr;
             if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
+            // y of an ACTBWD epilogue that lives in global memory: this thread's cells, requested in front of the products
+            float yv[kC4E];
+            if (ygp) {
+                typedef const __attribute__((address_space(1))) float* gf_t;
+#pragma unroll
+                for (int eh = 0; eh < kC4E; ++eh) {
+                    const int erow = erow0 + kC4ER * eh;
+                    yv[eh] = (ecol < N && erow < nrows) ? ((gf_t)ygp)[(size_t)(r0 + erow) * yld + ecol] : 0.f;
+                }
+            }
             if ((wave & (cgp - 1)) < CG) {
                 if (kper <= 16) chain4_linear<16, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
                 else if (kper <= 28) chain4_linear<28, BF, TS>(lin, src, part, wave, lane, cgs, kper, wts);
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                     if (acc_in) v += dst[erow * kCL + ecol];          // (uniform) the layer's earlier k-part: this thread's own cell
                     // (the epilogue's y slot holds 4-row blocks here: index it with this kernel's row stride)
                     if (ec.epi == CEPI_ACTBWD) {
-                        v *= act_grad_from_y(ec.act, (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);
+                        v *= act_grad_from_y(ec.act, ygp ? yv[eh] : (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
                     } else {
                         v = chain_epi(ec, r0 + erow, erow, ecol, v);
