@@ -87,7 +87,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
         m->fused_ok = m->fused_nb != 0 && fused_width_ok(m->h, m->ldh);       // (the arena's slab area is sized by the same test)
         // (a decoder input [z | condition | 1] of up to 2 x 208 columns: two k-parts on the 4-row kernel; the VAE's programs keep 208)
-        m->use_chain = (m->h + 1 <= 208) && (m->cp + 1 <= (cfg->model_kind == 3 || getenv("AAE_NO_WIDE_CHAIN") ? 208 : 2 * 208)) && getenv("AAE_NO_CHAIN") == nullptr;
+        m->use_chain = (m->h + 1 <= 208) && (m->c + 1 <= 208) && (m->cp + 1 <= (cfg->model_kind == 3 || getenv("AAE_NO_WIDE_CHAIN") ? 208 : 2 * 208)) &&
+                       getenv("AAE_NO_CHAIN") == nullptr;      // (the code itself has to fit a slot: only the condition block may exceed it)
         if (m->use_chain && (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess ||

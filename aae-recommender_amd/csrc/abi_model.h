@@ -215,7 +215,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
-    if (h + 1 <= 208 && cp + 1 <= 2 * 208 && c.model_kind != 3)      // layer-chain models (not the VAE's programs); a decoder input beyond 208 columns runs in two k-parts (abi_chains.h)
+    if (h + 1 <= 208 && m->c + 1 <= 208 && cp + 1 <= 2 * 208 && c.model_kind != 3)      // layer-chain models (not the VAE's programs); a decoder input beyond 208 columns runs in two k-parts (abi_chains.h)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
         {
             const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;

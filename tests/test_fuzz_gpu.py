@@ -60,7 +60,8 @@ def test_random_configuration_matches_oracle(seed, tiny):
 # 300-d condition), the narrowest wide input (209 columns: the second part is the bias column alone), the widest (416),
 # a part boundary inside the condition / right behind z, a batch beyond one fused launch.
 WIDE = [dict(N=300, h=40, c=50, B=37, inc=300), dict(N=120, h=200, c=10, B=100, inc=198), dict(N=500, h=64, c=100, B=64, inc=315),
-        dict(N=257, h=207, c=207, B=5, inc=33), dict(N=900, h=100, c=50, B=150, inc=300), dict(N=64, h=7, c=2, B=3, inc=206)]
+        dict(N=257, h=207, c=207, B=5, inc=33), dict(N=900, h=100, c=50, B=150, inc=300), dict(N=64, h=7, c=2, B=3, inc=206),
+        dict(N=200, h=30, c=300, B=9, inc=0), dict(N=150, h=20, c=210, B=6, inc=100)]      # (a code wider than a slot: layer by layer)
 
 
 @pytest.mark.parametrize("cut", [False, True])
@@ -117,7 +118,7 @@ def _check_configuration(cfg, r, seed):
             zr = np.zeros((Bs, c), dtype=np.float32)             # the reference's randint(0, 1) bernoulli prior
         cond = (r.standard_normal((Bs, inc)) * 0.4).astype(np.float32) if inc else None
         cdev = torch.as_tensor(cond, device=dev.device) if inc else None
-        if cfg["cut"] and h + 1 <= 208:
+        if cfg["cut"] and h + 1 <= 208 and c + 1 <= 208 and c + inc + 1 <= 416:     # (the cut form is the layer-chain models')
             dev.ae_forward(csr, 0, Bs, rows=sel, cond=cdev, masks=masks, z_real=zr)
             dev.output_layer_step()
             dev.ae_backward()
