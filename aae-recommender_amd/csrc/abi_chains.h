@@ -208,6 +208,13 @@ struct DwBuilder {
             // 0.459 | 0.413, 10 k 0.501 | 0.465, 20 k 0.575 | 0.553, 40 k 0.723 | 0.728; 512 rows x 4.6 k 0.304 | 0.282,
             // 10 k 0.329 | 0.314, 20 k 0.362 | 0.363).
             static const bool no_wave = getenv("AAE_NO_W1_WAVE") != nullptr;
+            // batches of one fused launch: four items per workgroup (w1_item_hybrid_body: same sums, a quarter of the workgroups)
+            static const bool no_hybrid = getenv("AAE_NO_W1_HYBRID") != nullptr;
+            if (!no_hybrid && m->rows <= 16 * kMB && sizeof(int) * w1_hybrid_lds_words(m->rows) <= kDwSmemBytes &&
+                (int64_t)m->cfg.max_nnz <= 512ll * w.nitem) {
+                w.wave_form = 2;
+                w.nitem = (w.nitem + 3) / 4;
+            } else
             if (!no_wave && m->rows > 16 * kMB && m->hot_list && (int64_t)m->N >= 40ll * m->rows) {
                 w.wave_form = 1;
                 w.nitem = (w.nitem + 3) / 4;
@@ -493,9 +500,13 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
                           (const long long*)m->step_ctr, m->rscale, m->doc_l1,
                           // open_step: the step-opening bookkeeping rides in this launch (advance_step_body) and the
                           // workgroups take the step number from the host (m->hstep == *step_ctr once the step is open)
-                          AdvanceJob{m->sc, m->step_ctr, m->lazy ? m->tab : nullptr, m->losses, open_step ? 1 : 0},
+                          // head: the prefetch's first launch (new stamp, empty list) rides here as well - the catch-up behind it then
+                          // starts a launch earlier, ahead of the output layer's critical launch instead of beside its first workgroups
+                          AdvanceJob{m->sc, m->step_ctr, m->lazy ? m->tab : nullptr, m->losses, open_step ? 1 : 0,
+                                     head ? m->stamp2 : nullptr, head ? m->ucount2 : nullptr},
                           (long long)(open_step ? m->hstep : -1));
     LAUNCHCHK("enc_gather");
+    m->pf_bumped = head;
     return AAE_OK;
 }
 
@@ -519,7 +530,8 @@ int launch_prefetch(aae_model* m, bool wait_head = true) {
     const int gy = std::max(1, std::min(16, chunks / 16 + 1));
     hipStream_t q = m->side;
     if (wait_head) HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));      // (else: the caller enqueues behind work that is ordered behind the step's head)
-    hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
+    if (!(wait_head && m->pf_bumped)) hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
+    m->pf_bumped = false;
     hipLaunchKernelGGL(uniq_items_kernel, dim3(b.n_rows, gy), dim3(256), 0, q, bv, m->mark2, m->stamp2, m->ulist2, m->ucount2);
     if (m->cfg.optimizer == AAE_OPT_ADAM) {
         const int grid = std::min(m->cfg.max_nnz, std::max(256, b.n_rows * 32));

@@ -117,6 +117,7 @@ struct aae_model {
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
     aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
     bool pf_pending; hipEvent_t ev_head, ev_pf;
+    bool pf_bumped = false;  // the running step's gather bumped the next batch's stamp (launch_prefetch skips its own launch)
     bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
     hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
     bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)

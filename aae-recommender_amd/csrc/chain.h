@@ -633,7 +633,8 @@ struct W1Job {
     float* bp; float* bm; float* bv1; float* bgrad; const OptScalars* sc;   // blocks [blk0, blk0 + ncol)
     int blk0, ncol;
     int nitem;            // > 0: blocks [blk0 + ncol, blk0 + ncol + nitem) run the item update (else a launch of its own follows)
-    int wave_form;        // 1: wide batch - the item blocks run the one-wave-per-item form (w1_update.h), items with more rows than
+    int wave_form;        // 2: batch of one fused launch - four items per block, wave form up to 16 rows, the others by the whole block
+                          // (w1_item_hybrid_body); 1: wide batch - the item blocks run the one-wave-per-item form (w1_update.h), items with more rows than
     int* hot; int* hot_count; int* hot_zero;    // kW1WaveRows go to the hot list (worked off by a launch behind this one); hot_zero: the NEXT use's counter
     W1Items items;
 };
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const W1Job& w = grp.w1;
         const int id = (int)blockIdx.x - w.blk0;
         if (id < w.ncol) colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem);
+        else if (w.wave_form == 2) w1_item_hybrid_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
         else if (w.wave_form) {
             if (id == w.ncol && threadIdx.x == 0) *w.hot_zero = 0;
             w1_item_wave_body(w.items, w.hot, w.hot_count, reinterpret_cast<unsigned*>(smem), (id - w.ncol) * 4 + (int)(threadIdx.x >> 6), w.nitem * 4);

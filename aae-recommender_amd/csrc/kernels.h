@@ -20,7 +20,8 @@ struct LazyTab { float nss_gen, nss_reg, ibc2, pad; };   // per step t: -lr_gen/
 
 // The step-opening bookkeeping (its own launch: advance_step_kernel at the end of this file; or the first 4 threads of
 // one workgroup of the step's first gather when nothing in between needs it - a launch costs ~4.5 us however little it does)
-struct AdvanceJob { OptScalars* sc; long long* ctr; LazyTab* tab; float* losses; int enabled; };
+struct AdvanceJob { OptScalars* sc; long long* ctr; LazyTab* tab; float* losses; int enabled;
+                    int* stamp2 = nullptr; int* ucount2 = nullptr; };   // != NULL: new stamp + empty list for the NEXT batch's distinct-item pass (bump_stamp_kernel's work)
 __device__ __forceinline__ void advance_step_body(OptScalars* sc, long long* ctr, LazyTab* tab, int* stamp, int* ucount,
                                                   float* losses, int i) {
     // (stamp == NULL: the step's unique-item list was built ahead of time, aae_prefetch_batch)
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
     }
     __syncthreads();
     if (adv.enabled && blockIdx.x == gridDim.x - 1 && tid < 64) advance_step_body(adv.sc, adv.ctr, adv.tab, nullptr, nullptr, adv.losses, tid);
+    if (adv.stamp2 && blockIdx.x == 0 && tid == 0) { *adv.stamp2 += 1; *adv.ucount2 = 0; }
     const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)(step_val >= 0 ? step_val : *step_ctr), 0) : 0;
     for (int c = tid; c < h; c += 1024) {
         float v = 0.f;

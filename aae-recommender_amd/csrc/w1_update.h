@@ -50,7 +50,7 @@ __host__ __device__ inline size_t w1_items_lds_words(int rows) { return 2 * (siz
 //                      and the four partial sums are added in wave order: still a function of the batch alone;
 //   the update         thread t owns column t of a 256-column chunk; its parameter and moments were requested before the
 //                      lists were built.
-__device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* w1_lds, int vblock, int vgrid) {
+__device__ __forceinline__ void w1_item_update_one(const W1Items& a, unsigned* w1_lds, int u, const OptScalars& s, bool upd) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = (a.rows + 31) >> 5;
@@ -60,11 +60,7 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
     float* xl = reinterpret_cast<float*>(rl + a.rows);     // [rows] their values
     float* part = xl + a.rows;                             // [4][256] the waves' partial sums of a column chunk
     int* s_n = reinterpret_cast<int*>(part + 4 * 256);
-    const int cnt = *a.ucount;
-    const bool upd = a.gout == nullptr;
-    OptScalars s;
-    if (upd) s = *a.sc;
-    for (int u = vblock; u < cnt; u += vgrid) {
+    {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
@@ -170,6 +166,13 @@ __device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* 
         if (upd && a.mark_synced && tid == 0) a.tsync[item] = (int)*a.step_ctr;
     }
 }
+__device__ __forceinline__ void w1_item_update_body(const W1Items& a, unsigned* w1_lds, int vblock, int vgrid) {
+    const int cnt = *a.ucount;
+    const bool upd = a.gout == nullptr;
+    OptScalars s;
+    if (upd) s = *a.sc;
+    for (int u = vblock; u < cnt; u += vgrid) w1_item_update_one(a, w1_lds, u, s, upd);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same update with one WAVE per item, for WIDE batches (beyond one fused launch's 112 rows: batch 512 on one GPU,
@@ -274,6 +277,122 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
             }
         }
         if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batches of one fused launch (<= 112 rows), inside the grouped weight-gradient launch: BOTH forms in one workgroup.  Nearly
+// every item of such a batch sits in one or two rows; with a 4-wave workgroup per item the ~1 800 items of 100 documents are
+// 3 200 workgroups, and beside the deferred output-layer launch (which holds 9/16 of the CUs) they run in ~7 rounds of a
+// latency chain four round trips deep: 27 us for the ae phase's launch against 12.5 us for the gen phase's, which runs alone
+// (kernel trace, r3).  Here a workgroup takes FOUR items, one per wave, in the wave form when the item has at most 16 rows -
+// exactly the case in which the workgroup form lets wave 0 add them all, in the same order: the results are the workgroup
+// form's bit for bit - and notes the others in an LDS bitmap; behind a barrier the four waves take those together in the
+// workgroup form.  No hot list, no second launch.
+// LDS: max(the workgroup form's, 4 x 4 x 16 words) + kW1HybWords.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kW1HybRows = 16;
+constexpr int kW1HybWords = 64;        // the deferred items' bitmap: (round, wave) pairs, 512 rounds
+__host__ __device__ inline size_t w1_hybrid_lds_words(int rows) {
+    const size_t a = w1_items_lds_words(rows), b = 4 * 4 * kW1HybRows;
+    return (a > b ? a : b) + kW1HybWords;
+}
+__device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* lds, int vblock, int vgrid) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* defer = lds + (w1_hybrid_lds_words(a.rows) - kW1HybWords);
+    for (int i = tid; i < kW1HybWords; i += 256) defer[i] = 0u;
+    __syncthreads();
+    int* rl = reinterpret_cast<int*>(lds) + wv * 4 * kW1HybRows;       // rows as found
+    float* xl = reinterpret_cast<float*>(rl + kW1HybRows);              // their values
+    int* rs = reinterpret_cast<int*>(xl + kW1HybRows);                  // rows, ascending
+    float* xs = reinterpret_cast<float*>(rs + kW1HybRows);              // their values x row scale
+    const int cnt = *a.ucount;
+    const bool upd = a.gout == nullptr;
+    OptScalars s;
+    if (upd) s = *a.sc;
+    const int u0 = vblock * 4, ustep = vgrid * 4;
+    int round = 0;
+    for (int u = u0 + wv; u < cnt; u += ustep, ++round) {
+        const int item = a.ulist[u];
+        const int tile = item / kTI, it = item - tile * kTI;
+        const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
+        const int c4 = 4 * lane;
+        const size_t o0 = (size_t)item * a.ldw + min(c4, a.ldw - 4);
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pm = pw, pv = pw;
+        if (upd) {
+            pw = *reinterpret_cast<const float4*>(a.W + o0);
+            if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o0); pv = *reinterpret_cast<const float4*>(a.V + o0); }
+        }
+        int n = 0;
+        for (int base = e0; base < e1; base += 64) {
+            const int e = base + lane, ec = min(e, e1 - 1);
+            const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
+            const bool hit = e < e1 && en_e == it;
+            const unsigned long long bal = __ballot(hit);
+            const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && k < kW1HybRows) { rl[k] = r; xl[k] = x; }
+            n += __popcll(bal);
+        }
+        if (n > kW1HybRows) {                           // more rows than one wave adds in the workgroup form: all four take it below
+            const int b = round * 4 + wv;
+            if (lane == 0) atomicOr(&defer[b >> 5], 1u << (b & 31));
+            continue;
+        }
+        if (lane < n) {                                 // rank by row (distinct rows: the batch's CSR is canonical)
+            const int r = rl[lane];
+            int k = 0;
+            for (int j = 0; j < n; ++j) k += rl[j] < r ? 1 : 0;
+            rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
+        }
+        for (int cb = 0; cb < a.h; cb += 256) {
+            const int cc = min(cb + c4, a.ld - 4);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int kU = 8;
+            for (int i0 = 0; i0 < n; i0 += kU) {
+                float4 g[kU]; float x[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    const int i = min(i0 + j, n - 1);
+                    const int r = rs[i];
+                    x[j] = i0 + j < n ? xs[i] : 0.f;
+                    const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
+                                                  : a.ga1 + (size_t)r * a.ld;
+                    g[j] = *reinterpret_cast<const float4*>(grow + cc);
+                }
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    acc.x += x[j] * g[j].x; acc.y += x[j] * g[j].y; acc.z += x[j] * g[j].z; acc.w += x[j] * g[j].w;
+                }
+            }
+            const int c = cb + c4;
+            if (c >= a.h) acc.x = 0.f;
+            if (c + 1 >= a.h) acc.y = 0.f;
+            if (c + 2 >= a.h) acc.z = 0.f;
+            if (c + 3 >= a.h) acc.w = 0.f;
+            const size_t o = (size_t)item * a.ldw + min(c, a.ldw - 4);
+            if (cb > 0 && upd) {
+                pw = *reinterpret_cast<const float4*>(a.W + o);
+                if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o); pv = *reinterpret_cast<const float4*>(a.V + o); }
+            }
+            if (c < a.ldw) {
+                if (!upd) *reinterpret_cast<float4*>(a.gout + o) = acc;
+                else {
+                    adam_update(pw.x, pm.x, pv.x, acc.x, s); adam_update(pw.y, pm.y, pv.y, acc.y, s);
+                    adam_update(pw.z, pm.z, pv.z, acc.z, s); adam_update(pw.w, pm.w, pv.w, acc.w, s);
+                    *reinterpret_cast<float4*>(a.W + o) = pw;
+                    if (!s.is_sgd) { *reinterpret_cast<float4*>(a.M + o) = pm; *reinterpret_cast<float4*>(a.V + o) = pv; }
+                }
+            }
+        }
+        if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
+    }
+    __syncthreads();
+    // the deferred items, in (round, wave) order, with all four waves
+    const int rounds = u0 < cnt ? (cnt - u0 + ustep - 1) / ustep : 0;
+    const int nbits = min(rounds * 4, kW1HybWords * 32);
+    for (int b = 0; b < nbits; ++b) {
+        if (!((defer[b >> 5] >> (b & 31)) & 1u)) continue;             // (uniform: LDS word read by every thread)
+        w1_item_update_one(a, lds, u0 + (b & 3) + (b >> 2) * ustep, s, upd);
     }
 }
 
