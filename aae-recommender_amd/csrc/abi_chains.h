@@ -210,8 +210,11 @@ struct DwBuilder {
             static const bool no_wave = getenv("AAE_NO_W1_WAVE") != nullptr;
             // batches of one fused launch: four items per workgroup (w1_item_hybrid_body: same sums, a quarter of the workgroups)
             static const bool no_hybrid = getenv("AAE_NO_W1_HYBRID") != nullptr;
+            static const bool hyb_any = getenv("AAE_W1_HYBRID_ANY") != nullptr;      // (tests: every shape through this form)
+            // (ms/step, four items per workgroup | one: C3 0.2528 | 0.2585, C2's shape 0.1685 | 0.1728, C1's - 1 k items, most of them
+            //  in many rows - 0.1438 | 0.1419: as for the wide batches' wave form, only with >= 40 items per row of the batch)
             if (!no_hybrid && m->rows <= 16 * kMB && sizeof(int) * w1_hybrid_lds_words(m->rows) <= kDwSmemBytes &&
-                (int64_t)m->cfg.max_nnz <= 512ll * w.nitem) {
+                (int64_t)m->cfg.max_nnz <= 512ll * w.nitem && ((int64_t)m->N >= 40ll * m->rows || hyb_any)) {
                 w.wave_form = 2;
                 w.nitem = (w.nitem + 3) / 4;
             } else

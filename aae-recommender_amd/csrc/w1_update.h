@@ -310,9 +310,12 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
     const bool upd = a.gout == nullptr;
     OptScalars s;
     if (upd) s = *a.sc;
-    const int u0 = vblock * 4, ustep = vgrid * 4;
+    // wave w of workgroup g takes items g + w * vgrid (+ rounds of 4 * vgrid): NEIGHBOURS in the list go to different workgroups.
+    // (The list is in arrival order of the distinct-item pass: the items every document holds - the ones with many rows, which
+    //  cost their workgroup a pass of the workgroup form each - sit together at its head.)
+    const int ustep = vgrid * 4;
     int round = 0;
-    for (int u = u0 + wv; u < cnt; u += ustep, ++round) {
+    for (int u = vblock + wv * vgrid; u < cnt; u += ustep, ++round) {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
@@ -388,11 +391,11 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
     }
     __syncthreads();
     // the deferred items, in (round, wave) order, with all four waves
-    const int rounds = u0 < cnt ? (cnt - u0 + ustep - 1) / ustep : 0;
+    const int rounds = vblock < cnt ? (cnt - vblock + ustep - 1) / ustep : 0;      // (of wave 0, the one with the most)
     const int nbits = min(rounds * 4, kW1HybWords * 32);
     for (int b = 0; b < nbits; ++b) {
         if (!((defer[b >> 5] >> (b & 31)) & 1u)) continue;             // (uniform: LDS word read by every thread)
-        w1_item_update_one(a, lds, u0 + (b & 3) + (b >> 2) * ustep, s, upd);
+        w1_item_update_one(a, lds, vblock + (b & 3) * vgrid + (b >> 2) * ustep, s, upd);
     }
 }
 
