@@ -379,8 +379,11 @@ def main():
             for _ in range(5):
                 next(it2)
             k2 = max(10, min(a.steps, 50))
+            for _ in range(10):
+                next(it2)
+            d2 = timed_steps(it2, k2, barrier)            # (timed without the per-kernel events, as the headline loop is)
             m2.hip.profile_enable(True, kernels=K_OUT)
-            d2 = timed_steps(it2, k2, barrier)
+            timed_steps(it2, 10, barrier)
             m2.hip.profile_enable(False)
             km2 = kernel_models(N, h, 512, X2.nnz / 16, c)
             ks2 = {}
