@@ -166,7 +166,9 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
     }
-    if (side_ok && m->fused_ok && !m->bf16 && m->split_wgs > 0 &&
+    // (bf16 mode too: its output layer runs the same kernels with every operand rounded to bf16 - DecFusedArgs::one_term - when
+    //  they are available; dec_fused_bf16.h's own pair otherwise, or with AAE_NO_BF16_X3)
+    if (side_ok && m->fused_ok && m->split_wgs > 0 && (!m->bf16 || getenv("AAE_NO_BF16_X3") == nullptr) &&
         (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
         bool ok = true;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -181,7 +183,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        m->split_ok = ok;
+        if (!m->bf16) m->split_ok = ok;
         static const bool no_x3 = getenv("AAE_NO_X3") != nullptr;
         m->x3_ok = ok && !no_x3
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -193,6 +195,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
+        if (m->bf16) {
+            m->bf16_x3 = m->x3_ok && ok && getenv("AAE_NO_OPT_X3") == nullptr;
+            if (!m->bf16_x3) m->x3_ok = false;
+            else m->split_ok = true;
+        }
         if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
             // Workgroups of the deferred launch (batches of one fused launch).  It has to end before the step does (the next
             // step opens behind it), and every CU it holds is one the step's own launches share with it: wide enough to take

@@ -281,7 +281,9 @@ static bool fused_decoder_applies(const aae_model* m) {
     // (512 x 100 k: 1.48 against 1.12 ms; 512 x 275 k, a C5 slice: 3.7 against 2.7 ms).  AAE_BLOCKED_ANY lifts the cap (tests).
     // r3: with both launches on the emulated product (dec_crit_x3.h: the deferred half of all blocks in ONE launch for any
     // vocabulary, dec_opt_blocks_x3_kernel) the cap is gone: 512 x 100 k 0.77 ms/step against 0.93 on the three GEMMs.
-    const bool blocked = !one && m->blocked_ok && !m->bf16 && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
+    // (bf16 mode on the rounded-operand kernels: only with the one-launch deferred half - the per-block launches are fp32 kernels)
+    const bool bf_blocks_ok = !m->bf16 || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr && getenv("AAE_NO_OPT_BLOCKS") == nullptr);
+    const bool blocked = !one && m->blocked_ok && !out_bf16(m) && bf_blocks_ok && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
                          m->cfg.grad_mode == AAE_GRAD_FUSED &&
                          (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr));
     return m->fused_ok && !m->force_unfused && (one || blocked) &&

@@ -101,6 +101,7 @@ struct aae_model {
     // ev_opt = the optimiser launch is done (join_deferred() makes a caller's stream wait for it)
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
+    bool bf16_x3 = false;    // bf16 mode with the output layer on the dec_crit_x3.h kernels (operands rounded to bf16: DecFusedArgs::one_term)
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')
     bool bucket_wide_ok = false;   // tile_bucket_wide_kernel may take its LDS
@@ -342,6 +343,9 @@ bool prof_pair(aae_model* m, int k, hipEvent_t* a, hipEvent_t* b) {
     m->prof_used[k]++;
     return true;
 }
+
+// bf16 mode whose output layer runs dec_fused_bf16.h's own kernels (not the rounded-operand form of the dec_crit_x3.h ones)
+static inline bool out_bf16(const aae_model* m) { return m->bf16 && !m->bf16_x3; }
 
 // The previous step's deferred optimiser launch (dec_fused.h kDecOpt on m->side) writes DEC_V3 and its moments and
 // reads dh2 / the G scratch / the decoder's step scalars: everything that touches those waits for it here.

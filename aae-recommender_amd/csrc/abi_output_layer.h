@@ -24,7 +24,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // nblk launches of the split form over equal row blocks
     const int nblk = m->have_batch ? row_blocks(m) : 1;
     const int Bb = (B + nblk - 1) / nblk;                        // rows per block (the last one may be shorter)
-    const size_t fused_lds = m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(Bb, h);
+    const size_t fused_lds = out_bf16(m) ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(Bb, h);
     const float* chain_part = nullptr; size_t chain_stride = 0;
     if (fused_decoder_applies(m)) {
         // ---- fused path (dec_fused.h): logits, BCE, dV3 + dec_optim and dA2 in one persistent kernel
@@ -43,6 +43,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.slabs = m->slabs.p; fa.slab_stride = (size_t)(nblk > 1 ? B : std::min(m->R, 16 * kMB)) * m->ldh; fa.ld_slab = m->ldh;
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
         fa.erow0 = 0; fa.acc = nullptr; fa.nblk = 1; fa.Bb = B;
+        fa.one_term = m->bf16_x3 ? 1 : 0;
         { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
         static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile
         static unsigned long long* ts_dev = nullptr;
@@ -62,7 +63,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // (AAE_DEC_TS: the timeline of the single launch - or, AAE_DEC_TS=x3, of the split form's critical launch dec_crit_x3.h)
         static const bool ts_x3 = want_ts && strcmp(getenv("AAE_DEC_TS"), "x3") == 0;
         static const bool ts_obk = want_ts && strcmp(getenv("AAE_DEC_TS"), "obk") == 0;
-        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !m->bf16)) && (fa.dbg_skip & ~(256 | 0xF000)) == 0) {
+        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !out_bf16(m))) && (fa.dbg_skip & ~(256 | 0xF000)) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3
@@ -96,7 +97,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 const int r = nblk - 1;
                 hipEvent_t start = nullptr, stop = r == nblk - 1 ? m->ev_crit : nullptr;
                 (void)prof_pair(m, AAE_K_DEC_CRIT, &start, &stop);
-                if (m->bf16) switch (m->fused_nb) {
+                if (out_bf16(m)) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
@@ -123,15 +124,15 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             // (dec_opt_blocks_kernel), else one launch per block with the dV3 partial going through Gacc
             static const bool no_obk = getenv("AAE_NO_OPT_BLOCKS") != nullptr;
             static const bool no_opt_x3 = getenv("AAE_NO_OPT_X3") != nullptr;
-            const bool one_opt = nblk > 1 && !m->bf16 && !no_obk && ntiles <= kOBT * m->n_cu &&
+            const bool one_opt = nblk > 1 && !out_bf16(m) && !no_obk && ntiles <= kOBT * m->n_cu &&
                                  dec_opt_blocks_lds_bytes(Bb) <= 160 * 1024;
             // (r3) the same on the emulated product, any vocabulary size: dec_opt_blocks_x3_kernel (dec_crit_x3.h)
             static const bool no_obk_x3 = getenv("AAE_NO_OPT_BLOCKS_X3") != nullptr;
-            if (nblk > 1 && !m->bf16 && m->x3_ok && !no_opt_x3 && !no_obk_x3 && !no_obk && m->dh2f.p) {
+            if (nblk > 1 && !out_bf16(m) && m->x3_ok && !no_opt_x3 && !no_obk_x3 && !no_obk && m->dh2f.p) {
                 DecFusedArgs b = fa;
                 b.nblk = nblk; b.Bb = Bb;
                 hipLaunchKernelGGL(dh2_frag_kernel, dim3((B + kXCH - 1) / kXCH, m->fused_nb), dim3(128), 0, m->side, m->dh2.p, m->ldh, B,
-                                   reinterpret_cast<u32x4_t*>(m->dh2f.p));
+                                   reinterpret_cast<u32x4_t*>(m->dh2f.p), b.one_term);
                 b.acc = m->dh2f.p;                      // (this kernel's reading of the field: the fragment image)
                 // tile groups of at most kXBT tiles, the same number (+-1 tile) for every workgroup and round
                 // Workgroups: one per ~16 tiles, between half and three quarters of the CUs (tools/debug/sweep_obk_wgs*.sh, late r3,
@@ -194,7 +195,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 if (nblk > 1) { b.acc = m->Gacc.p; b.gradV3 = r == nblk - 1 ? nullptr : m->Gacc.p; }
                 hipEvent_t start = nullptr, stop = nullptr;
                 (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
-                if (m->bf16) switch (m->fused_nb) {
+                if (out_bf16(m)) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<4, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
@@ -228,10 +229,12 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         {
             m->last_out_split = false; m->side_ordered = false;
             ProfScope ps(m, AAE_K_DEC_FUSED, s);
+            // (the single launch of bf16 mode is always dec_fused_bf16.h's own kernel: there is no rounded-operand form of it)
+            const size_t bf_lds = dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13);
             if (m->bf16) switch (m->fused_nb) {
-                case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
-                case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
-                default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kBT), fused_lds, s, fa); break;
+                case 4: hipLaunchKernelGGL(dec_fused_bf16_kernel<4>, dim3(grid), dim3(kBT), bf_lds, s, fa); break;
+                case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kBT), bf_lds, s, fa); break;
+                default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kBT), bf_lds, s, fa); break;
             } else switch (m->fused_nb) {
                 case 4: hipLaunchKernelGGL(dec_fused_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
                 case 7: hipLaunchKernelGGL(dec_fused_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
@@ -250,7 +253,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                         (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
                         (t[12] - t[7]) * 0.01);
             else {
-            if (m->bf16)
+            if (out_bf16(m))
                 for (int k = 0; k < 5; ++k) {
                     fprintf(stderr, "[dec_fused_bf16 arrivals at barrier %d, us after the unit's start]", k);
                     for (int w = 0; w < 16; ++w) fprintf(stderr, " %.2f", ((double)t[16 + 16 * k + w] - (double)t[0]) * 0.01);
@@ -260,7 +263,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
                     (t[6] - t[4]) * 0.01, (t[6] - t[0]) * 0.01, (double)(t[9] - t[8]),
                     (double)(t[9] - t[8]) / ((t[6] - t[0]) * 10.0));
-            if (m->bf16) fprintf(stderr, "[dec_fused_bf16 S0] barrier A=%.2f work=%.2f barrier B=%.2f us\n", (t[14] - t[0]) * 0.01, (t[15] - t[14]) * 0.01, (t[1] - t[15]) * 0.01);
+            if (out_bf16(m)) fprintf(stderr, "[dec_fused_bf16 S0] barrier A=%.2f work=%.2f barrier B=%.2f us\n", (t[14] - t[0]) * 0.01, (t[15] - t[14]) * 0.01, (t[1] - t[15]) * 0.01);
             fprintf(stderr, "[dec_fused wg 0] prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",
                     (t[11] - t[10]) * 0.01, (t[7] - t[11]) * 0.01, t[13], (t[7] - t[11]) * 0.01 / (double)(t[13] ? t[13] : 1),
                     (t[12] - t[7]) * 0.01);

@@ -33,7 +33,11 @@ namespace aae {
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 // the 3-term split of a pair of fp32 values and the six-term product: gemm_f32.h (x3_split_pair, x3_mfma)
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) { x3_split_pair(a, b, p1, p2, p3); }
+// (one: bf16 mode - the operand IS its first term, round-to-nearest-even; the other two images hold zeros)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3, bool one) {
+    x3_split_pair(a, b, p1, p2, p3);
+    if (one) { p2 = 0u; p3 = 0u; }
+}
 __device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) { return x3_mfma(a, b, c); }
 
 // Row stride (dwords) of a k-contiguous bf16 image with kc 32-wide k-steps, read with ONE ds_read_b128 per fragment (8
@@ -63,6 +67,7 @@ inline size_t dec_crit_x3_lds_bytes(int NB) {
 // instructions per wave, on a CU whose one scalar unit serves all its waves.
 template <int NB, bool TS = false>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
+    const bool one = a.one_term != 0;
     constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
     constexpr int NKS = (KC1 + 1) / 2;         // ... per k half
     constexpr int NKR = NKS > kXRegSteps ? kXRegSteps : NKS;   // ... of them in registers; the others' fragments in LDS, a private
@@ -153,10 +158,10 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
             if (g1 && row < B && k0 < a.ldh) x = *reinterpret_cast<const float4*>(src + k0);
             if (g1 && row < B && k0 + 4 < a.ldh) y = *reinterpret_cast<const float4*>(src + k0 + 4);
             unsigned p[3][4];
-            split3_pair(x.x, x.y, p[0][0], p[1][0], p[2][0]);
-            split3_pair(x.z, x.w, p[0][1], p[1][1], p[2][1]);
-            split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2]);
-            split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3]);
+            split3_pair(x.x, x.y, p[0][0], p[1][0], p[2][0], one);
+            split3_pair(x.z, x.w, p[0][1], p[1][1], p[2][1], one);
+            split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2], one);
+            split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3], one);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 float4 p = vreg[j];
                 if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
                 unsigned q0[3], q1[3];
-                split3_pair(p.x, p.y, q0[0], q0[1], q0[2]);
-                split3_pair(p.z, p.w, q1[0], q1[1], q1[2]);
+                split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
+                split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
                 unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fu32x2, make_float2(gA, gB)), rGt, (unsigned)pid * 8u,
                                                       (unsigned)tile * (unsigned)g_f4 * 16u, 0);
                 unsigned q[3];
-                split3_pair(gA, gB, q[0], q[1], q[2]);
+                split3_pair(gA, gB, q[0], q[1], q[2], one);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
             }
@@ -370,6 +375,7 @@ inline size_t dec_opt_x3_lds_bytes() { return sizeof(float) * ((size_t)3 * 128 *
 
 template <int NB>
 __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
+    const bool one = a.one_term != 0;
     constexpr int KR = 4;                       // 32-wide k-steps over the (<= 112 -> 128) batch rows
     static_assert(NB <= 13, "column blocks 10..12 are the ones split over two waves");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
             }
             unsigned p[3][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+            for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q], one);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
@@ -459,8 +465,8 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
         // ---- S0: the stored dL/dlogits tile -> split images; rotate the pipeline, request the next stage
         if (tid < g_f4) {
             unsigned q0[3], q1[3];
-            split3_pair(g_nxt.x, g_nxt.y, q0[0], q0[1], q0[2]);
-            split3_pair(g_nxt.z, g_nxt.w, q1[0], q1[1], q1[2]);
+            split3_pair(g_nxt.x, g_nxt.y, q0[0], q0[1], q0[2], one);
+            split3_pair(g_nxt.z, g_nxt.w, q1[0], q1[1], q1[2], one);
             unsigned* d = gB + (tid >> 3) * kXGS + (tid & 7) * 2;
 #pragma unroll
             for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (128 * kXGS)) = make_uint2(q0[t], q1[t]);
@@ -558,7 +564,8 @@ inline size_t dec_opt_blocks_x3_lds_bytes() { return sizeof(float) * std::max((s
 // x 16 bytes (lane (fr, fk) = column 16 cb + fr, rows 64 ch + 32 kc + 8 fk + {0..7}; beyond the batch / the row: zeros).
 // One launch per step in front of dec_opt_blocks_x3_kernel, on its stream: a multiplier then fetches a chunk's fragments
 // with six coalesced 16-byte loads instead of sixteen strided 4-byte ones plus the split, once per (group, chunk).
-__global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__ dh2, int ldh, int B, u32x4_t* __restrict__ out) {
+__global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__ dh2, int ldh, int B, u32x4_t* __restrict__ out, int one_term) {
+    const bool one = one_term != 0;
     const int ch = blockIdx.x, cb = blockIdx.y, nb = gridDim.y;
     const int kc = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
     const int c = 16 * cb + fr;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__
     }
     unsigned p[3][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+    for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q], one);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
@@ -580,6 +587,7 @@ __global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__
 
 template <int NB, bool TS = false>   // TS: debug timeline (AAE_DEC_TS=obk) of workgroup 0, steps 8 .. 15 of its first group, waves 0 and 12
 __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) {
+    const bool one = a.one_term != 0;
     constexpr int KR = kXCH / 32;
     // A term image of a step: [item half][row slot][8 dwords = 16 items], no padding.  ds_read_b64_tr_b16 is serviced in two
     // groups of 32 lanes (MI355X_MICROARCH.md, LDS) which name the rows {8g + q, 8(g+1) + q : q < 4} x 4 column chunks of 8
@@ -749,8 +757,8 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
             const int f = tid & (kXCH * 8 - 1);
             if ((f >> 3) >= B - kXCH * ch) g = make_float4(0.f, 0.f, 0.f, 0.f);
             unsigned q0[3], q1[3];
-            split3_pair(g.x, g.y, q0[0], q0[1], q0[2]);
-            split3_pair(g.z, g.w, q1[0], q1[1], q1[2]);
+            split3_pair(g.x, g.y, q0[0], q0[1], q0[2], one);
+            split3_pair(g.z, g.w, q1[0], q1[1], q1[2], one);
             unsigned* d = gB + (q & 1) * 3 * IMG + ((f >> 2) & 1) * (kXCH * 8) + slot_of(f >> 3) * 8 + (f & 3) * 2;
 #pragma unroll
             for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * IMG) = make_uint2(q0[t], q1[t]);

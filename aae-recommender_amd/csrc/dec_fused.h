@@ -82,7 +82,9 @@ struct DecFusedArgs {
     // erow0 then describe the WHOLE batch and the kernel derives its block's.  Slab (w / nblk) receives the rows of every
     // block once: gridDim.x / nblk slabs in all.
     int nblk, Bb;
-    int tpp = 0;                          // dec_opt_blocks_x3_kernel (dec_crit_x3.h): number of tile groups
+    int tpp = 0;
+    int one_term = 0;       // dec_crit_x3.h kernels: 1 = every operand keeps the FIRST term of its split only, i.e. is rounded to bf16
+                            // (bf16 mode on the same kernels: bf16 operands, fp32 accumulation)                          // dec_opt_blocks_x3_kernel (dec_crit_x3.h): number of tile groups
 };
 
 // MODE of dec_fused_kernel.  The step's critical path needs only dL/d(dh2) from this layer (the decoder's hidden
