@@ -501,8 +501,11 @@ def main():
             out["extra"] = extra
         if use_dp and hasattr(model._dp, "comm_stats"):
             out["collectives_per_step"] = model._dp.comm_stats()
-            out["dp_step_driver"] = ("library call (aae_dp_step), RCCL communicator of the library"
-                                     if getattr(model._dp, "_native", None) is not None else "python phases over torch.distributed")
+            native = getattr(model._dp, "_native", None) is not None
+            rccl = dist is not None and str(dist.get_backend()).lower() == "nccl"
+            out["dp_step_driver"] = (("library call (aae_dp_step), " + ("RCCL communicator of the library" if rccl else
+                                                                         "collectives through host-staged callbacks (functional check)"))
+                                     if native else "python phases over torch.distributed")
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(docs_per_s / cpu["value"], 1)
         result_line = json.dumps(out)
