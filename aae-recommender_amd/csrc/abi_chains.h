@@ -200,7 +200,7 @@ struct DwBuilder {
         if (!no_merge && !m->dense_step && !m->ext_first && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
             TRY(ensure_buckets(m, s));
             w.items = w1_items_args(m, ga1, 0, 0, which);
-            w.nitem = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+            w.nitem = std::max(1, std::min(std::min(m->cfg.max_nnz, std::max(256, m->rows * 32)), m->N));      // (<= distinct items possible)
             m->w1_items_merged = true;
             // wide batches (beyond one fused launch) over a large vocabulary: one wave per item, the head items through the hot
             // list behind the launch.  With few items per row of the batch (N < 40 rows) most items sit in many rows and the
@@ -347,7 +347,8 @@ int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int
     const size_t lds = sizeof(int) * w1_items_lds_words(m->rows);
     if (lds > 64 * 1024 && !m->w1_big_lds) return fail(AAE_ESTATE, "first-layer update: batch too large for the LDS row lists");
     ProfScope ps(m, AAE_K_ENC_W1_ADAM, s);
-    const int items = std::min(m->cfg.max_nnz, std::max(256, m->rows * 32));
+    // (grid-stride over the distinct items: never more workgroups than the vocabulary - an item slice - has items)
+    const int items = std::max(1, std::min(std::min(m->cfg.max_nnz, std::max(256, m->rows * 32)), m->N));
     hipLaunchKernelGGL(w1_item_update_kernel, dim3(items), dim3(256), lds, s, a);
     LAUNCHCHK("w1_item_update");
     return AAE_OK;
