@@ -15,7 +15,7 @@ from tools.synth import init_params
 from tools.synth import throughput_corpus
 
 N, h, c, B = int(os.environ.get("VR_N", 100000)), 200, 50, int(os.environ.get("VR_B", 100))     # B = docs per rank
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+world = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("VR_WORLD", 8))
 NB = int(os.environ.get("VR_BATCHES", 64))
 MEDIAN_LEN = int(os.environ.get("VR_MEDIAN_LEN", 20))
 
