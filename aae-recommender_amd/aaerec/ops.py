@@ -52,7 +52,7 @@ def _model(mid):
 class _CsrView:
     """What HipAAE._batch needs from a resident CSR matrix."""
 
-    def __init__(self, indptr, indices, values, max_row_nnz):
+    def __init__(self, indptr, indices, values, max_row_nnz, n_cols=None):
         if indptr.dtype != torch.int64 or indices.dtype != torch.int32 or values.dtype != torch.float32:
             raise TypeError("aaerec: CSR tensors must be int64 indptr, int32 indices, float32 values")
         if not (indptr.is_cuda and indices.is_cuda and values.is_cuda):
@@ -64,7 +64,11 @@ class _CsrView:
         # caching allocator hands a fresh per-batch indptr the same address and version, and raw-pointer writers such as
         # aae_dense_to_csr never bump the version - a stale maximum either raised for a valid call or let an undersized
         # bound through.  The training loop proper - fit() on a resident corpus - does not come through this shim.)
-        true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
+        # A bound of at least the vocabulary size holds for every canonical CSR row: no reduction, no host sync then.
+        if n_cols is not None and int(max_row_nnz) >= int(n_cols):
+            true_max = 0
+        else:
+            true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
         if int(max_row_nnz) < true_max:
             raise ValueError(f"aaerec: max_row_nnz={int(max_row_nnz)} but the CSR matrix has a row of {true_max} entries")
         self.nnz_per_row_max = int(max_row_nnz)
@@ -76,22 +80,25 @@ def _step(model, indptr, indices, values, rows, row_start, n_rows, max_row_nnz, 
     m = _model(model)
     if rows is not None and rows.dtype != torch.int32:
         raise TypeError("aaerec: rows must be int32")
-    m.step(_CsrView(indptr, indices, values, max_row_nnz), row_start, n_rows, rows=rows, cond=cond,
+    m.step(_CsrView(indptr, indices, values, max_row_nnz, m.N), row_start, n_rows, rows=rows, cond=cond,
            masks=list(masks) if masks else None, z_real=z_real)
     return m.tensor(_hip.T_ACT_LOSSES).reshape(-1)[:3].clone()      # (recon, disc, gen); no host sync
 
 
 def _encode(model, indptr, indices, values, row_start, n_rows, max_row_nnz):
-    return _model(model).encode(_CsrView(indptr, indices, values, max_row_nnz), row_start, n_rows)
+    m = _model(model)
+    return m.encode(_CsrView(indptr, indices, values, max_row_nnz, m.N), row_start, n_rows)
 
 
 def _predict(model, indptr, indices, values, row_start, n_rows, max_row_nnz, cond):
-    return _model(model).predict(_CsrView(indptr, indices, values, max_row_nnz), row_start, n_rows, cond=cond)
+    m = _model(model)
+    return m.predict(_CsrView(indptr, indices, values, max_row_nnz, m.N), row_start, n_rows, cond=cond)
 
 
 def _predict_topk(model, indptr, indices, values, row_start, n_rows, max_row_nnz, cond, k, exclude_known):
-    return _model(model).predict_topk(_CsrView(indptr, indices, values, max_row_nnz), row_start, n_rows, k, cond=cond,
-                                      exclude_known=exclude_known)
+    m = _model(model)
+    return m.predict_topk(_CsrView(indptr, indices, values, max_row_nnz, m.N), row_start, n_rows, k, cond=cond,
+                          exclude_known=exclude_known)
 
 
 for _name, _fn in (("step", _step), ("encode", _encode), ("predict", _predict), ("predict_topk", _predict_topk)):

@@ -331,22 +331,10 @@ class VocabParallelAAE(DataParallelAAE):
         import os
         if self.shard_first and hasattr(model, "dp_step") and hasattr(slice_model, "handle") and os.environ.get("AAE_DP_PYTHON") is None:
             if str(dist.get_backend(group)).lower() == "nccl":
-                # every rank must take the same driver: the ranks agree on whether the library's communicator came up, and
-                # if it did not on any of them, all keep the phase-by-phase driver over torch.distributed (RCCL as well)
-                err = None
-                try:
-                    self._native = rccl_collectives(model, dist, group)
-                except Exception as e:              # noqa: BLE001 - reported below, on every rank
-                    err = e
-                import torch
-                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=model.device)
-                if self.world > 1:
-                    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-                if int(ok.item()) == 0:
-                    import sys
-                    print("aaerec: the library's RCCL communicator is not available on every rank (%s); "
-                          "using the phase-by-phase driver over torch.distributed" % (err,), file=sys.stderr, flush=True)
-                    self._native = None
+                # every rank takes the same driver: rccl_collectives agrees (in lock-step collectives) on whether the library's
+                # communicator came up everywhere; if not, all keep the phase-by-phase driver over torch.distributed (RCCL too)
+                self._native_keep = rccl_collectives(model, dist, group)
+                self._native = None if self._native_keep is None else self._native_keep.table
             elif str(dist.get_backend(group)).lower() == "echo":     # (tools/vocab_rank_time.py: device-side stand-ins)
                 import ctypes as C
                 from . import _hip
@@ -594,26 +582,77 @@ class VocabParallelAAE(DataParallelAAE):
         return float(buf.item())
 
 
+class RcclTable:
+    """Owner of an aae_collectives table over a communicator the library created (aae_rccl_init): close() - also at
+    garbage collection - hands it back (aae_rccl_destroy).  `.table` is what aae_dp_step takes."""
+
+    def __init__(self, lib, table):
+        self.lib, self.table = lib, table
+
+    def close(self):
+        tab, self.table = self.table, None
+        if tab is not None and self.lib is not None:
+            import ctypes as C
+            self.lib.aae_rccl_destroy(C.byref(tab))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:               # noqa: BLE001 - interpreter shutdown: the library may be gone already
+            pass
+
+
 def rccl_collectives(model, dist, group=None):
     """An aae_collectives table (include/aaerec_hip.h) over an RCCL communicator the LIBRARY creates: rank 0 draws the
     ncclUniqueId (aae_rccl_unique_id), torch.distributed carries its 128 bytes to the other ranks, every rank joins
-    (aae_rccl_init).  The communicator lives as long as the returned object."""
+    (aae_rccl_init).  Returns an RcclTable (the communicator lives as long as it does) or None when the ranks agree that
+    the library's communicator is not available everywhere.
+
+    Every rank runs the SAME sequence of torch.distributed collectives whatever fails locally (a rank that skipped one
+    would leave its peers waiting in it for ever): 1. each rank probes librccl by itself (aae_rccl_unique_id: dlopen +
+    ncclGetUniqueId, no communication; rank 0's draw is the one used), 2. all_reduce(MIN) of the probe status, 3. only if
+    every probe succeeded: broadcast of the id and the collective ncclCommInitRank, 4. all_reduce(MIN) of the init status
+    (a rank whose init failed after its peers' succeeded; the peers drop their communicator again)."""
     import ctypes as C
+    import sys
     import torch
     from . import _hip
     lib = model.lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    buf = C.create_string_buffer(128)
-    if rank == 0:
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=model.device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    def give_up(stage, err):
+        print("aaerec: the library's RCCL communicator is not available on every rank (%s%s); using the phase-by-phase "
+              "driver over torch.distributed" % (stage, "" if err is None else ": %s" % (err,)), file=sys.stderr, flush=True)
+        return None
+    buf, err = C.create_string_buffer(128), None
+    try:
         _hip._check(lib.aae_rccl_unique_id(buf))
+    except Exception as e:              # noqa: BLE001 - agreed on below, by every rank
+        err = e
+    if not agree(err is None):
+        return give_up("librccl probe", err)
     t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(model.device)
     if world > 1:
         dist.broadcast(t, src=0, group=group)
     ident = bytes(t.cpu().numpy().tobytes())
     tab = _hip.AaeCollectives()
-    with model._on_device():
-        _hip._check(lib.aae_rccl_init(C.create_string_buffer(ident, 128), world, rank, C.byref(tab)))
-    return tab
+    try:
+        with model._on_device():
+            _hip._check(lib.aae_rccl_init(C.create_string_buffer(ident, 128), world, rank, C.byref(tab)))
+    except Exception as e:              # noqa: BLE001
+        err = e
+    owner = RcclTable(lib, tab) if err is None else None
+    if not agree(err is None):
+        if owner is not None:
+            owner.close()
+        return give_up("ncclCommInitRank", err)
+    return owner
 
 
 def python_collectives(model, dist, group=None):
@@ -652,17 +691,17 @@ def python_collectives(model, dist, group=None):
     def all_gather(ctx, send, recv, count, stream):
         x = fetch(send, count, stream)
         out = torch.empty(world * int(count), dtype=torch.float32)
-        raw.all_gather_into_tensor(out, x)
+        raw.all_gather_into_tensor(out, x, group=group)
         put(recv, out, stream)
 
     def reduce_scatter(ctx, send, recv, count, stream):
         x = fetch(send, world * int(count), stream)
-        raw.all_reduce(x)
+        raw.all_reduce(x, group=group)
         put(recv, x[rank * int(count):(rank + 1) * int(count)], stream)
 
     def all_reduce(ctx, buf, count, stream):
         x = fetch(buf, count, stream)
-        raw.all_reduce(x)
+        raw.all_reduce(x, group=group)
         put(buf, x, stream)
 
     cbs = (_hip._COLL_AG(guarded(all_gather)), _hip._COLL_AG(guarded(reduce_scatter)), _hip._COLL_AR(guarded(all_reduce)))

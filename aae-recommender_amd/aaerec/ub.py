@@ -16,6 +16,15 @@ from sklearn.feature_extraction.text import TfidfVectorizer
 from . import _hip
 
 
+class AutoEncoderMixin:
+    """Protocol mixin of the reference's sklearn-style autoencoders (reference aaerec/ub.py:5-11): a model with
+    transform() and inverse_transform() reconstructs by chaining them.  Kept here because out-of-scope modules of a user's
+    own reference checkout that fall through aaerec.__path__ (aaerec/svd.py:7) import it from this module."""
+
+    def reconstruct(self, X, y=None):
+        return self.inverse_transform(self.transform(X))
+
+
 class EmbeddedVectorizer:
     """ Weighted Bag-of-embedded-Words
 

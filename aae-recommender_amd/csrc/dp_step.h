@@ -30,11 +30,8 @@ struct NcclId { char internal[128]; };
 typedef int (*nccl_comm_init_rank_t)(void**, int, NcclId, int);
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;       // ncclDataType_t / ncclRedOp_t of rccl.h
 
-RcclApi* rccl_api() {
+RcclApi* rccl_open() {           // runs once (function-local static initialiser below: thread-safe since C++11)
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.lib ? &api : nullptr;
-    tried = true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
         api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (api.lib) break;
@@ -51,6 +48,10 @@ RcclApi* rccl_api() {
         dlclose(api.lib); api.lib = nullptr; return nullptr;
     }
     return &api;
+}
+RcclApi* rccl_api() {
+    static RcclApi* const api = rccl_open();
+    return api;
 }
 
 struct RcclCtx { void* comm; };

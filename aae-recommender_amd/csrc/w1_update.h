@@ -232,7 +232,7 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
         if (lane < n) {
             const int r = rl[lane];
             int k = 0;
-            for (int j = 0; j < n; ++j) k += rl[j] < r ? 1 : 0;
+            for (int j = 0; j < n; ++j) k += (rl[j] < r || (rl[j] == r && j < lane)) ? 1 : 0;   // total order: a duplicate (row, item) pair of a non-canonical CSR still gets a slot of its own
             rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
         }
         // (one wave: its LDS writes are in order before its reads - no barrier)
@@ -344,7 +344,7 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
         if (lane < n) {                                 // rank by row (distinct rows: the batch's CSR is canonical)
             const int r = rl[lane];
             int k = 0;
-            for (int j = 0; j < n; ++j) k += rl[j] < r ? 1 : 0;
+            for (int j = 0; j < n; ++j) k += (rl[j] < r || (rl[j] == r && j < lane)) ? 1 : 0;   // total order: a duplicate (row, item) pair of a non-canonical CSR still gets a slot of its own
             rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
         }
         for (int cb = 0; cb < a.h; cb += 256) {

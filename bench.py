@@ -348,6 +348,19 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
 
+    # The whole step against its own floor: ALGORITHMIC bytes and flops of one partial_fit - the output layer's
+    # parameter + optimiser stream (24 B per element of dec.lin3, read once / written once), the first layer's touched rows
+    # (3 forward gathers + 2 optimisers of 32 B per element), the hidden layers' Adam (28 B per element, the encoder's twice) -
+    # against max(bytes / HBM peak, flops / matrix peak of the line's dtype); per rank: its documents, its share of the layer
+    Nr = out_model.N if vocab else N
+    small = 2 * (h * (h + 1) + c * (h + 1)) + (h * (c + a.cond_inc + 1) + h * (h + 1)) + (h * (c + 1) + h * (h + 1) + h + 1)
+    step_bytes = 24.0 * Nr * (h + 1) + nnz_per_batch * h * (3 * 4 + 2 * 32) + 28.0 * small
+    step_flops = 6.0 * (Bg if vocab else B) * Nr * (h + 1) + 2.0 * B * (13 * h * (h + 1) + 11 * c * (h + 1)) + 10.0 * nnz_per_batch * h
+    floor_ms = max(step_bytes / (HBM_PEAK_GBS * 1e9), step_flops / (peak_tf * 1e12)) * 1e3
+    step_roofline = dict(bytes=round(step_bytes), flops=round(step_flops), floor_ms=round(floor_ms, 4),
+                         bound="hbm" if step_bytes / (HBM_PEAK_GBS * 1e9) >= step_flops / (peak_tf * 1e12) else "mfma",
+                         ms_per_step=round(dt / a.steps * 1e3, 4), frac=round(floor_ms / (dt / a.steps * 1e3), 4))
+
     raw = None
     extra = {}
     if world == 1 and not use_dp:
@@ -427,6 +440,31 @@ def main():
                                     docs_per_s=round(a.steps * B / dm, 1), ms_per_step=round(dm / a.steps * 1e3, 4), steps=a.steps,
                                     dtype="bf16", kernels=ks3)
             del m3, it3
+        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc:
+            # BASELINE.json configs[3] (C4, EconBiz-scale + title condition: |items| = 4 587 - nmi.txt:38 of the reference -,
+            # hidden 200, a 300-d constant document vector concatenated to the code - condition.py:312-316, 345-369 -, batch
+            # 1000 - eval/econis.py:45): the same fit() loop; tests/test_fullsize_gpu.py::test_c4_bench_shape_fit_path_matches_oracle
+            # holds exactly this combination of launches against the oracle
+            a4 = argparse.Namespace(**vars(a))
+            a4.hidden, a4.items, a4.cond_inc = 200, 4587, 300
+            B4, nb4 = 1000, 16
+            cl4 = ConditionList([("title", PretrainedWordEmbeddingCondition(_ConstVectors(a4.cond_inc), use_cuda=True))])
+            cd4 = [torch.randn(nb4 * B4, a4.cond_inc, device=dev) * 0.1]
+            m4 = make_model(a4, B4, None, conditions=cl4)
+            X4 = throughput_corpus(nb4 * B4, a4.items, median_len=a.median_len, seed=3456)
+            with contextlib.redirect_stdout(sys.stderr):
+                it4 = m4.fit_steps(X4, condition_data=cd4)
+                next(it4)
+            for _ in range(max(5, a.warmup)):
+                next(it4)
+            k4 = max(10, min(a.steps, 100))
+            d4 = [timed_steps(it4, k4, barrier) for _ in range(3)]
+            dm = float(np.median(d4))
+            extra["c4"] = dict(workload=f"C4 EconBiz-scale synthetic Bags + 300-d title condition (constant concatenated block): "
+                                        f"|items|={a4.items}, hidden={a4.hidden}, code={c}, fp32, batch={B4}, through fit()",
+                               docs_per_s=round(k4 * B4 / dm, 1), ms_per_step=round(dm / k4 * 1e3, 4), steps=k4, dtype="f32",
+                               cond_inc=a4.cond_inc)
+            del m4, it4
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -491,7 +529,7 @@ def main():
                                         if getattr(model._dp, "shard_first", False) else
                                         f"dp{world}, decoder output layer sharded over the vocabulary") if vocab else
                                        f"dp{world}, replicated decoder")},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kstats,
+            "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu, "kernels": kstats,
             **({"roofline_critical": roofline_critical} if roofline_critical else {}),
             "losses_last_step": [round(float(x), 5) for x in losses],
         }

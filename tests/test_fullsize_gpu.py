@@ -417,3 +417,98 @@ def test_slice_prefetch_is_still_waited_for_after_a_view_was_read_between_the_ph
     a, b = run(True), run(False)
     for t in a:
         assert torch.equal(a[t], b[t]), (t, float((a[t] - b[t]).abs().max()))
+
+
+class _ConstVectors:
+    """Stand-in for the fitted TF-IDF x word2vec vectoriser behind PretrainedWordEmbeddingCondition: the document vectors
+    come precomputed (condition.py:345-369 of the reference computes them once per dataset, outside the step)."""
+
+    def __init__(self, dim):
+        self.embedding = np.zeros((1, dim), dtype=np.float32)
+
+    def fit(self, x):
+        return self
+
+    def transform(self, x):
+        return x
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_c4_bench_shape_fit_path_matches_oracle(dtype, monkeypatch):
+    """BASELINE configs[3] at its bench shape THROUGH fit(): |items| = 4 587 (EconBiz, nmi.txt:38), hidden 200, code 50, a
+    300-d constant title condition (PretrainedWordEmbeddingCondition: condition.py:312-316, 345-369), batch 1000
+    (eval/econis.py:45).  AdversarialAutoEncoder(batch_size=1000, conditions=...).fit() creates the handle itself, so this
+    is the combination the benchmark's C4 line runs - the row-blocked output layer (blocked_output: one critical launch for
+    10 row blocks + one deferred optimiser launch), dec.lin1 as two k-parts of the chain program over 1 000 rows (351 input
+    columns), the workgroup-per-item form of the first layer's update (N < 40 x rows), the wide tile-bucket builder, the
+    next batch named ahead - with the randomness fit() draws on the host (rng_mode='reference': 12 dropout masks + z_real
+    per step) recorded and replayed through OracleAAE(conditions=[ConcatConst(300)]) on the same permutation batches:
+    losses after each of 3 steps, every parameter, predictions; fp32 at the fixture tolerances (1e-5 / 1e-5 / 1e-4), bf16
+    against OracleAAE(bf16=True) at tests/test_bf16_gpu.py's."""
+    from aaerec import _hip
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec.condition import ConditionList, PretrainedWordEmbeddingCondition
+    from oracle import aae_oracle as O
+    from tools.synth import throughput_corpus
+    N, h, c, inc, B, steps = 4587, 200, 50, 300, 1000, 3
+    X = throughput_corpus(steps * B, N, median_len=20, seed=45)
+    cond_all = (np.random.default_rng(8).standard_normal((steps * B, inc)) * 0.1).astype(np.float32)
+    conditions = ConditionList([("title", PretrainedWordEmbeddingCondition(_ConstVectors(inc), use_cuda=True))])
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3)
+    model = AdversarialAutoEncoder(n_hidden=h, n_code=c, batch_size=B, n_epochs=1, verbose=False, rng_mode="reference",
+                                   conditions=conditions, **({"dtype": "bf16"} if dtype == "bf16" else {}), **kw)
+    seen = {"params": None, "draws": [], "create": None}
+    load0, host0, init0 = _hip.HipAAE.load_params, AdversarialAutoEncoder._host_randomness, _hip.HipAAE.__init__
+
+    def load_params(self, params):
+        if seen["params"] is None:
+            seen["params"] = {k: np.array(v, copy=True) for k, v in params.items()}
+        return load0(self, params)
+
+    def host_randomness(self, rows):
+        masks, z_real = host0(self, rows)
+        seen["draws"].append(([m.numpy().copy() for m in masks], z_real.numpy().copy()))
+        return masks, z_real
+
+    def init(self, *a, **k):
+        seen["create"] = dict(k)
+        return init0(self, *a, **k)
+    monkeypatch.setattr(_hip.HipAAE, "load_params", load_params)
+    monkeypatch.setattr(_hip.HipAAE, "__init__", init)
+    monkeypatch.setattr(AdversarialAutoEncoder, "_host_randomness", host_randomness)
+    np.random.seed(4)
+    state = np.random.get_state()
+    torch.manual_seed(11)
+    losses = [model.hip.losses() for _ in model.fit_steps(X, condition_data=[cond_all])]     # (exhausted: fit())
+    np.random.set_state(state)
+    perm = np.arange(steps * B)
+    np.random.shuffle(perm)                              # fit()'s epoch permutation (aae.py:813-817 of the reference)
+    assert len(losses) == steps and len(seen["draws"]) == steps
+    assert seen["create"]["blocked_output"] and seen["create"]["cond_inc"] == inc and seen["create"]["max_batch"] == B
+    ora = O.OracleAAE(seen["params"], conditions=[O.ConcatConst(inc)], bf16=dtype == "bf16", **kw)
+    for s in range(steps):
+        idx = perm[s * B:(s + 1) * B]
+        Xb = X[idx]
+        masks, z_real = seen["draws"][s]
+        want = ora.partial_fit(Xb.indptr.astype(np.int64), Xb.indices, Xb.data.astype(np.float32), z_real, masks, [cond_all[idx]])
+        if dtype == "f32":
+            np.testing.assert_allclose(losses[s], want, rtol=1e-5, atol=1e-6, err_msg=f"losses, step {s}")
+        else:
+            np.testing.assert_allclose(losses[s], want, rtol=2e-4, atol=2e-6, err_msg=f"bf16 losses, step {s}")
+    sd = model.hip.state_dict()
+    worst = {k: _maxdiff(sd[k], w) for k, w in ora.p.items()}
+    print("C4 through fit(),", dtype, ": max |device - oracle| per tensor:", worst)
+    Xp, cp = X[:B], cond_all[:B]
+    want = ora.predict(Xp.indptr.astype(np.int64), Xp.indices, Xp.data.astype(np.float32), [cp])
+    got = model.predict(Xp, condition_data=[cp])
+    if dtype == "f32":
+        for k, d in worst.items():
+            assert d <= 1e-5, (k, d)
+        np.testing.assert_allclose(got, want, atol=1e-5)
+    else:
+        lr = 1e-3
+        for k, w in ora.p.items():
+            d = np.abs(sd[k].astype(np.float64) - w)
+            n_opt = 2 if k.startswith("enc.") else 1
+            assert float((d > 1e-4).mean()) <= 1e-2 and d.max() <= 3.0 * lr * steps * n_opt, (k, float((d > 1e-4).mean()), d.max())
+        assert _maxdiff(got, want) <= 2e-3, _maxdiff(got, want)

@@ -1181,11 +1181,29 @@ def _rccl_world1_worker(rank, port, ret):
     torch.manual_seed(5)
     m = _dp_model(True, data_parallel=True, dp_mode="vocab")
     m.fit(_dp_corpus())
-    ret["native"] = m._dp._native is not None and m._dp._native_keep is None       # (the RCCL table, not Python callbacks)
+    from aaerec.parallel import RcclTable
+    ret["native"] = m._dp._native is not None and isinstance(m._dp._native_keep, RcclTable)   # (the RCCL table, not Python callbacks)
     ret["state"] = m.hip.state_dict()
     ret["pred"] = m.predict(_dp_corpus()[:33])
     ret["stats"] = m._dp.comm_stats()
+    # SURVEY 8e's bar: 3 steps, 1e-5 (default learning rates; what differs from the single process is summation order only)
+    np.random.seed(6)
+    torch.manual_seed(6)
+    m3 = _three_step_model(data_parallel=True, dp_mode="vocab")
+    for _ in zip(range(3), m3.fit_steps(_dp_corpus())):
+        pass
+    m3._fit_finish()
+    ret["state3"] = m3.hip.state_dict()
+    ret["losses3"] = tuple(float(x) for x in m3.last_losses)
+    m._dp._native_keep.close()                      # aae_rccl_destroy (the communicator was never handed back)
+    m3._dp._native_keep.close()
     dist.destroy_process_group()
+
+
+def _three_step_model(**kw):
+    from aaerec.aae import AdversarialAutoEncoder
+    return AdversarialAutoEncoder(n_hidden=48, n_code=16, batch_size=40, n_epochs=1, dropout=(0.2, 0.2), verbose=False,
+                                  seed=4243, **kw)
 
 
 def test_native_step_driver_over_rccl_on_one_rank():
@@ -1210,6 +1228,17 @@ def test_native_step_driver_over_rccl_on_one_rank():
         d = np.abs(got["state"][k] - w)
         assert (d > 2e-4).sum() <= max(8, 0.01 * d.size) and d.max() < 0.02, f"{k}: {(d > 2e-4).sum()} off, max {d.max():.2e}"
     np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=2e-3)
+    # (above: 15 steps at gen_lr 0.01 with dropout - adversarial steps amplify an ulp of summation order, hence the wide
+    #  bound.)  The bar SURVEY 8e names - 3 steps within 1e-5 - at the reference's default learning rates:
+    np.random.seed(6)
+    torch.manual_seed(6)
+    one3 = _three_step_model()
+    for _ in zip(range(3), one3.fit_steps(X)):
+        pass
+    one3._fit_finish()
+    np.testing.assert_allclose(got["losses3"], one3.last_losses, rtol=1e-5, atol=1e-6)
+    for k, w in one3.hip.state_dict().items():
+        np.testing.assert_allclose(got["state3"][k], w, atol=1e-5, err_msg=k)
 
 
 def test_fit_on_two_ranks_through_the_python_step_driver(monkeypatch):
