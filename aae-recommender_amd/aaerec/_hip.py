@@ -118,6 +118,7 @@ _PROTOS = {
     "aae_read_losses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.c_void_p]),
     "aae_predict": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aae_predict_topk": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aae_rank_max_rows": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "aae_decode_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AaeBatch), C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "aae_encode": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch), C.c_void_p, C.c_void_p]),
@@ -454,6 +455,7 @@ class HipAAE:
         self._keep = []   # device buffers of the running step
         self._ga1_ld = None
         self._ext_first = False
+        self._rank_rows = {}
 
     def close(self):
         """Destroy the handle now (waits for its side stream)."""
@@ -599,13 +601,13 @@ class HipAAE:
         return out
 
     # ---- batches / randomness ----------------------------------------------------------
-    def _batch(self, csr, row_start, n_rows, rows=None):
+    def _batch(self, csr, row_start, n_rows, rows=None, bounded=True):
         b = AaeBatch()
         b.indptr_dev, b.indices_dev, b.values_dev = csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr()
         b.rows_dev = rows.data_ptr() if rows is not None else None
         b.row_start, b.n_rows = int(row_start), int(n_rows)
         b.nnz_bound = int(n_rows * max(1, csr.nnz_per_row_max))
-        if b.nnz_bound > self.cfg.max_nnz:
+        if bounded and b.nnz_bound > self.cfg.max_nnz:
             raise ValueError(f"batch may hold {b.nnz_bound} entries but the model was created with max_nnz="
                              f"{self.cfg.max_nnz}")
         b.max_row_nnz = int(csr.nnz_per_row_max)
@@ -988,9 +990,19 @@ class HipAAE:
             _check(self.lib.aae_predict(self.handle, C.byref(b), _ptr(cond), _ptr(out), out.shape[1], self._stream()))
         return out[:, :self.N]
 
+    def rank_max_rows(self, k=10):
+        """Rows one predict_topk / decode_topk call may rank (aae_rank_max_rows): far more than max_batch where the fused
+        predict -> rank kernels apply, max_batch otherwise."""
+        key = int(k)
+        if key not in self._rank_rows:
+            out = C.c_int32()
+            _check(self.lib.aae_rank_max_rows(self.handle, key, C.byref(out)))
+            self._rank_rows[key] = int(out.value)
+        return self._rank_rows[key]
+
     def predict_topk(self, csr, row_start, n_rows, k, cond=None, exclude_known=True):
-        """(ids int32 [n_rows, k], scaled scores float32 [n_rows, k]) - device tensors."""
-        b = self._batch(csr, row_start, n_rows)
+        """(ids int32 [n_rows, k], scaled scores float32 [n_rows, k]) - device tensors.  n_rows <= rank_max_rows(k)."""
+        b = self._batch(csr, row_start, n_rows, bounded=n_rows <= self.max_batch)     # (beyond max_batch: the fused rank path, which has no per-batch lists)
         idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
         if cond is not None:
@@ -1004,7 +1016,7 @@ class HipAAE:
         """Top-k of decode(zc) for the input rows csr[row_start : row_start + len(zc)] (aae_decode_topk)."""
         zc = zc.detach().to(self.device, torch.float32).contiguous()
         n_rows = zc.shape[0]
-        b = self._batch(csr, row_start, n_rows)
+        b = self._batch(csr, row_start, n_rows, bounded=n_rows <= self.max_batch)
         idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)
         with self._on_device():

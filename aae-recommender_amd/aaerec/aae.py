@@ -610,8 +610,11 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
     if self._slice is not None:
         self._dp.gather_output_layer()
     ids, vals = [], []
-    for start in range(0, Xs.shape[0], self.batch_size):
-        n = min(self.batch_size, Xs.shape[0] - start)
+    # rows per call: what one fused predict -> rank launch takes (aae_rank_max_rows: hundreds to thousands of rows, the
+    # parameter stream of dec.lin3 is read once per call), the training batch size otherwise
+    chunk = max(self.batch_size, min(self.hip.rank_max_rows(k), 2048))
+    for start in range(0, Xs.shape[0], chunk):
+        n = min(chunk, Xs.shape[0] - start)
         cond = None
         c_batch = [_take(c, slice(start, start + n)) for c in condition_data] if use_condition else None
         if use_condition and fused:
@@ -622,7 +625,9 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
             i, v = self.hip.predict_topk(csr, start, n, k, cond=cond, exclude_known=exclude_known)
         else:
             with torch.no_grad():
-                z = self.hip.encode(csr, start, n)
+                # (aae_encode takes the handle's per-batch buffers: batch_size rows at a time; the ranking is one call)
+                z = torch.cat([self.hip.encode(csr, s0, min(self.batch_size, start + n - s0))
+                               for s0 in range(start, start + n, self.batch_size)])
                 i, v = self.hip.decode_topk(self.conditions.encode_impose(z, c_batch), csr, start, k, exclude_known=exclude_known)
         ids.append(i)
         vals.append(v)

@@ -31,6 +31,7 @@
 #include "dec_fused.h"
 #include "dec_fused_bf16.h"
 #include "dec_crit_x3.h"
+#include "rank_x3.h"
 #include "chain.h"
 #include "chain4.h"
 #include "cond_embed.h"
@@ -41,6 +42,7 @@ using namespace aae;
 #include "abi_model.h"
 #include "abi_layers.h"
 #include "abi_chains.h"
+#include "abi_rank.h"
 
 // ------------------------------------------------------------------------------------------
 extern "C" {
@@ -120,6 +122,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 m->fused_ok = false;
         }
     }
+    m->rank_ok = m->fused_ok && m->use_chain4 && !m->vae && getenv("AAE_NO_RANK_FUSED") == nullptr && rank_set_attributes();
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(int) * w1_items_lds_words(16384))) == hipSuccess;
     (void)hipGetLastError();

@@ -67,6 +67,12 @@ int aae_predict_topk(aae_handle m, const aae_batch* batch, const float* cond_dev
                      int32_t* idx_out_dev, float* val_out_dev, void* stream) {
     if (!m || !idx_out_dev || !val_out_dev) return fail(AAE_EINVAL, "NULL argument");
     if (k < 1 || k > 32 || k > m->N) return fail(AAE_EINVAL, "k must be in [1, min(32, n_items)]");
+    if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
+    TRY(rank_check_batch(batch));
+    if (batch->n_rows >= 1 && batch->n_rows <= rank_rows_cap(m, k)) {   // fused: no [rows][N] matrix (abi_rank.h)
+        m->phase = 0;
+        return rank_predict(m, batch, cond_dev, k, exclude_known, idx_out_dev, val_out_dev, S(stream));
+    }
     TRY(aae_predict(m, batch, cond_dev, m->G.p, m->ldn, stream));      // scores into the [rows][N] scratch
     hipStream_t s = S(stream);
     if (k <= 10)
@@ -82,6 +88,13 @@ int aae_predict_topk(aae_handle m, const aae_batch* batch, const float* cond_dev
     return AAE_OK;
 }
 
+int aae_rank_max_rows(aae_handle m, int32_t k, int32_t* rows_out) {
+    if (!m || !rows_out) return fail(AAE_EINVAL, "NULL argument");
+    if (k < 1 || k > 32 || k > m->N) return fail(AAE_EINVAL, "k must be in [1, min(32, n_items)]");
+    *rows_out = std::max(m->R, rank_rows_cap(m, k));
+    return AAE_OK;
+}
+
 // the same for a caller-built decoder input (code | imposed conditions of any plugin kind): the second half of predict
 // (aae.py:855-866) + remove_non_missing / argtopk; `batch` names the input rows whose items are excluded
 int aae_decode_topk(aae_handle m, const float* zc_dev, int64_t zc_ld, const aae_batch* batch, int32_t k,
@@ -89,6 +102,11 @@ int aae_decode_topk(aae_handle m, const float* zc_dev, int64_t zc_ld, const aae_
     if (!m || !zc_dev || !idx_out_dev || !val_out_dev) return fail(AAE_EINVAL, "NULL argument");
     if (k < 1 || k > 32 || k > m->N) return fail(AAE_EINVAL, "k must be in [1, min(32, n_items)]");
     if (zc_ld < m->cp) return fail(AAE_EINVAL, "zc_ld < n_code + cond_inc");
+    TRY(rank_check_batch(batch));
+    if (batch->n_rows >= 1 && batch->n_rows <= rank_rows_cap(m, k)) {
+        m->phase = 0;
+        return rank_decode(m, zc_dev, zc_ld, batch, k, exclude_known, idx_out_dev, val_out_dev, S(stream));
+    }
     TRY(set_batch(m, batch));
     TRY(aae_decode(m, zc_dev, zc_ld, m->rows, m->G.p, m->ldn, stream));   // scores into the [rows][N] scratch
     hipStream_t s = S(stream);

@@ -1,0 +1,314 @@
+// Fused predict -> rank (reference aaerec/aae.py:840-870 predict, evaluation.py:183-199 remove_non_missing,
+// evaluation.py:20-58 argtopk): the decoder's output layer, its sigmoid, the row minimum / maximum the reference scales with,
+// the known-item mask and the top-k selection in ONE pass over dec.lin3 - the [rows, n_items] score matrix never exists in
+// HBM (r1-r3: aae_predict wrote it, 40 MB per 100 documents at C3, and topk_rows_kernel read it back with one workgroup per
+// row).  Any number of rows per launch (row blocks of 112), so the parameter stream is amortised over the whole call.
+//
+//   known_mask_kernel   the rows' known items as a bitmap [rows][ceil(N / 32)] (one workgroup per row) + dh2's bias column
+//   rank_x3_kernel      per tile of 32 items, one persistent 1024-thread workgroup per CU (the critical launch of the training
+//                       step, dec_crit_x3.h, minus everything backward): V3a tile -> three bf16 images (3-term split of the
+//                       fp32 values: fp32 products emulated on the bf16 matrix cores; one_term: bf16 mode), logits = dh2 * V3a^T
+//                       with dh2 split in registers, then - in the same phase as the NEXT tile's image build, two LDS-only
+//                       barriers per tile - the epilogue: sigmoid, minimum / maximum over ALL cells of the row, and every
+//                       thread's sorted top-K (registers) of its 4 items x the workgroup's tiles, known items skipped.  At
+//                       the end the 8 threads of a row merge their lists: K candidates + (min, max) per (row, workgroup).
+//   rank_merge_kernel   one workgroup per row: K rounds of block-wide argmax over the workgroups' sorted candidate lists,
+//                       scaled scores (v - min) / (max - min) as topk_rows_kernel (kernels.h) emits them.
+// Ties go to the smaller item id at every level, as in topk_rows_kernel.
+#pragma once
+#include "dec_crit_x3.h"
+
+namespace aae {
+
+struct RankArgs {
+    const float* dh2; int ldh;          // [B][ldh] decoder hidden activations, constant-1 column at h
+    const float* V3a; int ldv;          // [N][ldv] dec.lin3 augmented with its bias column
+    int N, B;                           // items, rows of this call
+    int nblk, Bb;                       // row blocks of Bb rows: workgroup w -> block w % nblk, tiles w / nblk, + gridDim.x / nblk, ...
+    const unsigned* known; int kw;      // [B][kw] bit (i & 31) of word (i >> 5): item i is one of the row's inputs; NULL: rank everything
+    float* cand_v; int* cand_i;         // [B][wgs][K] per-workgroup candidates, sorted descending
+    float* mm;                          // [B][wgs][2] per-workgroup (min, max) over all cells
+    int one_term;                       // bf16 mode: operands rounded to bf16 (first term of the split only)
+};
+
+// One workgroup per row: the row's known items -> its bitmap (known != NULL), and the bias input of the output layer: column
+// h of the row's dh2 = 1, the padding columns behind it = 0 (the chain program stores the layer's h outputs only; the
+// workspace held other data before)
+__global__ __launch_bounds__(256) void known_mask_kernel(BatchView bv, unsigned* __restrict__ known, int kw,
+                                                         float* __restrict__ dh2, int ldh, int h) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (h + tid < ldh) dh2[(size_t)row * ldh + h + tid] = tid == 0 ? 1.f : 0.f;
+    if (!known) return;
+    unsigned* k = known + (size_t)row * kw;
+    for (int i = tid; i < kw; i += 256) k[i] = 0u;
+    __syncthreads();
+    const int dc = bv.doc(row);
+    const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
+    for (int64_t e = lo + tid; e < hi; e += 256) {
+        const int i = bv.indices[e];
+        atomicOr(&k[i >> 5], 1u << (i & 31));
+    }
+}
+
+inline size_t rank_x3_lds_bytes(int NB) {
+    const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1);
+    const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kXRS + (size_t)lsteps * kMB * 3 * 64 * 4);
+}
+
+template <int NB, int K>
+__global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
+    const bool one = a.one_term != 0;
+    constexpr int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2;
+    constexpr int NKR = NKS > kXRegSteps ? kXRegSteps : NKS, NKL = NKS - NKR;
+    constexpr int S1 = x3_stride(KC1);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* v3K = reinterpret_cast<unsigned*>(lds);           // [3][32][S1] V3a tile, k = hidden column
+    float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [2][kGR][kXRS] the two k halves of the logits
+    u32x4_t* dAl = reinterpret_cast<u32x4_t*>(raw + 2 * kGR * kXRS);    // [kMB][NKL][3][64] dh2 fragments beyond the register steps
+
+    const int nblk = a.nblk > 1 ? a.nblk : 1;
+    const int blk = (int)blockIdx.x % nblk, wgi = (int)blockIdx.x / nblk, wgs = (int)gridDim.x / nblk;
+    if (wgi >= wgs) return;
+    const int erow0 = blk * a.Bb;
+    const int B = min(a.Bb, a.B - erow0);
+    const float* dh2_blk = a.dh2 + (size_t)erow0 * a.ldh;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ldv = a.ldv, N = a.N;
+    const int ntiles = (N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;
+
+    // the parameter stream: tensor base in a buffer descriptor, tile offset scalar, slot offset in one vector register;
+    // reads beyond the tensor return zero
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V3a), 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto load_span = [&](int tile, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+    };
+    // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
+    const int eb = tid >> 3, eq = tid & 7;
+    const bool erow = eb < B;
+    const unsigned* kn = a.known ? a.known + (size_t)(erow0 + min(eb, B - 1)) * a.kw : nullptr;
+    float4 vreg[NV];
+    int tile = wgi;
+    const int stride = wgs;
+    unsigned kw_next = 0u;
+    if (tile < ntiles) {
+        load_span(tile, vreg);
+        if (kn) kw_next = kn[tile];
+    }
+    for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kXRS; i += kNT) v3K[i] = 0u;
+
+    // dh2 -> split A fragments: wave w < 14 = (row block w % 7, k half w / 7), lane (fr, fk) holds row 16 mb + fr, k = 32 kc + 8 fk + {0..7}
+    const bool g1 = wave < 2 * kMB;
+    const int mb1 = wave % kMB, kh = wave / kMB;
+    bf16x8 dA[NKR][3];
+    {
+        const int row = 16 * mb1 + fr;
+        const float* src = dh2_blk + (size_t)min(row, B - 1) * a.ldh;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            const int k0 = 32 * (kh + 2 * j) + 8 * fk;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+            if (g1 && row < B && k0 < a.ldh) x = *reinterpret_cast<const float4*>(src + k0);
+            if (g1 && row < B && k0 + 4 < a.ldh) y = *reinterpret_cast<const float4*>(src + k0 + 4);
+            unsigned p[3][4];
+            split3_pair(x.x, x.y, p[0][0], p[1][0], p[2][0], one);
+            split3_pair(x.z, x.w, p[0][1], p[1][1], p[2][1], one);
+            split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2], one);
+            split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3], one);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
+                if (j < NKR) dA[j < NKR ? j : 0][t] = __builtin_bit_cast(bf16x8, v);
+                else if (g1 && kh == 0) dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane] = v;
+            }
+        }
+    }
+    const int nks = (KC1 - kh + 1) / 2;
+
+    int s_rc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+    }
+    float tv[K]; int ti[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    float vmin = INFINITY, vmax = -INFINITY;
+
+    // the epilogue of one finished tile: the thread's four cells
+    auto epilogue = [&](int i0, unsigned kword) {
+        if (!erow) return;
+        const float* r0 = raw + eb * kXRS + 4 * eq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * eq + j, item = i0 + n;
+            const float v = sigmoidf_(r0[j] + r0[kGR * kXRS + j]);
+            if (item < N) {
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+                if (!((kword >> n) & 1u) && v > tv[K - 1]) {
+                    tv[K - 1] = v; ti[K - 1] = item;
+#pragma unroll
+                    for (int s = K - 1; s > 0; --s) {
+                        if (tv[s] > tv[s - 1]) {
+                            const float fv = tv[s]; tv[s] = tv[s - 1]; tv[s - 1] = fv;
+                            const int iv = ti[s]; ti[s] = ti[s - 1]; ti[s - 1] = iv;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    __syncthreads();
+
+    int prev_i0 = -1; unsigned kw_prev = 0u;
+    for (; tile < ntiles; tile += stride) {
+        const int i0 = tile * kTI;
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int frz = fr + oz, fkz = fk + oz;
+        lds_barrier();                          // the previous tile's products are in `raw`, its readers of v3K are done
+        // ---- the previous tile's epilogue and this tile's images, one VALU phase
+        if (prev_i0 >= 0) epilogue(prev_i0, kw_prev);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (tid + kNT * j < tile_f4) {
+                float4 p = vreg[j];
+                if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned q0[3], q1[3];
+                split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
+                split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
+                unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
+            }
+        }
+        prev_i0 = i0; kw_prev = kw_next;
+        {
+            const int nt = min(tile + stride, ntiles - 1);
+            load_span(nt, vreg);
+            if (kn) kw_next = kn[nt];
+        }
+        lds_barrier();
+        // ---- logits of the wave's row block x both item halves over its k-steps -> its half's raw tile
+        if (g1) {
+            float* rw = raw + kh * (kGR * kXRS) + (16 * mb1 + 4 * fkz) * kXRS + frz;
+#pragma unroll
+            for (int nb2 = 0; nb2 < 2; ++nb2) {
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NKS; ++j)
+                    if (j < nks) {
+                        bf16x8 bb[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
+                        if (j < NKR) c = mfma_x3(dA[j < NKR ? j : 0], bb, c);
+                        else {
+                            bf16x8 al[3];
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane + oz]);
+                            c = mfma_x3(al, bb, c);
+                        }
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
+            }
+        }
+    }
+    lds_barrier();
+    if (prev_i0 >= 0) epilogue(prev_i0, kw_prev);
+
+    // ---- the 8 threads of a row merge their lists (K rounds of an 8-lane argmax, ties to the smaller item) -> K candidates
+    // of this workgroup for the row; its minimum / maximum
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); }
+    const size_t slot = (size_t)(erow0 + eb) * wgs + wgi;
+    if (erow && eq == 0) { a.mm[2 * slot] = vmin; a.mm[2 * slot + 1] = vmax; }
+    for (int r = 0; r < K; ++r) {
+        float bv = tv[0]; int bi = ti[0]; int who = eq;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64); const int ow = __shfl_xor(who, o, 64);
+            if (ov > bv || (ov == bv && (unsigned)oi < (unsigned)bi)) { bv = ov; bi = oi; who = ow; }
+        }
+        if (erow && eq == 0) { a.cand_v[slot * K + r] = bv; a.cand_i[slot * K + r] = bi; }
+        if (eq == who) {
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = -1;
+        }
+    }
+}
+
+// One workgroup per row: thread t < wgs holds workgroup t's sorted candidate list; K rounds of block-wide argmax.
+template <int K>
+__global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                         const float* __restrict__ mm, int wgs, int k_out,
+                                                         int* __restrict__ idx_out, float* __restrict__ val_out) {
+    __shared__ float s_val[4]; __shared__ int s_idx[4]; __shared__ int s_who[4];
+    __shared__ float s_min[4], s_max[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float tv[K]; int ti[K];
+    float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    for (int w = tid; w < wgs; w += 256) {          // (wgs <= 256: one list per thread; more: merged into the thread's list)
+        const size_t slot = (size_t)row * wgs + w;
+        vmin = fminf(vmin, mm[2 * slot]); vmax = fmaxf(vmax, mm[2 * slot + 1]);
+        for (int j = 0; j < K; ++j) {
+            const float v = cand_v[slot * K + j]; const int i = cand_i[slot * K + j];
+            if (v > tv[K - 1] || (v == tv[K - 1] && (unsigned)i < (unsigned)ti[K - 1])) {
+                tv[K - 1] = v; ti[K - 1] = i;
+#pragma unroll
+                for (int s = K - 1; s > 0; --s) {
+                    if (tv[s] > tv[s - 1] || (tv[s] == tv[s - 1] && (unsigned)ti[s] < (unsigned)ti[s - 1])) {
+                        const float fv = tv[s]; tv[s] = tv[s - 1]; tv[s - 1] = fv;
+                        const int iv = ti[s]; ti[s] = ti[s - 1]; ti[s - 1] = iv;
+                    }
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); }
+    if (lane == 0) { s_min[wave] = vmin; s_max[wave] = vmax; }
+    __syncthreads();
+    vmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float span = vmax - vmin;
+    const float inv = span > 0.f ? 1.f / span : 1.f;
+    for (int r = 0; r < k_out; ++r) {
+        float bv_ = tv[0]; int bi = ti[0]; int who = tid;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv_, o, 64); const int oi = __shfl_xor(bi, o, 64); const int ow = __shfl_xor(who, o, 64);
+            if (ov > bv_ || (ov == bv_ && (unsigned)oi < (unsigned)bi)) { bv_ = ov; bi = oi; who = ow; }
+        }
+        if (lane == 0) { s_val[wave] = bv_; s_idx[wave] = bi; s_who[wave] = who; }
+        __syncthreads();
+        float gv = s_val[0]; int gi = s_idx[0], gw = s_who[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > gv || (s_val[w] == gv && (unsigned)s_idx[w] < (unsigned)gi)) { gv = s_val[w]; gi = s_idx[w]; gw = s_who[w]; }
+        if (tid == 0) {
+            idx_out[(size_t)row * k_out + r] = gi;
+            val_out[(size_t)row * k_out + r] = gi >= 0 ? (gv - vmin) * inv : 0.f;
+        }
+        if (tid == gw) {
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = -1;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace aae

@@ -366,6 +366,12 @@ int aae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, flo
  * (<= 32) best item ids per row, best first, and their scaled scores: [rows][k]. */
 int aae_predict_topk(aae_handle h, const aae_batch* batch, const float* cond_dev, int32_t k,
                      int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream);
+/* Rows ONE aae_predict_topk / aae_decode_topk call may rank (>= max_batch).  Where the fused form applies (r4: the output
+ * layer, its sigmoid, the row minimum / maximum, the known-item mask and the top-k selection in one pass over dec.lin3 -
+ * the [rows, n_items] score matrix never exists in HBM; hidden widths of the layer-chain kernels) a call takes far more
+ * rows than a training batch - the parameter stream is then read once per call, not once per max_batch rows - and such a
+ * batch is exempt from the max_batch / max_nnz bounds of aae_batch.  Otherwise *rows_out = max_batch. */
+int aae_rank_max_rows(aae_handle h, int32_t k, int32_t* rows_out);
 /* The same behind a decoder input the caller built (AdversarialAutoEncoder.predict's second half, aae.py:855-866:
  * `z = conditions.encode_impose(z, c_batch)` with plugins of any kind, then dec): zc_dev [batch->n_rows][zc_ld],
  * zc_ld >= n_code + cond_inc; `batch` names the input rows (their items are the ones exclude_known removes). */
@@ -456,6 +462,7 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_CHAIN,            /* a layer-chain program: the hidden stacks of one phase (5 launches per step) */
        AAE_K_DEC_CRIT,         /* split form of the fused output layer, critical launch: logits + BCE + dA2 (+ dL/dlogits tiles) */
        AAE_K_DEC_OPT,          /* ... deferred launch on the library's side stream: dV3 + dec_optim behind the rest of the step */
+       AAE_K_RANK,             /* fused predict -> rank: output layer + sigmoid + min/max + known-item mask + per-workgroup top-k */
        AAE_K_N };
 /* on = 0: off; 1: every kernel id above; otherwise a selection: bit (k + 1) of `on` times kernel id k
  * (an event pair costs a few microseconds of stream time, so a timed run selects only what it reports) */
