@@ -138,7 +138,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     // beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains.
     m->split_wgs = std::max(1, (m->n_cu * 5) / 8);
     { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
-    m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->ev_head = m->ev_pf = nullptr;
+    m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->flushed_hstep = -1; m->ev_head = m->ev_pf = nullptr;
     bool side_ok = false;
     if (cfg->grad_mode == AAE_GRAD_FUSED) {
         // the handle's side stream (lowest priority) for work off the step's critical path: the deferred optimiser

@@ -122,6 +122,7 @@ struct aae_model {
     bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
     hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
     bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)
+    long long flushed_hstep = -1;                          // hstep at the last whole-matrix deferred-Adam flush of a rank call (abi_rank.h)
     bool rank_ok = false;                                  // rank_x3.h: predict -> rank fused (aae_predict_topk / aae_decode_topk), abi_rank.h
     bool side_ordered = false;                             // ... or put its dV3 GEMM there: the side stream is in order behind that step's output layer
 };

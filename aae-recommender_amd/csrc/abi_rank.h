@@ -99,6 +99,7 @@ int rank_from_dh2(aae_model* m, const RankPlan& p, const BatchView& bv, int k, i
     a.dh2 = p.dh2; a.ldh = m->ldh; a.V3a = m->P[P_V3].p; a.ldv = m->ldh; a.N = m->N; a.B = p.rows;
     a.nblk = p.nblk; a.Bb = kRankBb; a.known = exclude_known ? p.known : nullptr; a.kw = p.kw;
     a.cand_v = p.cand_v; a.cand_i = p.cand_i; a.mm = p.mm; a.one_term = m->bf16 ? 1 : 0;
+    { static const char* e = getenv("AAE_RANK_SKIP"); a.dbg = e ? atoi(e) : 0; }
     const int grid = p.wgs * p.nblk;
     {
         ProfScope ps(m, AAE_K_RANK, s);
@@ -109,9 +110,9 @@ int rank_from_dh2(aae_model* m, const RankPlan& p, const BatchView& bv, int k, i
         }
     }
     switch (p.K) {
-        case 10: hipLaunchKernelGGL(rank_merge_kernel<10>, dim3(p.rows), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
-        case 20: hipLaunchKernelGGL(rank_merge_kernel<20>, dim3(p.rows), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
-        default: hipLaunchKernelGGL(rank_merge_kernel<32>, dim3(p.rows), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
+        case 10: hipLaunchKernelGGL(rank_merge_kernel<10>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.rows, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
+        case 20: hipLaunchKernelGGL(rank_merge_kernel<20>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.rows, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
+        default: hipLaunchKernelGGL(rank_merge_kernel<32>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p.cand_v, p.cand_i, p.mm, p.rows, p.wgs, k, reinterpret_cast<int*>(idx_out), val_out); break;
     }
     LAUNCHCHK("rank_merge");
     return AAE_OK;
@@ -139,7 +140,10 @@ int rank_predict(aae_model* m, const aae_batch* batch, const float* cond_dev, in
                  float* val_out, hipStream_t s) {
     const int rows = batch->n_rows, h = m->h, c = m->c, cp = m->cp;
     TRY(join_deferred(m, s));
-    TRY(lazy_flush(m, s));                  // every row of enc.lin1 through the current step (a no-op pass when none is behind)
+    if (m->flushed_hstep != m->hstep) {     // every row of enc.lin1 through the current step: once after the last training step
+        TRY(lazy_flush(m, s));               // (rows fall behind only when a step opens: hstep counts them)
+        m->flushed_hstep = m->hstep;
+    }
     const RankPlan p = rank_plan(m, rows, k, m->G.p);
     const BatchView bv = rank_view(batch);
     {

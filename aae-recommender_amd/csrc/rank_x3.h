@@ -9,11 +9,12 @@
 //                       step, dec_crit_x3.h, minus everything backward): V3a tile -> three bf16 images (3-term split of the
 //                       fp32 values: fp32 products emulated on the bf16 matrix cores; one_term: bf16 mode), logits = dh2 * V3a^T
 //                       with dh2 split in registers, then - in the same phase as the NEXT tile's image build, two LDS-only
-//                       barriers per tile - the epilogue: sigmoid, minimum / maximum over ALL cells of the row, and every
+//                       barriers per tile - the epilogue on the LOGITS (the sigmoid is monotone: it is applied to the winners
+//                       and to the row's extremes only, in the merge): minimum / maximum over ALL cells of the row, and every
 //                       thread's sorted top-K (registers) of its 4 items x the workgroup's tiles, known items skipped.  At
 //                       the end the 8 threads of a row merge their lists: K candidates + (min, max) per (row, workgroup).
-//   rank_merge_kernel   one workgroup per row: K rounds of block-wide argmax over the workgroups' sorted candidate lists,
-//                       scaled scores (v - min) / (max - min) as topk_rows_kernel (kernels.h) emits them.
+//   rank_merge_kernel   one wave per row: K rounds of wave-wide argmax over the workgroups' sorted candidate lists, the
+//                       winners' sigmoids scaled (v - min) / (max - min) as topk_rows_kernel (kernels.h) emits them.
 // Ties go to the smaller item id at every level, as in topk_rows_kernel.
 #pragma once
 #include "dec_crit_x3.h"
@@ -29,6 +30,7 @@ struct RankArgs {
     float* cand_v; int* cand_i;         // [B][wgs][K] per-workgroup candidates, sorted descending
     float* mm;                          // [B][wgs][2] per-workgroup (min, max) over all cells
     int one_term;                       // bf16 mode: operands rounded to bf16 (first term of the split only)
+    int dbg;                            // timing-only ablation mask (AAE_RANK_SKIP), 0 in production
 };
 
 // One workgroup per row: the row's known items -> its bitmap (known != NULL), and the bias input of the output layer: column
@@ -50,10 +52,12 @@ __global__ __launch_bounds__(256) void known_mask_kernel(BatchView bv, unsigned*
     }
 }
 
+constexpr int kRRS = 36;       // row stride (floats) of the raw-logit halves [b][n]: 16-byte aligned rows for the epilogue's float4 reads
+
 inline size_t rank_x3_lds_bytes(int NB) {
     const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1);
     const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
-    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kXRS + (size_t)lsteps * kMB * 3 * 64 * 4);
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kRRS + (size_t)lsteps * kMB * 3 * 64 * 4);
 }
 
 template <int NB, int K>
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
     constexpr int S1 = x3_stride(KC1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned* v3K = reinterpret_cast<unsigned*>(lds);           // [3][32][S1] V3a tile, k = hidden column
-    float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [2][kGR][kXRS] the two k halves of the logits
-    u32x4_t* dAl = reinterpret_cast<u32x4_t*>(raw + 2 * kGR * kXRS);    // [kMB][NKL][3][64] dh2 fragments beyond the register steps
+    float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [2][kGR][kRRS] the two k halves of the logits
+    u32x4_t* dAl = reinterpret_cast<u32x4_t*>(raw + 2 * kGR * kRRS);    // [kMB][NKL][3][64] dh2 fragments beyond the register steps
 
     const int nblk = a.nblk > 1 ? a.nblk : 1;
     const int blk = (int)blockIdx.x % nblk, wgi = (int)blockIdx.x / nblk, wgs = (int)gridDim.x / nblk;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
         load_span(tile, vreg);
         if (kn) kw_next = kn[tile];
     }
-    for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kXRS; i += kNT) v3K[i] = 0u;
+    for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kRRS; i += kNT) v3K[i] = 0u;
 
     // dh2 -> split A fragments: wave w < 14 = (row block w % 7, k half w / 7), lane (fr, fk) holds row 16 mb + fr, k = 32 kc + 8 fk + {0..7}
     const bool g1 = wave < 2 * kMB;
@@ -148,15 +152,16 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
 
     // the epilogue of one finished tile: the thread's four cells
     auto epilogue = [&](int i0, unsigned kword) {
-        if (!erow) return;
-        const float* r0 = raw + eb * kXRS + 4 * eq;
+        if (!erow || (a.dbg & 2)) return;
+        const float4 lA = *reinterpret_cast<const float4*>(raw + eb * kRRS + 4 * eq);
+        const float4 lB = *reinterpret_cast<const float4*>(raw + kGR * kRRS + eb * kRRS + 4 * eq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = 4 * eq + j, item = i0 + n;
-            const float v = sigmoidf_(r0[j] + r0[kGR * kXRS + j]);
+            const float v = (&lA.x)[j] + (&lB.x)[j];       // the LOGIT: sigmoid is monotone - applied to the winners only (merge)
             if (item < N) {
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-                if (!((kword >> n) & 1u) && v > tv[K - 1]) {
+                if (!((kword >> n) & 1u) && v > tv[K - 1] && !(a.dbg & 1)) {
                     tv[K - 1] = v; ti[K - 1] = item;
 #pragma unroll
                     for (int s = K - 1; s > 0; --s) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
         if (prev_i0 >= 0) epilogue(prev_i0, kw_prev);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            if (tid + kNT * j < tile_f4) {
+            if (tid + kNT * j < tile_f4 && !(a.dbg & 8)) {
                 float4 p = vreg[j];
                 if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
                 unsigned q0[3], q1[3];
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
         }
         lds_barrier();
         // ---- logits of the wave's row block x both item halves over its k-steps -> its half's raw tile
-        if (g1) {
-            float* rw = raw + kh * (kGR * kXRS) + (16 * mb1 + 4 * fkz) * kXRS + frz;
+        if (g1 && !(a.dbg & 4)) {
+            float* rw = raw + kh * (kGR * kRRS) + (16 * mb1 + 4 * fkz) * kRRS + frz;
 #pragma unroll
             for (int nb2 = 0; nb2 < 2; ++nb2) {
                 f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
                         }
                     }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
+                for (int r = 0; r < 4; ++r) rw[r * kRRS + 16 * nb2] = c[r];
             }
         }
     }
@@ -250,24 +255,30 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
     }
 }
 
-// One workgroup per row: thread t < wgs holds workgroup t's sorted candidate list; K rounds of block-wide argmax.
+// One WAVE per row (4 rows per workgroup): lane t holds the sorted candidate lists of workgroups t, t + 64, ... (one list
+// when the call has >= 4 row blocks, its own list as it stands); K rounds of a wave-wide argmax over the lanes' heads - no
+// barrier, no LDS.  Candidates and extremes are logits; the scores the reference ranks are their sigmoids: emitted for the
+// k winners, scaled by the row's (sigmoid(min), sigmoid(max)) as topk_rows_kernel (kernels.h) scales.
 template <int K>
 __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
-                                                         const float* __restrict__ mm, int wgs, int k_out,
+                                                         const float* __restrict__ mm, int rows, int wgs, int k_out,
                                                          int* __restrict__ idx_out, float* __restrict__ val_out) {
-    __shared__ float s_val[4]; __shared__ int s_idx[4]; __shared__ int s_who[4];
-    __shared__ float s_min[4], s_max[4];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
     float tv[K]; int ti[K];
     float vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
-    for (int w = tid; w < wgs; w += 256) {          // (wgs <= 256: one list per thread; more: merged into the thread's list)
+    for (int w = lane; w < wgs; w += 64) {
         const size_t slot = (size_t)row * wgs + w;
         vmin = fminf(vmin, mm[2 * slot]); vmax = fmaxf(vmax, mm[2 * slot + 1]);
-        for (int j = 0; j < K; ++j) {
-            const float v = cand_v[slot * K + j]; const int i = cand_i[slot * K + j];
-            if (v > tv[K - 1] || (v == tv[K - 1] && (unsigned)i < (unsigned)ti[K - 1])) {
+        if (w == lane) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) { tv[j] = cand_v[slot * K + j]; ti[j] = cand_i[slot * K + j]; }
+        } else {
+            for (int j = 0; j < K; ++j) {               // a further list of this lane: merged in (sorted: stop at the first loser)
+                const float v = cand_v[slot * K + j]; const int i = cand_i[slot * K + j];
+                if (!(v > tv[K - 1] || (v == tv[K - 1] && (unsigned)i < (unsigned)ti[K - 1]))) break;
                 tv[K - 1] = v; ti[K - 1] = i;
 #pragma unroll
                 for (int s = K - 1; s > 0; --s) {
@@ -280,34 +291,24 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
         }
     }
     for (int o = 32; o > 0; o >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); }
-    if (lane == 0) { s_min[wave] = vmin; s_max[wave] = vmax; }
-    __syncthreads();
-    vmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
-    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    const float span = vmax - vmin;
+    const float smin = sigmoidf_(vmin), smax = sigmoidf_(vmax);
+    const float span = smax - smin;
     const float inv = span > 0.f ? 1.f / span : 1.f;
     for (int r = 0; r < k_out; ++r) {
-        float bv_ = tv[0]; int bi = ti[0]; int who = tid;
+        float bv_ = tv[0]; int bi = ti[0]; int who = lane;
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv_, o, 64); const int oi = __shfl_xor(bi, o, 64); const int ow = __shfl_xor(who, o, 64);
             if (ov > bv_ || (ov == bv_ && (unsigned)oi < (unsigned)bi)) { bv_ = ov; bi = oi; who = ow; }
         }
-        if (lane == 0) { s_val[wave] = bv_; s_idx[wave] = bi; s_who[wave] = who; }
-        __syncthreads();
-        float gv = s_val[0]; int gi = s_idx[0], gw = s_who[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (s_val[w] > gv || (s_val[w] == gv && (unsigned)s_idx[w] < (unsigned)gi)) { gv = s_val[w]; gi = s_idx[w]; gw = s_who[w]; }
-        if (tid == 0) {
-            idx_out[(size_t)row * k_out + r] = gi;
-            val_out[(size_t)row * k_out + r] = gi >= 0 ? (gv - vmin) * inv : 0.f;
+        if (lane == 0) {
+            idx_out[(size_t)row * k_out + r] = bi;
+            val_out[(size_t)row * k_out + r] = bi >= 0 ? (sigmoidf_(bv_) - smin) * inv : 0.f;
         }
-        if (tid == gw) {
+        if (lane == who) {
 #pragma unroll
             for (int j = 0; j < K - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
             tv[K - 1] = -INFINITY; ti[K - 1] = -1;
         }
-        __syncthreads();
     }
 }
 

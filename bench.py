@@ -155,8 +155,8 @@ def kernel_models(N, h, B, nnz_per_batch, c=50):
     }
 
 
-NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt"]
-K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED, K_CHAIN, K_CRIT, K_OPT = range(9)
+NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt", "rank"]
+K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED, K_CHAIN, K_CRIT, K_OPT, K_RANK = range(10)
 K_OUT = (K_BCE, K_DA2, K_DV3, K_FUSED, K_CRIT, K_OPT)       # the decoder output layer's kernels, whichever path runs
 
 
@@ -465,6 +465,40 @@ def main():
                                docs_per_s=round(k4 * B4 / dm, 1), ms_per_step=round(dm / k4 * 1e3, 4), steps=k4, dtype="f32",
                                cond_inc=a4.cond_inc)
             del m4, it4
+        if not a.no_extra and not a.cond_inc:
+            # SURVEY 8f rank 1 / VERDICT r3: predict -> remove_non_missing -> top-k on the device (reference aae.py:840-870,
+            # evaluation.py:183-199, 20-58) with the headline model, documents of the resident corpus, 512 rows per library
+            # call (aae_predict_topk: the fused rank kernels of csrc/rank_x3.h - no [rows, items] matrix in HBM); k = 10.
+            # docs/s = rows ranked / wall time of back-to-back calls; the rank kernel itself from HIP events on the launch stream
+            rows_pc = min(512, hip.rank_max_rows(10), X.shape[0])
+            calls = max(8, min(40, (X.shape[0] - rows_pc) // rows_pc))
+            for i in range(3):
+                hip.predict_topk(csr, i * rows_pc, rows_pc, 10)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(calls):
+                hip.predict_topk(csr, (i * rows_pc) % (X.shape[0] - rows_pc + 1), rows_pc, 10)
+            barrier()
+            dpt = (time.perf_counter() - t0) / calls
+            hip.profile_enable(True, kernels=(K_RANK,))
+            for i in range(8):
+                hip.predict_topk(csr, i * rows_pc, rows_pc, 10)
+            barrier()
+            hip.profile_enable(False)
+            ms_r, n_r = hip.profile_read(K_RANK)
+            pt = dict(workload=f"predict -> known-item mask -> top-10 on the device, |items|={N}, hidden={h}, {rows_pc} documents per call",
+                      docs_per_s=round(rows_pc / dpt, 1), ms_per_call=round(dpt * 1e3, 4), us_per_100_docs=round(dpt / rows_pc * 1e8, 2),
+                      rows_per_call=rows_pc, k=10, fused=bool(hip.rank_max_rows(10) > B))
+            if n_r:
+                us = ms_r / n_r * 1e3
+                fl, by = 2.0 * rows_pc * N * (h + 1), 4.0 * N * (h + 1)
+                tf = fl / us * 1e-6
+                pt["roofline"] = dict(kernel="rank_x3", bound="mfma", achieved=round(tf, 2), peak=peak_tf, unit="TFLOP/s",
+                                      frac=round(tf / peak_tf, 4), avg_us=round(us, 2), traffic=None,
+                                      algorithmic_flops=fl, algorithmic_bytes=by, GBps=round(by / us * 1e-3, 1),
+                                      **({"peak_emulated": round(MFMA_BF16_PEAK_TF / 6.0, 1),
+                                          "frac_emulated": round(tf / (MFMA_BF16_PEAK_TF / 6.0), 4)} if a.dtype == "f32" else {}))
+            extra["predict_topk"] = pt
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:

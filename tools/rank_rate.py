@@ -24,7 +24,8 @@ hip = m.hip
 csr = DeviceCSR(X, hip.device)
 cap = hip.rank_max_rows(10)
 print(f"rank_max_rows(10) = {cap}", flush=True)
-for rows in [r for r in (100, 256, 512, 1024, 2048) if r <= cap]:
+ROWS = [int(x) for x in os.environ.get("RR_ROWS", "100,256,512,1024,2048").split(",")]
+for rows in [r for r in ROWS if r <= cap]:
     reps = max(3, 4096 // rows)
     for timed in (False, True):
         torch.cuda.synchronize()
@@ -43,7 +44,7 @@ for rows in [r for r in (100, 256, 512, 1024, 2048) if r <= cap]:
         fl, by = 2.0 * rows * N * (h + 1), 4.0 * N * (h + 1)
         line += f" | rank kernel {us:7.1f} us = {fl / us * 1e-6:6.1f} TFLOP/s ({fl / us * 1e-6 / 157.3:.2f} of fp32 MFMA, {fl / us * 1e-6 / 416.7:.2f} of the emulated product), {by / us * 1e-3:6.0f} GB/s"
     print(line, flush=True)
-for name, fn in (("predict_topk through the model (k=10)", lambda: m.predict_topk(X, k=10)),):
+for name, fn in ((("predict_topk through the model (k=10)", lambda: m.predict_topk(X, k=10)),) if "RR_ROWS" not in os.environ else ()):
     out = fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{name:46s} {DOCS / dt:9.0f} docs/s", flush=True)
