@@ -494,7 +494,7 @@ class AdversarialAutoEncoder:
                 c_batch = None
                 if use_condition:
                     idx = perm[start:stop]
-                    c_batch = [_take(c, idx) for c in condition_data]
+                    c_batch = [_take(c, idx, rows) for c in condition_data]
                 self._run_step(csr, 0, int(rows.numel()), rows, c_batch)
                 if self.verbose:
                     self.last_losses = self._losses()
@@ -637,8 +637,12 @@ def _predict_topk(self, X, k=10, condition_data=None, exclude_known=True):
 AdversarialAutoEncoder.predict_topk = _predict_topk
 
 
-def _take(c, idx):
-    """Row selection on whatever a condition's transform produced (ndarray, sparse, list)."""
+def _take(c, idx, rows_dev=None):
+    """Row selection on whatever a condition's transform produced (ndarray, sparse, list, tensor).  rows_dev: the same
+    selection as a device tensor - condition data that already lives in HBM is then selected there (indexing a device
+    tensor with a host array is a blocking copy on the compute stream: host and GPU in lock-step, every step)."""
+    if rows_dev is not None and torch.is_tensor(c) and c.is_cuda:
+        return c.index_select(0, rows_dev.to(torch.int64))
     if isinstance(c, (list, tuple)):
         if isinstance(idx, slice):
             return list(c[idx])

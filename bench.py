@@ -381,7 +381,8 @@ def main():
         barrier()
         rdt = time.perf_counter() - t0
         raw = dict(docs_per_s=round(a.steps * B / rdt, 1), ms_per_step=round(rdt / a.steps * 1e3, 4))
-        if not a.no_extra and a.dtype == "f32" and B != 512 and not a.cond_inc:
+        want_extra = set(os.environ.get("AAE_BENCH_EXTRAS", "b512,c2_bf16,c4,predict_topk").split(","))   # (debugging aid)
+        if not a.no_extra and a.dtype == "f32" and B != 512 and not a.cond_inc and "b512" in want_extra:
             # SURVEY 8d asks for the MFMA-bound batch (512) next to the reference's default batch
             a2 = argparse.Namespace(**vars(a))
             m2 = make_model(a2, 512, None)
@@ -408,8 +409,9 @@ def main():
                                            frac_mfma=round(km2[NAMES[kid]]["flops"] / avg_s / 1e12 / MFMA_F32_PEAK_TF, 4))
             extra["b512"] = dict(docs_per_s=round(k2 * 512 / d2, 1), ms_per_step=round(d2 / k2 * 1e3, 4), steps=k2,
                                  kernels=ks2)
-            del m2, it2
-        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc:
+            m2.hip.close()      # (destroy the handle - and its side stream - now: the model object sits in a reference cycle, and an idle
+            del m2, it2       #  handle's low-priority stream keeps a hardware queue the next model's deferred launches would otherwise get)
+        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc and "c2_bf16" in want_extra:
             # BASELINE.json configs[1] (C2, RCV1-scale: |items| = 47 000, hidden 100, bf16 matrix-core inputs) next to the
             # headline config, so that the driver's line carries it: the same fit() loop at the reference's batch 100
             a3 = argparse.Namespace(**vars(a))
@@ -439,8 +441,9 @@ def main():
                                              f"inputs / fp32 accumulate, master weights and Adam, batch={B}, through fit()",
                                     docs_per_s=round(a.steps * B / dm, 1), ms_per_step=round(dm / a.steps * 1e3, 4), steps=a.steps,
                                     dtype="bf16", kernels=ks3)
-            del m3, it3
-        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc:
+            m3.hip.close()      # (destroy the handle - and its side stream - now: the model object sits in a reference cycle, and an idle
+            del m3, it3       #  handle's low-priority stream keeps a hardware queue the next model's deferred launches would otherwise get)
+        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc and "c4" in want_extra:
             # BASELINE.json configs[3] (C4, EconBiz-scale + title condition: |items| = 4 587 - nmi.txt:38 of the reference -,
             # hidden 200, a 300-d constant document vector concatenated to the code - condition.py:312-316, 345-369 -, batch
             # 1000 - eval/econis.py:45): the same fit() loop; tests/test_fullsize_gpu.py::test_c4_bench_shape_fit_path_matches_oracle
@@ -463,9 +466,10 @@ def main():
             extra["c4"] = dict(workload=f"C4 EconBiz-scale synthetic Bags + 300-d title condition (constant concatenated block): "
                                         f"|items|={a4.items}, hidden={a4.hidden}, code={c}, fp32, batch={B4}, through fit()",
                                docs_per_s=round(k4 * B4 / dm, 1), ms_per_step=round(dm / k4 * 1e3, 4), steps=k4, dtype="f32",
-                               cond_inc=a4.cond_inc)
-            del m4, it4
-        if not a.no_extra and not a.cond_inc:
+                               cond_inc=a4.cond_inc, repeat_ms_per_step=[round(d / k4 * 1e3, 4) for d in d4])
+            m4.hip.close()      # (destroy the handle - and its side stream - now: the model object sits in a reference cycle, and an idle
+            del m4, it4       #  handle's low-priority stream keeps a hardware queue the next model's deferred launches would otherwise get)
+        if not a.no_extra and not a.cond_inc and "predict_topk" in want_extra:
             # SURVEY 8f rank 1 / VERDICT r3: predict -> remove_non_missing -> top-k on the device (reference aae.py:840-870,
             # evaluation.py:183-199, 20-58) with the headline model, documents of the resident corpus, 512 rows per library
             # call (aae_predict_topk: the fused rank kernels of csrc/rank_x3.h - no [rows, items] matrix in HBM); k = 10.
