@@ -155,6 +155,8 @@ _PROTOS = {
     "aae_rccl_destroy": (C.c_int, [C.POINTER(AaeCollectives)]),
     "aae_dp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AaeCollectives), C.POINTER(AaeBatch), C.POINTER(AaeBatch),
                               C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_shard_step": (C.c_int, [C.c_void_p, C.POINTER(AaeCollectives), C.POINTER(AaeBatch), C.POINTER(AaeBatch), C.c_void_p,
+                                 C.POINTER(AaeRngInject), C.c_float, C.c_void_p]),
     "aae_memcpy_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aae_echo_collectives": (C.c_int, [C.c_int32, C.POINTER(AaeCollectives)]),
     "aae_set_input_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -775,6 +777,25 @@ class HipAAE:
             _check(self.lib.aae_dp_step(self.handle, slice_model.handle, C.byref(coll), C.byref(b), C.byref(g),
                                         C.byref(nxt) if nxt is not None else None, _ptr(cond),
                                         C.byref(inj) if inj else None, self._stream()))
+
+    def shard_step(self, coll, csr, row_start, n_rows, item_share, rows=None, next_rows=None, cond=None, masks=None, z_real=None):
+        """One partial_fit of the item-sharded model with replicated hidden stacks as ONE library call (aae_shard_step):
+        this handle = an item slice of enc.lin1 / dec.lin3 + a full copy of the hidden layers; the batch is the GLOBAL batch
+        in the slice's corpus; three all-reduces of [rows, n_hidden] partial sums through `coll`.  next_rows = (row_start,
+        rows) of the next global batch (named ahead)."""
+        b = self._batch(csr, row_start, n_rows, rows)
+        nxt = None
+        if next_rows is not None:
+            nxt = self._batch(csr, next_rows[0], next_rows[2], next_rows[1])
+            self._pf_keep = (csr, next_rows[1])
+        inj = self._inject(masks, z_real)
+        if cond is not None:
+            cond = upload(cond, self.device, torch.float32).contiguous()
+            self._keep.append(cond)
+        self._keep.append(rows)
+        with self._on_device():
+            _check(self.lib.aae_shard_step(self.handle, C.byref(coll), C.byref(b), C.byref(nxt) if nxt is not None else None,
+                                           _ptr(cond), C.byref(inj) if inj else None, float(item_share), self._stream()))
 
     def a1_rows(self, n_rows):
         """[n_rows, ld] view of the first layer's pre-activations."""

@@ -114,8 +114,8 @@ class AdversarialAutoEncoder:
         if rng_mode not in ("device", "reference"):
             raise ValueError("rng_mode must be 'device' or 'reference'")
         self.device, self.rng_mode, self.seed, self.data_parallel = device, rng_mode, seed, data_parallel
-        if dp_mode not in ("vocab", "vocab_out", "replicated"):
-            raise ValueError("dp_mode must be 'vocab', 'vocab_out' or 'replicated'")
+        if dp_mode not in ("vocab", "vocab_out", "replicated", "shard"):
+            raise ValueError("dp_mode must be 'vocab', 'vocab_out', 'replicated' or 'shard'")
         # data_parallel (torch.distributed, one process per GPU): 'vocab' shards both vocabulary-wide matrices - the
         # decoder's output layer and the encoder's first layer - over the items (aaerec.parallel.VocabParallelAAE: the
         # ranks exchange [global batch, n_hidden] activations only), 'vocab_out' the output layer alone (the first
@@ -221,7 +221,7 @@ class AdversarialAutoEncoder:
             activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
-            grad_mode="export" if dist is not None else "fused", device=self.device,
+            grad_mode="export" if dist is not None and self.dp_mode != "shard" else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
             unfused_decoder=self._unfused_decoder, dense_noise=getattr(self, "_dense_noise", False),
             # batches of 113..1664 rows: the output layer as row blocks of the fused kernel (one critical launch for all
@@ -233,7 +233,10 @@ class AdversarialAutoEncoder:
         self.enc_optim, self.dec_optim = _OptimView(self, "enc"), _OptimView(self, "dec")
         self.gen_optim, self.disc_optim = _OptimView(self, "gen"), _OptimView(self, "disc")
         if dist is not None:
-            from .parallel import DataParallelAAE, VocabParallelAAE, item_items
+            from .parallel import DataParallelAAE, VocabParallelAAE, ItemShardedAAE, item_items
+            if self.dp_mode == "shard" and not self._vocab_sharded(code_inc):
+                raise NotImplementedError("dp_mode='shard' needs conditions the kernels handle themselves (none, constant "
+                                          "concatenated blocks, device-native CategoricalConditions): use dp_mode='replicated'")
             if self._vocab_sharded(code_inc):
                 # this rank's items: rank, rank + world, ... (the vocabulary is frequency-sorted: interleaving gives
                 # every rank the same share of each batch's entries)
@@ -254,10 +257,15 @@ class AdversarialAutoEncoder:
                     # split form (one critical launch for all blocks, one deferred optimiser launch), DESIGN.md 7.3
                     # (with the output layer ALONE sharded the packed-row exchange of the first layer reads the slice's
                     #  tensors between the phases and would wait for the deferred launch: three GEMMs stay faster there)
-                    blocked_output=self.dp_mode == "vocab" and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
+                    blocked_output=self.dp_mode in ("vocab", "shard") and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
                 self._slice.load_params(sl_params)
-                self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
-                                            shard_first_layer=self.dp_mode == "vocab", interleaved=True)
+                if self.dp_mode == "shard":
+                    # ONE training handle per rank: its item slice of both vocabulary-wide layers + the hidden layers, the
+                    # whole global batch through it, three all-reduces of partial sums per step (parallel.ItemShardedAAE)
+                    self._dp = ItemShardedAAE(self.hip, self._slice, dist, n_items, group=dist_group, interleaved=True)
+                else:
+                    self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
+                                                shard_first_layer=self.dp_mode == "vocab", interleaved=True)
             else:
                 self._dp = DataParallelAAE(self.hip, dist, group=dist_group)
 
@@ -265,7 +273,7 @@ class AdversarialAutoEncoder:
         """dp_mode='vocab' applies when the step has no cut at the condition boundary (no conditions, constant
         concatenated blocks, CategoricalConditions the kernels train themselves) and the batches are the corpus' own
         rows (no per-epoch corruption hook)."""
-        if self.dp_mode not in ("vocab", "vocab_out") or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
+        if self.dp_mode not in ("vocab", "vocab_out", "shard") or type(self)._epoch_csr is not AdversarialAutoEncoder._epoch_csr:
             return False
         return not self.conditions or code_inc == 0 or self._is_constant_concat() or self._is_device_native()
 
@@ -339,7 +347,9 @@ class AdversarialAutoEncoder:
                           cond=cond, masks=masks, z_real=z_real)
             if trainable:
                 # every rank gathers dL/d(condition block) of the whole batch and applies the identical update
-                self._native_cond_update(n_rows, self._dp.gather_rows(hip.cond_grad(n_rows)), self._g_c_batch)
+                # (dp_mode='shard': the training handle saw the whole batch - nothing to gather)
+                src = self._slice if self.dp_mode == "shard" else hip
+                self._native_cond_update(n_rows, self._dp.gather_rows(src.cond_grad(n_rows)), self._g_c_batch)
         elif self._dp is not None:
             cond_fn = self._cond_fn(c_batch) if use_condition else None
             self._dp.step(csr, row_start, n_rows, global_rows=getattr(self._dp, "global_rows", None), rows=rows,
@@ -464,7 +474,7 @@ class AdversarialAutoEncoder:
                     # every rank walks the same permutation (same np.random state) and takes its
                     # contiguous share of the global batch; a tail batch with fewer rows than
                     # ranks is skipped on all ranks
-                    if self._slice is not None:
+                    if self._slice is not None and self.dp_mode != "shard":
                         # vocabulary-sharded output layer: equal shares (a tail batch loses < world documents)
                         stop = start + (stop - start) // self._dp.world * self._dp.world
                     lo, hi = self._dp.shard(start, stop)
@@ -475,7 +485,9 @@ class AdversarialAutoEncoder:
                         # the slice model's next (global) batch: its distinct items and their deferred-Adam catch-up
                         # run behind this step's deferred optimiser launch (_hip.prefetch)
                         gn = start + self.batch_size
-                        gs = gn + (min(gn + self.batch_size, n_docs) - gn) // self._dp.world * self._dp.world
+                        gs = min(gn + self.batch_size, n_docs)
+                        if self.dp_mode != "shard":
+                            gs = gn + (gs - gn) // self._dp.world * self._dp.world
                         if gs > gn:
                             self._slice.prefetch(self._slice_csr, 0, gs - gn, perm_dev[gn:gs])
                     # first-layer packets: no share of this batch names more distinct items than it has entries
@@ -516,7 +528,7 @@ class AdversarialAutoEncoder:
     def _losses(self):
         """(recon, disc, gen) of the last step; under dp_mode='vocab' the reconstruction loss lives in the item slices
         (a collective: every rank calls this at the same points)."""
-        losses = self.hip.losses()
+        losses = (self._slice if self.dp_mode == "shard" and self._slice is not None else self.hip).losses()
         if self._slice is not None:
             losses = (self._dp.recon_loss(),) + tuple(losses[1:])
         return losses

@@ -582,6 +582,118 @@ class VocabParallelAAE(DataParallelAAE):
         return float(buf.item())
 
 
+class ItemShardedAAE:
+    """dp_mode='shard' (r4; csrc/dp_step.h aae_shard_step): the third data-parallel scheme.
+
+    Every rank holds ONE training handle (`slice_model`): its item slice of the two vocabulary-wide layers (rows of
+    dec.lin3, columns of enc.lin1, with their optimiser states) and a full copy of every hidden layer, and runs the WHOLE
+    global batch through the hidden stacks.  Same inputs -> same activations, same small-layer gradients, same optimiser
+    updates on every rank: the hidden layers stay identical with NO gradient exchange.  What crosses the ranks are the
+    three partial sums over the item slices, each ONE all-reduce of [global rows, n_hidden] floats:
+
+        x * enc.lin1^T (ae phase)  |  dL/d(dh2) of the output layer  |  x * enc.lin1^T (Enc_eval of the disc phase)
+
+    3 collectives per partial_fit (the both-sharded scheme: 7, plus gradient packets and a second handle's step), at the
+    price of the hidden stacks running on world x the rows - launches that are latency-bound on a mostly idle chip.
+    `model` is the full-vocabulary handle the replica API reads after fit() (predict, state_dict): gather_output_layer()
+    fills it from the slices; it takes no part in a step."""
+    shard_first = True
+
+    def __init__(self, model, slice_model, dist, n_items, group=None, interleaved=True):
+        self.model, self.slice, self.dist, self.group = model, slice_model, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_items = n_items
+        self.interleaved = bool(interleaved)
+        self.items = item_items(n_items, self.rank, self.world, self.interleaved)
+        self.n_slice = _slice_len(self.items, n_items)
+        self.global_rows = None
+        self.w1_rows = None
+        self._gathered = False
+        self._coll_last = (0, 0)
+        slice_model.set_first_layer_external(True)
+        self._native = self._native_keep = None
+        backend = str(dist.get_backend(group)).lower()
+        if not hasattr(slice_model, "handle"):
+            # a stand-in without the library behind it (the CPU models of tests/test_parallel_gloo.py): it gets the
+            # torch.distributed-like object itself and all-reduces its three partial sums through it
+            self._native = (dist, group)
+        elif backend == "nccl":
+            self._native_keep = rccl_collectives(slice_model, dist, group)
+            if self._native_keep is not None:
+                self._native = self._native_keep.table
+        elif backend == "echo":                     # (tools/vocab_rank_time.py: device-side stand-ins)
+            import ctypes as C
+            from . import _hip
+            self._native = _hip.AaeCollectives()
+            _hip._check(slice_model.lib.aae_echo_collectives(self.world, C.byref(self._native)))
+        if self._native is None:                    # any other torch.distributed-like object (host-staged gloo, stand-ins;
+            self._native, self._native_keep = python_collectives(slice_model, dist, group)     # RCCL through callbacks as the fallback)
+
+    def shard(self, start, stop):
+        """Every rank takes the whole global batch [start, stop)."""
+        return (start, stop) if stop > start else (None, None)
+
+    def step(self, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None, cond=None,
+             masks=None, z_real=None, next_rows=None):
+        """g_rows / g_row_start select the global batch in `slice_csr` (this rank's columns of the corpus); cond, masks,
+        z_real cover all of its rows.  (csr / rows / row_start - a rank's own share in the other schemes - are unused.)"""
+        self.slice.shard_step(self._native, slice_csr, g_row_start, global_rows, self.n_slice / float(self.n_items),
+                              rows=g_rows, next_rows=next_rows, cond=cond, masks=masks, z_real=z_real)
+        self._gathered = False
+        ld = self.slice.a1_rows(1).stride(0)
+        self._coll_last = (2 if getattr(self.slice, "ae_only", False) else 3,
+                           (2 if getattr(self.slice, "ae_only", False) else 3) * global_rows * ld * 4)
+
+    def comm_stats(self):
+        return {"collectives": self._coll_last[0], "bytes": self._coll_last[1]}
+
+    def sync_conditions(self, conditions):
+        """Condition plugins see the whole batch on every rank: their gradients are complete and identical - nothing to sum."""
+        return None
+
+    def gather_rows(self, t):
+        return t                                    # (every rank already holds all rows)
+
+    def recon_loss(self):
+        """Reconstruction loss of the last step over all items: the slices' means weighted by their sizes."""
+        import torch
+        part = torch.tensor([self.slice.losses()[0] * self.n_slice / float(self.n_items)], dtype=torch.float64)
+        nccl = str(self.dist.get_backend(self.group)).lower() == "nccl"
+        buf = part.to(self.slice.device) if nccl else part
+        if self.world > 1:
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(buf.item())
+
+    def gather_output_layer(self):
+        """The trained model into the full-vocabulary handle: every rank's rows of dec.lin3 and enc.lin1, and the hidden
+        layers (identical on all ranks: copied from this rank's training handle).  Collective."""
+        import torch
+        from ._hip import T_ENC_W1T, T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DEC_V3, T_DISC_D1, T_DISC_D2, T_DISC_D3
+        if self._gathered:
+            return
+        m, sl, d = self.model, self.slice, self.dist
+        sl.sync()
+        m.sync()
+        rows = -(-self.n_items // self.world)
+        for tid in (T_DEC_V3, T_ENC_W1T):
+            full, mine = m.tensor(tid, padded=True), sl.tensor(tid, padded=True)
+            send = torch.zeros(rows, full.shape[1], dtype=full.dtype, device=full.device)
+            send[:mine.shape[0]] = mine
+            recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
+            if self.world > 1:
+                d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            else:
+                recv = send
+            for r in range(self.world):
+                it = item_items(self.n_items, r, self.world, self.interleaved)
+                full[it] = recv[r * rows:r * rows + _slice_len(it, self.n_items)]
+        for tid in (T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DISC_D1, T_DISC_D2, T_DISC_D3):
+            m.tensor(tid, padded=True).copy_(sl.tensor(tid, padded=True))
+        m.params_changed()
+        self._gathered = True
+
+
 class RcclTable:
     """Owner of an aae_collectives table over a communicator the library created (aae_rccl_init): close() - also at
     garbage collection - hands it back (aae_rccl_destroy).  `.table` is what aae_dp_step takes."""

@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-512 extra line")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
-    ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated"), default="vocab",
+    ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated", "shard"), default="vocab",
                     help="N > 1: 'vocab' shards both vocabulary-wide matrices (decoder output layer, encoder first "
                          "layer) over the items, the ranks exchange [global batch, n_hidden] blocks only "
                          "(aaerec.parallel.VocabParallelAAE); 'vocab_out' shards the output layer alone; 'replicated' keeps "
@@ -563,7 +563,9 @@ def main():
                        "timed_repeats": len(dts), "repeat_ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts],
                        "profiled_repeat": 0,
                        "parallelism": (f"dp{world}" if not use_dp else
-                                       (f"dp{world}, decoder output layer and encoder first layer sharded over the vocabulary"
+                                       (f"dp{world}, item slices of both vocabulary-wide layers + replicated hidden stacks on the global batch, "
+                                        f"3 all-reduces of partial sums per step" if a.dp == "shard" else
+                                        f"dp{world}, decoder output layer and encoder first layer sharded over the vocabulary"
                                         if getattr(model._dp, "shard_first", False) else
                                         f"dp{world}, decoder output layer sharded over the vocabulary") if vocab else
                                        f"dp{world}, replicated decoder")},

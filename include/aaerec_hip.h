@@ -438,6 +438,18 @@ int aae_rccl_destroy(aae_collectives* c);
 int aae_dp_step(aae_handle replica, aae_handle slice, const aae_collectives* coll, const aae_batch* local,
                 const aae_batch* global_slice, const aae_batch* next_global_slice, const float* cond_dev,
                 const aae_rng_inject* inject, void* stream);
+/* The third data-parallel scheme (r4): ONE handle per rank = its item slice of the two vocabulary-wide layers
+ * + a full copy of the hidden layers, the WHOLE global batch through the hidden stacks on every rank (identical inputs ->
+ * identical small-layer gradients and updates: no gradient exchange), and three all-reduces of [global rows, n_hidden]
+ * partial sums per partial_fit (the first layer's pre-activations, dL/d(dh2), the first layer again for Enc_eval) - against 7
+ * collectives, gradient packets and a second handle in aae_dp_step.  north_star's "RCCL all-reduce ... over xGMI": these are
+ * the only all-reduces the step needs.  Reference: aae.py:745-766 over the global batch.
+ *   handle      fused optimiser, aae_set_first_layer_external(1), aae_set_doc_l1, max_batch = the global batch
+ *   batch       the GLOBAL batch in the handle's corpus (its items' columns); next_batch: named ahead (aae_prefetch_batch) or NULL
+ *   item_share  items of this handle / items of the model (the BCE is a mean over all items)
+ *   cond_dev    the condition block of ALL rows; inject as aae_step (masks / z_real of all rows) */
+int aae_shard_step(aae_handle h, const aae_collectives* coll, const aae_batch* batch, const aae_batch* next_batch,
+                   const float* cond_dev, const aae_rng_inject* inject, float item_share, void* stream);
 /* a single-process stand-in table (measurement aid: one rank's compute with every exchange replaced by device copies of the
  * same shapes - all_gather = the operand repeated `world` times, reduce_scatter = its first chunk, all_reduce = identity;
  * rank 0 of `world`) */

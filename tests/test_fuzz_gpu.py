@@ -323,7 +323,7 @@ def test_random_decoder_and_vae_steps_match_oracle(seed):
         _close_enough(got[k], w, 5e-5, 6e-3, f"vae N={N} h={h} c={c} inc={inc} B={B} {k}")
 
 
-@pytest.mark.parametrize("scheme", ["vocab", "replicated", "vocab2"])
+@pytest.mark.parametrize("scheme", ["vocab", "replicated", "vocab2", "shard"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "6"))))
 def test_random_multi_rank_runs_match_oracle(seed, scheme):
     """Both data-parallel drivers with 2-4 ranks as threads on this GPU over random shapes: vocabularies that do not
@@ -334,7 +334,7 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
     import scipy.sparse as sp
     import torch
     from aaerec._hip import HipAAE, DeviceCSR
-    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_items
+    from aaerec.parallel import DataParallelAAE, VocabParallelAAE, ItemShardedAAE, item_items
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
     from test_parity_abi_gpu import _ThreadDist
@@ -362,9 +362,10 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
     def rank_main(rk):
         try:
             dist.bind(rk)
-            inter = scheme == "vocab2" and seed % 3 != 0      # items rk, rk + world, ... (what fit() uses) or [lo, hi)
+            inter = scheme in ("vocab2", "shard") and seed % 3 != 0      # items rk, rk + world, ... (what fit() uses) or [lo, hi)
             items = item_items(N, rk, world, inter)
-            m = HipAAE(N, h, c, cond_inc=inc, max_batch=Bl, rng_mode="inject", grad_mode="export", dp_world=world, **kw)
+            m = HipAAE(N, h, c, cond_inc=inc, max_batch=Bl, rng_mode="inject", grad_mode="fused" if scheme == "shard" else "export",
+                       dp_world=world, **kw)
             m.load_params(params)
             sp_params = dict(params)
             sp_params["dec.lin3.weight"], sp_params["dec.lin3.bias"] = params["dec.lin3.weight"][items], params["dec.lin3.bias"][items]
@@ -386,6 +387,22 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
             sl = HipAAE(len(sp_params["dec.lin3.bias"]), h, c, cond_inc=inc, max_batch=B, rng_mode="inject", blocked_output=bool(seed % 2), **kw)
             sl.load_params(sp_params)
             slices[rk] = sl
+            if scheme == "shard":
+                # ONE training handle per rank (its item slice + the hidden layers), the WHOLE batch through it, three
+                # all-reduces of partial sums per step (aae_shard_step); `m` only receives the result
+                sh = ItemShardedAAE(m, sl, dist, N, interleaved=inter)
+                for ip, idx, val, masks, zr, cond, want in steps:
+                    X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+                    sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=m.device))
+                    sh.step(None, 0, B, DeviceCSR(X[:, items].tocsr(), m.device), 0, B,
+                            cond=torch.as_tensor(cond, device=m.device) if inc else None, masks=masks, z_real=zr)
+                    loss = sh.recon_loss()
+                    if rk == 0:
+                        np.testing.assert_allclose(loss, want[0], rtol=5e-5)
+                        np.testing.assert_allclose(sl.losses()[1:], want[1:], rtol=5e-5, atol=2e-6)
+                assert sh.comm_stats()["collectives"] == 3
+                sh.gather_output_layer()
+                return
             vp = VocabParallelAAE(m, sl, dist, N, shard_first_layer=scheme == "vocab2", interleaved=inter)
             for ip, idx, val, masks, zr, cond, want in steps:
                 X = sp.csr_matrix((val, idx, ip), shape=(B, N))

@@ -849,10 +849,12 @@ def _dp_corpus():
 
 
 @pytest.mark.parametrize("adversarial", [False, True])
-@pytest.mark.parametrize("mode", ["vocab", "vocab_out", "replicated"])
+@pytest.mark.parametrize("mode", ["vocab", "vocab_out", "replicated", "shard"])
 def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
     """fit() on two ranks - batches of 40 documents, 20 per rank, in 'vocab' mode each rank owning 250 of the 500 items'
-    rows of dec.lin3 AND columns of enc.lin1 ('vocab_out': of dec.lin3 only) - against one process: same parameters, same
+    rows of dec.lin3 AND columns of enc.lin1 ('vocab_out': of dec.lin3 only; 'shard': the same item slices, but ONE handle
+    per rank that runs all 40 documents through its own copy of the hidden layers - three all-reduces of partial sums per
+    step, no gradient exchange: aae_shard_step) - against one process: same parameters, same
     predictions.  Plain AutoEncoder without dropout, and the
     adversarial model with dropout + prior drawn by the device generator (keyed by global row, one seed)."""
     import torch.multiprocessing as mp
@@ -878,8 +880,9 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
         assert abs(got["loss"] - one.last_losses[0]) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["vocab", "shard"])
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
-def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce):
+def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce, mode):
     """The vocabulary-sharded scheme with a constant block and a device-native CategoricalCondition: every rank
     gathers dL/d(condition block) of the whole batch and applies the identical SparseAdam update ('mean' pads each
     share to the whole batch's width, as the single process does)."""
@@ -888,7 +891,7 @@ def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce):
     port = free_port()
     with mp.get_context("spawn").Manager() as mgr:       # (a fork()ed manager process would inherit this process's GPU objects)
         ret = mgr.dict()
-        mp.spawn(_fit_worker, args=(2, port, "vocab", ret, reduce), nprocs=2, join=True)
+        mp.spawn(_fit_worker, args=(2, port, mode, ret, reduce), nprocs=2, join=True)
         got = dict(ret)
     assert got["sliced"]
     X = _dp_corpus()
@@ -1195,8 +1198,20 @@ def _rccl_world1_worker(rank, port, ret):
     m3._fit_finish()
     ret["state3"] = m3.hip.state_dict()
     ret["losses3"] = tuple(float(x) for x in m3.last_losses)
+    # the third scheme (dp_mode='shard': aae_shard_step, three all-reduces) over the library's RCCL communicator
+    np.random.seed(6)
+    torch.manual_seed(6)
+    ms = _three_step_model(data_parallel=True, dp_mode="shard")
+    for _ in zip(range(3), ms.fit_steps(_dp_corpus())):
+        pass
+    ms._fit_finish()
+    ret["shard_native"] = isinstance(ms._dp._native_keep, RcclTable)
+    ret["shard_state3"] = ms.hip.state_dict()
+    ret["shard_losses3"] = tuple(float(x) for x in ms.last_losses)
+    ret["shard_stats"] = ms._dp.comm_stats()
     m._dp._native_keep.close()                      # aae_rccl_destroy (the communicator was never handed back)
     m3._dp._native_keep.close()
+    ms._dp._native_keep.close()
     dist.destroy_process_group()
 
 
@@ -1239,6 +1254,11 @@ def test_native_step_driver_over_rccl_on_one_rank():
     np.testing.assert_allclose(got["losses3"], one3.last_losses, rtol=1e-5, atol=1e-6)
     for k, w in one3.hip.state_dict().items():
         np.testing.assert_allclose(got["state3"][k], w, atol=1e-5, err_msg=k)
+    # ... and the same bar for dp_mode='shard' (3 all-reduces per step on the library's communicator)
+    assert got["shard_native"] and got["shard_stats"]["collectives"] == 3
+    np.testing.assert_allclose(got["shard_losses3"], one3.last_losses, rtol=1e-5, atol=1e-6)
+    for k, w in one3.hip.state_dict().items():
+        np.testing.assert_allclose(got["shard_state3"][k], w, atol=1e-5, err_msg="shard " + k)
 
 
 def test_fit_on_two_ranks_through_the_python_step_driver(monkeypatch):

@@ -594,6 +594,130 @@ def test_two_ranks_with_both_vocabulary_wide_layers_sharded_equal_single_process
     np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)
 
 
+class ShardStandIn:
+    """dp_mode='shard' on the oracle (include/aaerec_hip.h: aae_shard_step): ONE model per rank = an item slice of both
+    vocabulary-wide layers (BothSliceReplica) + every hidden layer with its own optimisers (BothLocalReplica, fed the
+    WHOLE batch), three all-reduces of [rows, n_hidden] partial sums and no gradient exchange."""
+
+    def __init__(self, params, lo, hi, rank, **kw):
+        self.hid = BothLocalReplica(params, **kw)
+        self.sl = BothSliceReplica(params, lo, hi, kw.get("gen_lr", 1e-3), kw.get("reg_lr", 1e-3),
+                                   normalize=kw.get("normalize_inputs", True))
+        self.rank = rank
+        self.collectives = 0
+
+    def set_first_layer_external(self, on=True):
+        pass
+
+    def set_doc_l1(self, l1):
+        self.sl.set_doc_l1(l1)
+
+    def a1_rows(self, n):
+        return self.hid.a1_rows(n)
+
+    def losses(self):
+        return (self.sl.loss, 0.0, 0.0)
+
+    def _all_reduce(self, coll, t):
+        d, group = coll
+        d.all_reduce(t, op=d.ReduceOp.SUM, group=group)
+        self.collectives += 1
+
+    def shard_step(self, coll, slice_csr, row_start, n_rows, item_share, rows=None, next_rows=None, cond=None, masks=None,
+                   z_real=None):
+        hid, sl, B = self.hid, self.sl, n_rows
+        h = sl.w1["w1"].shape[0]
+        bias = hid.first_layer_bias() if self.rank == 0 else None
+        hid.set_grad_scale(1.0)
+        # ae phase
+        sl.first_layer_forward(slice_csr, row_start, B, bias=bias)
+        a1 = sl.a1_rows(B)
+        self._all_reduce(coll, a1)
+        hid.a1_rows(B).copy_(a1)
+        hid.ae_forward(None, 0, B, masks=masks, z_real=z_real)
+        sl.dh2_rows(B)[:] = hid.dh2_rows(B)
+        sl.set_grad_scale(item_share)
+        sl.output_layer_step()
+        da2 = sl.da2_rows(B)
+        self._all_reduce(coll, da2)
+        hid.da2_rows(B).copy_(da2)
+        hid.ae_backward()
+        hid.apply_updates(0)
+        hid.apply_updates(1)
+        ga1 = hid.ga1_rows(B).clone().reshape(-1)
+        sl.first_layer_update(0, ga1, rows_per_block=B, block_stride=B * h)
+        # disc phase (Enc_eval with the updated first layer), gen phase
+        sl.first_layer_forward(bias=bias)
+        a1 = sl.a1_rows(B)
+        self._all_reduce(coll, a1)
+        hid.a1_rows(B).copy_(a1)
+        hid.disc_step()
+        hid.apply_updates(3)
+        hid.gen_step()
+        hid.apply_updates(2)
+        ga1 = hid.ga1_rows(B).clone().reshape(-1)
+        sl.first_layer_update(2, ga1, rows_per_block=B, block_stride=B * h)
+
+
+def _worker_shard(rank, world, port, name, ret):
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.parallel import ItemShardedAAE, item_slice
+    fx = Fixture(name)
+    N = fx.cfg["N"]
+    lo, hi = item_slice(N, rank, world)
+    model = ShardStandIn(fx.init_params(), lo, hi, rank, **fx.model_kwargs())
+    sh = ItemShardedAAE(None, model, dist, N, interleaved=False)
+    losses = []
+    for s in range(fx.steps):
+        ip, idx, val = fx.batch(s)
+        B = len(ip) - 1
+        X = sp.csr_matrix((val, idx, ip), shape=(B, N))
+        Xs = X[:, lo:hi].tocsr()
+        model.set_doc_l1(np.asarray(abs(X).sum(1)).reshape(-1))
+        sh.step(None, 0, B, (Xs.indptr, Xs.indices, Xs.data), 0, B, masks=fx.masks(s), z_real=fx.z[f"step{s}.z_real"])
+        losses.append(sh.recon_loss())
+    small = {k: v.copy() for k, v in model.hid.o.p.items() if not k.startswith("dec.lin3") and k != "enc.lin1.weight"}
+    if rank == 0:
+        ret.update(small)
+        ret["recon_losses"] = losses
+        ret["collectives"] = model.collectives
+        ret["stats"] = sh.comm_stats()
+    ret[f"v3w{rank}"], ret[f"v3b{rank}"], ret[f"w1{rank}"] = model.sl.p["w"].copy(), model.sl.p["b"].copy(), model.sl.w1["w1"].copy()
+    flat = torch.from_numpy(np.concatenate([v.ravel() for v in small.values()]))
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(other[0], o) for o in other)          # the hidden layers, never exchanged: bitwise the same
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["step_masks", "step_nodrop_gauss"])
+def test_two_ranks_item_sharded_with_replicated_hidden_stacks_equal_single_process(name):
+    """ItemShardedAAE (dp_mode='shard') over real gloo collectives, world 2: every rank owns half the items' rows of
+    dec.lin3 and columns of enc.lin1 and runs the WHOLE batch through its own copy of the hidden layers; three all-reduces
+    of [rows, n_hidden] partial sums per step and nothing else.  Every parameter and the reconstruction loss equal the
+    reference's single-process fixtures; the never-exchanged hidden layers are bitwise identical on both ranks."""
+    port = free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_shard, args=(2, port, name, ret), nprocs=2, join=True)
+        got = dict(ret)
+    fx = Fixture(name)
+    want = fx.expected_params(fx.steps - 1)
+    for k, w in want.items():
+        if not k.startswith("dec.lin3") and k != "enc.lin1.weight":
+            np.testing.assert_allclose(got[k], w, atol=1e-5, rtol=0, err_msg=k)
+    np.testing.assert_allclose(np.concatenate([got["v3w0"], got["v3w1"]]), want["dec.lin3.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(np.concatenate([got["v3b0"], got["v3b1"]]), want["dec.lin3.bias"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(np.concatenate([got["w10"], got["w11"]], axis=1), want["enc.lin1.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(got["recon_losses"], [fx.z[f"step{s}.losses"][0] for s in range(fx.steps)], rtol=1e-5)
+    assert got["collectives"] == 3 * fx.steps and got["stats"]["collectives"] == 3
+
+
 def test_item_ownership_partitions_the_vocabulary():
     """item_items: every item has exactly one owner, interleaved or contiguous, for vocabularies that do not divide by the
     world size; the slice object indexes NumPy arrays and SciPy CSR columns alike."""

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "aae-recommender
 import numpy as np
 import torch
 from aaerec._hip import HipAAE, DeviceCSR
-from aaerec.parallel import DataParallelAAE, VocabParallelAAE, item_slice
+from aaerec.parallel import DataParallelAAE, VocabParallelAAE, ItemShardedAAE, item_slice
 from tools.synth import init_params
 from tools.synth import throughput_corpus
 
@@ -73,7 +73,7 @@ def timeit(step, steps=int(os.environ.get('VR_STEPS', 200)), warm=int(os.environ
 
 
 csr = DeviceCSR(X, dev)
-SCHEMES = os.environ.get("VR_SCHEMES", "replicated,vocab,both").split(",")
+SCHEMES = os.environ.get("VR_SCHEMES", "replicated,vocab,both,shard").split(",")
 # ---- replicated decoder (the current default for N > 1) -------------------------------------------------------
 if "replicated" in SCHEMES:
     m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 256, grad_mode="export", dp_world=world, w1_cap=w1_cap)
@@ -141,3 +141,18 @@ if "both" in SCHEMES:
     per_step = {k: v / (int(os.environ.get('VR_STEPS', 200)) + int(os.environ.get('VR_WARM', 30))) for k, v in d3.bytes.items()}
     print(f"world {world}: both vocabulary-wide layers sharded   {t_vp2:.3f} ms/step of compute per rank; exchanged per step: "
           + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in per_step.items()), flush=True)
+    del vp, m, sl
+    torch.cuda.empty_cache()
+# ---- item slices + REPLICATED hidden stacks: one handle per rank, the whole global batch through it, 3 all-reduces ----------
+if "shard" in SCHEMES:
+    sl = HipAAE(hi - lo, h, c, max_batch=Bg, max_nnz=Bg * 256, blocked_output=True)
+    sl.load_params(sp)
+    sl.set_doc_l1(torch.as_tensor(np.asarray(abs(X).sum(1), dtype=np.float32).reshape(-1), device=dev))
+    d4 = EchoDist(world)
+    sh = ItemShardedAAE(None, sl, d4, N, interleaved=INTER)
+    PF = os.environ.get("VR_PREFETCH", "1") != "0"
+    t_sh = timeit(lambda i: ((sl.prefetch(slice_csr, ((i + 1) % NB) * Bg, Bg) if PF else None),
+                             sh.step(None, 0, Bg, slice_csr, (i % NB) * Bg, Bg)))
+    st = sh.comm_stats()
+    print(f"world {world}: item slices + replicated hidden stacks (dp_mode='shard')   {t_sh:.3f} ms/step of compute per rank; "
+          f"{st['collectives']} all-reduces of {st['bytes'] / st['collectives'] / 1e6:.2f} MB per step", flush=True)
