@@ -96,7 +96,7 @@ class AdversarialAutoEncoder:
     def __init__(self, n_hidden=100, n_code=50, gen_lr=0.001, reg_lr=0.001, prior="gauss", prior_scale=None,
                  batch_size=100, n_epochs=500, optimizer="adam", normalize_inputs=True, activation="ReLU",
                  dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab", dtype="f32"):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="shard", dtype="f32"):
         self.prior = prior.lower()
         self.prior_scale = prior_scale
         self.prior_sampler = PRIOR_SAMPLERS[self.prior]
@@ -116,7 +116,10 @@ class AdversarialAutoEncoder:
         self.device, self.rng_mode, self.seed, self.data_parallel = device, rng_mode, seed, data_parallel
         if dp_mode not in ("vocab", "vocab_out", "replicated", "shard"):
             raise ValueError("dp_mode must be 'vocab', 'vocab_out', 'replicated' or 'shard'")
-        # data_parallel (torch.distributed, one process per GPU): 'vocab' shards both vocabulary-wide matrices - the
+        # data_parallel (torch.distributed, one process per GPU): 'shard' (default, r4) gives every rank ONE handle with its
+        # item slice of both vocabulary-wide matrices and a full copy of the hidden layers, runs the whole global batch
+        # through it and all-reduces three [global batch, n_hidden] partial sums per step (parallel.ItemShardedAAE);
+        # 'vocab' shards both vocabulary-wide matrices - the
         # decoder's output layer and the encoder's first layer - over the items (aaerec.parallel.VocabParallelAAE: the
         # ranks exchange [global batch, n_hidden] activations only), 'vocab_out' the output layer alone (the first
         # layer's row-sparse gradient travels as packed rows), 'replicated' keeps everything on every rank
@@ -215,13 +218,16 @@ class AdversarialAutoEncoder:
                 params[k] = flat[off:off + n].reshape(params[k].shape).copy()
                 off += n
             seed = int(flat[off:off + 2].view(np.float64)[0])
+        # dp_mode='shard' (the default): the full-vocabulary handle only receives the trained model (predict, state_dict);
+        # conditions the kernels cannot train themselves fall back to the replicated scheme, as under 'vocab'
+        shard = dist is not None and self.dp_mode == "shard" and self._vocab_sharded(code_inc)
         self.hip = _hip.HipAAE(
             n_items, self.n_hidden, self.n_code, cond_inc=code_inc, max_batch=self.batch_size,
             max_nnz=None if max_row_nnz is None else self.batch_size * max(1, int(max_row_nnz)),
             activation=self.activation, prior=self.prior, prior_scale=self.prior_scale, optimizer=self.optimizer,
             normalize_inputs=self.normalize_inputs, dropout=self.dropout, gen_lr=self.gen_lr, reg_lr=self.reg_lr,
             rng_mode="device" if self.rng_mode == "device" else "inject", seed=seed,
-            grad_mode="export" if dist is not None and self.dp_mode != "shard" else "fused", device=self.device,
+            grad_mode="export" if dist is not None and not shard else "fused", device=self.device,
             dp_world=dist_world, w1_cap=w1_cap, ae_only=self._ae_only, dtype=self.dtype,
             unfused_decoder=self._unfused_decoder, dense_noise=getattr(self, "_dense_noise", False),
             # batches of 113..1664 rows: the output layer as row blocks of the fused kernel (one critical launch for all
@@ -234,9 +240,6 @@ class AdversarialAutoEncoder:
         self.gen_optim, self.disc_optim = _OptimView(self, "gen"), _OptimView(self, "disc")
         if dist is not None:
             from .parallel import DataParallelAAE, VocabParallelAAE, ItemShardedAAE, item_items
-            if self.dp_mode == "shard" and not self._vocab_sharded(code_inc):
-                raise NotImplementedError("dp_mode='shard' needs conditions the kernels handle themselves (none, constant "
-                                          "concatenated blocks, device-native CategoricalConditions): use dp_mode='replicated'")
             if self._vocab_sharded(code_inc):
                 # this rank's items: rank, rank + world, ... (the vocabulary is frequency-sorted: interleaving gives
                 # every rank the same share of each batch's entries)
@@ -259,7 +262,7 @@ class AdversarialAutoEncoder:
                     #  tensors between the phases and would wait for the deferred launch: three GEMMs stay faster there)
                     blocked_output=self.dp_mode in ("vocab", "shard") and os.environ.get("AAE_SLICE_THREE_KERNEL") is None)
                 self._slice.load_params(sl_params)
-                if self.dp_mode == "shard":
+                if shard:
                     # ONE training handle per rank: its item slice of both vocabulary-wide layers + the hidden layers, the
                     # whole global batch through it, three all-reduces of partial sums per step (parallel.ItemShardedAAE)
                     self._dp = ItemShardedAAE(self.hip, self._slice, dist, n_items, group=dist_group, interleaved=True)
@@ -295,7 +298,8 @@ class AdversarialAutoEncoder:
     def _is_device_native(self):
         """Every condition is a concatenated block the kernels can produce and train themselves: a constant block or
         a CategoricalCondition with its table on this GPU."""
-        dev = self.hip.device
+        dev = self.hip.device if self.hip is not None else \
+            torch.device(self.device if self.device is not None else "cuda:{}".format(torch.cuda.current_device()))
         return all(getattr(c, "constant_concat", False) or (hasattr(c, "device_native") and c.device_native(dev))
                    for c in self.conditions.values())
 
@@ -584,7 +588,7 @@ class AutoEncoder(AdversarialAutoEncoder):
 
     def __init__(self, n_hidden=100, n_code=50, lr=0.001, batch_size=100, n_epochs=500, optimizer="adam",
                  normalize_inputs=True, activation="ReLU", dropout=(.2, .2), conditions=None, verbose=True,
-                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="vocab"):
+                 device=None, rng_mode="device", seed=None, data_parallel=None, dp_mode="shard"):
         super().__init__(n_hidden=n_hidden, n_code=n_code, gen_lr=lr, reg_lr=lr, prior="gauss", batch_size=batch_size,
                          n_epochs=n_epochs, optimizer=optimizer, normalize_inputs=normalize_inputs,
                          activation=activation, dropout=dropout, conditions=conditions, verbose=verbose,

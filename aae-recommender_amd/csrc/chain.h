@@ -667,14 +667,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int K = J.rows;
     const int mmax4 = ((J.M + 3) & ~3) - 4, nmax4 = ((J.N + 3) & ~3) - 4;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        float4 ra[NV], rb[NV];
+    // The slab loop is a chain of dependent round trips (load -> LDS -> products): the NEXT slab's rows are requested before
+    // this slab's products, from clamped (always valid) addresses, unconditionally - a batch of 800-1000 rows is 13-16 slabs
+    // (r3: one round trip each, 47 us per launch at 800 rows; the products and their order are unchanged).
+    float4 ra[NV], rb[NV];
+    auto request = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + 256 * q, kr = min(k0 + f / (TS / 4), K - 1), cq = (f % (TS / 4)) * 4;
             ra[q] = *reinterpret_cast<const float4*>(J.G + (size_t)kr * J.ldg + min(m0 + cq, mmax4));
             rb[q] = *reinterpret_cast<const float4*>(J.X + (size_t)kr * J.ldx + min(n0 + cq, nmax4));
         }
+    };
+    request(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             *reinterpret_cast<float4*>(&As[kr * LDT + cq]) = va;
             *reinterpret_cast<float4*>(&Bs[kr * LDT + cq]) = vb;
         }
+        request(k0 + BK);                       // (beyond the batch: the last row again, never stored)
         __syncthreads();
         const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll

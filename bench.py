@@ -61,8 +61,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-512 extra line")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel (gradient export) path even on 1 rank")
-    ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated", "shard"), default="vocab",
-                    help="N > 1: 'vocab' shards both vocabulary-wide matrices (decoder output layer, encoder first "
+    ap.add_argument("--dp", choices=("vocab", "vocab_out", "replicated", "shard"), default="shard",
+                    help="N > 1: 'shard' (default) = one handle per rank with its item slice of both vocabulary-wide matrices + "
+                         "the hidden layers, the global batch through it, three all-reduces of [global batch, n_hidden] partial "
+                         "sums per step (aaerec.parallel.ItemShardedAAE); 'vocab' shards both vocabulary-wide matrices (decoder output layer, encoder first "
                          "layer) over the items, the ranks exchange [global batch, n_hidden] blocks only "
                          "(aaerec.parallel.VocabParallelAAE); 'vocab_out' shards the output layer alone; 'replicated' keeps "
                          "everything on every rank and exchanges dense gradients (DataParallelAAE)")
