@@ -583,7 +583,7 @@ class VocabParallelAAE(DataParallelAAE):
 
 
 class ItemShardedAAE:
-    """dp_mode='shard' (r4; csrc/dp_step.h aae_shard_step, DESIGN.md 5.3): the third data-parallel scheme.
+    """dp_mode='shard' (r4; csrc/dp_step.h aae_shard_step, DESIGN.md 5): the third data-parallel scheme.
 
     Every rank holds ONE training handle (`slice_model`): its item slice of the two vocabulary-wide layers (rows of
     dec.lin3, columns of enc.lin1, with their optimiser states) and a full copy of every hidden layer, and runs the WHOLE

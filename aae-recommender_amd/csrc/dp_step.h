@@ -227,7 +227,7 @@ int aae_dp_step(aae_handle m, aae_handle sl, const aae_collectives* c, const aae
     return AAE_OK;
 }
 
-// One partial_fit of the ITEM-SHARDED model with REPLICATED hidden stacks (dp_mode = 'shard', DESIGN.md 5.3; r4): ONE handle
+// One partial_fit of the ITEM-SHARDED model with REPLICATED hidden stacks (dp_mode = 'shard', DESIGN.md 5; r4): ONE handle
 // per rank holds its item slice of the two vocabulary-wide layers (rows of dec.lin3, columns of enc.lin1, their optimiser
 // states) and a full copy of every hidden layer, and runs the WHOLE global batch through the hidden stacks.  Every rank then
 // computes the same activations, the same small-layer gradients and the same optimiser updates from the same inputs - the

@@ -438,7 +438,7 @@ int aae_rccl_destroy(aae_collectives* c);
 int aae_dp_step(aae_handle replica, aae_handle slice, const aae_collectives* coll, const aae_batch* local,
                 const aae_batch* global_slice, const aae_batch* next_global_slice, const float* cond_dev,
                 const aae_rng_inject* inject, void* stream);
-/* The third data-parallel scheme (r4; DESIGN.md 5.3): ONE handle per rank = its item slice of the two vocabulary-wide layers
+/* The third data-parallel scheme (r4; DESIGN.md 5): ONE handle per rank = its item slice of the two vocabulary-wide layers
  * + a full copy of the hidden layers, the WHOLE global batch through the hidden stacks on every rank (identical inputs ->
  * identical small-layer gradients and updates: no gradient exchange), and three all-reduces of [global rows, n_hidden]
  * partial sums per partial_fit (the first layer's pre-activations, dL/d(dh2), the first layer again for Enc_eval) - against 7
