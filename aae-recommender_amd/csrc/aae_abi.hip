@@ -202,6 +202,15 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             m->bf16_x3 = m->x3_ok && ok && getenv("AAE_NO_OPT_X3") == nullptr;
             if (!m->bf16_x3) m->x3_ok = false;
             else m->split_ok = true;
+            // (measured again in r4 and NOT the default: both launches get faster - critical 35 -> 26 us, deferred 85 -> 73 us at
+            //  C2 - and the step SLOWER, 0.172 -> 0.184 ms: the earlier, shorter deferred launch is dispatched in front of the
+            //  ae phase's chain program (a 14 us hole on the main stream) and the weight-gradient launch beside it takes 32 us
+            //  instead of 11; no deferred width between 32 and 96 workgroups recovers it - profiles/r4_c2_bf16_one_term.txt)
+            m->bf16_one = m->bf16_x3 && getenv("AAE_BF16_ONE") != nullptr
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            (void)hipGetLastError();
         }
         if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
             // Workgroups of the deferred launch (batches of one fused launch).  It has to end before the step does (the next

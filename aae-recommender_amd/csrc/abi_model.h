@@ -101,6 +101,7 @@ struct aae_model {
     // ev_opt = the optimiser launch is done (join_deferred() makes a caller's stream wait for it)
     bool split_ok; int split_wgs; bool opt_pending;
     hipStream_t side; hipEvent_t ev_crit, ev_opt;
+    bool bf16_one = false;   // ... on their one-term instantiations (AAE_BF16_ONE=1; default: the run-time form, five zero products - see aae_create)
     bool bf16_x3 = false;    // bf16 mode with the output layer on the dec_crit_x3.h kernels (operands rounded to bf16: DecFusedArgs::one_term)
     float* Gt;               // [ntiles][rows][32] dL/dlogits of the running step (aliases the [R][N] scratch G)
     Ten Xn; const float* noise_next; int64_t noise_ld; bool dense_step;   // cfg.dense_noise: dense noisy encoder input (DenoisingAutoEncoder corrupt='gauss')

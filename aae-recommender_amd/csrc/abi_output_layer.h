@@ -103,6 +103,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecCrit>), dim3(grid), dim3(kBT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
                 } else if (m->x3_ok) {
                     const uint32_t lds3 = (uint32_t)dec_crit_x3_lds_bytes(m->fused_nb);
+                    if (m->bf16_one) switch (m->fused_nb) {     // bf16 mode: the one-term instantiation (one matrix instruction per product)
+                    case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    } else
                     switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
@@ -202,6 +207,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 } else if (r == 0 && nblk == 1 && m->x3_ok && !no_opt_x3) {
                     // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
                     const uint32_t lds3 = (uint32_t)dec_opt_x3_lds_bytes();
+                    if (m->bf16_one) switch (m->fused_nb) {
+                    case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    default: hipExtLaunchKernelGGL((dec_opt_x3_kernel<13, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    } else
                     switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;

@@ -39,6 +39,11 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p1, unsi
     if (one) { p2 = 0u; p3 = 0u; }
 }
 __device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) { return x3_mfma(a, b, c); }
+template <bool ONE>
+__device__ __forceinline__ f32x4 mfma_xt(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+    if constexpr (ONE) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    else return x3_mfma(a, b, c);
+}
 
 // Row stride (dwords) of a k-contiguous bf16 image with kc 32-wide k-steps, read with ONE ds_read_b128 per fragment (8
 // consecutive k per lane): 16 kc + 8 = a stride of 32 bytes mod 64.  ds_read_b128 is serviced in four groups of 16 lanes
@@ -65,9 +70,13 @@ inline size_t dec_crit_x3_lds_bytes(int NB) {
 // TS: the debug build with in-kernel stamps (AAE_DEC_TS=x3).  The production build carries none: every stamp site is a lane
 // test + two exec-mask instructions + a branch in all 16 waves, eight of them per tile - a quarter of the tile loop's ~100 scalar
 // instructions per wave, on a CU whose one scalar unit serves all its waves.
-template <int NB, bool TS = false>   // NB = ceil((h + 1) / 16) column blocks
+// ONE (r4): bf16 mode's instantiation - every operand IS its first term (round-to-nearest-even bf16), so the other two images
+// are neither built nor read and a product is ONE matrix instruction instead of six (the run-time form, a.one_term on the
+// three-term instantiation, multiplies five zero terms: measured in r3 as 36.7 vs 27.9 us at C2).
+template <int NB, bool TS = false, bool ONE = false>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
-    const bool one = a.one_term != 0;
+    const bool one = ONE || a.one_term != 0;
+    constexpr int NT = ONE ? 1 : 3;            // term images in use
     constexpr int KC1 = (NB + 1) / 2;          // 32-wide k-steps over the h + 1 hidden columns
     constexpr int NKS = (KC1 + 1) / 2;         // ... per k half
     constexpr int NKR = NKS > kXRegSteps ? kXRegSteps : NKS;   // ... of them in registers; the others' fragments in LDS, a private
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
             split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2], one);
             split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3], one);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
                 if (j < NKR) dA[j < NKR ? j : 0][t] = __builtin_bit_cast(bf16x8, v);
                 else if (g1 && kh == 0) dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane] = v;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
                 unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
+                for (int t = 0; t < NT; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
             }
         }
         ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
@@ -247,13 +256,13 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                     if (j < nks) {
                         bf16x8 bb[3];
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
-                        if (j < NKR) c = mfma_x3(dA[j < NKR ? j : 0], bb, c);
+                        for (int t = 0; t < NT; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
+                        if (j < NKR) c = mfma_xt<ONE>(dA[j < NKR ? j : 0], bb, c);
                         else {
                             bf16x8 al[3];
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane + oz]);
-                            c = mfma_x3(al, bb, c);
+                            for (int t = 0; t < NT; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane + oz]);
+                            c = mfma_xt<ONE>(al, bb, c);
                         }
                     }
 #pragma unroll
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 unsigned q[3];
                 split3_pair(gA, gB, q[0], q[1], q[2], one);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
+                for (int t = 0; t < NT; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
             }
         }
         lds_barrier();
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 const int lz = lane + oz, q = (lz >> 2) & 3, p = lz & 3;
                 const unsigned* base = v3K + (8 * fkz + q) * S1 + 8 * cb + 2 * p;        // (16 cb + 4 p) bf16 = 8 cb + 2 p dwords
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1)));
                     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -319,8 +328,8 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
             for (int q = 0; q < kMB; ++q) {     // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
                 bf16x8 ga[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) ga[t] = x3_frag(gK + t * (kGR * S3), 16 * q + frz, S3, 0, fkz);
-                acc3[q] = mfma_x3(ga, vt, acc3[q]);
+                for (int t = 0; t < NT; ++t) ga[t] = x3_frag(gK + t * (kGR * S3), 16 * q + frz, S3, 0, fkz);
+                acc3[q] = mfma_xt<ONE>(ga, vt, acc3[q]);
             }
         }
         stamp(4);
@@ -373,9 +382,10 @@ constexpr int kXGS = 20;       // row stride (dwords) of a G image row: 32 bf16 
 
 inline size_t dec_opt_x3_lds_bytes() { return sizeof(float) * ((size_t)3 * 128 * kXGS + (size_t)kTI * kSO + 64); }
 
-template <int NB>
+template <int NB, bool ONE = false>      // ONE: bf16 mode (first terms only, one matrix instruction per product - see dec_crit_x3_kernel)
 __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
-    const bool one = a.one_term != 0;
+    const bool one = ONE || a.one_term != 0;
+    constexpr int NT = ONE ? 1 : 3;
     constexpr int KR = 4;                       // 32-wide k-steps over the (<= 112 -> 128) batch rows
     static_assert(NB <= 13, "column blocks 10..12 are the ones split over two waves");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q], one);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
                 dB[kc][t] = __builtin_bit_cast(bf16x8, v);
             }
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
             split3_pair(g_nxt.z, g_nxt.w, q1[0], q1[1], q1[2], one);
             unsigned* d = gB + (tid >> 3) * kXGS + (tid & 7) * 2;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (128 * kXGS)) = make_uint2(q0[t], q1[t]);
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<uint2*>(d + t * (128 * kXGS)) = make_uint2(q0[t], q1[t]);
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) p_cur[j] = p_nxt[j];
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
                 for (int kc = 0; kc < KR; ++kc) {
                     bf16x8 ga[3];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         const unsigned* pb = base + t * (128 * kXGS) + 32 * kc * kXGS;
                         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb));
                         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 4 * kXGS));
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
                         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         ga[t] = __builtin_bit_cast(bf16x8, v);
                     }
-                    c = mfma_x3(ga, dB[kc], c);
+                    c = mfma_xt<ONE>(ga, dB[kc], c);
                 }
                 // C map: row = item 16 nb2 + 4 fk + r, column = 16 cb + fr
 #pragma unroll
