@@ -516,3 +516,109 @@ def test_c4_bench_shape_fit_path_matches_oracle(dtype, monkeypatch):
             #  of the C2 test: 1.2 % of its elements beyond 1e-4 after 3 steps, none beyond 0.8 lr.)
             assert float((d > 1e-4).mean()) <= 2e-2 and d.max() <= 3.0 * lr * steps * n_opt, (k, float((d > 1e-4).mean()), d.max())
         assert _maxdiff(got, want) <= 2e-3, _maxdiff(got, want)
+
+
+class _IdentityDist:
+    """torch.distributed stand-in of ONE rank of `world`: all-reduce = identity (the other ranks' partial sums are zero)."""
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world, backend):
+        self.world, self.backend = world, backend
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return self.backend
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        return None
+
+
+def test_c5_rank_step_of_the_item_sharded_scheme():
+    """Config C5 under dp_mode='shard' (the default data-parallel scheme since r4; aae_shard_step): what ONE of the 8 ranks
+    runs per step - its 275 000 of the 2.2 M items (interleaved ownership: rank r holds items r, r + 8, ...) of enc.lin1 and
+    dec.lin3 with their optimiser states, a full copy of the hidden layers, and the WHOLE global batch of 512 documents
+    through the hidden stacks: first layer's share (complete-document L1 norms), chain programs over 512 rows, the
+    row-blocked output layer over 275 000 x 512, the per-item first-layer updates, disc and gen phases - as ONE library call
+    with the three all-reduces replaced by the identity (aae_echo_collectives: the other ranks' partial sums taken as zero).
+    Two consecutive steps against the NumPy stand-in of tests/test_parallel_gloo.py (ShardStandIn, itself held to the
+    reference's fixtures over real gloo collectives there) with the same identity all-reduce: losses, the item slices of
+    both vocabulary-wide layers, every hidden layer."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from aaerec.parallel import ItemShardedAAE
+    from test_parallel_gloo import ShardStandIn
+    from tools.synth import init_params, throughput_corpus
+    N, world, rank, h, c, B = 2200000, 8, 3, 200, 50, 512
+    Ns = len(range(rank, N, world))
+    rng = np.random.default_rng(31)
+    params = init_params(Ns, h, c, seed=7)            # (hidden layers at their widths; the two big layers at the slice's size)
+    params["enc.lin1.weight"] = (params["enc.lin1.weight"] * np.float32(20.0)).astype(np.float32)      # (1/sqrt(275 000) initial scale: lift a1 off zero)
+    Xg = throughput_corpus(2 * B, N, median_len=60, seed=19)
+    l1 = np.asarray(abs(Xg).sum(1)).reshape(-1).astype(np.float32)
+    X = Xg[:, rank::world].tocsr()
+    X.sort_indices()
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=2e-3)
+    sl = HipAAE(Ns, h, c, max_batch=B, rng_mode="inject", blocked_output=True, **kw)
+    sl.load_params(params)
+    sl.set_doc_l1(torch.from_numpy(l1).to(sl.device))
+    sh = ItemShardedAAE(None, sl, _IdentityDist(world, "echo"), N, interleaved=True)
+    ref = ShardStandIn({k: v.copy() for k, v in params.items()}, 0, Ns, 0, **kw)
+    ref.set_doc_l1(l1)
+    rsh = ItemShardedAAE(None, ref, _IdentityDist(world, "none"), N, interleaved=True)
+    assert abs(sh.n_slice - Ns) == 0 and rsh.n_slice == Ns
+    csr = DeviceCSR(X, sl.device)
+    host = (X.indptr.astype(np.int64), X.indices, X.data.astype(np.float32))
+    for s in range(2):
+        masks = _masks(rng, B, h)
+        z_real = rng.standard_normal((B, c)).astype(np.float32)
+        sh.step(None, 0, B, csr, s * B, B, masks=masks, z_real=z_real)
+        rsh.step(None, 0, B, host, s * B, B, masks=masks, z_real=z_real)
+        got, want = sl.losses(), (ref.sl.loss, ref.hid.o.losses[1], ref.hid.o.losses[2])
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6, err_msg=f"step {s}")
+    assert sh.comm_stats()["collectives"] == 3
+    sd = sl.state_dict()
+    worst = {"dec.lin3.weight": _maxdiff(sd["dec.lin3.weight"], ref.sl.p["w"]), "dec.lin3.bias": _maxdiff(sd["dec.lin3.bias"], ref.sl.p["b"]),
+             "enc.lin1.weight": _maxdiff(sd["enc.lin1.weight"], ref.sl.w1["w1"])}
+    for k, v in ref.hid.o.p.items():
+        if not k.startswith("dec.lin3") and k != "enc.lin1.weight":
+            worst[k] = _maxdiff(sd[k], v)
+    print("C5 rank step, dp_mode='shard': max |device - stand-in| per tensor:", worst)
+    for k, d in worst.items():
+        assert d <= 1e-5, (k, d)
+
+
+def test_c3_batch_512_row_blocked_step_matches_oracle():
+    """bench.py's extra.b512 path against the ORACLE directly (it was pinned only transitively - blocked ==
+    three-kernel, three-kernel == oracle elsewhere): |items| = 100 000, hidden 200, batch 512, the handle created as
+    AdversarialAutoEncoder creates it for 113..1664-row batches (blocked_output: ONE critical launch for the 5 row blocks,
+    dec_opt_blocks_x3_kernel deferred - four passes of <= 6 tiles per workgroup -, the wide tile-bucket builder, the
+    one-wave-per-item first-layer update with its hot list, chains over 512 rows).  Two full partial_fit steps with injected
+    masks and prior draws against the NumPy oracle over the WHOLE [512, 100 000] problem: losses and every parameter."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from tools.synth import init_params, throughput_corpus
+    N, h, c, B, steps = 100000, 200, 50, 512, 2
+    params = init_params(N, h, c, seed=5)
+    X = throughput_corpus(steps * B, N, median_len=20, seed=81)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3)
+    dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", blocked_output=True, **kw)
+    dev.load_params(params)
+    ora = O.OracleAAE({k: v.copy() for k, v in params.items()}, **kw)
+    csr = DeviceCSR(X, dev.device)
+    rng = np.random.default_rng(9)
+    for s in range(steps):
+        masks, z_real = _masks(rng, B, h), rng.standard_normal((B, c)).astype(np.float32)
+        dev.step(csr, s * B, B, masks=masks, z_real=z_real)
+        Xb = X[s * B:(s + 1) * B]
+        want = ora.partial_fit(Xb.indptr.astype(np.int64), Xb.indices, Xb.data.astype(np.float32), z_real, masks)
+        np.testing.assert_allclose(dev.losses(), want, rtol=1e-5, atol=1e-6, err_msg=f"losses, step {s}")
+    sd = dev.state_dict()
+    worst = {k: _maxdiff(sd[k], w) for k, w in ora.p.items()}
+    print("C3 at batch 512 (row-blocked output layer): max |device - oracle| per tensor:", worst)
+    for k, d in worst.items():
+        assert d <= 1e-5, (k, d)

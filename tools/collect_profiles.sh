@@ -3,7 +3,7 @@
 # Leaves under gpurun_out/: <tag>_bench.json (default bench.py run), <tag>_kernel_stats.csv (rocprofv3 --kernel-trace
 # --stats of the same command), <tag>_bf16_* (the C2 line), pmc_fetch.txt / pmc_write.txt / pmc_mfma.txt (separate
 # --pmc passes).  Progress lines go to stdout (a silent run is taken to be hung).
-tag=${1:-r3}
+tag=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root" && mkdir -p gpurun_out
 echo "[collect] bench f32"; python3 bench.py > gpurun_out/${tag}_bench.log 2>&1; tail -1 gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench.json
