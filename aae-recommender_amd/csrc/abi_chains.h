@@ -192,12 +192,13 @@ struct DwBuilder {
         w.ncol = (m->h + 63) / 64;
         // the row-sparse weight gradient + optimiser of the layer rides along while its row lists fit the kernel's static LDS
         // (batches up to ~2 500 rows); not for the dense noisy input (a dense product follows) or an external
-        // first layer (the rows live with their item slices)
+        // first layer (the rows live with their item slices) - unless this handle IS the owner of its slice's rows
+        // (own_first: aae_shard_step)
         static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
         w.nitem = 0;
         m->w1_items_merged = false;
         w.wave_form = 0;
-        if (!no_merge && !m->dense_step && !m->ext_first && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
+        if (!no_merge && !m->dense_step && (!m->ext_first || m->own_first) && sizeof(int) * w1_items_lds_words(m->rows) <= kDwSmemBytes) {
             TRY(ensure_buckets(m, s));
             w.items = w1_items_args(m, ga1, 0, 0, which);
             w.nitem = std::max(1, std::min(std::min(m->cfg.max_nnz, std::max(256, m->rows * 32)), m->N));      // (<= distinct items possible)
@@ -746,7 +747,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
     TRY(dw.add_first_layer(m, ga1_ptr(m), O_GEN, s));
     TRY(dw.launch(s));
-    if (m->ext_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
+    if (m->ext_first && !m->own_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
     return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
 }
 

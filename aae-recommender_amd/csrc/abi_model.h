@@ -54,6 +54,8 @@ struct aae_model {
     bool only_output_layer;  // aae_output_layer_step: stop after the output layer, dL/d(dh2) summed into da2
     const float* doc_l1;     // aae_set_doc_l1: L1 norms of the complete documents (a handle that holds an item slice of them)
     bool ext_first;          // aae_set_first_layer_external: AAE_T_ACT_A1 comes from the caller, dL/d(a1) goes back to it
+    bool own_first;          // ... but the layer's rows of THIS handle's items live here and are trained here (aae_shard_step: the
+                             // pre-activations come all-reduced over the item slices, the per-item update rides in the weight-gradient launch)
     bool ae_only;            // plain AutoEncoder (reference aae.py:221-458): no disc_step / gen_step
     bool vae;                // VAE (reference vae.py:47-266): P_W3 = [fc21; fc22] (2c rows), no V2/W2, KL term
     bool bf16;               // cfg.dtype = 1: bf16 matrix-core inputs for the GEMM-shaped products (fp32 accumulate / master / Adam)

@@ -144,7 +144,7 @@ int aae_ae_encoder_backward(aae_handle m, const float* dz_dev, int64_t dz_ld, vo
             TRY(dw.add_first_layer(m, ga1_ptr(m), O_ENC, s)); m->w1_merged = true;
             TRY(dw.launch(s));
         }
-        if (!m->ext_first) TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
+        if (!m->ext_first || m->own_first) TRY(encoder_first_layer_update(m, m->gb3.p, O_ENC, s, m->w1_merged));
         m->phase = 3;
         return AAE_OK;
     }

@@ -251,6 +251,7 @@ int aae_shard_step(aae_handle m, const aae_collectives* c, const aae_batch* batc
     if (m->cfg.cond_inc > 0 && !cond_dev) return fail(AAE_EINVAL, "cond_inc > 0 needs cond_dev");
     if (!(item_share > 0.f && item_share <= 1.f)) return fail(AAE_EINVAL, "aae_shard_step: item_share must be in (0, 1]");
     hipStream_t s = S(stream);
+    m->own_first = true;            // its rows of enc.lin1 are trained here: their per-item update rides in the weight-gradient launches
     const float* bias = c->rank == 0 ? m->P[P_B1].p : nullptr;      // exactly one share adds the (replicated) bias
     if (next_batch) TRY(aae_prefetch_batch(m, next_batch));
     // ---- ae phase
@@ -271,15 +272,13 @@ int aae_shard_step(aae_handle m, const aae_collectives* c, const aae_batch* batc
     m->grad_scale = 1.f;
     TRY(rc);
     TRY(c->all_reduce(c->ctx, m->da2.p, cnt, stream));
-    TRY(aae_ae_backward(m, nullptr, 0, stream));                     // hidden layers backward + their optimisers: the same on every rank
-    TRY(aae_first_layer_update(m, nullptr, m->ldh, 0, 0, O_ENC, stream));
+    TRY(aae_ae_backward(m, nullptr, 0, stream));                     // hidden layers backward + their optimisers (the same on every rank), enc_optim on its rows of enc.lin1
     if (m->ae_only) { m->phase = 0; return AAE_OK; }
     // ---- disc phase (Enc_eval with the updated first layer), gen phase
     TRY(aae_first_layer_forward(m, nullptr, bias, stream));
     TRY(c->all_reduce(c->ctx, m->a1.p, cnt, stream));
     TRY(aae_disc_step(m, nullptr, stream));
-    TRY(aae_gen_step(m, nullptr, stream));
-    TRY(aae_first_layer_update(m, nullptr, m->ldh, 0, 0, O_GEN, stream));
+    TRY(aae_gen_step(m, nullptr, stream));                           // (gen_optim on its rows of enc.lin1 included)
     return AAE_OK;
 }
 
