@@ -65,6 +65,17 @@ int rank_rows_cap(const aae_model* m, int k) {
 
 template <int NB>
 int launch_rank_nb(const RankArgs& a, int K, int grid, hipStream_t s) {
+    static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
+    if (!v1 && (K == 10 || (K == 20 && NB < 13))) {          // (the other list sizes spill registers in the v2 mapping: they keep v1)
+        const uint32_t lds2 = (uint32_t)rank_x3v2_lds_bytes(NB);
+        switch (K) {
+            case 10: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10>), dim3(grid), dim3(kNT), lds2, s, a); break;
+            case 20: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 20>), dim3(grid), dim3(kNT), lds2, s, a); break;
+            default: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 32>), dim3(grid), dim3(kNT), lds2, s, a); break;
+        }
+        LAUNCHCHK("rank_x3v2");
+        return AAE_OK;
+    }
     const uint32_t lds = (uint32_t)rank_x3_lds_bytes(NB);
     switch (K) {
         case 10: hipLaunchKernelGGL((rank_x3_kernel<NB, 10>), dim3(grid), dim3(kNT), lds, s, a); break;
@@ -85,6 +96,14 @@ bool rank_set_attributes() {
     set(reinterpret_cast<const void*>(rank_x3_kernel<7, 20>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 32>), 7);
     set(reinterpret_cast<const void*>(rank_x3_kernel<13, 10>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 20>), 13);
     set(reinterpret_cast<const void*>(rank_x3_kernel<13, 32>), 13);
+    auto set2 = [&](const void* f, int NB) {
+        ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_x3v2_lds_bytes(NB)) == hipSuccess;
+    };
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 10>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 20>), 4);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 32>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 10>), 7);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 20>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 32>), 7);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 10>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 20>), 13);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 32>), 13);
     (void)hipGetLastError();
     return ok;
 }

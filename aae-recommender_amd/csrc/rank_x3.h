@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void known_mask_kernel(BatchView bv, unsigned*
 
 constexpr int kRRS = 36;       // row stride (floats) of the raw-logit halves [b][n]: 16-byte aligned rows for the epilogue's float4 reads
 
+inline size_t rank_x3v2_lds_bytes(int NB) {
+    const int KC1 = (NB + 1) / 2, S1 = x3_stride(KC1);
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)4 * kGR * kRRS);
+}
+
 inline size_t rank_x3_lds_bytes(int NB) {
     const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1);
     const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
@@ -227,6 +232,209 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
                     }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rw[r * kRRS + 16 * nb2] = c[r];
+            }
+        }
+    }
+    lds_barrier();
+    if (prev_i0 >= 0) epilogue(prev_i0, kw_prev);
+
+    // ---- the 8 threads of a row merge their lists (K rounds of an 8-lane argmax, ties to the smaller item) -> K candidates
+    // of this workgroup for the row; its minimum / maximum
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); }
+    const size_t slot = (size_t)(erow0 + eb) * wgs + wgi;
+    if (erow && eq == 0) { a.mm[2 * slot] = vmin; a.mm[2 * slot + 1] = vmax; }
+    for (int r = 0; r < K; ++r) {
+        float bv = tv[0]; int bi = ti[0]; int who = eq;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64); const int ow = __shfl_xor(who, o, 64);
+            if (ov > bv || (ov == bv && (unsigned)oi < (unsigned)bi)) { bv = ov; bi = oi; who = ow; }
+        }
+        if (erow && eq == 0) { a.cand_v[slot * K + r] = bv; a.cand_i[slot * K + r] = bi; }
+        if (eq == who) {
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = -1;
+        }
+    }
+}
+
+// v2 (r4): the GEMM's wave mapping.  v1 (the critical launch's: wave = (row block, k half)) has every one of 14 waves read
+// the tile's B fragments for itself - 0.5 LDS operand reads per matrix instruction, and the phase ran at half the pipe's rate
+// (ablation: 2.2 us per tile for 1.0 us of pipe time).  Here wave = (row-block PAIR rp = wave / 4, k QUARTER kq): one B
+// fragment serves both row blocks of the pair (0.25 reads per instruction), all 16 waves multiply, the four k quarters'
+// partial sums meet in the epilogue (4 raw tiles instead of 2), and the quarter a wave takes is rotated by its pair,
+// kq = (wave + rp) & 3, so that every SIMD (wave & 3) gets 12-13 of the 49 (row block, k-step) units.
+template <int NB, int K>
+__global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
+    const bool one = a.one_term != 0;
+    constexpr int KC1 = (NB + 1) / 2, NKQ = (KC1 + 3) / 4;       // 32-wide k-steps over the h + 1 hidden columns; per k quarter
+    constexpr int S1 = x3_stride(KC1);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* v3K = reinterpret_cast<unsigned*>(lds);           // [3][32][S1] V3a tile, k = hidden column
+    float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [4][kGR][kRRS] the four k quarters of the logits
+
+    const int nblk = a.nblk > 1 ? a.nblk : 1;
+    const int blk = (int)blockIdx.x % nblk, wgi = (int)blockIdx.x / nblk, wgs = (int)gridDim.x / nblk;
+    if (wgi >= wgs) return;
+    const int erow0 = blk * a.Bb;
+    const int B = min(a.Bb, a.B - erow0);
+    const float* dh2_blk = a.dh2 + (size_t)erow0 * a.ldh;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ldv = a.ldv, N = a.N;
+    const int ntiles = (N + kTI - 1) / kTI;
+    const int f4_per_row = ldv / 4, tile_f4 = kTI * f4_per_row;
+    constexpr int NV = 2;
+
+    // the parameter stream: tensor base in a buffer descriptor, tile offset scalar, slot offset in one vector register;
+    // reads beyond the tensor return zero
+    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V3a), 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    auto load_span = [&](int tile, float4* r) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+    };
+    // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
+    const int eb = tid >> 3, eq = tid & 7;
+    const bool erow = eb < B;
+    const unsigned* kn = a.known ? a.known + (size_t)(erow0 + min(eb, B - 1)) * a.kw : nullptr;
+    float4 vreg[NV];
+    int tile = wgi;
+    const int stride = wgs;
+    unsigned kw_next = 0u;
+    if (tile < ntiles) {
+        load_span(tile, vreg);
+        if (kn) kw_next = kn[tile];
+    }
+    for (int i = tid; i < 3 * kTI * S1 + 4 * kGR * kRRS; i += kNT) v3K[i] = 0u;
+
+    // dh2 -> split A fragments: wave = (row-block pair rp, k quarter kq); lane (fr, fk) of a fragment holds row 16 mb + fr,
+    // k = 32 kc + 8 fk + {0..7}, kc = kq + 4 j
+    const int rp = wave >> 2, kq = (wave + rp) & 3;
+    const int nblk2 = min(2, kMB - 2 * rp);     // row blocks of this pair (the last pair of 7 blocks: one)
+    bf16x8 dA[2][NKQ][3];
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+        const int row = 16 * (2 * rp + bq) + fr;
+        const float* src = dh2_blk + (size_t)min(row, B - 1) * a.ldh;
+#pragma unroll
+        for (int j = 0; j < NKQ; ++j) {
+            const int k0 = 32 * (kq + 4 * j) + 8 * fk;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+            if (bq < nblk2 && row < B && k0 < a.ldh) x = *reinterpret_cast<const float4*>(src + k0);
+            if (bq < nblk2 && row < B && k0 + 4 < a.ldh) y = *reinterpret_cast<const float4*>(src + k0 + 4);
+            unsigned p[3][4];
+            split3_pair(x.x, x.y, p[0][0], p[1][0], p[2][0], one);
+            split3_pair(x.z, x.w, p[0][1], p[1][1], p[2][1], one);
+            split3_pair(y.x, y.y, p[0][2], p[1][2], p[2][2], one);
+            split3_pair(y.z, y.w, p[0][3], p[1][3], p[2][3], one);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
+                dA[bq][j][t] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+    }
+    const int nks = kq < KC1 ? (KC1 - kq + 3) / 4 : 0;          // k-steps this wave really has
+
+    int s_rc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+    }
+    float tv[K]; int ti[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    float vmin = INFINITY, vmax = -INFINITY;
+
+    // the epilogue of one finished tile: the thread's four cells
+    auto epilogue = [&](int i0, unsigned kword) {
+        if (!erow || (a.dbg & 2)) return;
+        const float4 q0 = *reinterpret_cast<const float4*>(raw + eb * kRRS + 4 * eq);
+        const float4 q1 = *reinterpret_cast<const float4*>(raw + kGR * kRRS + eb * kRRS + 4 * eq);
+        const float4 q2 = *reinterpret_cast<const float4*>(raw + 2 * kGR * kRRS + eb * kRRS + 4 * eq);
+        const float4 q3 = *reinterpret_cast<const float4*>(raw + 3 * kGR * kRRS + eb * kRRS + 4 * eq);
+        const float4 lA = make_float4(q0.x + q1.x, q0.y + q1.y, q0.z + q1.z, q0.w + q1.w);
+        const float4 lB = make_float4(q2.x + q3.x, q2.y + q3.y, q2.z + q3.z, q2.w + q3.w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * eq + j, item = i0 + n;
+            const float v = (&lA.x)[j] + (&lB.x)[j];       // the LOGIT: sigmoid is monotone - applied to the winners only (merge)
+            if (item < N) {
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+                if (!((kword >> n) & 1u) && v > tv[K - 1] && !(a.dbg & 1)) {
+                    tv[K - 1] = v; ti[K - 1] = item;
+#pragma unroll
+                    for (int s = K - 1; s > 0; --s) {
+                        if (tv[s] > tv[s - 1]) {
+                            const float fv = tv[s]; tv[s] = tv[s - 1]; tv[s - 1] = fv;
+                            const int iv = ti[s]; ti[s] = ti[s - 1]; ti[s - 1] = iv;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    __syncthreads();
+
+    int prev_i0 = -1; unsigned kw_prev = 0u;
+    for (; tile < ntiles; tile += stride) {
+        const int i0 = tile * kTI;
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int frz = fr + oz, fkz = fk + oz;
+        lds_barrier();                          // the previous tile's products are in `raw`, its readers of v3K are done
+        // ---- the previous tile's epilogue and this tile's images, one VALU phase
+        if (prev_i0 >= 0) epilogue(prev_i0, kw_prev);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (tid + kNT * j < tile_f4 && !(a.dbg & 8)) {
+                float4 p = vreg[j];
+                if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned q0[3], q1[3];
+                split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
+                split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
+                unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
+            }
+        }
+        prev_i0 = i0; kw_prev = kw_next;
+        {
+            const int nt = min(tile + stride, ntiles - 1);
+            load_span(nt, vreg);
+            if (kn) kw_next = kn[nt];
+        }
+        lds_barrier();
+        // ---- logits of the wave's row-block pair x both item halves over its k-steps -> its quarter's raw tile
+        if (nks > 0 && !(a.dbg & 4)) {
+            float* rw = raw + kq * (kGR * kRRS) + (32 * rp + 4 * fkz) * kRRS + frz;
+#pragma unroll
+            for (int nb2 = 0; nb2 < 2; ++nb2) {
+                f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+                for (int j = 0; j < NKQ; ++j)
+                    if (j < nks) {
+                        bf16x8 bb[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kq + 4 * j, fkz);
+                        c0 = mfma_x3(dA[0][j], bb, c0);
+                        if (nblk2 > 1) c1 = mfma_x3(dA[1][j], bb, c1);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r * kRRS + 16 * nb2] = c0[r];
+                if (nblk2 > 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rw[(16 + r) * kRRS + 16 * nb2] = c1[r];
+                }
             }
         }
     }
