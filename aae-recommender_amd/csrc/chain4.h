@@ -74,6 +74,10 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
         for (int j = 0; j < MK / 4; ++j) { wq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0)); so += st; }
 #endif
         if (wts && lane == 0) wts[wave] = wall_clock64();
+        // Every weight load of the layer is requested before its first product: left to itself hipcc sinks the loads between
+        // the products (r4, ISA: two loads, s_waitcnt vmcnt(0), four products, one load, vmcnt(1), ... - 2-3 KB in flight per
+        // wave instead of 13).  Same-box A/B of the two builds: 0.2521 -> 0.2502 ms/step, chain launches 28.3 -> 27.4 us.
+        __builtin_amdgcn_sched_barrier(0);
         const float4* a4 = reinterpret_cast<const float4*>(src + (lane & 3) * kCL + k0);
         f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
@@ -260,6 +264,8 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             one_done = true;
             chain_barrier();
             if (wts && tid == 0) { wts[50] = wall_clock64(); wts[51] = clock64(); }
+            // (measured, r4: requesting this context with the op's other descriptor fields, in front of the matrix phase, costs
+            //  46 spilled scalar registers and 0.6 % of the step)
             const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
             if (wts && tid == 0) wts[52] = wall_clock64();
 #ifdef C4_NO_EPI
