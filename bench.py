@@ -583,7 +583,7 @@ def main():
             out["collectives_per_step"] = model._dp.comm_stats()
             native = getattr(model._dp, "_native", None) is not None
             rccl = dist is not None and str(dist.get_backend()).lower() == "nccl"
-            out["dp_step_driver"] = (("library call (aae_dp_step), " + ("RCCL communicator of the library" if rccl else
+            out["dp_step_driver"] = (("library call (" + ("aae_shard_step" if a.dp == "shard" else "aae_dp_step") + "), " + ("RCCL communicator of the library" if rccl else
                                                                          "collectives through host-staged callbacks (functional check)"))
                                      if native else "python phases over torch.distributed")
         if cpu:

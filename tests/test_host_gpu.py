@@ -941,7 +941,7 @@ def test_conditioned_recommender_through_bags_attributes():
     assert mrr_cond > 0.3 and mrr_cond > mrr_plain + 0.05, (mrr_cond, mrr_plain)
 
 
-@pytest.mark.parametrize("dp", ["vocab", "replicated"])
+@pytest.mark.parametrize("dp", ["shard", "vocab", "replicated"])
 def test_bench_spawns_its_own_ranks(dp):
     """`python bench.py --gpus 2` the way the driver starts it - no launcher: bench.py spawns one process per rank before
     touching the GPU and relays rank 0's single JSON line.  On this one-GPU box the ranks share device 0 and their
@@ -963,6 +963,8 @@ def test_bench_spawns_its_own_ranks(dp):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["global_batch"] == 200 and out["value"] > 0
     assert np.all(np.isfinite(out["losses_last_step"]))
+    if dp == "shard":            # the default scheme: three all-reduces per step, the library's step driver
+        assert out["collectives_per_step"]["collectives"] == 3 and "3 all-reduces" in out["config"]["parallelism"]
 
 
 def test_dense_batches_are_compacted_on_the_device():
