@@ -170,9 +170,15 @@ def maybe_close(fh):
 class Evaluation:
     """Year split -> vocabulary -> pruning -> drop `drop` items per test bag -> train/predict/score."""
 
-    def __init__(self, dataset, year, metrics=METRICS, logfile=sys.stdout, logdir=None):
+    def __init__(self, dataset, year, metrics=METRICS, logfile=sys.stdout, logdir=None, topk=True):
         self.dataset, self.year, self.metrics = dataset, year, metrics
         self.logfile, self.logdir = logfile, logdir
+        # topk: a recommender that can rank on the device (predict_topk: the fused predict -> remove_non_missing -> top-k
+        # pass, only [n, k] ids cross PCIe) is asked for its k best items instead of the dense [n, items] score matrix
+        # whenever every requested metric is bounded at k (mrr@k, map@k, p@k, P@1: they only ever look at the k best
+        # predictions - the numbers are those of the dense pipeline, tests/test_host_gpu.py) and no prediction dump (logdir)
+        # is wanted.  topk=False keeps the reference's dense pipeline for every recommender.
+        self.topk = topk
         self.train_set = self.test_set = self.x_test = self.y_test = None
 
     def setup(self, seed=42, min_elements=1, max_features=None, min_count=None, drop=1):
@@ -203,6 +209,15 @@ class Evaluation:
         self.train_set, self.test_set = train_set, test_set
         return self
 
+    def _bounded_k(self):
+        """The largest k of the requested metrics when ALL of them are bounded names (<= 32: what predict_topk ranks), else None."""
+        ks = []
+        for m in self.metrics:
+            if not isinstance(m, str) or m not in BOUNDED_METRICS:
+                return None
+            ks.append(BOUNDED_METRICS[m].k)
+        return max(ks) if ks and max(ks) <= 32 else None
+
     def __call__(self, recommenders, batch_size=None):
         if any(v is None for v in (self.train_set, self.test_set, self.x_test, self.y_test)):
             raise UserWarning("Call .setup() before running the experiment")
@@ -222,14 +237,21 @@ class Evaluation:
             fh = maybe_open(self.logfile)
             print("Training took {} seconds.".format(timedelta(seconds=timer() - t0)), file=fh)
             t1 = timer()
-            y_pred = rec.predict(test_set)
-            y_pred = y_pred.toarray() if sp.issparse(y_pred) else np.asarray(y_pred)
-            y_pred = remove_non_missing(y_pred, self.x_test, copy=True)
-            print("Prediction took {} seconds.".format(timedelta(seconds=timer() - t1)), file=fh)
-            if self.logdir:
-                np.save(os.path.join(self.logdir, repr(rec)), y_pred)
-            t1 = timer()
-            results = evaluate(self.y_test, y_pred, metrics=self.metrics, batch_size=batch_size)
+            kmax = self._bounded_k()
+            if self.topk and kmax is not None and not self.logdir and hasattr(rec, "predict_topk"):
+                top_ids, _ = rec.predict_topk(test_set, k=kmax)
+                print("Prediction took {} seconds.".format(timedelta(seconds=timer() - t1)), file=fh)
+                t1 = timer()
+                results = evaluate_topk(self.y_test, top_ids, list(self.metrics))
+            else:
+                y_pred = rec.predict(test_set)
+                y_pred = y_pred.toarray() if sp.issparse(y_pred) else np.asarray(y_pred)
+                y_pred = remove_non_missing(y_pred, self.x_test, copy=True)
+                print("Prediction took {} seconds.".format(timedelta(seconds=timer() - t1)), file=fh)
+                if self.logdir:
+                    np.save(os.path.join(self.logdir, repr(rec)), y_pred)
+                t1 = timer()
+                results = evaluate(self.y_test, y_pred, metrics=self.metrics, batch_size=batch_size)
             print("Evaluation took {} seconds.".format(timedelta(seconds=timer() - t1)), file=fh)
             print("\nResults:\n", file=fh)
             for metric, (mean, std) in zip(self.metrics, results):

@@ -246,6 +246,17 @@ def test_recommender_with_bags_and_evaluation_harness(capsys):
     assert 0.15 < mrr <= 1.0, mrr
     out = capsys.readouterr().out
     assert "Training took" in out and "- mrr@10:" in out
+    # (every metric bounded at k: the harness asked the recommender for its top 10 on the device - predict_topk - instead of
+    #  the dense score matrix.)  The reference's dense pipeline on the same run of the same seeds gives the same numbers:
+    def run(topk):
+        np.random.seed(3)
+        torch.manual_seed(3)
+        e = Evaluation(bags, 2009, metrics=["mrr@10", "map@10", "p@5", "P@1"], logfile=None, topk=topk).setup(min_elements=2, drop=1)
+        return e([AAERecommender(n_hidden=40, n_code=16, n_epochs=10, batch_size=50, gen_lr=0.01, verbose=False, seed=11)])[0]
+    fast, dense = run(True), run(False)
+    np.testing.assert_allclose(np.asarray(fast), np.asarray(dense), atol=1e-12)
+    ev2 = Evaluation(bags, 2009, metrics=["mrr@10", "mrr"], logfile=None)
+    assert ev2._bounded_k() is None and Evaluation(bags, 2009, metrics=["mrr@5", "p@20"], logfile=None)._bounded_k() == 20
 
 
 def test_per_step_buffers_are_released_every_step():
