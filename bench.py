@@ -263,7 +263,8 @@ def main():
     # The event pairs ride in the FIRST timed repeat of K steps only (`profiled_repeat`): they cost that repeat ~4 % (a
     # timing event carries a system-scope release the plain launch does not), the other repeats run as production does and
     # the median over all of them is `value`.
-    out_model.profile_enable(True, kernels=K_OUT)
+    if os.environ.get("AAE_BENCH_NO_PROF") is None:          # (debugging aid: a kernel trace of the loop without the timing events)
+        out_model.profile_enable(True, kernels=K_OUT)
     dts = [timed_steps(it, a.steps, barrier)]
     out_model.profile_enable(False)
     repeats = a.repeats or (5 if dts[0] < 0.25 else 1)
