@@ -218,6 +218,7 @@ struct DwBuilder {
                 (int64_t)m->cfg.max_nnz <= 512ll * w.nitem && ((int64_t)m->N >= 40ll * m->rows || hyb_any)) {
                 w.wave_form = 2;
                 w.nitem = (w.nitem + 3) / 4;
+                { static const int wgs_env = getenv("AAE_W1_WGS") ? atoi(getenv("AAE_W1_WGS")) : 0; if (wgs_env > 0) w.nitem = wgs_env; }   // (sweep)
             } else
             if (!no_wave && m->rows > 16 * kMB && m->hot_list && (int64_t)m->N >= 40ll * m->rows) {
                 w.wave_form = 1;
