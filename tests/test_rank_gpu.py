@@ -138,3 +138,40 @@ def test_fused_rank_matches_oracle_predict_and_chunked_calls_agree():
     assert np.all(np.abs(ov[d] - vals[d]) <= 2e-6)
     with pytest.raises(RuntimeError):
         old.predict_topk(csr, 0, rows, k)               # beyond max_batch without the fused path: refused, not truncated
+
+
+@pytest.mark.parametrize("N,h,c,R,rows,k", [(33, 8, 3, 4, 3, 5), (40, 200, 50, 2, 1, 32), (1000, 32, 8, 16, 1500, 10), (64, 5, 2, 100, 100, 1),
+                                             (20000, 120, 20, 10, 9, 20)])
+def test_fused_rank_degenerate_shapes(N, h, c, R, rows, k):
+    """Edges of the fused rank path: a vocabulary of one (ragged) tile, one row, k = 1 and k = 32, far more rows than the
+    training batch on a small vocabulary (14 row blocks, fewer workgroups per block than tiles), rows whose input is most
+    of the vocabulary (fewer than k items left to rank: the tail of the list is -1 / 0.0 as in the two-kernel path)."""
+    from aaerec._hip import HipAAE, DeviceCSR
+    from tools.synth import init_params
+    r = np.random.default_rng(N + rows)
+    dev = HipAAE(N, h, c, max_batch=R, rng_mode="device", seed=1)
+    params = init_params(N, h, c, seed=3)
+    params["dec.lin3.weight"] = params["dec.lin3.weight"] * 6.0
+    dev.load_params(params)
+    cap = dev.rank_max_rows(k)
+    rows = min(rows, cap)
+    max_len = N - 2 if N <= 64 else 30            # (small vocabularies: rows that name nearly every item)
+    ip, idx, val, docs = _corpus(r, N, rows, max_len)
+    csr = DeviceCSR.from_arrays(ip, idx, val, N, dev.device)
+    ids, vals = dev.predict_topk(csr, 0, rows, k)
+    ids, vals = ids.cpu().numpy(), vals.cpu().numpy()
+    full = np.concatenate([dev.predict(csr, s, min(R, rows - s)).cpu().numpy() for s in range(0, rows, R)])
+    for b in range(rows):
+        row = full[b]
+        lo, hi = row.min(), row.max()
+        sc = (row - lo) / (hi - lo) if hi > lo else np.zeros_like(row)
+        free = np.setdiff1d(np.arange(N), docs[b])
+        n_ok = min(k, len(free))
+        assert np.all(ids[b, n_ok:] == -1) and np.all(vals[b, n_ok:] == 0.0), (b, ids[b], len(free))
+        got = ids[b, :n_ok]
+        assert len(set(got.tolist())) == n_ok and not (set(got.tolist()) & set(docs[b].tolist()))
+        np.testing.assert_allclose(vals[b, :n_ok], sc[got], atol=2e-6)
+        assert np.all(np.diff(vals[b, :n_ok]) <= 1e-6)
+        if n_ok:
+            kth = np.sort(sc[free])[-n_ok]
+            assert np.all(sc[got] >= kth - 2e-6)
