@@ -147,7 +147,10 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 // 144 / 160; an item slice of 12.5 k items x 800 rows 0.382 / 0.379 / 0.400 / 0.387 ms of per-rank compute on
                 // 96 / 128 / 160 / 192.  (Beyond 3/4 of the chip the step's own launches lose more than this one gains.)
                 static const int obk_env = getenv("AAE_OBK_WGS") ? atoi(getenv("AAE_OBK_WGS")) : 0;
-                const int by_tiles = std::max(m->n_cu / 2, std::min(m->n_cu * 3 / 4, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
+                // (a slice of thousands of tiles - C5: 275 k items x 512 rows, 8 594 tiles - outlasts the step's tail by far: 7/8 of the
+                //  chip there, r4: one rank's step 1.58 | 1.52 | 1.61 | 1.59 ms on 192 | 224 | 240 | 256 workgroups)
+                const int wg_cap = ntiles >= 4096 ? m->n_cu * 7 / 8 : m->n_cu * 3 / 4;
+                const int by_tiles = std::max(m->n_cu / 2, std::min(wg_cap, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
                 const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : by_tiles), std::min(ntiles, m->n_cu)));
                 const int rounds = (ntiles + g3 * kXBT - 1) / (g3 * kXBT);
                 b.tpp = g3 * rounds;
