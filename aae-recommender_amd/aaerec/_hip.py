@@ -155,6 +155,7 @@ _PROTOS = {
     "aae_rccl_destroy": (C.c_int, [C.POINTER(AaeCollectives)]),
     "aae_dp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AaeCollectives), C.POINTER(AaeBatch), C.POINTER(AaeBatch),
                               C.POINTER(AaeBatch), C.c_void_p, C.POINTER(AaeRngInject), C.c_void_p]),
+    "aae_dp_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "aae_shard_step": (C.c_int, [C.c_void_p, C.POINTER(AaeCollectives), C.POINTER(AaeBatch), C.POINTER(AaeBatch), C.c_void_p,
                                  C.POINTER(AaeRngInject), C.c_float, C.c_void_p]),
     "aae_memcpy_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -754,6 +755,11 @@ class HipAAE:
         with self._on_device():
             _check(self.lib.aae_apply_gathered(self.handle, int(which_a), int(which_b), _ptr(packets), int(peer_stride),
                                                int(n_peers), int(span_offset), self._stream()))
+
+    def dp_reserve(self, n_rows, world):
+        """Set-up for dp_step: the gathered-packet scratch for `world` ranks x n_rows local documents (aae_dp_reserve)."""
+        with self._on_device():
+            _check(self.lib.aae_dp_reserve(self.handle, int(n_rows), int(world)))
 
     def dp_step(self, slice_model, coll, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=None, g_rows=None,
                 next_global=None, cond=None, masks=None, z_real=None):

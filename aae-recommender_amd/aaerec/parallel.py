@@ -367,6 +367,9 @@ class VocabParallelAAE(DataParallelAAE):
         self._set_rng_rows(n_rows, global_rows)
         if self.shard_first and self._native is not None:
             # the whole step - kernels and collectives - enqueued by ONE library call (aae_dp_step, csrc/dp_step.h)
+            if getattr(self, "_reserved", None) != n_rows:      # (set-up, once per batch shape: no allocation inside a step)
+                m.dp_reserve(n_rows, self.world)
+                self._reserved = n_rows
             m.dp_step(sl, self._native, csr, row_start, n_rows, slice_csr, g_row_start, global_rows, rows=rows, g_rows=g_rows,
                       cond=cond, masks=masks, z_real=z_real)
             self._gathered = False

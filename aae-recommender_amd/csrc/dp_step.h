@@ -145,6 +145,30 @@ int aae_memcpy_sync(void* dst, const void* src, size_t bytes, void* stream) {
     return AAE_OK;
 }
 
+// floats of one rank's gathered packet [dL/d(a1) rows of n documents | small-layer gradients incl. the decoder's]
+static int64_t dp_packet_floats(const aae_model* m, int n) {
+    const Ten& e = m->Gr[P_V2];
+    const size_t start = m->ga1x.off + (size_t)(m->ga1x.rows - n) * m->ga1x.ld * sizeof(float);
+    const size_t end = e.off + (size_t)e.rows * e.ld * sizeof(float);
+    return (int64_t)((end - start) / sizeof(float));
+}
+
+// The scratch aae_dp_step gathers the ranks' packets into (world x the larger packet of n_rows local documents), allocated
+// HERE - at set-up time - instead of inside the first step (a hipMalloc in the step); aae_dp_step still grows it
+// when a caller skipped this.
+int aae_dp_reserve(aae_handle m, int32_t n_rows, int32_t world) {
+    if (!m) return fail(AAE_EINVAL, "handle is NULL");
+    if (m->cfg.grad_mode != AAE_GRAD_EXPORT || !m->ga1x.p) return fail(AAE_ESTATE, "aae_dp_reserve: the replica needs grad_mode = export");
+    if (n_rows < 1 || n_rows > m->R || world < 1) return fail(AAE_EINVAL, "aae_dp_reserve: n_rows in [1, max_batch], world >= 1");
+    const size_t need = (size_t)dp_packet_floats(m, n_rows) * world;
+    if (m->dp_scratch_floats >= need) return AAE_OK;
+    if (m->dp_scratch) (void)hipFree(m->dp_scratch);
+    m->dp_scratch = nullptr; m->dp_scratch_floats = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->dp_scratch), need * sizeof(float)));
+    m->dp_scratch_floats = need;
+    return AAE_OK;
+}
+
 // One partial_fit of the data-parallel model (aae.py:745-766 over the global batch): `replica` = this rank's replica
 // handle (grad_mode export, first layer external), `slice` = its item-slice handle (fused optimiser; enc.lin1 and dec.lin3
 // rows of its items), local = this rank's documents in the replica's corpus, global_slice = the GLOBAL batch (rank-major:
@@ -189,12 +213,7 @@ int aae_dp_step(aae_handle m, aae_handle sl, const aae_collectives* c, const aae
     };
     float* pk; int64_t pkf, soff;
     packet(true, &pk, &pkf, &soff);                     // (the larger of the two packets sizes the scratch)
-    if (m->dp_scratch_floats < (size_t)pkf * world) {
-        if (m->dp_scratch) (void)hipFree(m->dp_scratch);
-        m->dp_scratch = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->dp_scratch), (size_t)pkf * world * sizeof(float)));
-        m->dp_scratch_floats = (size_t)pkf * world;
-    }
+    if (m->dp_scratch_floats < (size_t)pkf * world) TRY(aae_dp_reserve(m, n, world));      // (a caller that did not reserve at set-up)
     float* allp = m->dp_scratch;
 
     // ---- ae phase

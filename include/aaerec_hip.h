@@ -435,6 +435,9 @@ typedef struct aae_collectives {
 int aae_rccl_unique_id(char id_out[128]);
 int aae_rccl_init(const char id[128], int32_t world, int32_t rank, aae_collectives* out);
 int aae_rccl_destroy(aae_collectives* c);
+/* set-up: the replica's scratch for the gathered packets of `world` ranks x n_rows local documents (else aae_dp_step
+ * allocates it in its first call) */
+int aae_dp_reserve(aae_handle replica, int32_t n_rows, int32_t world);
 int aae_dp_step(aae_handle replica, aae_handle slice, const aae_collectives* coll, const aae_batch* local,
                 const aae_batch* global_slice, const aae_batch* next_global_slice, const float* cond_dev,
                 const aae_rng_inject* inject, void* stream);
