@@ -122,6 +122,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 m->fused_ok = false;
         }
     }
+    m->late_enabled = getenv("AAE_NO_LATE_JOIN") == nullptr;
     m->rank_ok = m->fused_ok && m->use_chain4 && !m->vae && getenv("AAE_NO_RANK_FUSED") == nullptr && rank_set_attributes();
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(int) * w1_items_lds_words(16384))) == hipSuccess;
@@ -224,7 +225,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             const double t_tile = 3.3 + 0.0131 * m->h;
             int w = (int)(ntiles * t_tile / 82.0 / 8.0 + 0.5) * 8;
             w = std::max(w, std::min(ntiles, 64));
-            m->split_wgs = std::max(1, std::min(w, m->n_cu * 9 / 16));
+            // r4, late join (abi_model.h: the launch may run on into the next step's forward pass, so it need not end with the
+            // step): half the chip at most - C3 0.2493 (early join, 144) -> 0.2430 ms/step on 128; 0.2515 / 0.2483 / 0.2497 /
+            // 0.2492 on 112 / 120 / 136 / 144 (sharp: 124 -> 0.2459, 132 -> 0.2503); the early join on 128: 0.2608.  C2 (formula:
+            // 80) is flat from 64 to 96 either way (tools/debug/late_join_sweep*.sh).
+            const int cap = m->late_enabled ? m->n_cu / 2 : m->n_cu * 9 / 16;
+            m->split_wgs = std::max(1, std::min(w, cap));
         }
     }
     hipStream_t s = S(stream);

@@ -125,6 +125,11 @@ struct aae_model {
     bool pf_after_opt = false;                             // the pending prefetch was enqueued behind the pending deferred launch
     hipEvent_t ev_bk = nullptr; bool bk_pending = false;   // the tile buckets of the running batch, built on the side stream (aae_first_layer_forward)
     bool last_out_split = false;                           // the last output-layer pass ran as critical + deferred launch(es)
+    // Late join: the deferred launch of step t may run into step t+1's forward pass when it reads private copies of what
+    // that pass rewrites (dh2s / sc_snap, written by step t's critical launch): the wait for it then sits in front of step
+    // t+1's output layer (aae_ae_decode_backward) instead of at the step's opening.  late_ok = the pending launch is one.
+    Ten dh2s; OptScalars* sc_snap = nullptr;
+    bool late_enabled = false, late_ok = false;
     long long flushed_hstep = -1;                          // hstep at the last whole-matrix deferred-Adam flush of a rank call (abi_rank.h)
     bool rank_ok = false;                                  // rank_x3.h: predict -> rank fused (aae_predict_topk / aae_decode_topk), abi_rank.h
     bool side_ordered = false;                             // ... or put its dV3 GEMM there: the side stream is in order behind that step's output layer
@@ -309,6 +314,11 @@ size_t layout(aae_model* m, char* base, bool dry) {
     m->losses = a.take(4, nullptr);
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
     m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
+    m->dh2s = Ten(); m->sc_snap = nullptr;
+    if (c.grad_mode == AAE_GRAD_FUSED) {        // the late join's operand copies (one row block: <= 16 kMB rows)
+        m->dh2s = a.mat(std::min(R, 16 * kMB), h + 1, m->ldh);
+        m->sc_snap = reinterpret_cast<OptScalars*>(a.take((sizeof(OptScalars) + 3) / sizeof(float), nullptr));
+    }
     return (a.off + 255) & ~(size_t)255;
 }
 
@@ -359,7 +369,25 @@ int join_deferred(aae_model* m, hipStream_t s) {
     //  launch by aae_step's path and behind it by an item slice's, so both marks are waited for when both are pending)
     if (m->opt_pending) HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
     if (m->pf_pending && (!m->opt_pending || m->pf_after_opt)) HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0));
-    m->opt_pending = m->pf_pending = false;
+    m->opt_pending = m->pf_pending = m->late_ok = false;
+    return AAE_OK;
+}
+
+// ... at the opening of a training step (ae_encode_impl): a pending deferred launch that reads its private operand copies
+// (late_ok) keeps running - only the prefetch enqueued in front of it is waited for; join_output_layer() below is its join
+int join_step_open(aae_model* m, hipStream_t s) {
+    if (!(m->opt_pending && m->late_ok && !m->pf_after_opt)) return join_deferred(m, s);
+    if (m->pf_pending) { HIPCHK(hipStreamWaitEvent(s, m->ev_pf, 0)); m->pf_pending = false; }
+    return AAE_OK;
+}
+
+// ... in front of the output layer (it reads and writes what the deferred launch of the step before does: dec.lin3 and
+// its Adam moments, the stored dL/dlogits tiles).  A prefetch started by THIS step stays pending: the side stream runs
+// it behind the launch waited for here.
+int join_output_layer(aae_model* m, hipStream_t s) {
+    if (!m->opt_pending) return AAE_OK;
+    HIPCHK(hipStreamWaitEvent(s, m->ev_opt, 0));
+    m->opt_pending = m->late_ok = false;
     return AAE_OK;
 }
 // behind work enqueued on the side stream: what join_deferred waits for

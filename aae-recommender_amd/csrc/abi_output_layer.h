@@ -17,6 +17,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     if (m->only_output_layer) { /* ACT_DH2 is the input */ }
     else if (m->use_chain) { if (!m->dec_hidden_done) TRY(chain_dec_hidden(m, true, B, s)); }
     else TRY(decoder_hidden_forward(m, true, mk2, mk3, B, s));
+    TRY(join_output_layer(m, s));       // a deferred launch of the step before that was left running at this step's opening (late join)
     const float gscale = m->grad_scale / ((float)B * (float)N);
     DropSpec d1 = make_drop(m, 0, true, mk2, nullptr, B, h, 2);
     DropSpec d2 = make_drop(m, 1, true, mk3, nullptr, B, h, 3);
@@ -83,6 +84,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             // in LDS and takes every (grid / nblk)-th tile (dec_fused.h); 8 launches of 1.5 tile rounds each (-> 2, plus an
             // 84 KB prologue per workgroup and launch) cost 8 x 26.5 us on a 12.5 k-item slice, one launch of 12.2 rounds
             // what the 100-row step's critical launch costs
+            // late join (abi_model.h): single row block on the emulated product - dec_crit_x3_kernel sets the deferred launch's
+            // dh2 and step scalars aside, dec_opt_x3_kernel reads the copies
+            static const bool no_opt_x3_l = getenv("AAE_NO_OPT_X3") != nullptr;
+            const bool late = m->late_enabled && nblk == 1 && m->x3_ok && !out_bf16(m) && !no_opt_x3_l && !want_ts &&
+                              m->dh2s.p && m->sc_snap && B <= m->dh2s.rows && grid >= B;
             const int wgs = nblk > 1 ? std::max(1, m->n_cu / nblk) : grid;
             const int crit_grid = nblk > 1 ? wgs * nblk : grid;
             n_loss_partials = crit_grid;
@@ -93,6 +99,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 // the timing pair's stop event doubles as that event.
                 DecFusedArgs b = fa;
                 b.nblk = nblk; b.Bb = Bb;
+                if (late) { b.dh2_snap = m->dh2s.p; b.sc_snap = m->sc_snap; }
                 const int grid = crit_grid;
                 const int r = nblk - 1;
                 hipEvent_t start = nullptr, stop = r == nblk - 1 ? m->ev_crit : nullptr;
@@ -125,6 +132,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 if (r == nblk - 1) HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
             }
             const int g2 = std::min(ntiles, std::min(m->split_wgs, m->n_cu));
+            bool late_launched = false;
             // nblk > 1 and at most kOBT tiles per workgroup on the chip: the deferred half of every block in ONE launch
             // (dec_opt_blocks_kernel), else one launch per block with the dV3 partial going through Gacc
             static const bool no_obk = getenv("AAE_NO_OPT_BLOCKS") != nullptr;
@@ -210,6 +218,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 } else if (r == 0 && nblk == 1 && m->x3_ok && !no_opt_x3) {
                     // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
                     const uint32_t lds3 = (uint32_t)dec_opt_x3_lds_bytes();
+                    if (late) { b.dh2 = m->dh2s.p; b.sc = m->sc_snap; late_launched = true; }
                     if (m->bf16_one) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
                     case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
@@ -233,6 +242,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             }
             TRY(side_done(m, m->ev_opt));
             m->opt_pending = true;
+            m->late_ok = late_launched;
             m->last_out_split = true; m->side_ordered = true;
             // an item slice's next batch (named ahead): its distinct items and their deferred-Adam catch-up behind the
             // deferred launch on the same stream (ordered behind this step's head by ev_crit; rows of the running batch

@@ -18,7 +18,8 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     TRY(set_batch(m, batch));
     remember_inject(m, inj, true);
     hipStream_t s = S(stream);
-    TRY(join_deferred(m, s));       // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2
+    TRY(join_step_open(m, s));      // the previous step's optimiser pass over DEC_V3 reads the step scalars and dh2 (or its
+                                    // own copies of them: it then runs on into this step's forward pass - late join)
     m->hstep++;
     // the list of this batch's distinct items and their catch-up were built while the previous step ran
     const bool ahead = m->pf_built && m->pf_step == m->hstep && same_batch(m->pf_built_batch, *batch) && m->lazy;

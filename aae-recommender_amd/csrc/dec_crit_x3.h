@@ -149,6 +149,14 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         load_range(tile + stride, fe0, fe1);
         load_entry(ne0);
     }
+    // ---- the deferred launch's operands, set aside (late join, abi_output_layer.h): it reads dh2 and the layer's step
+    // scalars when it starts, and the NEXT step's forward pass - which it may now overlap - rewrites both.  One row per
+    // workgroup (single row block only: the host passes NULL otherwise).
+    if (a.dh2_snap && (int)blockIdx.x < a.B) {
+        if (tid < a.ldh / 4)
+            reinterpret_cast<float4*>(a.dh2_snap + (size_t)blockIdx.x * a.ldh)[tid] = reinterpret_cast<const float4*>(a.dh2 + (size_t)blockIdx.x * a.ldh)[tid];
+        if (blockIdx.x == 0 && tid == kNT - 1) *a.sc_snap = *a.sc;
+    }
     // ---- once per workgroup: zero the images (k padding of v3K, rows >= B of gK, the target tile)
     for (int i = tid; i < 3 * kTI * S1 + 2 * kGR * kXRS + 3 * kGR * S3 + kGR * kXT; i += kNT) v3K[i] = 0u;
 

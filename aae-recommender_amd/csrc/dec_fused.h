@@ -85,6 +85,10 @@ struct DecFusedArgs {
     int tpp = 0;
     int one_term = 0;       // dec_crit_x3.h kernels: 1 = every operand keeps the FIRST term of its split only, i.e. is rounded to bf16
                             // (bf16 mode on the same kernels: bf16 operands, fp32 accumulation)                          // dec_opt_blocks_x3_kernel (dec_crit_x3.h): number of tile groups
+    // late join (abi_output_layer.h): dec_crit_x3_kernel copies dh2 and *sc here for the deferred launch, which then
+    // reads nothing the next step's forward pass rewrites (NULL: no copy)
+    float* dh2_snap = nullptr;
+    OptScalars* sc_snap = nullptr;
 };
 
 // MODE of dec_fused_kernel.  The step's critical path needs only dL/d(dh2) from this layer (the decoder's hidden

@@ -156,6 +156,53 @@ def test_split_output_layer_equals_the_single_launch_and_views_wait_for_the_defe
     np.testing.assert_allclose(split.predict(csr, 0, B).cpu().numpy(), single.predict(csr, 0, B).cpu().numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("N,h,B,dtype", [(100000, 200, 100, "f32"), (47000, 100, 100, "f32"), (47000, 100, 100, "bf16"), (20000, 200, 64, "f32")])
+def test_late_join_of_the_deferred_launch_changes_no_result(N, h, B, dtype, monkeypatch):
+    """Late join (csrc/abi_model.h: join_step_open / join_output_layer): the deferred optimiser launch of step t keeps running
+    while step t+1's forward pass goes on - it reads the copies of dh2 and of the layer's step scalars that step t's critical
+    launch set aside - and step t+1 waits for it in front of its own output layer.  Against a handle created with
+    AAE_NO_LATE_JOIN=1 (every step opens behind the deferred launch, as up to r3) on the same batches and device randomness:
+    the same arithmetic in the same order, so dec.lin3 and both Adam moments agree to the scatter-atomics bound of the test
+    above (2e-6; a deferred launch that read the NEXT step's dh2 or step scalars would be a whole Adam step, 1e-3, off) at
+    every step - views taken right behind a step, with the launch still running -, through batch-size changes, a predict
+    call between steps (it reads dec.lin3: joined inside) and the phase-wise entry points."""
+    from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC
+    from tools.synth import init_params, throughput_corpus
+    c, steps = 50, 10
+    params = init_params(N, h, c, seed=6)
+    X = throughput_corpus(steps * B, N, median_len=20, seed=31)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3, rng_mode="device", seed=5, **({"dtype": "bf16"} if dtype == "bf16" else {}))
+    late = HipAAE(N, h, c, max_batch=B, **kw)
+    monkeypatch.setenv("AAE_NO_LATE_JOIN", "1")
+    early = HipAAE(N, h, c, max_batch=B, **kw)
+    monkeypatch.delenv("AAE_NO_LATE_JOIN")
+    for m in (late, early):
+        m.load_params(params)
+    csr = DeviceCSR(X, late.device)
+    tids = (T_DEC_V3, T_ADAM_DEC + 4, T_ADAM_DEC + 5)
+    tol = 2e-6 if dtype == "f32" else 2e-5
+
+    def same(what):
+        for t in tids:
+            a, b = late.tensor(t, padded=True).clone(), early.tensor(t, padded=True).clone()
+            assert float((a - b).abs().max()) <= tol, (what, t)
+    for s in range(steps):
+        for m in (late, early):
+            m.step(csr, s * B, B)
+        if s in (0, 1, 4, steps - 1):
+            same(f"step {s}")
+        if s == 5:      # a call that reads dec.lin3 between two steps
+            np.testing.assert_allclose(late.predict(csr, 0, B).cpu().numpy(), early.predict(csr, 0, B).cpu().numpy(), atol=2e-6 if dtype == "f32" else 2e-4)
+    for s, rows in enumerate((37, B, 5, 64, B)):
+        for m in (late, early):
+            m.step(csr, s * B, min(rows, B))
+    same("ragged batches")
+    np.testing.assert_allclose(late.losses(), early.losses(), rtol=1e-5 if dtype == "f32" else 1e-3)
+    sa, sb = late.state_dict(), early.state_dict()
+    for k in sa:
+        np.testing.assert_allclose(sa[k], sb[k], atol=tol * (1 if dtype == "f32" else 50), err_msg=k)
+
+
 @pytest.mark.parametrize("Ns,B,h", [(12500, 105, 200), (12500, 800, 200), (25000, 512, 200), (4587, 1000, 200), (50000, 200, 200), (275000, 512, 200),
                                     (6000, 300, 50), (9000, 230, 100), (40000, 512, 100), (3000, 130, 61)])
 def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, h, monkeypatch):
