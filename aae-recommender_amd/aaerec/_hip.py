@@ -425,10 +425,10 @@ class HipAAE:
             raise ValueError("dtype must be 'f32' or 'bf16'")
         cfg.dtype = DTYPE_BF16 if dtype == "bf16" else DTYPE_F32
         # batches beyond one fused launch's 112 rows as row-blocked launches of the fused output layer (up to 1664 rows;
-        # DESIGN.md 3.2e) instead of the three-kernel path.  Built for the item slices of the vocabulary-sharded scheme
-        # (VERDICT r1 item 3), measured SLOWER than the three GEMMs there (0.50 -> 0.87 ms of per-rank compute at world
-        # 8): opt-in, off everywhere by default
-        cfg.blocked_output = 1 if (blocked_output and dtype == "f32" and grad_mode != "export") else 0
+        # DESIGN.md 3.1) instead of the three streaming GEMMs: what fit() asks for at such batch sizes and the item
+        # slices of the sharded schemes always.  Both dtypes since late r4 (bf16 on the rounded-operand form of the same
+        # kernels: C3's shape at batch 512 1.01 -> 0.56 ms/step, C4 0.50 -> 0.40)
+        cfg.blocked_output = 1 if (blocked_output and grad_mode != "export") else 0
         # DenoisingAutoEncoder(corrupt='gauss'): room for the dense noisy encoder input (set_input_noise before a step)
         cfg.dense_noise = 1 if dense_noise else 0
         self.dtype = dtype

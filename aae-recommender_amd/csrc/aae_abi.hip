@@ -203,14 +203,25 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             m->bf16_x3 = m->x3_ok && ok && getenv("AAE_NO_OPT_X3") == nullptr;
             if (!m->bf16_x3) m->x3_ok = false;
             else m->split_ok = true;
-            // (measured again in r4 and NOT the default: both launches get faster - critical 35 -> 26 us, deferred 85 -> 73 us at
-            //  C2 - and the step SLOWER, 0.172 -> 0.184 ms: the earlier, shorter deferred launch is dispatched in front of the
-            //  ae phase's chain program (a 14 us hole on the main stream) and the weight-gradient launch beside it takes 32 us
-            //  instead of 11; no deferred width between 32 and 96 workgroups recovers it - profiles/r4_c2_bf16_one_term.txt)
-            m->bf16_one = m->bf16_x3 && getenv("AAE_BF16_ONE") != nullptr
+            // The one-term instantiations (first terms only, ONE matrix instruction per product; AAE_NO_BF16_ONE: the three-term
+            // kernels multiplying five zero terms).  Both launches get faster - critical 35 -> 27 us, deferred 85 -> 74 us at C2 -
+            // and for most of r4 the STEP got slower, 0.173 -> 0.186 ms (profiles/r4_c2_bf16_one_term.txt): the one-term deferred
+            // kernel needs 78 VGPRs instead of 126, so six of its waves fit a SIMD, its 1024-thread workgroup no longer fills
+            // its CU, and the dispatcher deals the step's own weight-gradient / gather workgroups onto the CUs where it streams
+            // 24 B per parameter (the weight-gradient launch beside it: 32 us instead of 11).  Its launch now claims 150 KB of
+            // LDS (abi_output_layer.h), which no other workgroup of the step fits beside: 0.1648 ms at the old width, 0.162-0.164
+            // on 48-64 workgroups (tools/debug/bf16_one_sweep.sh; a claim of 120 KB leaves the 24 KB weight-gradient workgroups
+            // in: 0.1865).
+            m->bf16_one = m->bf16_x3 && getenv("AAE_NO_BF16_ONE") == nullptr
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             (void)hipGetLastError();
         }
         if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
@@ -222,9 +233,9 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             // 0.2651-0.2655, 160 -> 0.2683, 176 -> 0.282; C2 (1469 tiles, 100) 64 -> 0.1806, 80 -> 0.1710, 96 -> 0.1721,
             // 128 -> 0.177, 160 -> 0.185.
             const int ntiles = (m->N + 31) / 32;
-            const double t_tile = 3.3 + 0.0131 * m->h;
-            int w = (int)(ntiles * t_tile / 82.0 / 8.0 + 0.5) * 8;
-            w = std::max(w, std::min(ntiles, 64));
+            const double t_tile = (3.3 + 0.0131 * m->h) * (m->bf16_one ? 0.87 : 1.0);     // (one-term products: 4.0 us at 100)
+            int w = (int)(ntiles * t_tile / (m->bf16_one ? 165.0 : 82.0) / 8.0 + 0.5) * 8;      // (C3's shape in bf16: 0.2230 / 0.2264 / 0.2317 / 0.2374 ms on 96 / 112 / 128 / 144)
+            w = std::max(w, std::min(ntiles, m->bf16_one ? 48 : 64));
             // r4, late join (abi_model.h: the launch may run on into the next step's forward pass, so it need not end with the
             // step): half the chip at most - C3 0.2493 (early join, 144) -> 0.2430 ms/step on 128; 0.2515 / 0.2483 / 0.2497 /
             // 0.2492 on 112 / 120 / 136 / 144 (sharp: 124 -> 0.2459, 132 -> 0.2503); the early join on 128: 0.2608.  C2 (formula:

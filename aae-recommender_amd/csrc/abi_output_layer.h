@@ -217,7 +217,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                 } else if (r == 0 && nblk == 1 && m->x3_ok && !no_opt_x3) {
                     // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
-                    const uint32_t lds3 = (uint32_t)dec_opt_x3_lds_bytes();
+                    // (one-term instantiation: 78 VGPRs - six of its waves fit a SIMD, so the step's own launches would be dealt onto
+                    //  its CUs and run beside its streams; its LDS claim is raised until no other workgroup of the step fits there)
+                    static const int lds_kb = getenv("AAE_OPT_LDS_KB") ? atoi(getenv("AAE_OPT_LDS_KB")) : -1;
+                    const uint32_t lds_nat = (uint32_t)dec_opt_x3_lds_bytes();
+                    const uint32_t lds3 = lds_kb > 0 ? std::max(lds_nat, (uint32_t)lds_kb * 1024u) : (m->bf16_one ? std::max(lds_nat, 150u * 1024u) : lds_nat);
                     if (late) { b.dh2 = m->dh2s.p; b.sc = m->sc_snap; late_launched = true; }
                     if (m->bf16_one) switch (m->fused_nb) {
                     case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
