@@ -64,7 +64,7 @@ inline size_t dec_crit_x3_lds_bytes(int NB) {
     const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1), S3 = x3_stride(1);
     const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
     return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kXRS + (size_t)3 * kGR * S3 + (size_t)kGR * kXT + 64 +
-                            (size_t)lsteps * kMB * 3 * 64 * 4);
+                            (size_t)lsteps * kMB * 3 * 64 * 4 + (lsteps ? (size_t)2 * kMB * 64 * 4 : 0));
 }
 
 // TS: the debug build with in-kernel stamps (AAE_DEC_TS=x3).  The production build carries none: every stamp site is a lane
@@ -91,6 +91,11 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     float* tgt = reinterpret_cast<float*>(gK + 3 * kGR * S3);  // [kGR][kXT]   non-zero BCE targets of the tile (else 0)
     float* red = tgt + kGR * kXT;                              // [64]
     u32x4_t* dAl = reinterpret_cast<u32x4_t*>(red + 64);        // [kMB][NKL][3][64] spilled-by-design dh2 fragments (k half 0 only)
+    // (late r4) ... and, where a k-step lives there, the THIRD term of the last register step of both k halves [2][kMB][64]:
+    // with the next tile's S0 in the GEMM3 phase the allocator was 4 registers short and chose a dh2 fragment to keep in
+    // scratch memory - this is the same choice with an LDS read instead of a scratch reload
+    constexpr bool XT = NKL > 0 && !ONE;
+    u32x4_t* dAx = dAl + kMB * NKL * 3 * 64;
 
     // row blocks of one launch (item slices of the data-parallel scheme, dec_fused.h): this workgroup's block and tiles
     const int nblk = a.nblk > 1 ? a.nblk : 1;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         load_span(tile, vreg);
         load_range(tile, ne0, ne1);
         load_range(tile + stride, fe0, fe1);
+        ne0 = __builtin_amdgcn_readfirstlane(ne0); ne1 = __builtin_amdgcn_readfirstlane(ne1);
         load_entry(ne0);
     }
     // ---- the deferred launch's operands, set aside (late join, abi_output_layer.h): it reads dh2 and the layer's step
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const u32x4_t v = {p[t][0], p[t][1], p[t][2], p[t][3]};
-                if (j < NKR) dA[j < NKR ? j : 0][t] = __builtin_bit_cast(bf16x8, v);
+                if (XT && j == NKR - 1 && t == 2) { if (g1) dAx[(kh * kMB + mb1) * 64 + lane] = v; }
+                else if (j < NKR) dA[j < NKR ? j : 0][t] = __builtin_bit_cast(bf16x8, v);
                 else if (g1 && kh == 0) dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane] = v;
             }
         }
@@ -212,6 +219,45 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     auto stamp = [&](int k) { if (TS && a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
     __syncthreads();
 
+    // ---- S0 of tile X: its V3a (in vreg, requested a tile ahead) -> the three bf16 images; its CSR entries -> tgt; the
+    // requests for the tile after it.  Since late r4 it runs in the phase of the PREVIOUS tile's GEMM3 (below): that product's
+    // only reads of v3K are one transposed fragment set per wave, taken in front of BCE - behind the barrier that closes BCE
+    // the images, like tgt, belong to the next tile.  One barrier and the S0 phase less per tile.
+    auto stage = [&](int X) {
+        const int x0 = X * kTI;
+        const bool ragged = x0 + kTI > N;       // (uniform) only the vocabulary's last tile has rows beyond N
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (tid + kNT * j < tile_f4) {
+                float4 p = vreg[j];
+                int src;                                // (opaque copy: what is derived from it is recomputed here, not hoisted
+                asm volatile("v_mov_b32 %0, %1" : "=v"(src) : "v"(s_rc[j]));     //  out of the tile loop and spilled)
+                if (ragged && x0 + (src >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned q0[3], q1[3];
+                split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
+                split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
+                unsigned* d = v3K + (src >> 6) * S1 + 2 * (src & 63);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
+            }
+        }
+        // (the ranges are workgroup-uniform values that arrive through vector loads: the pair requested a whole tile ago moves
+        //  to scalar registers here - two VGPRs less across the tile loop)
+        ce0 = ne0; ce1 = ne1; ne0 = __builtin_amdgcn_readfirstlane(fe0); ne1 = __builtin_amdgcn_readfirstlane(fe1);
+        {
+            const int rb = (ent_bn >> 5) - erow0;       // (row-blocked launches: entries of other row blocks are not ours)
+            if (tid < ce1 - ce0 && (unsigned)rb < (unsigned)B) tgt[rb * kXT + (ent_bn & 31)] = ent_v;
+            for (int e = ce0 + kNT + tid; e < ce1; e += kNT) {      // tiles with more than 1024 entries (tiny vocabularies)
+                const int r2 = a.te.eb[e] - erow0;
+                if ((unsigned)r2 < (unsigned)B) tgt[r2 * kXT + a.te.en[e]] = a.te.ev[e];
+            }
+        }
+        load_range(X + 2 * stride, fe0, fe1);
+        load_entry(ne0);
+    };
+    if (tile < ntiles) stage(tile);
+    lds_barrier();
+
     for (; tile < ntiles; tile += stride, ++iter) {
         const int i0 = tile * kTI;
         // A zero the compiler cannot see through: the LDS operand addresses of the phases are built from it, so they are
@@ -221,36 +267,10 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         int oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
         const int frz = fr + oz, fkz = fk + oz;
+        int lanez;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lanez) : "v"(lane));
         stamp(0);
-        lds_barrier();                          // the previous tile's readers of v3K (GEMM3) are done
         stamp(14);
-        // ---- S0: this tile's V3a -> the three bf16 images; its CSR entries -> tgt; request the next stage
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            if (tid + kNT * j < tile_f4) {
-                float4 p = vreg[j];
-                if (i0 + (s_rc[j] >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
-                unsigned q0[3], q1[3];
-                split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
-                split3_pair(p.z, p.w, q1[0], q1[1], q1[2], one);
-                unsigned* d = v3K + (s_rc[j] >> 6) * S1 + 2 * (s_rc[j] & 63);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) *reinterpret_cast<uint2*>(d + t * (kTI * S1)) = make_uint2(q0[t], q1[t]);
-            }
-        }
-        ce0 = ne0; ce1 = ne1; ne0 = fe0; ne1 = fe1;
-        {
-            const int rb = (ent_bn >> 5) - erow0;       // (row-blocked launches: entries of other row blocks are not ours)
-            if (tid < ce1 - ce0 && (unsigned)rb < (unsigned)B) tgt[rb * kXT + (ent_bn & 31)] = ent_v;
-            for (int e = ce0 + kNT + tid; e < ce1; e += kNT) {      // tiles with more than 1024 entries (tiny vocabularies)
-                const int r2 = a.te.eb[e] - erow0;
-                if ((unsigned)r2 < (unsigned)B) tgt[r2 * kXT + a.te.en[e]] = a.te.ev[e];
-            }
-        }
-        load_span(min(tile + stride, ntiles - 1), vreg);
-        load_range(tile + 2 * stride, fe0, fe1);
-        load_entry(ne0);
-        lds_barrier();
         stamp(1);
 
         // ---- GEMM1: logits of the wave's row block x both item halves over its k-steps -> its half's raw tile
@@ -265,11 +285,15 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                         bf16x8 bb[3];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
-                        if (j < NKR) c = mfma_xt<ONE>(dA[j < NKR ? j : 0], bb, c);
+                        if (XT && j == NKR - 1) {
+                            bf16x8 aa[3] = {dA[j < NKR ? j : 0][0], dA[j < NKR ? j : 0][1],
+                                            __builtin_bit_cast(bf16x8, dAx[(kh * kMB + mb1) * 64 + lanez])};
+                            c = mfma_xt<ONE>(aa, bb, c);
+                        } else if (j < NKR) c = mfma_xt<ONE>(dA[j < NKR ? j : 0], bb, c);
                         else {
                             bf16x8 al[3];
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lane + oz]);
+                            for (int t = 0; t < NT; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lanez]);
                             c = mfma_xt<ONE>(al, bb, c);
                         }
                     }
@@ -277,6 +301,9 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
             }
         }
+        // the next tile's V3a: requested HERE, behind the phase with the most live registers (its 8 would be the ones that
+        // spill), BCE and GEMM3 ahead of its use in stage() - ~2 us, an HBM round trip
+        load_span(min(tile + stride, ntiles - 1), vreg);
         lds_barrier();
         stamp(2);
 
@@ -309,29 +336,31 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 for (int t = 0; t < NT; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
             }
         }
+        // ---- GEMM3's B operand (dA2[b][c] += sum_n G[b][n] V3a[n][c]; wave w < NB owns column block w for every row block):
+        // the transpose of 2 x (4 items x 16 columns) of the v3K rows per term - ds_read_b64_tr_b16, lane 4 q + p of a 16-lane
+        // group names row q, columns 4 p .. 4 p + 3 of its block.  Read HERE, behind BCE's own work and in front of the barrier that closes
+        // it: from that barrier on the images are the next tile's.
+        bf16x8 vt[3];
+        if (own) {
+            const int lz = lane + oz, q = (lz >> 2) & 3, p = lz & 3;
+            const unsigned* base = v3K + (8 * fkz + q) * S1 + 8 * cb + 2 * p;        // (16 cb + 4 p) bf16 = 8 cb + 2 p dwords
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1)));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1) + 4 * S1));
+                typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                vt[t] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
         lds_barrier();
         stamp(3);
 
-        // ---- GEMM3: dA2[b][c] += sum_n G[b][n] V3a[n][c] for the wave's column block, every row block.  k-order of a
-        // fragment (both operands): element j = item 8 fk + j - what x3_frag reads from the gK rows; the B operand's fragment is
-        // the transpose of 2 x (4 items x 16 columns) of the v3K rows: ds_read_b64_tr_b16, lane 4 q + p of a 16-lane group
-        // names row q, columns 4 p .. 4 p + 3 of its block
+        // ---- GEMM3 of this tile and the next tile's S0 (its images, its targets, the requests behind it) in one phase.
+        // k-order of a fragment (both operands): element j = item 8 fk + j - what x3_frag reads from the gK rows
         if (own) {
-            bf16x8 vt[3];
-            {
-                const int lz = lane + oz, q = (lz >> 2) & 3, p = lz & 3;
-                const unsigned* base = v3K + (8 * fkz + q) * S1 + 8 * cb + 2 * p;        // (16 cb + 4 p) bf16 = 8 cb + 2 p dwords
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1)));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4_t __attribute__((address_space(3)))*)(base + t * (kTI * S1) + 4 * S1));
-                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-                    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    vt[t] = __builtin_bit_cast(bf16x8, v);
-                }
-            }
 #pragma unroll
             for (int q = 0; q < kMB; ++q) {     // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
                 bf16x8 ga[3];
@@ -340,7 +369,12 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 acc3[q] = mfma_xt<ONE>(ga, vt, acc3[q]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(tile + stride);
         stamp(4);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();                          // gK's readers are done; the next tile's images and targets are in place
+        __builtin_amdgcn_sched_barrier(0);
         stamp(5);
         stamp(6);
     }
