@@ -64,7 +64,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // (AAE_DEC_TS: the timeline of the single launch - or, AAE_DEC_TS=x3, of the split form's critical launch dec_crit_x3.h)
         static const bool ts_x3 = want_ts && strcmp(getenv("AAE_DEC_TS"), "x3") == 0;
         static const bool ts_obk = want_ts && strcmp(getenv("AAE_DEC_TS"), "obk") == 0;
-        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !out_bf16(m))) && (fa.dbg_skip & ~(256 | 0xF000)) == 0) {
+        if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !out_bf16(m))) && (fa.dbg_skip & ~(256 | 0xF000 | 0x30000)) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
             // partials and stored dL/dlogits tiles of its own), then per row block one deferred launch that adds its dV3

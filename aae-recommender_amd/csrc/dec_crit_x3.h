@@ -443,6 +443,12 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
     const OptScalars sc = *a.sc;
     const bool do_adam = a.gradV3 == nullptr;
     typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
+    if (a.dbg_skip & 0x10000) return;           // (TIMING ONLY, AAE_DEC_SKIP=65536: the step without its deferred launch's traffic)
+    if (a.dbg_skip & 0x20000) {                 // (TIMING ONLY, 131072: its CUs held for 135 us without any memory traffic)
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 13500ull) __builtin_amdgcn_s_sleep(32);
+        return;
+    }
 
     for (int i = tid; i < 3 * 128 * kXGS; i += kNT) gB[i] = 0u;
 
