@@ -123,6 +123,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         }
     }
     m->late_enabled = getenv("AAE_NO_LATE_JOIN") == nullptr;
+    m->early_enabled = getenv("AAE_NO_EARLY_PREFETCH") == nullptr;
+    m->early_any = getenv("AAE_EARLY_ANY") != nullptr;        // (tests: the early prefetch at every batch size)
     m->rank_ok = m->fused_ok && m->use_chain4 && !m->vae && getenv("AAE_NO_RANK_FUSED") == nullptr && rank_set_attributes();
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(int) * w1_items_lds_words(16384))) == hipSuccess;
@@ -153,7 +155,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                   hipEventCreateWithFlags(&m->ev_opt, evflags) == hipSuccess &&
                   hipEventCreateWithFlags(&m->ev_head, evflags) == hipSuccess &&
                   hipEventCreateWithFlags(&m->ev_pf, evflags) == hipSuccess &&
-                  hipEventCreateWithFlags(&m->ev_bk, evflags) == hipSuccess;
+                  hipEventCreateWithFlags(&m->ev_bk, evflags) == hipSuccess &&
+                  hipEventCreateWithFlags(&m->ev_end, evflags) == hipSuccess;
         if (!side_ok) {
             if (m->side) (void)hipStreamDestroy(m->side);
             m->side = nullptr;
@@ -278,6 +281,7 @@ int aae_destroy(aae_handle h) {
     if (h->ev_head) (void)hipEventDestroy(h->ev_head);
     if (h->ev_pf) (void)hipEventDestroy(h->ev_pf);
     if (h->ev_bk) (void)hipEventDestroy(h->ev_bk);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->prof_ev) {
         for (int k = 0; k < AAE_K_N; ++k)
             for (auto& pr : h->prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -385,6 +389,7 @@ int aae_set_lr(aae_handle h, double gen_lr, double reg_lr) {
     HIPCHK(hipMemcpy(hs, h->sc, sizeof(hs), hipMemcpyDeviceToHost));
     hs[O_ENC].lr = gen_lr; hs[O_DEC].lr = gen_lr; hs[O_GEN].lr = reg_lr; hs[O_DISC].lr = reg_lr;
     HIPCHK(hipMemcpy(h->sc, hs, sizeof(hs), hipMemcpyHostToDevice));
+    h->spec_tab_ok = false;             // (the table entry written a step early was computed with the old rates)
     return AAE_OK;
 }
 

@@ -231,9 +231,13 @@ struct DwBuilder {
         }
         return AAE_OK;
     }
-    int launch(hipStream_t s) {
+    // (done: an event riding on the launch's completion - only taken when nothing of this builder follows the launch)
+    int launch(hipStream_t s, hipEvent_t done = nullptr, bool* marked = nullptr) {
         int blocks = tiles;
         if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
+        if (marked) *marked = done && !mh;
+        if (done && !mh) hipExtLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g);
+        else
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
         if (mh) TRY(launch_w1_hot(mh, s));
@@ -526,9 +530,11 @@ static bool same_batch(const aae_batch& a, const aae_batch& b) {
 // aae_prefetch_batch, second half: the hinted batch's unique-item list + deferred-Adam catch-up (through the RUNNING
 // step, whose scalars advance_step has published by the time ev_head fires) on the side stream, into the second list
 // set.  Rows of the running batch are skipped: the step's own updates bring them to the same step.
-int launch_prefetch(aae_model* m, bool wait_head = true) {
+// (early: behind the mark on the step BEFORE this one - ev_end - instead of on this step's opening gather)
+int launch_prefetch(aae_model* m, bool wait_head = true, bool early = false) {
     const aae_batch& b = m->pf_batch;
     m->pf_armed = false;
+    m->pf_this_step = true;
     m->pf_after_opt = !wait_head;
     if (!m->side || !m->mark2 || !m->lazy) return AAE_OK;
     BatchView bv; bv.indptr = b.indptr_dev; bv.indices = b.indices_dev; bv.values = b.values_dev;
@@ -537,15 +543,16 @@ int launch_prefetch(aae_model* m, bool wait_head = true) {
     const int chunks = std::max(1, std::min(64, (mr + 15) / 16));
     const int gy = std::max(1, std::min(16, chunks / 16 + 1));
     hipStream_t q = m->side;
-    if (wait_head) HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));      // (else: the caller enqueues behind work that is ordered behind the step's head)
-    if (!(wait_head && m->pf_bumped)) hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
+    if (early) HIPCHK(hipStreamWaitEvent(q, m->ev_end, 0));
+    else if (wait_head) HIPCHK(hipStreamWaitEvent(q, m->ev_head, 0));      // (else: the caller enqueues behind work that is ordered behind the step's head)
+    if (early || !(wait_head && m->pf_bumped)) hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, q, m->stamp2, m->ucount2);
     m->pf_bumped = false;
     hipLaunchKernelGGL(uniq_items_kernel, dim3(b.n_rows, gy), dim3(256), 0, q, bv, m->mark2, m->stamp2, m->ulist2, m->ucount2);
     if (m->cfg.optimizer == AAE_OPT_ADAM) {
         const int grid = std::min(m->cfg.max_nnz, std::max(256, b.n_rows * 32));
         hipLaunchKernelGGL(w1_catchup_kernel, dim3(grid), dim3(256), 0, q, m->ulist2, m->ucount2, m->N, m->tsync,
                            m->P[P_W1T].p, m->M[0][P_W1T].p, m->V[0][P_W1T].p, m->M[1][P_W1T].p, m->V[1][P_W1T].p,
-                           m->ldw1, m->h, m->tab, m->step_ctr, 0, m->mark, m->stamp);
+                           m->ldw1, m->h, m->tab, m->step_ctr, 0, m->mark, m->stamp, early ? m->hstep : -1ll);
     }
     LAUNCHCHK("prefetch (unique items + catch-up of the next batch)");
     TRY(side_done(m, m->ev_pf));
@@ -747,7 +754,13 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
     TRY(dw.add_first_layer(m, ga1_ptr(m), O_GEN, s));
-    TRY(dw.launch(s));
+    // the step's last launch when the first layer's update rode in it: the side stream's mark for the NEXT step's early
+    // prefetch rides on its completion (only while batches are being named ahead: a mark nobody waits for costs ~2 us)
+    const bool mark_end = m->early_enabled && m->pf_this_step && m->w1_items_merged && !m->ext_first && m->side && m->ev_end &&
+                          (m->rows > 16 * kMB || m->early_any);
+    bool marked = false;
+    TRY(dw.launch(s, mark_end ? m->ev_end : nullptr, &marked));
+    m->end_marked = marked;
     if (m->ext_first && !m->own_first) return AAE_OK;           // dL/d(a1) waits in AAE_T_ACT_GA1 for the owner(s) of the first layer
     return encoder_first_layer_update(m, m->gb3.p, O_GEN, s, true);
 }

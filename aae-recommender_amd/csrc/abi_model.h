@@ -130,6 +130,11 @@ struct aae_model {
     // t+1's output layer (aae_ae_decode_backward) instead of at the step's opening.  late_ok = the pending launch is one.
     Ten dh2s; OptScalars* sc_snap = nullptr;
     bool late_enabled = false, late_ok = false;
+    // Early prefetch (abi_chains.h: launch_prefetch): the side stream's mark rides on the completion of the step's LAST launch
+    // (a signal in front of the next step's wait costs ~2 us, on the opening gather in front of a kernel 5-6) and the next
+    // batch's list + catch-up start beside the opening gather.  end_marked: the step before carried the mark; spec_tab_ok: the
+    // optimiser table's entry of the coming step was written a step early and no host call has touched the scalars since
+    hipEvent_t ev_end = nullptr; bool end_marked = false, spec_tab_ok = false, pf_this_step = false, early_enabled = false, early_any = false;
     long long flushed_hstep = -1;                          // hstep at the last whole-matrix deferred-Adam flush of a rank call (abi_rank.h)
     bool rank_ok = false;                                  // rank_x3.h: predict -> rank fused (aae_predict_topk / aae_decode_topk), abi_rank.h
     bool side_ordered = false;                             // ... or put its dV3 GEMM there: the side stream is in order behind that step's output layer

@@ -103,6 +103,7 @@ int aae_load_adam(aae_handle h, int which, int layer, const float* m_w, const fl
         HIPCHK(hipMemcpy(&hs, h->sc + which, sizeof(hs), hipMemcpyDeviceToHost));
         hs.t = step;
         HIPCHK(hipMemcpy(h->sc + which, &hs, sizeof(hs), hipMemcpyHostToDevice));
+        h->spec_tab_ok = false;
         if (which == O_ENC || which == O_GEN) {
             // enc_optim and gen_optim step together; the rng/lazy step counter follows them
             long long t = step;

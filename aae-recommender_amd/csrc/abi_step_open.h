@@ -24,6 +24,8 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     // the list of this batch's distinct items and their catch-up were built while the previous step ran
     const bool ahead = m->pf_built && m->pf_step == m->hstep && same_batch(m->pf_built_batch, *batch) && m->lazy;
     m->pf_built = false;
+    const bool end_marked = m->end_marked, spec_ok = m->spec_tab_ok;      // (of the step before; this step's advance renews the table entry)
+    m->end_marked = false; m->pf_this_step = false; m->spec_tab_ok = m->lazy;
     if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
     // With the batch's list built ahead nothing sits between the step-opening bookkeeping and the first gather: it rides
     // in that launch (one launch floor, ~4.5 us, less per step)
@@ -96,8 +98,14 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     const bool pf = m->pf_armed && m->side && m->mark2 && m->lazy && m->use_chain;
     if (m->pf_armed && !pf) m->pf_armed = false;
     if (m->use_chain) {
-        TRY(gather_first_layer(m, true, m->inj.masks_dev[0], 0, s, pf, fold_advance));
-        if (pf) TRY(launch_prefetch(m));
+        // early prefetch (abi_model.h): marked by the step before, this batch's own lists in place (the catch-up skips its rows
+        // by them), the table entry of this step written a step early and untouched since
+        // (wide batches only: at 100 rows the 3 200 small workgroups of the catch-up, started this early, sit on the CUs the forward
+        //  chain's 25 workgroups need whole - C3 0.2386 -> 0.2420 ms/step; C4, 1 000 rows: 0.3932 -> 0.3826; AAE_EARLY_ANY: tests)
+        const bool early = pf && ahead && end_marked && spec_ok && m->early_enabled && (m->rows > 16 * kMB || m->early_any);
+        if (early) TRY(launch_prefetch(m, true, true));
+        TRY(gather_first_layer(m, true, m->inj.masks_dev[0], 0, s, pf && !early, fold_advance));
+        if (pf && !early) TRY(launch_prefetch(m));
         TRY(chain_ae_forward(m, with_dec, cond_dev, z_out, s));
         m->phase = 1;
         return AAE_OK;

@@ -41,6 +41,17 @@ __device__ __forceinline__ void advance_step_body(OptScalars* sc, long long* ctr
         const int slot = (int)(s.t & (kLazyTabCap - 1));
         if (i == 0) { tab[slot].nss_gen = s.neg_step_size; tab[slot].ibc2 = s.inv_bc2_sqrt; }
         if (i == 2) tab[slot].nss_reg = s.neg_step_size;
+        // ... and the entry of the step AFTER this one, one step early (the same expressions at t + 1: the next call writes the
+        // same bits again): the next batch's catch-up may then start before that step's own bookkeeping has run
+        // (launch_prefetch, early).  A learning rate changed from the host in between makes it stale: the host falls back.
+        float nss1 = (float)(-s.lr), ib1 = 1.f;
+        if (!s.is_sgd) {
+            const double b1n = 1.0 - pow(0.9, (double)(s.t + 1)), b2n = 1.0 - pow(0.999, (double)(s.t + 1));
+            nss1 = (float)(-(s.lr / b1n)); ib1 = (float)(1.0 / sqrt(b2n));
+        }
+        const int slot1 = (int)((s.t + 1) & (kLazyTabCap - 1));
+        if (i == 0) { tab[slot1].nss_gen = nss1; tab[slot1].ibc2 = ib1; }
+        if (i == 2) tab[slot1].nss_reg = nss1;
     }
 }
 
@@ -586,9 +597,10 @@ __global__ __launch_bounds__(256) void w1_catchup_kernel(const int* __restrict__
                                                          float* __restrict__ V3, int ld, int h,
                                                          const LazyTab* __restrict__ tab, const long long* step_ctr,
                                                          int upto_off, const int* __restrict__ skip_mark = nullptr,
-                                                         const int* __restrict__ skip_stamp = nullptr) {
+                                                         const int* __restrict__ skip_stamp = nullptr, long long upto_abs = -1) {
+    // (upto_abs >= 0: the step number from the host - the early prefetch runs beside the launch that advances *step_ctr)
     __shared__ LazyTab stab[kLazyReplay];
-    const int upto = (int)*step_ctr + upto_off;
+    const int upto = upto_abs >= 0 ? (int)upto_abs : (int)*step_ctr + upto_off;
     const int cnt = ulist ? *ucount : n_rows_all;
     // skip_mark (the prefetch of the NEXT batch's rows while a step runs): rows of the RUNNING batch are left alone -
     // the step's own two updates bring them to `upto`

@@ -144,14 +144,20 @@ def test_abi_rejects_bad_calls():
         m.step(csr, 0, fx.cfg["B"] + 1)    # more rows than max_batch
 
 
-@pytest.mark.parametrize("prefetch", [False, True])
-def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps(prefetch):
+@pytest.mark.parametrize("prefetch", [False, True, "early"])
+def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps(prefetch, monkeypatch):
     """The lazy W1T optimiser (rows of absent items are updated when next read, replay truncated
     after 128 steps) against the oracle's eager dense Adam: 260 steps over a 900-item vocabulary
     where most items are seen only a few times, so gaps of 0..250 steps all occur.
     prefetch: every batch is named one step ahead (aae_prefetch_batch: its unique-item list and catch-up are built on
     the side stream while the step before it runs) - except that every 7th hint is left out and every 11th names a
-    batch that does not come (both must fall back to the step's own catch-up)."""
+    batch that does not come (both must fall back to the step's own catch-up).
+    'early' (late r4): the same with the early form of the prefetch forced onto this batch size (AAE_EARLY_ANY; the library
+    takes it for batches beyond one fused launch): the side stream's mark rides on the LAST launch of the step before, the
+    catch-up runs beside the step's opening gather on the optimiser-table entry written a step early and the step number from
+    the host - and falls back to the mark on the gather after every missing or wrong hint."""
+    if prefetch == "early":
+        monkeypatch.setenv("AAE_EARLY_ANY", "1")
     from aaerec._hip import HipAAE, DeviceCSR
     from oracle import aae_oracle as O
     from oracle.dense_torch_port import init_params
