@@ -506,6 +506,19 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
     DropSpec d1 = make_drop(m, 0, train, mk1, nullptr, B, h, sid1);
     ProfScope ps(m, AAE_K_ENC_GATHER, s);
     size_t shm = (size_t)16 * r4(h) * sizeof(float);
+    // wide batches: four waves per document (eight documents per CU instead of two; a document is ~20 entries: five per wave).
+    // ms/step, 16 | 4 waves: C3 at batch 512 0.651 | 0.646, C4 (1 000 rows) 0.389 | 0.381; C2's shape at batch 500 0.327 | 0.331,
+    // C3 at batch 100 0.239 | 0.251 (tools/debug/gather4_ab.sh)
+    static const int g4_rows = getenv("AAE_GATHER4_ROWS") ? atoi(getenv("AAE_GATHER4_ROWS")) : 512;
+    if (B >= g4_rows) {
+        hipExtLaunchKernelGGL(enc_gather_kernel_t<4>, dim3(B), dim3(256), (uint32_t)(shm / 4), s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
+                              (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
+                              m->a1.p, m->eh1.p, m->ldh, (int)m->cfg.activation, d1, (uint64_t)m->cfg.seed,
+                              (const long long*)m->step_ctr, m->rscale, m->doc_l1,
+                              AdvanceJob{m->sc, m->step_ctr, m->lazy ? m->tab : nullptr, m->losses, open_step ? 1 : 0,
+                                         head ? m->stamp2 : nullptr, head ? m->ucount2 : nullptr},
+                              (long long)(open_step ? m->hstep : -1));
+    } else
     hipExtLaunchKernelGGL(enc_gather_kernel, dim3(B), dim3(1024), (uint32_t)shm, s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
                           (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
                           m->a1.p, m->eh1.p, m->ldh, (int)m->cfg.activation, d1, (uint64_t)m->cfg.seed,

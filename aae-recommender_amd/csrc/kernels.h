@@ -63,7 +63,8 @@ __device__ __forceinline__ void advance_step_body(OptScalars* sc, long long* ctr
 // dependent HBM round trip deep), each lane a float4 of the 800-byte (h=200) weight row, partial
 // sums meet in LDS.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const float* __restrict__ W1T, int ldw,
+template <int NW>      // waves per document: 16, or 4 for wide batches (late r4: eight documents per CU instead of two)
+__global__ __launch_bounds__(64 * NW) void enc_gather_kernel_t(BatchView bv, const float* __restrict__ W1T, int ldw,
                                                          const float* __restrict__ b1, int h, int normalize,
                                                          float* __restrict__ a1, float* __restrict__ y, int ld,
                                                          int act, DropSpec d, uint64_t seed, const long long* step_ctr,
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
     // from step_val (the host's count of opened steps = what *step_ctr holds once the step is open), not from memory
     // doc_l1 != NULL: the L1 norms of the COMPLETE documents, indexed by document (the batch holds only the columns of one
     // item slice of them, aae_set_doc_l1); b1 == NULL: no bias (a partial sum that meets the other slices' elsewhere)
-    extern __shared__ __attribute__((aligned(16))) float part[];   // [16][hp]
-    __shared__ float red[16];
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [NW][hp]
+    __shared__ float red[NW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hp = (h + 3) & ~3;
     const int dc = bv.doc(b);
@@ -85,19 +86,19 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
         s = 1.f / fmaxf(doc_l1[dc], 1e-12f);
     } else if (normalize) {
         float l1 = 0.f;
-        for (int64_t e = lo + tid; e < hi; e += 1024) l1 += fabsf(bv.values[e]);
+        for (int64_t e = lo + tid; e < hi; e += 64 * NW) l1 += fabsf(bv.values[e]);
         l1 = wave_sum(l1);
         if (lane == 0) red[wave] = l1;
         __syncthreads();
         l1 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) l1 += red[w];
+        for (int w = 0; w < NW; ++w) l1 += red[w];
         s = 1.f / fmaxf(l1, 1e-12f);
     }
     if (tid == 0) rscale[b] = s;
     for (int c0 = lane * 4; c0 < hp; c0 += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t e = lo + wave; e < hi; e += 16) {
+        for (int64_t e = lo + wave; e < hi; e += NW) {
             const int idx = bv.indices[e];
             float x = bv.values[e];
             if (normalize) x *= s;
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
     if (adv.enabled && blockIdx.x == gridDim.x - 1 && tid < 64) advance_step_body(adv.sc, adv.ctr, adv.tab, nullptr, nullptr, adv.losses, tid);
     if (adv.stamp2 && blockIdx.x == 0 && tid == 0) { *adv.stamp2 += 1; *adv.ucount2 = 0; }
     const uint64_t key = d.device_rng ? rng_key(seed, (uint64_t)(step_val >= 0 ? step_val : *step_ctr), 0) : 0;
-    for (int c = tid; c < h; c += 1024) {
+    for (int c = tid; c < h; c += 64 * NW) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) v += part[w * hp + c];
+        for (int w = 0; w < NW; ++w) v += part[w * hp + c];
         if (b1) v += b1[c];
         a1[(size_t)b * ld + c] = v;
         if (y) {
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(1024) void enc_gather_kernel(BatchView bv, const fl
         }
     }
 }
+
+#define enc_gather_kernel enc_gather_kernel_t<16>
 
 // y = act(dropout(a))  elementwise over [rows][h]  (gen_step re-uses disc_step's a1)
 __global__ void drop_act_kernel(const float* __restrict__ a, float* __restrict__ y, int rows, int h, int ld,
