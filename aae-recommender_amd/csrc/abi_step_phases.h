@@ -290,6 +290,16 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         ProfScope ps(m, AAE_K_ENC_GATHER, s);
         const size_t shm = (size_t)16 * r4(m->h) * sizeof(float);
         DropSpec none; memset(&none, 0, sizeof(none));
+        // (four waves per document for wide batches, as gather_first_layer: an item slice holds 1 / world of a document's entries)
+        static const int g4_rows = getenv("AAE_GATHER4_ROWS") ? atoi(getenv("AAE_GATHER4_ROWS")) : 512;
+        if (m->rows >= g4_rows)
+        hipExtLaunchKernelGGL(enc_gather_kernel_t<4>, dim3(m->rows), dim3(256), (uint32_t)(shm / 4), s, nullptr, pf ? m->ev_head : nullptr, 0,
+                              m->bv, (const float*)m->P[P_W1T].p, m->ldw1, bias_dev, m->h, (int)m->cfg.normalize_inputs,
+                              m->a1.p, (float*)nullptr, m->ldh, (int)m->cfg.activation, none, (uint64_t)m->cfg.seed,
+                              (const long long*)m->step_ctr, m->rscale, m->doc_l1,
+                              AdvanceJob{m->sc, m->step_ctr, m->lazy ? m->tab : nullptr, m->losses, fold_advance ? 1 : 0},
+                              (long long)(fold_advance ? m->hstep : -1));
+        else
         hipExtLaunchKernelGGL(enc_gather_kernel, dim3(m->rows), dim3(1024), (uint32_t)shm, s, nullptr, pf ? m->ev_head : nullptr, 0,
                               m->bv, (const float*)m->P[P_W1T].p, m->ldw1, bias_dev, m->h, (int)m->cfg.normalize_inputs,
                               m->a1.p, (float*)nullptr, m->ldh, (int)m->cfg.activation, none, (uint64_t)m->cfg.seed,
