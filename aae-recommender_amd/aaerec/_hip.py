@@ -8,6 +8,7 @@ There is NO CPU fallback: importing this module without the built library, or cr
 model without a GPU, raises.
 """
 import ctypes as C
+import itertools
 import weakref
 import os
 
@@ -17,7 +18,7 @@ import torch  # must be imported before the library so both share one HIP runtim
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AAE_HIP_LIB") or os.path.join(_HERE, "libaaerec_hip.so")     # (AAE_HIP_LIB: A/B builds of the library)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5}
 FINALS = {"linear": 0, "softmax": 1, "sigmoid": 2}
 OPTIMIZERS = {"adam": 0, "sgd": 1}
@@ -64,7 +65,7 @@ class AaeConfig(C.Structure):
 class AaeBatch(C.Structure):
     _fields_ = [("indptr_dev", C.c_void_p), ("indices_dev", C.c_void_p), ("values_dev", C.c_void_p),
                 ("rows_dev", C.c_void_p), ("row_start", C.c_int32), ("n_rows", C.c_int32),
-                ("nnz_bound", C.c_int32), ("max_row_nnz", C.c_int32)]
+                ("nnz_bound", C.c_int32), ("max_row_nnz", C.c_int32), ("generation", C.c_int64)]
 
 
 class AaeRngInject(C.Structure):
@@ -319,12 +320,29 @@ def csr_embed(csr, table):
     return out
 
 
+_GENERATION = itertools.count(1)
+
+
+def row_ids(rows, generation):
+    """Tag a device int32 row-id tensor with the caller's content id (aae_batch.generation, ABI 3): the same id for every
+    view of one buffer while its content stands, a new one after any rewrite or re-allocation.  A batch whose row ids carry
+    no tag is never matched with work built ahead for it (aae_prefetch_batch): a slice of a tensor is a new Python object at
+    an address the allocator may have handed out before, and nothing but the caller knows whether the ids in it changed."""
+    rows._aae_generation = int(generation)
+    return rows
+
+
 class DeviceCSR:
-    """A CSR matrix resident in HBM (int64 indptr, int32 indices, float32 values)."""
+    """A CSR matrix resident in HBM (int64 indptr, int32 indices, float32 values).  `generation` names its content
+    (aae_batch.generation): unique per object; call touch() after rewriting the arrays in place."""
+
+    def touch(self):
+        self.generation = next(_GENERATION)
 
     def __init__(self, X, device):
         X = X.tocsr()
         X.sum_duplicates()
+        self.generation = next(_GENERATION)
         self.shape = X.shape
         self.nnz_per_row_max = int(np.diff(X.indptr).max()) if X.shape[0] else 0
         self.indptr = upload(X.indptr.astype(np.int64), device)
@@ -347,6 +365,7 @@ class DeviceCSR:
         rows, n_cols = X.shape
         dense = upload(X, dev)
         self = cls.__new__(cls)
+        self.generation = next(_GENERATION)
         self.shape = (rows, n_cols)
         cap = int(max(1, min(int(capacity), rows * n_cols)))
         self.indptr = torch.empty(rows + 1, dtype=torch.int64, device=dev)
@@ -369,6 +388,7 @@ class DeviceCSR:
     @classmethod
     def from_arrays(cls, indptr, indices, values, n_cols, device):
         self = cls.__new__(cls)
+        self.generation = next(_GENERATION)
         self.shape = (len(indptr) - 1, n_cols)
         self.nnz_per_row_max = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
         self.indptr = upload(np.asarray(indptr, dtype=np.int64), device)
@@ -614,6 +634,11 @@ class HipAAE:
             raise ValueError(f"batch may hold {b.nnz_bound} entries but the model was created with max_nnz="
                              f"{self.cfg.max_nnz}")
         b.max_row_nnz = int(csr.nnz_per_row_max)
+        # the content id a named-ahead batch is matched by (ABI 3): the matrix's generation and the row ids' (row_ids());
+        # 0 - never matched - when either is unknown
+        cg = int(getattr(csr, "generation", 0))
+        rg = 1 if rows is None else int(getattr(rows, "_aae_generation", 0))
+        b.generation = ((cg << 32) ^ rg) & 0x7FFFFFFFFFFFFFFF if cg and rg else 0
         return b
 
     def _inject(self, masks, z_real):
@@ -788,7 +813,7 @@ class HipAAE:
         """One partial_fit of the item-sharded model with replicated hidden stacks as ONE library call (aae_shard_step):
         this handle = an item slice of enc.lin1 / dec.lin3 + a full copy of the hidden layers; the batch is the GLOBAL batch
         in the slice's corpus; three all-reduces of [rows, n_hidden] partial sums through `coll`.  next_rows = (row_start,
-        rows) of the next global batch (named ahead)."""
+        rows, n_rows) of the next global batch (named ahead; rows = device int32 row ids or None)."""
         b = self._batch(csr, row_start, n_rows, rows)
         nxt = None
         if next_rows is not None:

@@ -337,6 +337,9 @@ class AdversarialAutoEncoder:
         masks = z_real = None
         if self.rng_mode == "reference":
             masks, z_real = self._host_randomness(n_rows)
+            if self._dp is not None and hasattr(self._dp, "agree_randomness"):
+                # dp_mode='shard': every rank runs the whole batch through its own copy of the hidden layers - rank 0's draws
+                masks, z_real = self._dp.agree_randomness(masks, z_real)
         hip = self.hip
         use_condition = c_batch is not None
         if self._dp is not None and self._slice is not None:
@@ -471,6 +474,12 @@ class AdversarialAutoEncoder:
                 from .parallel import broadcast_array
                 perm = broadcast_array(self._dp.dist, self._dp.group, perm.astype(np.int64), self.hip.device)
             perm_dev = torch.as_tensor(perm.astype(np.int32), device=self.hip.device)
+            # content id of this epoch's row ids (aae_batch.generation): every window of perm_dev below carries it, so the
+            # batch a step runs is matched with the one named ahead by content, not by the address the allocator gave it
+            perm_gen = next(_hip._GENERATION)
+
+            def window(a, b):
+                return _hip.row_ids(perm_dev[a:b], perm_gen)
             csr = self._epoch_csr(csr0)
             for start in range(0, n_docs, self.batch_size):
                 stop = min(start + self.batch_size, n_docs)
@@ -493,20 +502,20 @@ class AdversarialAutoEncoder:
                         if self.dp_mode != "shard":
                             gs = gn + (gs - gn) // self._dp.world * self._dp.world
                         if gs > gn:
-                            self._slice.prefetch(self._slice_csr, 0, gs - gn, perm_dev[gn:gs])
+                            self._slice.prefetch(self._slice_csr, 0, gs - gn, window(gn, gs))
                     # first-layer packets: no share of this batch names more distinct items than it has entries
                     shares = np.array_split(row_len[perm[start:stop]], self._dp.world)
                     self._dp.w1_rows = int(max(sh.sum() for sh in shares)) + 8
                     if self._slice is not None:
-                        self._g_rows = perm_dev[start:stop]
+                        self._g_rows = window(start, stop)
                         if use_condition and not self._is_constant_concat():
                             self._g_c_batch = [_take(c, perm[start:stop]) for c in condition_data]
                     start, stop = lo, hi
-                rows = perm_dev[start:stop]
+                rows = window(start, stop)
                 nxt = start + self.batch_size           # (single process) the batch after this one: see _hip.prefetch
                 if self._dp is None and nxt < n_docs:
                     self.hip.prefetch(csr, 0, min(nxt + self.batch_size, n_docs) - nxt,
-                                      perm_dev[nxt:min(nxt + self.batch_size, n_docs)])
+                                      window(nxt, min(nxt + self.batch_size, n_docs)))
                 c_batch = None
                 if use_condition:
                     idx = perm[start:stop]

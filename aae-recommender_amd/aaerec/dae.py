@@ -45,6 +45,7 @@ class DenoisingAutoEncoder(AutoEncoder):
     # ---- corruption ------------------------------------------------------------------------------
     def _thinned(self, csr, keep):
         out = _hip.DeviceCSR.__new__(_hip.DeviceCSR)
+        out.touch()                                              # (new values: a content id of its own, aae_batch.generation)
         out.shape, out.nnz_per_row_max = csr.shape, csr.nnz_per_row_max
         out.indptr, out.indices = csr.indptr, csr.indices
         out.values = csr.values * keep.to(csr.values.dtype)

@@ -64,11 +64,9 @@ class _CsrView:
         # caching allocator hands a fresh per-batch indptr the same address and version, and raw-pointer writers such as
         # aae_dense_to_csr never bump the version - a stale maximum either raised for a valid call or let an undersized
         # bound through.  The training loop proper - fit() on a resident corpus - does not come through this shim.)
-        # A bound of at least the vocabulary size holds for every canonical CSR row: no reduction, no host sync then.
-        if n_cols is not None and int(max_row_nnz) >= int(n_cols):
-            true_max = 0
-        else:
-            true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
+        # (r4 skipped the reduction when the bound was at least the vocabulary size - true for a canonical row only: the
+        #  library also takes rows with duplicate (row, item) pairs (w1_update.h), which can be longer than n_cols.  ADVICE r4.)
+        true_max = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.indptr.numel() > 1 else 0
         if int(max_row_nnz) < true_max:
             raise ValueError(f"aaerec: max_row_nnz={int(max_row_nnz)} but the CSR matrix has a row of {true_max} entries")
         self.nnz_per_row_max = int(max_row_nnz)

@@ -651,6 +651,31 @@ class ItemShardedAAE:
     def comm_stats(self):
         return {"collectives": self._coll_last[0], "bytes": self._coll_last[1]}
 
+    def agree_randomness(self, masks, z_real):
+        """rng_mode='reference': rank 0's host draws (the 12 dropout masks and z_real of the WHOLE batch) on every rank.
+        The hidden stacks are replicated with no gradient exchange, so they stay identical only while every rank applies the
+        same masks and the same prior sample; each process draws from its own torch generator, and nothing else makes
+        those agree (a per-rank torch.manual_seed(rank) is enough to break it).  One broadcast per step; the device
+        generator (rng_mode='device') is keyed by the global row and needs none."""
+        if self.world == 1 or not hasattr(self.dist, "broadcast"):
+            return masks, z_real
+        import numpy as np
+        import torch
+        z = np.ascontiguousarray(z_real.detach().cpu().numpy(), dtype=np.float32)
+        parts = [np.ascontiguousarray(m.cpu().numpy(), dtype=np.uint8).ravel() for m in masks if m is not None]
+        flat = np.concatenate(parts + [z.view(np.uint8).ravel()])
+        flat = broadcast_array(self.dist, self.group, flat, getattr(self.slice, "device", None))
+        out, off = [], 0
+        for m in masks:
+            if m is None:
+                out.append(None)
+                continue
+            n = m.numel()
+            out.append(torch.from_numpy(flat[off:off + n].reshape(tuple(m.shape)).copy()))
+            off += n
+        zr = torch.from_numpy(flat[off:off + z.nbytes].view(np.float32).reshape(z.shape).copy())
+        return out, zr
+
     def sync_conditions(self, conditions):
         """Condition plugins see the whole batch on every rank: their gradients are complete and identical - nothing to sum."""
         return None
@@ -694,7 +719,41 @@ class ItemShardedAAE:
         for tid in (T_ENC_B1, T_ENC_W2, T_ENC_W3, T_DEC_V1, T_DEC_V2, T_DISC_D1, T_DISC_D2, T_DISC_D3):
             m.tensor(tid, padded=True).copy_(sl.tensor(tid, padded=True))
         m.params_changed()
+        self._gather_optimiser_state()
         self._gathered = True
+
+    def _gather_optimiser_state(self):
+        """The four optimisers' state into the full-vocabulary handle (enc_optim.state_dict() & co. read it there):
+        the moments of the two vocabulary-wide layers travel with their rows, those of the hidden layers are this rank's own
+        (identical on every rank), the step counters follow.  sl.sync() has replayed the postponed first-layer updates, so
+        the rows carry the counters' step."""
+        import ctypes as C
+        import torch
+        from ._hip import T_ADAM_ENC, T_ADAM_GEN, T_ADAM_DEC, T_ADAM_DISC, O_ENC, O_DEC, O_GEN, O_DISC, _check
+        m, sl, d = self.model, self.slice, self.dist
+        rows = -(-self.n_items // self.world)
+        wide = [T_ADAM_ENC, T_ADAM_ENC + 1, T_ADAM_GEN, T_ADAM_GEN + 1, T_ADAM_DEC + 4, T_ADAM_DEC + 5]
+        small = [T_ADAM_ENC + k for k in range(2, 8)] + [T_ADAM_GEN + k for k in range(2, 8)] + \
+                [T_ADAM_DEC + k for k in range(4)] + [T_ADAM_DISC + k for k in range(6)]
+        for tid in wide:
+            full, mine = m.tensor(tid, padded=True), sl.tensor(tid, padded=True)
+            send = torch.zeros(rows, full.shape[1], dtype=full.dtype, device=full.device)
+            send[:mine.shape[0]] = mine
+            recv = torch.empty(self.world * rows, full.shape[1], dtype=full.dtype, device=full.device)
+            if self.world > 1:
+                d.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            else:
+                recv = send
+            for r in range(self.world):
+                it = item_items(self.n_items, r, self.world, self.interleaved)
+                full[it] = recv[r * rows:r * rows + _slice_len(it, self.n_items)]
+        for tid in small:
+            m.tensor(tid, padded=True).copy_(sl.tensor(tid, padded=True))
+        torch.cuda.synchronize(m.device)
+        for oid in (O_ENC, O_DEC, O_GEN, O_DISC):
+            step = C.c_int64()
+            _check(sl.lib.aae_store_adam(sl.handle, oid, 2, None, None, None, None, C.byref(step)))
+            _check(m.lib.aae_load_adam(m.handle, oid, 2, None, None, None, None, step.value))
 
 
 class RcclTable:

@@ -321,6 +321,7 @@ int aae_prefetch_batch(aae_handle h, const aae_batch* next) {
     if (!next->indptr_dev || !next->indices_dev || !next->values_dev) return fail(AAE_EINVAL, "batch pointers are NULL");
     if (next->n_rows < 1 || next->n_rows > h->R) return fail(AAE_EINVAL, "batch n_rows outside [1, max_batch]");
     if (next->nnz_bound > h->cfg.max_nnz) return fail(AAE_EINVAL, "batch nnz_bound > max_nnz");
+    if (next->generation == 0) { h->pf_armed = false; return AAE_OK; }      // (no content id: no step could ever match it)
     h->pf_batch = *next;
     h->pf_armed = true;
     return AAE_OK;

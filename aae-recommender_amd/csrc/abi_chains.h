@@ -140,8 +140,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     LAUNCHCHK("chain_kernel");
     if (want_ts) {
         unsigned long long h[128];
-        hipStreamSynchronize(s);
-        hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost));
         static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "DISC_HEAD", "PRIOR"};
         fprintf(stderr, "[chain rows=%d nops=%d total=%.2fus]", cb.P.rows, cb.P.nops, (h[cb.P.nops] - h[0]) * 0.01);
         for (int i = 0; i < cb.P.nops; ++i)
@@ -232,9 +232,12 @@ struct DwBuilder {
         return AAE_OK;
     }
     // (done: an event riding on the launch's completion - only taken when nothing of this builder follows the launch)
+    // the chain program in front of this launch left its adversarial loss as n per-row terms: one more workgroup sums them
+    void add_loss(aae_model* m, int n, int slot) { g.loss.enabled = 1; g.loss.terms = m->adv_terms; g.loss.n = n; g.loss.out = m->losses + slot; }
     int launch(hipStream_t s, hipEvent_t done = nullptr, bool* marked = nullptr) {
         int blocks = tiles;
         if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
+        if (g.loss.enabled) blocks += 1;
         if (marked) *marked = done && !mh;
         if (done && !mh) hipExtLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g);
         else
@@ -536,8 +539,10 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
 }
 
 static bool same_batch(const aae_batch& a, const aae_batch& b) {
+    // (ABI 3: pointer identity is not content identity - the caller's generation id has to agree as well, and 0 means "none given")
     return a.indptr_dev == b.indptr_dev && a.indices_dev == b.indices_dev && a.values_dev == b.values_dev &&
-           a.rows_dev == b.rows_dev && a.row_start == b.row_start && a.n_rows == b.n_rows;
+           a.rows_dev == b.rows_dev && a.row_start == b.row_start && a.n_rows == b.n_rows &&
+           a.generation != 0 && a.generation == b.generation;
 }
 
 // aae_prefetch_batch, second half: the hinted batch's unique-item list + deferred-Adam catch-up (through the RUNNING
@@ -691,7 +696,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     }
     {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
         ChainBuilder cb(m, 2 * B);
-        cb.P.loss_slot = 1;
+        cb.P.loss_slot = 1; cb.P.loss_terms = m->adv_terms;
         if (merged) {
             chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
             if (m->cfg.enc_final != AAE_FINAL_LINEAR) { ChainOp& f = cb.add(cop(COP_FINAL_FWD, 2, 2, c)); f.aux = m->cfg.enc_final; }
@@ -725,6 +730,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     dw.add(m, m->ga3.p, 4, m->xh2.p, m->ldh, 2 * B, P_D3, O_DISC);
     dw.add(m, m->gb0.p, m->ldh, m->xh1.p, m->ldh, 2 * B, P_D2, O_DISC);
     dw.add(m, m->gb1.p, m->ldh, m->zin.p, m->ldz, 2 * B, P_D1, O_DISC);
+    dw.add_loss(m, 2 * B, 1);
     return dw.launch(s);
 }
 
@@ -734,7 +740,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c;
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
-    cb.P.loss_slot = 2;
+    cb.P.loss_slot = 2; cb.P.loss_terms = m->adv_terms;
     cb.add(cop_load(m->a1.p, m->ldh, 0, h));
     ChainOp& e1 = cb.add(cop(COP_DROPACT, 0, 1, h));
     e1.d = make_drop(m, 0, true, I.masks_dev[8], nullptr, B, h, 8); e1.one_col = h; cop_out(e1, m->eh1.p, m->ldh);
@@ -767,6 +773,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     dw.add(m, m->ga3.p, m->ldz, m->eh2.p, m->ldh, B, P_W3, O_GEN);
     dw.add(m, m->gb2.p, m->ldh, m->eh1.p, m->ldh, B, P_W2, O_GEN);
     TRY(dw.add_first_layer(m, ga1_ptr(m), O_GEN, s));
+    dw.add_loss(m, B, 2);
     // the step's last launch when the first layer's update rode in it: the side stream's mark for the NEXT step's early
     // prefetch rides on its completion (only while batches are being named ahead: a mark nobody waits for costs ~2 us)
     const bool mark_end = m->early_enabled && m->pf_this_step && m->w1_items_merged && !m->ext_first && m->side && m->ev_end &&

@@ -89,6 +89,7 @@ struct aae_model {
     int* pslot; int* ptag;   // data parallel, peers > 1: [N][peers] slot of an item's row in each peer's packet / its stamp
     int chunks;              // grid.y of the per-entry kernels for the running batch
     float* losses;
+    float* adv_terms;
     OptScalars* sc;          // [4]
     long long* step_ctr;
     // state of the running step
@@ -317,6 +318,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
         m->tev2 = a.take((size_t)c.max_nnz, nullptr);
     }
     m->losses = a.take(4, nullptr);
+    m->adv_terms = a.take((size_t)R2, nullptr);     // per-row adversarial loss terms of the running chain program (chain.h: loss_terms)
     m->sc = reinterpret_cast<OptScalars*>(a.take(4 * sizeof(OptScalars) / sizeof(float), nullptr));
     m->step_ctr = reinterpret_cast<long long*>(a.take(2, nullptr));
     m->dh2s = Ten(); m->sc_snap = nullptr;

@@ -167,9 +167,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 (void)prof_pair(m, AAE_K_DEC_OPT, &start, &stop);
                 if (ts_obk && m->fused_nb == 13) {
                     hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13, true>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b);
-                    hipStreamSynchronize(m->side);
+                    HIPCHK(hipStreamSynchronize(m->side));
                     unsigned long long t[128];
-                    hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+                    HIPCHK(hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost));
                     for (int w = 0; w < 2; ++w) {
                         fprintf(stderr, "[dec_opt_blocks_x3 wave %d, steps 8..15, us: products | split | to the next barrier;  spare wave: - | split | requests | wait for the slot | to the next barrier]", w ? 12 : 0);
                         for (int q = 0; q < 8; ++q) {
@@ -271,8 +271,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         LAUNCHCHK("dec_fused");
         if (want_ts) {
             unsigned long long t[128];
-            hipStreamSynchronize(s);
-            hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(t, ts_dev, sizeof(t), hipMemcpyDeviceToHost));
             if (m->last_out_split && ts_obk) { /* printed at the launch */ }
             else if (m->last_out_split)
                 fprintf(stderr, "[dec_crit_x3 tile 5] barrier=%.2f S0=%.2f GEMM1=%.2f BCE=%.2f GEMM3=%.2f | wg 0: prologue=%.2f loop=%.2f (%llu tiles, %.2f each) epilogue=%.2f us\n",

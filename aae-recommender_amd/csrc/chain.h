@@ -81,6 +81,10 @@ struct ChainProgram {
     int nops, rows, act;
     uint64_t seed; const long long* step_ctr;
     float* loss_out; int loss_slot;     // COP_ADV accumulates -mean(log ...) here (atomicAdd of per-row terms)
+    float* loss_terms;                  // != NULL: the per-row terms go to loss_terms[row] instead (plain stores; the weight-gradient
+                                        // launch behind the program sums them in a fixed order, DwGroup::loss).  r5: 1 000-2 000 atomic
+                                        // adds on ONE address (a 1 000-row batch) are ~12 ns each at the memory side, and the wave's next
+                                        // weight loads return behind its atomic (one in-order vmcnt): 8 us per program, losses not bit-stable
     int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
     unsigned long long* ts;             // debug (AAE_CHAIN_TS): per-op 100 MHz timestamps of workgroup 0, else NULL
     BucketJob bk;                       // enabled: one extra workgroup builds the fused decoder's tile buckets
@@ -573,7 +577,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                 else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
                 gv = gg * dv * (1.f - dv) * op.scale;
                 if (t == 0) {
-                    atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                    if (P.loss_terms) P.loss_terms[grow] = -l * invB;
+                    else atomicAdd(P.loss_out + P.loss_slot, -l * invB);
                     if (op.aux_ptr) op.aux_ptr[(size_t)grow * op.aux_ld] = gv;
                 }
             }
@@ -595,7 +600,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     if (op.aux == 0 && g >= B) { l = logf(1.f - dv + kTiny); gg = invB / (1.f - dv + kTiny); }
                     else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
                     gv = gg * dv * (1.f - dv) * op.scale;
-                    atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                    if (P.loss_terms) P.loss_terms[g] = -l * invB;
+                    else atomicAdd(P.loss_out + P.loss_slot, -l * invB);
                 }
                 dst[lrow * kCL] = gv;
             }
@@ -638,13 +644,28 @@ struct W1Job {
     int* hot; int* hot_count; int* hot_zero;    // kW1WaveRows go to the hot list (worked off by a launch behind this one); hot_zero: the NEXT use's counter
     W1Items items;
 };
-struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; };
+// the adversarial loss of the chain program in front of this launch: its per-row terms (ChainProgram::loss_terms) summed in a
+// fixed order by one extra workgroup (the launch's last) -> *out
+struct LossJob { int enabled; const float* terms; int n; float* out; };
+struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; LossJob loss; };
 constexpr int kDwSmemBytes = 2 * 64 * (32 + 16) * 4;       // static LDS of grouped_dw_kernel (2 * BK * LDT floats)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
     constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
     static_assert(sizeof(float) * 2 * BK * LDT == kDwSmemBytes, "kDwSmemBytes");
+    if (grp.loss.enabled && blockIdx.x == gridDim.x - 1) {           // (uniform) the loss terms' sum: thread t adds terms t, t + 256, ...
+        float acc = 0.f;                                              // in index order, the 256 sums meet in a fixed tree
+        for (int i = threadIdx.x; i < grp.loss.n; i += 256) acc += grp.loss.terms[i];
+        smem[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) smem[threadIdx.x] += smem[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *grp.loss.out = smem[0];
+        return;
+    }
     if (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0) {          // (uniform) first-layer workgroups
         const W1Job& w = grp.w1;
         const int id = (int)blockIdx.x - w.blk0;

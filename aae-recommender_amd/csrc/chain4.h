@@ -431,7 +431,8 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                     else { l = logf(dv + kTiny); gg = -invB / (dv + kTiny); }
                     gv = gg * dv * (1.f - dv) * qscale;
                     if (lane == 0) {
-                        atomicAdd(P.loss_out + P.loss_slot, -l * invB);
+                        if (P.loss_terms) P.loss_terms[grow] = -l * invB;       // (summed by the weight-gradient launch behind the program)
+                        else atomicAdd(P.loss_out + P.loss_slot, -l * invB);
                         if (qaux_ptr) qaux_ptr[(size_t)grow * qaux_ld] = gv;
                     }
                 }

@@ -218,29 +218,29 @@ int aae_dp_step(aae_handle m, aae_handle sl, const aae_collectives* c, const aae
 
     // ---- ae phase
     TRY(aae_first_layer_forward(sl, global_slice, bias, stream));
-    TRY(c->reduce_scatter(c->ctx, a1_all, a1, blk, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->reduce_scatter(c->ctx, a1_all, a1, blk, stream)); }
     TRY(aae_ae_forward(m, local, cond_dev, inject, stream));
-    TRY(c->all_gather(c->ctx, dh2, dh2_all, blk, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->all_gather(c->ctx, dh2, dh2_all, blk, stream)); }
     TRY(aae_output_layer_step(sl, nullptr, stream));
-    TRY(c->reduce_scatter(c->ctx, da2_all, da2, blk, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->reduce_scatter(c->ctx, da2_all, da2, blk, stream)); }
     TRY(aae_ae_backward(m, nullptr, 0, stream));
-    TRY(c->all_gather(c->ctx, pk, allp, pkf, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->all_gather(c->ctx, pk, allp, pkf, stream)); }
     TRY(aae_apply_gathered(m, O_ENC, O_DEC, allp, pkf, world, soff, stream));
     TRY(aae_first_layer_update(sl, allp, ldh, n, pkf, O_ENC, stream));
     if (m->ae_only) return AAE_OK;
     // ---- disc phase (Enc_eval with the updated first layer), gen phase
     TRY(aae_first_layer_forward(sl, nullptr, bias, stream));
-    TRY(c->reduce_scatter(c->ctx, a1_all, a1, blk, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->reduce_scatter(c->ctx, a1_all, a1, blk, stream)); }
     TRY(aae_disc_step(m, nullptr, stream));
     {
         const Ten& d1 = m->Gr[P_D1]; const Ten& d3 = m->Gr[P_D3];
         const int64_t cnt = (int64_t)((d3.off + (size_t)d3.rows * d3.ld * sizeof(float) - d1.off) / sizeof(float));
-        TRY(c->all_reduce(c->ctx, reinterpret_cast<float*>(m->base + d1.off), cnt, stream));
+        { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->all_reduce(c->ctx, reinterpret_cast<float*>(m->base + d1.off), cnt, stream)); }
     }
     TRY(aae_apply_updates(m, O_DISC, stream));
     TRY(aae_gen_step(m, nullptr, stream));
     packet(false, &pk, &pkf, &soff);
-    TRY(c->all_gather(c->ctx, pk, allp, pkf, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, S(stream)); TRY(c->all_gather(c->ctx, pk, allp, pkf, stream)); }
     TRY(aae_apply_gathered(m, O_GEN, -1, allp, pkf, world, soff, stream));
     TRY(aae_first_layer_update(sl, allp, ldh, n, pkf, O_GEN, stream));
     return AAE_OK;
@@ -276,7 +276,7 @@ int aae_shard_step(aae_handle m, const aae_collectives* c, const aae_batch* batc
     // ---- ae phase
     TRY(aae_first_layer_forward(m, batch, bias, stream));           // opens the step: this slice's share of x * enc.lin1^T
     const int64_t cnt = (int64_t)m->rows * m->ldh;
-    TRY(c->all_reduce(c->ctx, m->a1.p, cnt, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, s); TRY(c->all_reduce(c->ctx, m->a1.p, cnt, stream)); }
     remember_inject(m, inject, false);
     m->dec_hidden_done = false; m->enc_bwd_done = false;
     TRY(chain_ae_forward(m, true, cond_dev, nullptr, s));           // every row of the batch: dropout + activation on a1, hidden layers -> dh2
@@ -290,12 +290,12 @@ int aae_shard_step(aae_handle m, const aae_collectives* c, const aae_batch* batc
     const int rc = aae_output_layer_step(m, nullptr, stream);       // its items' logits, BCE, dV3 + dec_optim, dL/d(dh2) partial
     m->grad_scale = 1.f;
     TRY(rc);
-    TRY(c->all_reduce(c->ctx, m->da2.p, cnt, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, s); TRY(c->all_reduce(c->ctx, m->da2.p, cnt, stream)); }
     TRY(aae_ae_backward(m, nullptr, 0, stream));                     // hidden layers backward + their optimisers (the same on every rank), enc_optim on its rows of enc.lin1
     if (m->ae_only) { m->phase = 0; return AAE_OK; }
     // ---- disc phase (Enc_eval with the updated first layer), gen phase
     TRY(aae_first_layer_forward(m, nullptr, bias, stream));
-    TRY(c->all_reduce(c->ctx, m->a1.p, cnt, stream));
+    { ProfScope ps(m, AAE_K_COLLECTIVE, s); TRY(c->all_reduce(c->ctx, m->a1.p, cnt, stream)); }
     TRY(aae_disc_step(m, nullptr, stream));
     TRY(aae_gen_step(m, nullptr, stream));                           // (gen_optim on its rows of enc.lin1 included)
     return AAE_OK;

@@ -157,8 +157,22 @@ def kernel_models(N, h, B, nnz_per_batch, c=50):
     }
 
 
-NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt", "rank"]
-K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED, K_CHAIN, K_CRIT, K_OPT, K_RANK = range(10)
+def step_floor(Nr, h, c, cond_inc, B_out, B, nnz_per_batch, peak_tf, ms_per_step):
+    """One partial_fit against its own floor: ALGORITHMIC bytes (the output layer's parameter + optimiser stream, 24 B per
+    element of dec.lin3; the first layer's touched rows: 3 forward gathers + 2 optimisers of 32 B per element; the hidden
+    layers' Adam, 28 B per element, the encoder's twice) and flops, against max(bytes / HBM peak, flops / matrix peak of the
+    line's dtype).  Nr items x B_out rows in the output layer (a rank's item slice x the global batch when sharded)."""
+    small = 2 * (h * (h + 1) + c * (h + 1)) + (h * (c + cond_inc + 1) + h * (h + 1)) + (h * (c + 1) + h * (h + 1) + h + 1)
+    step_bytes = 24.0 * Nr * (h + 1) + nnz_per_batch * h * (3 * 4 + 2 * 32) + 28.0 * small
+    step_flops = 6.0 * B_out * Nr * (h + 1) + 2.0 * B * (13 * h * (h + 1) + 11 * c * (h + 1)) + 10.0 * nnz_per_batch * h
+    floor_ms = max(step_bytes / (HBM_PEAK_GBS * 1e9), step_flops / (peak_tf * 1e12)) * 1e3
+    return dict(bytes=round(step_bytes), flops=round(step_flops), floor_ms=round(floor_ms, 4),
+                bound="hbm" if step_bytes / (HBM_PEAK_GBS * 1e9) >= step_flops / (peak_tf * 1e12) else "mfma",
+                ms_per_step=round(ms_per_step, 4), frac=round(floor_ms / ms_per_step, 4))
+
+
+NAMES = ["enc_gather", "dec_bce_fwd", "dec_da2", "dec_dv3_adam", "enc_w1_adam", "dec_fused", "chain", "dec_crit", "dec_opt", "rank", "collective"]
+K_GATHER, K_BCE, K_DA2, K_DV3, K_W1, K_FUSED, K_CHAIN, K_CRIT, K_OPT, K_RANK, K_COLL = range(11)
 K_OUT = (K_BCE, K_DA2, K_DV3, K_FUSED, K_CRIT, K_OPT)       # the decoder output layer's kernels, whichever path runs
 
 
@@ -304,6 +318,40 @@ def main():
     model.hip.profile_enable(False)
     collect((K_GATHER, K_W1, K_CHAIN), extra_steps, time.perf_counter() - t0, model.hip)
 
+    # N > 1: what the step spends in its collectives (event pairs on the step's stream around every call of the collectives
+    # table, a pass of its own behind the timed region): per rank the time from "this rank reaches the collective" to "it has
+    # the result" - the transfer AND the wait for the slowest rank.  The rank that waits least is the one the others wait for:
+    # min over ranks ~ the collective itself, max - min ~ the ranks' skew; step time minus a rank's collective time = its compute.
+    dp_breakdown = None
+    if use_dp:
+        handles = [hh for hh in (model.hip, model._slice) if hh is not None]
+        for hh in handles:
+            hh.profile_enable(True, kernels=(K_COLL,))
+        t0 = time.perf_counter()
+        for _ in range(extra_steps):
+            next(it)
+        barrier()
+        wall_c = time.perf_counter() - t0
+        ms_c = n_c = 0
+        for hh in handles:
+            hh.profile_enable(False)
+            ms, n = hh.profile_read(K_COLL)
+            ms_c, n_c = ms_c + ms, n_c + n
+        if n_c:
+            per_step = ms_c / extra_steps
+            lo = hi = per_step
+            if dist is not None and world > 1:
+                t = torch.tensor([per_step, -per_step], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                hi, lo = float(t[0].item()), -float(t[1].item())
+            step_ms = wall_c / extra_steps * 1e3
+            dp_breakdown = dict(collectives_per_step=round(n_c / extra_steps, 2), collective_us_avg_rank0=round(ms_c / n_c * 1e3, 2),
+                                collective_ms_per_step_rank0=round(per_step, 4), collective_ms_per_step_min_over_ranks=round(lo, 4),
+                                collective_ms_per_step_max_over_ranks=round(hi, 4), ms_per_step_this_pass=round(step_ms, 4),
+                                compute_ms_per_step_slowest_rank=round(step_ms - lo, 4),
+                                note="event pairs around the collectives table's calls, a pass of its own (not the timed region); a rank's "
+                                     "collective time includes its wait for the slowest rank")
+
     peak_tf = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
     roofline = roofline_critical = None
 
@@ -356,13 +404,7 @@ def main():
     # (3 forward gathers + 2 optimisers of 32 B per element), the hidden layers' Adam (28 B per element, the encoder's twice) -
     # against max(bytes / HBM peak, flops / matrix peak of the line's dtype); per rank: its documents, its share of the layer
     Nr = out_model.N if vocab else N
-    small = 2 * (h * (h + 1) + c * (h + 1)) + (h * (c + a.cond_inc + 1) + h * (h + 1)) + (h * (c + 1) + h * (h + 1) + h + 1)
-    step_bytes = 24.0 * Nr * (h + 1) + nnz_per_batch * h * (3 * 4 + 2 * 32) + 28.0 * small
-    step_flops = 6.0 * (Bg if vocab else B) * Nr * (h + 1) + 2.0 * B * (13 * h * (h + 1) + 11 * c * (h + 1)) + 10.0 * nnz_per_batch * h
-    floor_ms = max(step_bytes / (HBM_PEAK_GBS * 1e9), step_flops / (peak_tf * 1e12)) * 1e3
-    step_roofline = dict(bytes=round(step_bytes), flops=round(step_flops), floor_ms=round(floor_ms, 4),
-                         bound="hbm" if step_bytes / (HBM_PEAK_GBS * 1e9) >= step_flops / (peak_tf * 1e12) else "mfma",
-                         ms_per_step=round(dt / a.steps * 1e3, 4), frac=round(floor_ms / (dt / a.steps * 1e3), 4))
+    step_roofline = step_floor(Nr, h, c, a.cond_inc, (Bg if vocab else B), B, nnz_per_batch, peak_tf, dt / a.steps * 1e3)
 
     raw = None
     extra = {}
@@ -384,7 +426,7 @@ def main():
         barrier()
         rdt = time.perf_counter() - t0
         raw = dict(docs_per_s=round(a.steps * B / rdt, 1), ms_per_step=round(rdt / a.steps * 1e3, 4))
-        want_extra = set(os.environ.get("AAE_BENCH_EXTRAS", "b512,c2_bf16,c4,predict_topk").split(","))   # (debugging aid)
+        want_extra = set(os.environ.get("AAE_BENCH_EXTRAS", "b512,c2_bf16,c4,c5_world1,predict_topk").split(","))   # (debugging aid)
         if not a.no_extra and a.dtype == "f32" and B != 512 and not a.cond_inc and "b512" in want_extra:
             # SURVEY 8d asks for the MFMA-bound batch (512) next to the reference's default batch
             a2 = argparse.Namespace(**vars(a))
@@ -472,6 +514,42 @@ def main():
                                cond_inc=a4.cond_inc, repeat_ms_per_step=[round(d / k4 * 1e3, 4) for d in d4])
             m4.hip.close()      # (destroy the handle - and its side stream - now: the model object sits in a reference cycle, and an idle
             del m4, it4       #  handle's low-priority stream keeps a hardware queue the next model's deferred launches would otherwise get)
+        if not a.no_extra and a.dtype == "f32" and (N, h) == (100000, 200) and not a.cond_inc and "c5_world1" in want_extra:
+            # BASELINE.json configs[4] (C5, MPD-scale: |items| = 2 200 000 tracks, hidden 200, batch 512, playlists of median
+            # length 60) WHOLE on one MI355X (19 GB of its 288): the N = 1 anchor of the 8-GPU configuration, through the same
+            # fit() loop; tests/test_fullsize_gpu.py::test_c5_whole_vocabulary_on_one_gpu_matches_the_chunked_stand_in holds
+            # this shape against the oracle's stand-in
+            a5 = argparse.Namespace(**vars(a))
+            a5.hidden, a5.items = 200, 2200000
+            B5, nb5 = 512, 8
+            m5 = make_model(a5, B5, None)
+            X5 = throughput_corpus(nb5 * B5, a5.items, median_len=60, seed=5678)
+            with contextlib.redirect_stdout(sys.stderr):
+                it5 = m5.fit_steps(X5)
+                next(it5)
+            for _ in range(3):
+                next(it5)
+            k5 = 10
+            d5 = [timed_steps(it5, k5, barrier) for _ in range(2)]
+            m5.hip.profile_enable(True, kernels=K_OUT)
+            timed_steps(it5, 5, barrier)
+            m5.hip.profile_enable(False)
+            km5 = kernel_models(a5.items, a5.hidden, B5, X5.nnz / nb5, c)
+            ks5 = {}
+            for kid in K_OUT:
+                ms, n = m5.hip.profile_read(kid)
+                if n:
+                    avg_s = ms / n * 1e-3
+                    ks5[NAMES[kid]] = dict(avg_us=round(avg_s * 1e6, 2), TFLOPs=round(km5[NAMES[kid]]["flops"] / avg_s / 1e12, 2),
+                                           GBps=round(km5[NAMES[kid]]["bytes"] / avg_s / 1e9, 1))
+            dm = float(np.median(d5))
+            extra["c5_world1"] = dict(workload=f"C5 MPD-scale synthetic Bags WHOLE on one GPU: |items|={a5.items}, hidden={a5.hidden}, code={c}, "
+                                               f"fp32, batch={B5}, median document length 60, through fit()",
+                                      docs_per_s=round(k5 * B5 / dm, 1), ms_per_step=round(dm / k5 * 1e3, 4), steps=k5, dtype="f32",
+                                      step_roofline=step_floor(a5.items, a5.hidden, c, 0, B5, B5, X5.nnz / nb5, MFMA_F32_PEAK_TF, dm / k5 * 1e3),
+                                      kernels=ks5)
+            m5.hip.close()
+            del m5, it5, X5
         if not a.no_extra and not a.cond_inc and "predict_topk" in want_extra:
             # SURVEY 8f rank 1 / VERDICT r3: predict -> remove_non_missing -> top-k on the device (reference aae.py:840-870,
             # evaluation.py:183-199, 20-58) with the headline model, documents of the resident corpus, 512 rows per library
@@ -580,6 +658,8 @@ def main():
             out["raw_step"] = raw
         if extra:
             out["extra"] = extra
+        if dp_breakdown:
+            out["dp_breakdown"] = dp_breakdown
         if use_dp and hasattr(model._dp, "comm_stats"):
             out["collectives_per_step"] = model._dp.comm_stats()
             native = getattr(model._dp, "_native", None) is not None

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AAE_ABI_VERSION 2
+#define AAE_ABI_VERSION 3
 
 /* error codes */
 #define AAE_OK 0
@@ -114,6 +114,10 @@ typedef struct aae_batch {
     int32_t n_rows;
     int32_t nnz_bound;        /* upper bound on the entries of these rows (<= cfg.max_nnz) */
     int32_t max_row_nnz;      /* upper bound on the entries of any one of these rows; 0 = unknown */
+    int64_t generation;       /* ABI 3: caller-supplied id of the CONTENT these pointers name (the CSR arrays and rows_dev): a new
+                               * value whenever any of them is rewritten in place or freed and allocated again.  0 = none given.
+                               * Only aae_prefetch_batch's matching reads it: a step takes the work built ahead for a named
+                               * batch only when pointers, row window AND a non-zero generation are equal. */
 } aae_batch;
 
 /* Injected randomness for one partial_fit, in the reference's draw order:
@@ -478,6 +482,8 @@ enum { AAE_K_ENC_GATHER = 0,   /* sparse row gather of the first encoder layer *
        AAE_K_DEC_CRIT,         /* split form of the fused output layer, critical launch: logits + BCE + dA2 (+ dL/dlogits tiles) */
        AAE_K_DEC_OPT,          /* ... deferred launch on the library's side stream: dV3 + dec_optim behind the rest of the step */
        AAE_K_RANK,             /* fused predict -> rank: output layer + sigmoid + min/max + known-item mask + per-workgroup top-k */
+       AAE_K_COLLECTIVE,       /* a collective of aae_dp_step / aae_shard_step: event pair on the step's stream around the table's call
+                                * (what the rank waits: the transfer AND the slowest rank's arrival) */
        AAE_K_N };
 /* on = 0: off; 1: every kernel id above; otherwise a selection: bit (k + 1) of `on` times kernel id k
  * (an event pair costs a few microseconds of stream time, so a timed run selects only what it reports) */
@@ -512,11 +518,12 @@ int aae_join_output_layer(aae_handle h, void* stream);
  * torch.optim.Adam did eagerly in enc_optim.step() / gen_optim.step(), aae.py:706,742) - runs on the handle's side
  * stream while the step before it executes, instead of opening the next step.  A hint, not a promise: a next step on
  * any other batch (other pointers / row window) ignores it and does the work itself.
- * HARD PRECONDITION: the step recognises the named batch by its pointers and row window, not by content - between this
- * call and the step that runs the batch, the CSR arrays and the row-id buffer `rows_dev` it names must neither be
- * rewritten in place nor freed and re-allocated (a refilled buffer at the same address would be taken for the batch whose
- * item list was built ahead: rows missing from that list get no update).  A caller that recycles batch buffers does
- * not hint.
+ * The step recognises the named batch by its pointers, its row window and aae_batch.generation (ABI 3; r1-r4 went by the
+ * pointers alone, and a buffer refilled in place or re-allocated at the same address was silently taken for the batch
+ * whose item list had been built ahead - rows missing from that list got no update).  The caller bumps `generation`
+ * whenever it rewrites or re-allocates any array the batch names; a batch with generation 0 is never matched, and naming
+ * one here is accepted and ignored.  What stays the caller's duty is what any asynchronous reader asks: the named arrays
+ * must stay allocated and unchanged until the work built from them has run (the step after the next, or aae_join).
  * grad_mode = fused only (otherwise accepted and ignored). */
 int aae_prefetch_batch(aae_handle h, const aae_batch* next);
 int aae_set_split(aae_handle h, int32_t workgroups);

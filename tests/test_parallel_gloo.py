@@ -718,6 +718,49 @@ def test_two_ranks_item_sharded_with_replicated_hidden_stacks_equal_single_proce
     assert got["collectives"] == 3 * fx.steps and got["stats"]["collectives"] == 3
 
 
+def _worker_shard_rng(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aae-recommender_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec.aae import AdversarialAutoEncoder
+    from aaerec.parallel import ItemShardedAAE, item_slice
+    fx = Fixture("step_masks")
+    N = fx.cfg["N"]
+    lo, hi = item_slice(N, rank, world)
+    sh = ItemShardedAAE(None, ShardStandIn(fx.init_params(), lo, hi, rank, **fx.model_kwargs()), dist, N, interleaved=False)
+    # the host model of rng_mode='reference', never built (no GPU here): its draw routine and the step's agreement hook
+    host = AdversarialAutoEncoder(n_hidden=fx.cfg["h"], n_code=fx.cfg["c"], dropout=(0.2, 0.0), rng_mode="reference", verbose=False)
+    torch.manual_seed(1000 + rank)                     # the ranks' generators do NOT coincide
+    own = host._host_randomness(24)
+    masks, z_real = sh.agree_randomness(*own)
+    assert [m is None for m in masks] == [m is None for m in own[0]]
+    flat = torch.cat([m.reshape(-1).float() for m in masks if m is not None] + [z_real.reshape(-1)])
+    mine = torch.cat([m.reshape(-1).float() for m in own[0] if m is not None] + [own[1].reshape(-1)])
+    every = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(every, flat)
+    ret[f"agreed{rank}"] = all(torch.equal(every[0], e) for e in every)
+    ret[f"own{rank}"] = bool(torch.equal(flat, mine))
+    ret[f"dtypes{rank}"] = (str(masks[0].dtype), str(z_real.dtype), tuple(z_real.shape), tuple(masks[0].shape))
+    dist.destroy_process_group()
+
+
+def test_item_sharded_ranks_with_different_generators_apply_rank_zeros_draws():
+    """dp_mode='shard' + rng_mode='reference' (ADVICE r4): the hidden stacks are replicated with no gradient exchange, so
+    every rank must apply the SAME dropout masks and prior sample to the whole batch.  Two ranks seeded differently: after
+    ItemShardedAAE.agree_randomness both hold rank 0's draws (rank 1's own differ), shapes and dtypes as drawn."""
+    port = free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_shard_rng, args=(2, port, ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got["agreed0"] and got["agreed1"]
+    assert got["own0"] and not got["own1"]
+    fx = Fixture("step_masks")
+    assert got["dtypes0"] == got["dtypes1"] == ("torch.uint8", "torch.float32", (24, fx.cfg["c"]), (24, fx.cfg["h"]))
+
+
 def test_item_ownership_partitions_the_vocabulary():
     """item_items: every item has exactly one owner, interleaved or contiguous, for vocabularies that do not divide by the
     world size; the slice object indexes NumPy arrays and SciPy CSR columns alike."""

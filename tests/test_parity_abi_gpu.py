@@ -197,6 +197,53 @@ def test_deferred_adam_matches_eager_oracle_over_many_sparse_steps(prefetch, mon
     assert st["step"] == steps
 
 
+def test_a_refilled_batch_buffer_at_the_same_address_is_not_taken_for_the_batch_named_ahead():
+    """ABI 3: a batch named with aae_prefetch_batch is matched by pointers, row window AND the caller's
+    content id (aae_batch.generation), not by the pointers alone.  A caller that recycles ONE device buffer: it names the
+    buffer as the next batch while it still holds this step's documents, then refills it in place (DeviceCSR.touch(): new
+    generation) and runs the next step on it.  With pointer identity (r1-r4) that step took the item list built from the
+    OLD content - first-layer rows missing from it got no update; now it must do its own list, and 40 such steps equal
+    the oracle's.  An untouched buffer named ahead still matches (the same loop with honest hints is
+    test_deferred_adam_matches_eager_oracle_over_many_sparse_steps)."""
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle import aae_oracle as O
+    from oracle.dense_torch_port import init_params
+    rng = np.random.default_rng(11)
+    N, h, c, B, steps = 700, 12, 6, 8, 40
+    params = init_params(N, h, c, seed=4)
+    kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=(0.0, 0.0))
+    dev = HipAAE(N, h, c, max_batch=B, rng_mode="inject", **kw)
+    dev.load_params(params)
+    ora = O.OracleAAE(params, **kw)
+    per_row = 5
+    buf = DeviceCSR.from_arrays(np.arange(0, (B + 1) * per_row, per_row), np.zeros(B * per_row, dtype=np.int32),
+                                np.ones(B * per_row, dtype=np.float32), N, dev.device)
+    ptrs = (buf.indptr.data_ptr(), buf.indices.data_ptr(), buf.values.data_ptr())
+    gens = set()
+    for s in range(steps):
+        rows = [np.sort(rng.choice(N, size=per_row, replace=False)) for _ in range(B)]
+        idx = np.concatenate(rows).astype(np.int32)
+        ip = np.arange(0, (B + 1) * per_row, per_row).astype(np.int64)
+        zr = rng.standard_normal((B, c)).astype(np.float32)
+        torch.cuda.synchronize()                       # (the work built from the old content has run: the refill races with nothing)
+        buf.indices.copy_(torch.from_numpy(idx))       # the recycled buffer: same tensors, same addresses, new documents
+        buf.touch()
+        gens.add(buf.generation)
+        assert ptrs == (buf.indptr.data_ptr(), buf.indices.data_ptr(), buf.values.data_ptr())
+        dev.prefetch(buf, 0, B)                        # "the next batch" = this buffer, named while it holds THIS step's rows:
+        dev.step(buf, 0, B, z_real=zr)                 # its item list is built beside this step, for the step after it
+        want = ora.partial_fit(ip, idx, np.ones(len(idx), dtype=np.float32), zr)
+        if s % 10 == 0 or s == steps - 1:
+            np.testing.assert_allclose(dev.losses(), want, rtol=2e-4, atol=1e-6, err_msg=f"step {s}")
+    assert len(gens) == steps
+    got = dev.state_dict()
+    for k, w in ora.p.items():
+        np.testing.assert_allclose(got[k], w, atol=3e-5, rtol=0, err_msg=k)
+    st = dev.adam_state("gen")
+    np.testing.assert_allclose(st["lin1.weight"][1], ora.opt_gen.v["enc.lin1.weight"], atol=1e-12, rtol=1e-3)
+
+
 @pytest.mark.parametrize("N,h,c,B", [(5000, 200, 50, 100), (3001, 100, 50, 37), (4096, 200, 50, 104)])
 def test_fused_decoder_equals_unfused_path_at_headline_width(N, h, c, B):
     """The persistent fused decoder kernel (dec_fused.h, used for B <= ~104) against the
