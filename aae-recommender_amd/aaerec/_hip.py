@@ -165,7 +165,7 @@ _PROTOS = {
     "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),
 }
-K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN, K_DEC_CRIT, K_DEC_OPT = range(9)
+K_ENC_GATHER, K_DEC_BCE_FWD, K_DEC_DA2, K_DEC_DV3_ADAM, K_ENC_W1_ADAM, K_DEC_FUSED, K_CHAIN, K_DEC_CRIT, K_DEC_OPT, K_RANK, K_COLLECTIVE = range(11)
 
 _lib = None
 

@@ -34,6 +34,7 @@
 #include "rank_x3.h"
 #include "chain.h"
 #include "chain4.h"
+#include "chain16x3.h"
 #include "cond_embed.h"
 #include "w1_update.h"
 
@@ -106,6 +107,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
+        m->x16_rows = x16_min_rows();
+        m->x16_ok = m->use_chain4 && m->FXi[P_W2] != nullptr &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess;
         m->force_unfused = cfg->unfused_decoder == 1;   // debugging / A-B switch: unfused_decoder = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;

@@ -24,7 +24,7 @@ ChainOp cop_linear(int kind, int src, int dst, const Ten& W, int K, int N, int e
 void cop_out(ChainOp& o, float* out, int ld, int row0 = 0) { o.out = out; o.ldo = ld; o.out_row0 = row0; }
 
 W4Copies w4_of(const aae_model* m, int pid) {
-    return W4Copies{m->PT[pid].p, m->D4[pid].p, (int)m->P[pid].rows, (int)m->P[pid].cols};
+    return W4Copies{m->PT[pid].p, m->D4[pid].p, (int)m->P[pid].rows, (int)m->P[pid].cols, m->FXi[pid], m->DXi[pid], m->FXBi[pid], kCWide};
 }
 // where dL/d(a1) of the encoder backward goes: gb3, or (external first layer, export mode) the tail of ga1x
 float* ga1_ptr(const aae_model* m) {
@@ -44,6 +44,7 @@ void ensure_pt(aae_model* m, int pid, hipStream_t s) {
 ChainOp cop_fwd(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
     ChainOp o = cop_linear(COP_LINEAR, src, dst, m->P[pid], K, N, epi);
     if (m->PT[pid].p) { ensure_pt(m, pid, s); o.W4 = m->PT[pid].p; o.ns4 = (int)m->P[pid].rows; }
+    if (m->FXi[pid]) { o.WX = m->FXi[pid]; o.xpl = ((int)m->P[pid].rows + 15) & ~15; }
     return o;
 }
 
@@ -52,11 +53,11 @@ ChainOp cop_fwd(aae_model* m, int pid, int src, int dst, int K, int N, int epi, 
 ChainOp cop_dx(aae_model* m, int pid, int src, int dst, int K, int N, int epi, hipStream_t s) {
     ChainOp o = cop_linear(COP_LINEAR_DX, src, dst, m->P[pid], K, N, epi);       // (Wkn = the matrix itself: k-major for this product)
     if (m->D4[pid].p) { ensure_pt(m, pid, s); o.W4 = m->D4[pid].p; o.ns4 = (int)m->P[pid].cols; }
+    if (m->DXi[pid]) { o.WX = m->DXi[pid]; o.xpl = ((int)m->P[pid].cols + 15) & ~15; }
     return o;
 }
 
 struct ChainBuilder;
-constexpr int kCWide = 208;        // columns of a slot row a layer may read (chain.h: kCL = 212)
 // The decoder's first layer reads [z | condition | 1] - wider than a slot row when the condition is (C4: 50 + 300 + 1).
 // Such a layer runs as two ops (4-row kernel): input columns [0, 208) from one slot, the rest from a second one, the second op
 // adding to the first one's products before the epilogue (ChainOp::acc_in); its dX as two ops over the input columns.
@@ -90,6 +91,7 @@ ChainOp& add_dec_in_fwd(ChainBuilder& cb, aae_model* m, int srcA, int srcB, int 
     ChainOp b = cop_fwd(m, P_V1, srcB, dst, cp + 1 - kCWide, h, CEPI_DROPACT, s);
     b.W += kCWide;
     if (b.W4) b.W4 += (size_t)(kCWide / 4) * b.ns4 * 4;          // (F4: chunk stride = outputs x 4 floats)
+    b.WX = m->FXBi[P_V1];                                         // (the split copy counted from input column kCWide, or NULL)
     b.acc_in = 1;
     return cb.add(b);
 }
@@ -101,6 +103,7 @@ ChainOp& add_dec_in_dx(ChainBuilder& cb, aae_model* m, int src, int dstA, int ds
         ChainOp b = cop_dx(m, P_V1, src, dstB, h, cp - kCWide, CEPI_NONE, s);
         b.W += kCWide; b.Wkn += kCWide;
         if (b.W4) b.W4 += (size_t)kCWide * 4;                     // (D4: [k chunk][input column][4])
+        if (b.WX) b.WX += (size_t)kCWide * 32;                    // (DX: [k-step][term][input column][32])
         cop_out(b, m->gzc.p + kCWide, m->ldc);
         if (dzc_out) { b.out2 = dzc_out + kCWide; b.ldo2 = cp; }
         cb.add(b);
@@ -109,6 +112,90 @@ ChainOp& add_dec_in_dx(ChainBuilder& cb, aae_model* m, int src, int dstA, int ds
     cop_out(a, m->gzc.p, m->ldc);
     if (dzc_out) { a.out2 = dzc_out; a.ldo2 = cp; }
     return a;
+}
+
+// chain16x3.h keeps 7 slots: the program's slot numbers (up to 10, one per value for readability) are renamed by live range.
+// A value = one full write of a slot and the reads up to the next full write; it holds a physical slot from its write to its
+// last read.  false: more than 7 values live at once (the caller stays on the 4-row kernel).
+static bool x16_remap_slots(ChainProgram& P) {
+    constexpr int kL = 16, kMaxVal = 2 * kCMaxOps + kL;
+    struct Use { int src, y, fake, dst; };          // the values an op's slot fields name (-1: field not used)
+    Use use[kCMaxOps];
+    int cur[kL], last[kMaxVal], phys[kMaxVal], nval = 0;
+    for (int i = 0; i < kL; ++i) cur[i] = -1;
+    bool bad = false;
+    auto read_of = [&](int logical, int at) {      // the value a slot holds when op `at` reads it
+        if (logical < 0 || logical >= kL) { bad = true; return 0; }
+        if (cur[logical] < 0) { cur[logical] = nval; phys[nval] = -1; ++nval; }      // (read before any write: a value of its own)
+        last[cur[logical]] = at;
+        return cur[logical];
+    };
+    for (int i = 0; i < P.nops && !bad; ++i) {
+        const ChainOp& o = P.ops[i];
+        Use u = {-1, -1, -1, -1};
+        bool modify = false;                       // the op reads (part of) what dst holds: no new value
+        switch (o.kind) {
+            case COP_LINEAR: case COP_LINEAR_DX:
+                u.src = read_of(o.src, i);
+                if (o.epi == CEPI_ACTBWD && !o.y_glb) u.y = read_of(o.yslot, i);
+                modify = o.acc_in != 0;
+                break;
+            case COP_LOAD: modify = o.dst_col0 > 0; break;
+            case COP_DROPACT: u.src = read_of(o.src, i); break;
+            case COP_STORE: case COP_FINAL_FWD: modify = true; break;
+            case COP_FINAL_BWD: case COP_DISC_HEAD: u.src = read_of(o.src, i); u.y = read_of(o.yslot, i); break;
+            case COP_PRIOR: if (o.fake_slot >= 0) u.fake = read_of(o.fake_slot, i); break;
+            default: break;
+        }
+        if (modify) u.dst = read_of(o.dst, i);
+        else {
+            if (o.dst < 0 || o.dst >= kL || nval >= kMaxVal - 1) return false;
+            cur[o.dst] = nval; last[nval] = i; phys[nval] = -1; u.dst = nval++;
+        }
+        if (nval >= kMaxVal - 1) return false;
+        use[i] = u;
+    }
+    if (bad) return false;
+    int owner[kX16Slots];                            // physical slot -> the value that holds it
+    for (int p = 0; p < kX16Slots; ++p) owner[p] = -1;
+    auto place = [&](int v, int at) {
+        if (v < 0 || phys[v] >= 0) return true;
+        for (int p = 0; p < kX16Slots; ++p)
+            if (owner[p] < 0 || last[owner[p]] < at) { owner[p] = v; phys[v] = p; return true; }
+        return false;
+    };
+    for (int i = 0; i < P.nops; ++i) {
+        const Use& u = use[i];
+        if (!place(u.src, i) || !place(u.y, i) || !place(u.fake, i) || !place(u.dst, i)) return false;
+    }
+    for (int i = 0; i < P.nops; ++i) {
+        ChainOp& o = P.ops[i];
+        const Use& u = use[i];
+        if (u.src >= 0) o.src = phys[u.src];
+        if (u.y >= 0) o.yslot = phys[u.y];
+        if (u.fake >= 0) o.fake_slot = phys[u.fake];
+        o.dst = phys[u.dst];
+        if (o.kind == COP_FINAL_FWD) o.src = o.dst;
+    }
+    return true;
+}
+
+static bool x16_program_ok(const ChainProgram& P) {
+    for (int i = 0; i < P.nops; ++i) {
+        const ChainOp& o = P.ops[i];
+        switch (o.kind) {
+            case COP_LINEAR: case COP_LINEAR_DX:
+                if (!o.WX || o.N > kCWide || o.K > kX16Kp) return false;
+                break;
+            case COP_LOAD: if (o.dst_col0 + o.N > kX16Kp) return false; break;
+            case COP_DROPACT: case COP_SLABSUM: case COP_STORE: case COP_FINAL_FWD: case COP_FINAL_BWD: case COP_PRIOR: case COP_DISC_HEAD:
+                if (o.N > kCWide) return false;
+                break;
+            default: return false;                 // (COP_ADV, COP_ACTBWD, COP_REPARAM*: the VAE's programs and the 16-row fp32 kernel's)
+        }
+        if (o.one_col >= kX16Kp) return false;
+    }
+    return true;
 }
 
 int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
@@ -130,6 +217,31 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     for (int i = 0; i < cb.P.nops; ++i)
         if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in || cb.P.ops[i].y_glb) && !four)
             return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
+    // wide batches: 16 rows per workgroup on the bf16 matrix cores (chain16x3.h)
+    if (four && m->x16_ok && cb.P.rows >= m->x16_rows && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
+        ChainProgram X = cb.P;
+        if (x16_remap_slots(X)) {
+            const int grid16 = (X.rows + kX16R - 1) / kX16R;
+            if (want_ts && !m->bf16) hipLaunchKernelGGL((chain16x3_kernel<false, true>), dim3(grid16), dim3(kX16T), kX16Lds, s, X);
+            else if (m->bf16) hipLaunchKernelGGL(chain16x3_kernel<true>, dim3(grid16), dim3(kX16T), kX16Lds, s, X);
+            else hipLaunchKernelGGL(chain16x3_kernel<false>, dim3(grid16), dim3(kX16T), kX16Lds, s, X);
+            LAUNCHCHK("chain16x3_kernel");
+            if (want_ts && !m->bf16) {
+                unsigned long long h[128];
+                HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(hipMemcpy(h, ts_dev, sizeof(h), hipMemcpyDeviceToHost));
+                static const char* names[] = {"LOAD", "LINEAR", "LINEAR_DX", "FINAL_FWD", "FINAL_BWD", "ADV", "DROPACT", "SLABSUM", "ACTBWD", "STORE", "REPARAM", "REPARAM_BWD", "DISC_HEAD", "PRIOR"};
+                fprintf(stderr, "[chain16x3 rows=%d nops=%d total=%.2fus; per op: whole (products | epilogue | barrier)]", X.rows, X.nops, (h[3 * X.nops] - h[0]) * 0.01);
+                for (int i = 0; i < X.nops; ++i) {
+                    const bool lin = X.ops[i].kind == COP_LINEAR || X.ops[i].kind == COP_LINEAR_DX;
+                    fprintf(stderr, " %s(K%d,N%d)=%.2f", names[X.ops[i].kind], X.ops[i].K, X.ops[i].N, (h[3 * i + 3] - h[3 * i]) * 0.01);
+                    if (lin) fprintf(stderr, "(%.2f|%.2f|%.2f)", (h[3 * i + 1] - h[3 * i]) * 0.01, (h[3 * i + 2] - h[3 * i + 1]) * 0.01, (h[3 * i + 3] - h[3 * i + 2]) * 0.01);
+                }
+                fprintf(stderr, "\n");
+            }
+            return AAE_OK;
+        }
+    }
     if (four) {
         const int grid4 = (cb.P.rows + kR4 - 1) / kR4 + (cb.P.bk.enabled ? 1 : 0);
         if (want_ts && !m->bf16) hipLaunchKernelGGL((chain4_kernel<false, true>), dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
@@ -282,6 +394,18 @@ void chain_encoder_tail(aae_model* m, ChainBuilder& cb, bool train, const uint8_
 // The fused decoder's tile buckets depend on the batch only: the step's first chain launch carries their builder
 // as one extra workgroup (chain.h), off the critical path.
 static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m->rows + kRowBlock - 1) / kRowBlock; }
+// The fused output-layer kernels address dec.lin3 (and its moments) as  descriptor base + tile's byte offset (a 32-bit scalar
+// register) + the lane's offset inside the tile (vector register; 2^31 for a lane without a cell: dropped by the descriptor's
+// range check).  The range check sees the SUM of both offsets (measured, r5: with a fixed descriptor the tiles beyond byte 2^31
+// of a 2.9 M-item layer read zeros and dropped their stores), so r1-r4 kept these layers below 2^31 bytes - 2.63 M items at
+// hidden 200, while PubMed's and ACM's vocabularies (nmi.txt:68,85 of the reference) are 2.9 M and 2.6 M.  Since r5 the
+// descriptors cover a moving WINDOW of the tensors (X3Window, dec_fused.h) and the scalar offset counts from the window's first
+// tile: the limit is the Gt buffer's and the 32-bit tile arithmetic's, 4 GiB.  AAE_FUSED_SPAN_BITS=31 restores the old rule.
+static size_t fused_span_limit(const aae_model* m) {
+    const char* e = getenv("AAE_FUSED_SPAN_BITS");
+    const int bits = e ? atoi(e) : (out_bf16(m) ? 31 : 32);     // (dec_fused_bf16.h's kernels keep fixed descriptors)
+    return ((size_t)1 << bits) - ((size_t)1 << 24);       // (head room: the padding tiles behind the tensor, the last span of a tile)
+}
 static bool fused_decoder_applies(const aae_model* m) {
     const bool one = m->rows <= 16 * kMB;
     // The row-blocked form pays while its deferred half (2 * rows * N * (h + 1) flop of GEMM2 at the optimiser kernel's
@@ -296,7 +420,9 @@ static bool fused_decoder_applies(const aae_model* m) {
                          m->cfg.grad_mode == AAE_GRAD_FUSED &&
                          (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr));
     return m->fused_ok && !m->force_unfused && (one || blocked) &&
-           ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < ((size_t)1 << 31) &&      /* (stores without a cell are dropped by a buffer bounds check at offset 2^31) */
+           ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < fused_span_limit(m) &&
+           /* (the stored dL/dlogits tiles of a row block, [tiles][rows][32] floats, stay behind ONE fixed descriptor) */
+           ((size_t)m->N + 2 * kTI) * (size_t)((m->rows + row_blocks(m) - 1) / row_blocks(m)) * sizeof(float) < ((size_t)1 << 31) &&
            (m->bf16 ? dec_fused_bf16_lds_bytes(m->fused_nb) : dec_fused_lds_bytes((m->rows + row_blocks(m) - 1) / row_blocks(m), m->h)) <= 160 * 1024;
 }
 // counting sort of the running batch's entries into the fused output layer's 32-item tiles (buckets.h / dec_fused.h)
@@ -366,6 +492,7 @@ int launch_w1_items(aae_model* m, const float* ga1, int rpb, size_t bstride, int
 static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const int ntiles = (m->N + kTI - 1) / kTI;
     const size_t need = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
+    if (m->x16_ok && m->rows >= m->x16_rows) return;      // (the wide-batch chain kernel carries no builder; only a forced AAE_X16_ROWS meets a batch this small)
     if (m->buckets_valid || !fused_decoder_applies(m) || ntiles > kBucketMaxTiles || m->rows > kBucketMaxDocs ||
         need > (size_t)kCSlots * kCR * kCL * sizeof(float) || getenv("AAE_NO_PIGGYBACK"))
         return;

@@ -47,6 +47,8 @@ struct aae_model {
     // transposed copies [in + 1][out] of the hidden layers' augmented weights: chain.h's dX ops read rows [0, in) with
     // the forward layers' access pattern, chain4.h's forward layers read all of it (n contiguous).  Kept in step by the fused / grouped optimiser kernels;
     // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
+    unsigned short* FXi[NP]; unsigned short* DXi[NP]; unsigned short* FXBi[NP];   // the split (three bf16 planes) copies for chain16x3.h, or NULL
+    bool x16_ok; int x16_rows;                   // wide-batch chain kernel usable / from how many rows of a program on
     Ten PT[NP]; Ten D4[NP]; bool pt_ok[NP];      // PT = the F4 copy, D4 = the dX copy (device_common.h W4Copies)
     // activations
     Ten a1, eh1, eh2, zc, dh1, dh2, G, slabs, gb0, gb1, gb2, gb3, gzc, ga3, zin, xh1, xh2, dout, zsave, da2;
@@ -199,6 +201,13 @@ int validate(const aae_config* c) {
     return AAE_OK;
 }
 
+// Programs of at least this many rows run on the 16-row chain kernel (chain16x3.h); AAE_X16_ROWS overrides (tests: 1 = always).
+// A layer op is bound by getting its weights through ONE CU's vector-memory path (64 B/clk): 160 KB of fp32 per 201 x 200 layer on
+// the 4-row kernel, 280 KB of split terms on the 16-row one - its workgroup takes ~2x the time for 4x the rows, so it pays where
+// the 4-row launch needs two rounds and more of the CUs it gets (r5, same-box A/B, from 256 | 1024 rows | never: C4 0.397 | 0.351 |
+// 0.365 ms/step, C3 at batch 512 0.665 | 0.657 | 0.673, one rank's step at world 8 0.340 | 0.289 | 0.298).
+inline int x16_min_rows() { const char* e = getenv("AAE_X16_ROWS"); return e ? atoi(e) : 1024; }       // (read per model: at aae_create)
+
 // lays the model out; with dry=true only measures
 size_t layout(aae_model* m, char* base, bool dry) {
     const aae_config& c = m->cfg;
@@ -233,7 +242,8 @@ size_t layout(aae_model* m, char* base, bool dry) {
     if (c.grad_mode == AAE_GRAD_EXPORT)
         for (int i = P_B1; i < NP; ++i) m->Gr[i] = a.mat(m->P[i].rows, m->P[i].cols, m->P[i].ld, i == P_V3 ? 2 * kTI : 0);
     for (int i = 0; i < NP; ++i) { m->PT[i] = Ten(); m->D4[i] = Ten(); m->pt_ok[i] = false; }
-    if (h + 1 <= 208 && m->c + 1 <= 208 && cp + 1 <= 2 * 208 && c.model_kind != 3)      // layer-chain models (not the VAE's programs); a decoder input beyond 208 columns runs in two k-parts (abi_chains.h)
+    const bool chain_copies = h + 1 <= 208 && m->c + 1 <= 208 && cp + 1 <= 2 * 208 && c.model_kind != 3;
+    if (chain_copies)      // layer-chain models (not the VAE's programs); a decoder input beyond 208 columns runs in two k-parts (abi_chains.h)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2})
         {
             const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols;
@@ -241,6 +251,15 @@ size_t layout(aae_model* m, char* base, bool dry) {
             //  chain4.h; the A operand is zero there)
             m->PT[pid] = a.mat((Nc + 3) / 4, 4 * M, 4 * M, kW4Pad);      // F4 [(in + 1 + 3) / 4][out][4]: k = input column (the bias is k = in)
             m->D4[pid] = a.mat((M + 3) / 4, 4 * Nc, 4 * Nc, kW4Pad);     // D4 [(out + 3) / 4][in + 1][4]: k = output row
+        }
+    // the split weight copies of the wide-batch chain kernel (chain16x3.h): only for models that can see such a batch
+    for (int i = 0; i < NP; ++i) m->FXi[i] = m->DXi[i] = m->FXBi[i] = nullptr;
+    if (chain_copies && m->R2 >= x16_min_rows() && getenv("AAE_NO_X16") == nullptr)
+        for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2}) {
+            const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols, Mp = (M + 15) & ~15, Np = (Nc + 15) & ~15;
+            m->FXi[pid] = reinterpret_cast<unsigned short*>(a.take((size_t)(((Nc + 31) / 32) * 3 * Mp * 32 + 1) / 2, nullptr));
+            m->DXi[pid] = reinterpret_cast<unsigned short*>(a.take((size_t)(((M + 31) / 32) * 3 * Np * 32 + 1) / 2, nullptr));
+            if (Nc > kCWide) m->FXBi[pid] = reinterpret_cast<unsigned short*>(a.take((size_t)(((Nc - kCWide + 31) / 32) * 3 * Mp * 32 + 1) / 2, nullptr));
         }
     const int R = m->R, R2 = m->R2;
     m->a1 = a.mat(R, h, m->ldh);   m->eh1 = a.mat(R, h + 1, m->ldh);  m->eh2 = a.mat(R, h + 1, m->ldh);

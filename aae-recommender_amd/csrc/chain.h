@@ -21,6 +21,7 @@ namespace aae {
 constexpr int kCR = 16;        // rows per workgroup
 constexpr int kCL = 212;       // slot row stride (floats): widths up to 208, 16-byte aligned rows
 constexpr int kCSlots = 10;
+constexpr int kCWide = 208;    // columns of a slot row a layer may read (16-byte aligned rows of kCL floats); a wider decoder input runs in two k-parts
 constexpr int kCT = 1024;      // threads per workgroup
 constexpr int kCW = kCT / 64;  // waves: 16 (one 16-column block of a layer per wave) or 8 (two blocks per wave)
 constexpr int kCQ = (13 + kCW - 1) / kCW;   // blocks per wave (N <= 208 -> 13 blocks)
@@ -56,6 +57,7 @@ struct ChainOp {
     const float* W; int ldw;            // weights / global source (COP_LOAD, COP_SLABSUM)
     const float* Wkn; int ldkn;         // the same layer's matrix in k-major form [K][N] (n contiguous) for chain4.h
     const float* W4; int ns4;           // ... and k4-interleaved [(K + 3) / 4][ns4][4] (device_common.h), or NULL
+    const unsigned short* WX; int xpl;  // ... and split into three bf16 planes for chain16x3.h (device_common.h FX / DX; xpl = rows of a plane), or NULL
     int epi, yslot;                     // epilogue; slot holding y for ACTBWD / FINAL_BWD
     DropSpec d;
     float* out; int ldo; int out_row0;  // optional global store of dst[:, 0:N] at rows out_row0 + r

@@ -122,14 +122,17 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     // The stream: tensor base in a buffer descriptor (scalar registers), the tile's byte offset in a scalar
     // register, this thread's slot offset in ONE vector register (+ an immediate); reads beyond the tensor return zero
     // (the dispatcher keeps fused layers below 2 GB)
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
+    // (r5: the descriptor covers a WINDOW of the tensor that starts at tile seg0 - the range check looks at the sum of the scalar
+    //  and the vector offset and a descriptor spans < 2^31 bytes, while PubMed's / ACM's dec.lin3 of the reference's dataset table
+    //  is 2.4 GB at hidden 200; the window moves up, at a tile's start, once that tile lies 2^30 bytes into it: x3_window)
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    X3Window win(N, ldv, tile_bytes);
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
     };
     float4 vreg[NV];
     int tile = wgi;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 
     for (; tile < ntiles; tile += stride, ++iter) {
         const int i0 = tile * kTI;
+        if (win.moves(tile)) rP = win.desc(a.V3a);          // (uniform; never for a layer below 2^30 bytes)
         // A zero the compiler cannot see through: the LDS operand addresses of the phases are built from it, so they are
         // recomputed per tile (a few VALU) instead of being hoisted out of the tile loop and held in registers across
         // every phase - at 128 VGPRs that hoisting spilled, and a scratch reload waits for every older global load in
@@ -482,18 +486,16 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
     }
 
     // the streams: tensor bases in buffer descriptors, tile offset scalar, slot offset in one vector register
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    X3Window win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors, as in the critical launch)
+    const float* gbase = a.gradV3 ? a.gradV3 : a.V3a;
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V), rG = win.desc(gbase);
     const int g_f4 = B * (kTI / 4);             // float4 per stored tile (<= 1024: B <= 128)
     const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
     const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(a.Gt, 0, gbytes, 0x00020000);
-    const unsigned lane_off = (unsigned)tid * 16u;
-    const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 2));
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 2));
     };
     auto ldg = [&](int tile) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rGt, tid < g_f4 ? lane_off : 0x80000000u, (unsigned)tile * (unsigned)g_f4 * 16u, 2));
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
 
     for (; tile < ntiles; tile += stride) {
         const int i0 = tile * kTI;
+        if (win.moves(tile)) { rP = win.desc(a.V3a); rM = win.desc(a.M); rV = win.desc(a.V); rG = win.desc(gbase); }
         int oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
         const int lz = lane + oz;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
         for (int j = 0; j < NV; ++j) {
             const bool valid = tid + kNT * j < tile_f4 && i0 + (s_rc[j] >> 6) < N;
             const float4 g = *reinterpret_cast<const float4*>(os + (s_rc[j] >> 6) * kSO + (s_rc[j] & 63) * 4);
-            const unsigned so = (unsigned)tile * tile_bytes;
+            const unsigned so = win.so(tile);
             const unsigned vo = valid ? lane_off + (unsigned)(kNT * 16 * j) : 0x80000000u;
             float4 p = p_cur[j], mm = mreg[j], vv = sreg[j];
             adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);
@@ -674,14 +677,12 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
     const int nch = (B + kXCH - 1) / kXCH;
     const int cb = min(wave, NB - 1);
 
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    X3Window win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors: it starts at a group's first tile)
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V);
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 2));
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 2));
     };
     // Roles: waves 0 .. NB multiply (wave w = column block w, both item halves - the last block's halves on two waves,
     // below) and go from a step's barrier straight into their products.  The stored dL/dlogits rows of a step arrive by LDS-DMA (global_load_lds_dwordx4: no register
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
     for (int grp = blockIdx.x; grp < G; grp += gridDim.x) {
         const int t0 = (int)(((long long)grp * ntiles) / G), nt = (int)(((long long)(grp + 1) * ntiles) / G) - t0;
         if (nt <= 0) continue;
+        if (win.moves(t0)) { rP = win.desc(a.V3a); rM = win.desc(a.M); rV = win.desc(a.V); }
         const int Q = nch * nt;                         // steps q = ch * nt + j
         const bool stamp_wg = TS && a.ts && blockIdx.x == 0 && grp == (int)blockIdx.x && lane == 0;
 
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
                     const int row = (tid + kNT * u) / f4_per_row;       // (only for the bound check below)
                     const bool valid = tid + kNT * u < tile_f4 && i0 + row < N && on;
                     const float4 g = *reinterpret_cast<const float4*>(os + j * (kTI * kSO) + s_rc[u]);
-                    const unsigned so = (unsigned)tile * tile_bytes;
+                    const unsigned so = win.so(tile);
                     const unsigned vo = valid ? lane_off + (unsigned)(kNT * 16 * u) : 0x80000000u;
                     float4 p = pr[cur][u], mm = mr[cur][u], vv = vr[cur][u];
                     adam_update(p.x, mm.x, vv.x, g.x, sc); adam_update(p.y, mm.y, vv.y, g.y, sc);

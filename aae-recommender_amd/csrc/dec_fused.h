@@ -115,6 +115,28 @@ inline size_t dec_fused_lds_bytes(int B, int h) {
 // kernel (each tile's rows are read and written by the same lanes), so LDS ordering is all it needs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The window of dec.lin3 (and of its moments: same shape) that the kernels' buffer descriptors cover.  A descriptor spans less
+// than 2^31 bytes and its range check sees the scalar + vector offset, but the layer of a 2.9 M-item vocabulary is 2.4 GB
+// (r1-r4 sent such layers to the three streaming GEMMs).  A workgroup walks its tiles in ascending order, 0.3-8 MB apart, and
+// touches the tile in hand and the next one or two: the window starts at tile seg0 and moves up - at the START of a tile's
+// iteration, to that tile - once the tile lies 2^30 bytes into it; what was requested through the old descriptor is unaffected
+// (a descriptor is read when the instruction issues).  All scalar: a compare per tile, never taken below 2^30 bytes.
+struct X3Window {
+    int seg0; unsigned seg_tiles, tile_bytes; size_t total;
+    __device__ X3Window(int N, int ldv, unsigned tb) : seg0(0), seg_tiles((1u << 30) / tb), tile_bytes(tb), total((size_t)N * ldv * sizeof(float)) {}
+    __device__ __forceinline__ bool moves(int tile) {
+        if ((unsigned)(tile - seg0) <= seg_tiles) return false;
+        seg0 = tile;
+        return true;
+    }
+    __device__ __forceinline__ unsigned so(int tile) const { return (unsigned)(tile - seg0) * tile_bytes; }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const float* base) const {      // (beyond the tensor: reads return zero, stores are dropped)
+        const size_t off = (size_t)seg0 * tile_bytes;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + off / sizeof(float), 0,
+                                                 (unsigned)min((size_t)0x7FFFFFF0u, total - off), 0x00020000);
+    }
+};
+
 template <int NB, int MODE = kDecFused>   // NB = ceil((h + 1) / 16) column blocks
 __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     constexpr bool kFwd = MODE != kDecOpt && MODE != kDecOptAcc;     // GEMM1, entries, GEMM3, loss, slabs
@@ -212,11 +234,9 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     //   m/v(t) before GEMM2(t); parameter stores of S5(t) retire behind GEMM3(t).
     float4 vreg[NV], mreg[NV], sreg[NV], areg[NV];
     typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.V3a, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.gradV3 ? a.gradV3 : a.V3a, 0, tbytes, 0x00020000);
+    X3Window win(a.N, ldv, (unsigned)(kTI * ldv) * 4u);       // (r5: the window of the tensors the store descriptors cover - layers beyond 2^31 bytes)
+    const float* gbase = a.gradV3 ? a.gradV3 : a.V3a;
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V), rG = win.desc(gbase);
     int tile = wgi;
     const int stride = wgs;
     const int last_e = max(a.te.start[ntiles] - 1, 0);        // clamp for the unconditional entry loads
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     auto stamp = [&](int k) { if (a.ts && blockIdx.x == 0 && tid == 0 && iter == 5) { a.ts[k] = wall_clock64(); if (k == 0 || k == 6) a.ts[8 + k / 6] = clock64(); } };
     for (; tile < ntiles; tile += stride, ++iter) {
         const int i0 = tile * kTI;
+        if (win.moves(tile)) { rP = win.desc(a.V3a); rM = win.desc(a.M); rV = win.desc(a.V); rG = win.desc(gbase); }
         // A zero the compiler cannot see through: the LDS operand pointers of the three GEMMs are built from
         // it, so they are recomputed per tile (~30 VALU) instead of being hoisted out of the tile loop and held
         // in ~20 VGPRs across every phase - at 128 VGPRs (16 waves/CU) that hoisting spilled to scratch, and a
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
             float4 g = *reinterpret_cast<const float4*>(os + slot_os(j));
             if (kAccIn) { g.x += areg[j].x; g.y += areg[j].y; g.z += areg[j].z; g.w += areg[j].w; }
             // the tile span is contiguous: byte offset = (i0 * ldv + 4 * slot) * 4
-            const unsigned so = (unsigned)((size_t)((a.dbg_skip & 128) ? (int)blockIdx.x * kTI : i0) * ldv) * 4u;
+            const unsigned so = win.so((a.dbg_skip & 128) ? (int)blockIdx.x : tile);
             const unsigned vo = valid ? (unsigned)(tid + kNT * j) * 16u : 0x80000000u;
             const float* ps = v3s + slot_v3(j);
             float4 p = make_float4(ps[0], ps[1], ps[2], ps[3]);

@@ -152,17 +152,75 @@ namespace aae {
 // Both are kept in step with P by the optimiser epilogues that write P (w4_put4 / w4_put1) and re-derived by
 // interleave4_kernel after any other writer.
 // ---------------------------------------------------------------------------------------------
-struct W4Copies { float* f4; float* d4; int M, N; };      // f4 == NULL: the layer has none
+// r5: wide batches run the layer chains 16 rows per workgroup on the bf16 matrix cores with every fp32 product emulated by
+// six bf16 products (chain16x3.h, as the output layer since r3): the B operand of v_mfma_f32_16x16x32_bf16 is a lane's
+// 8 consecutive k of one column as bf16, and splitting 40 000 weights into three bf16 terms per workgroup and op would cost more
+// vector work than the products.  So the split weights are kept as a third and fourth copy, three bf16 planes each:
+//   FX (forward, k = input column i, n = output row o):   FX[(((i >> 5) * 3 + t) * Mp + o) * 32 + (i & 31)]     Mp = M up to 16
+//   DX (dX,      k = output row o,   n = input column i): DX[(((o >> 5) * 3 + t) * Np + i) * 32 + (o & 31)]     Np = N up to 16
+//   FXB: FX with k counted from input column `split` (the second k-part of a layer whose input is wider than a slot)
+// term t of a weight w: w = t0 + t1 + t2 exactly, each a bf16 value (round to nearest even of what is left).  Planes never
+// written (k beyond the matrix, columns beyond it) stay zero for the life of the arena: the kernel reads whole 32-deep
+// k-steps and 16-column tiles unclamped.  fx == NULL: the model never runs a batch wide enough (aae_create).
+struct W4Copies { float* f4; float* d4; int M, N; unsigned short* fx; unsigned short* dx; unsigned short* fxb; int split; };      // f4 == NULL: the layer has none
 constexpr int kW4Pad = 4;      // zero k-chunk rows behind a k4-interleaved copy (what an unclamped run of chunks may read)
+typedef __bf16 w4_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned w4_rne_pair(float a, float b) {       // (low half = a) v_cvt_pk_bf16_f32: ties to even
+    w4_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, w4_bf16x2));
+}
+// v -> its three bf16 terms (bit patterns)
+__device__ __forceinline__ void w4_split3(float v, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
+    const unsigned p0 = w4_rne_pair(v, 0.f);
+    const float r1 = v - __uint_as_float(p0 << 16);
+    const unsigned p1 = w4_rne_pair(r1, 0.f);
+    const float r2 = r1 - __uint_as_float(p1 << 16);
+    t0 = (unsigned short)p0; t1 = (unsigned short)p1; t2 = (unsigned short)w4_rne_pair(r2, 0.f);
+}
+__device__ __forceinline__ void w4x_put1(const W4Copies& c, int o, int i, float v) {
+    unsigned short t[3];
+    w4_split3(v, t[0], t[1], t[2]);
+    const int Mp = (c.M + 15) & ~15, Np = (c.N + 15) & ~15;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        c.fx[((size_t)((i >> 5) * 3 + q) * Mp + o) * 32 + (i & 31)] = t[q];
+        c.dx[((size_t)((o >> 5) * 3 + q) * Np + i) * 32 + (o & 31)] = t[q];
+    }
+    if (c.fxb && i >= c.split) {
+        const int j = i - c.split;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c.fxb[((size_t)((j >> 5) * 3 + q) * Mp + o) * 32 + (j & 31)] = t[q];
+    }
+}
 // element (o, i) of P just became v
 __device__ __forceinline__ void w4_put1(const W4Copies& c, int o, int i, float v) {
     c.f4[((size_t)(i >> 2) * c.M + o) * 4 + (i & 3)] = v;
     c.d4[((size_t)(o >> 2) * c.N + i) * 4 + (o & 3)] = v;
+    if (c.fx) w4x_put1(c, o, i, v);
 }
 // elements (o, i .. i + 3), i % 4 == 0, i + 3 < N
 __device__ __forceinline__ void w4_put4(const W4Copies& c, int o, int i, float4 v) {
     *reinterpret_cast<float4*>(c.f4 + ((size_t)(i >> 2) * c.M + o) * 4) = v;
     float* d = c.d4 + ((size_t)(o >> 2) * c.N + i) * 4 + (o & 3);
     d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+    if (c.fx) {
+        // FX: the four k are neighbours inside one 32-deep step (i % 4 == 0): one 8-byte store per term; DX: four columns
+        unsigned short t[4][3];
+        w4_split3(v.x, t[0][0], t[0][1], t[0][2]); w4_split3(v.y, t[1][0], t[1][1], t[1][2]);
+        w4_split3(v.z, t[2][0], t[2][1], t[2][2]); w4_split3(v.w, t[3][0], t[3][1], t[3][2]);
+        const int Mp = (c.M + 15) & ~15, Np = (c.N + 15) & ~15;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const uint2 pk = make_uint2((unsigned)t[0][q] | ((unsigned)t[1][q] << 16), (unsigned)t[2][q] | ((unsigned)t[3][q] << 16));
+            *reinterpret_cast<uint2*>(c.fx + ((size_t)((i >> 5) * 3 + q) * Mp + o) * 32 + (i & 31)) = pk;
+            unsigned short* dq = c.dx + ((size_t)((o >> 5) * 3 + q) * Np + i) * 32 + (o & 31);
+            dq[0] = t[0][q]; dq[32] = t[1][q]; dq[64] = t[2][q]; dq[96] = t[3][q];
+            if (c.fxb && i >= c.split) {     // (split % 4 == 0: the four k stay neighbours)
+                const int j = i - c.split;
+                *reinterpret_cast<uint2*>(c.fxb + ((size_t)((j >> 5) * 3 + q) * Mp + o) * 32 + (j & 31)) = pk;
+            }
+        }
+    }
 }
 }  // namespace aae

@@ -93,14 +93,14 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
 
     // the parameter stream: tensor base in a buffer descriptor, tile offset scalar, slot offset in one vector register;
     // reads beyond the tensor return zero
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V3a), 0, tbytes, 0x00020000);
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    X3Window win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
     };
     // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
     const int eb = tid >> 3, eq = tid & 7;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
 
     int prev_i0 = -1; unsigned kw_prev = 0u;
     for (; tile < ntiles; tile += stride) {
+        if (win.moves(tile)) rP = win.desc(a.V3a);
         const int i0 = tile * kTI;
         int oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
@@ -292,14 +293,14 @@ __global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
 
     // the parameter stream: tensor base in a buffer descriptor, tile offset scalar, slot offset in one vector register;
     // reads beyond the tensor return zero
-    const unsigned tbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V3a), 0, tbytes, 0x00020000);
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
+    X3Window win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
+    __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), (unsigned)tile * tile_bytes, 0));
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
     };
     // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
     const int eb = tid >> 3, eq = tid & 7;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
 
     int prev_i0 = -1; unsigned kw_prev = 0u;
     for (; tile < ntiles; tile += stride) {
+        if (win.moves(tile)) rP = win.desc(a.V3a);
         const int i0 = tile * kTI;
         int oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));

@@ -243,6 +243,57 @@ def test_row_blocked_output_layer_equals_the_three_kernel_path(Ns, B, h, monkeyp
         assert _maxdiff(a, b) <= tol + 1e-4 * float(np.abs(b).max()), (tid, _maxdiff(a, b))
 
 
+@pytest.mark.parametrize("B", [100, 208])
+def test_fused_output_layer_beyond_two_gib(B):
+    """vocabularies whose dec.lin3 exceeds 2^31 bytes - PubMed's 2 896 764 and ACM's 2 631 128 items of the
+    reference's own dataset table (nmi.txt:68,85) at hidden 200: 2.37 GB per tensor - stay on the fused output layer (r1-r4
+    fell back to the three streaming GEMMs with [B, N] in HBM above 2.63 M items).  2 900 000 items, hidden 200, one fused
+    launch (100 rows) and the row-blocked form (208 rows), two consecutive steps: dL/d(dh2), loss, EVERY row of dec.lin3 and of
+    both dec_optim moments against the three-kernel path; the profile counters say which kernels ran."""
+    from aaerec._hip import HipAAE, DeviceCSR, T_DEC_V3, T_ADAM_DEC, K_DEC_CRIT, K_DEC_FUSED, K_DEC_BCE_FWD
+    from tools.synth import throughput_corpus
+    Ns, h, c = 2900000, 200, 50
+    assert (Ns + 64) * 204 * 4 > 2 ** 31
+    rng = np.random.default_rng(Ns + B)
+    k = 1.0 / np.sqrt(h)
+    full = {"dec.lin3.weight": ((rng.random((Ns, h), dtype=np.float32) * 2 - 1) * np.float32(k)),
+            "dec.lin3.bias": ((rng.random(Ns, dtype=np.float32) * 2 - 1) * np.float32(k))}
+    X = throughput_corpus(2 * B, Ns, median_len=30, seed=Ns)
+    fused = HipAAE(Ns, h, c, max_batch=B, max_nnz=B * 256, rng_mode="inject", blocked_output=B > 112)
+    plain = HipAAE(Ns, h, c, max_batch=B, max_nnz=B * 256, rng_mode="inject", unfused_decoder=True)
+    for m in (fused, plain):
+        m.load_params(full)
+        m.set_grad_scale(0.25)
+    del full
+    fused.profile_enable(True, kernels=(K_DEC_CRIT, K_DEC_FUSED))
+    plain.profile_enable(True, kernels=(K_DEC_BCE_FWD,))
+    csr = DeviceCSR(X, fused.device)
+    for s in range(2):
+        dh2 = np.abs(rng.standard_normal((B, h + 1))).astype(np.float32) * 0.5
+        dh2[rng.random((B, h + 1)) < 0.4] = 0.0
+        dh2[:, h] = 1.0
+        for m in (fused, plain):
+            m.dh2_rows(B)[:, :h + 1].copy_(torch.from_numpy(dh2))
+            m.output_layer_step(csr, s * B, B)
+        np.testing.assert_allclose(fused.losses()[0], plain.losses()[0], rtol=1e-5)
+        got, want = fused.da2_rows(B)[:, :h].cpu().numpy(), plain.da2_rows(B)[:, :h].cpu().numpy()
+        scale = float(np.abs(want).max())
+        assert _maxdiff(got, want) <= 2e-5 * scale + 1e-12, (s, _maxdiff(got, want), scale)
+    torch.cuda.synchronize()
+    # (a layer this large in ONE row block runs the single fused launch - its deferred half would outlast the step -, the
+    #  row-blocked form the critical launch + the deferred launch over all blocks: abi_output_layer.h)
+    ran = fused.profile_read(K_DEC_FUSED)[1] if B <= 112 else fused.profile_read(K_DEC_CRIT)[1]
+    assert ran == 2, "the fused output layer did not run"
+    assert plain.profile_read(K_DEC_BCE_FWD)[1] >= 2, "the three-kernel path did not run"
+    for tid in (T_DEC_V3, T_ADAM_DEC + 4, T_ADAM_DEC + 5):
+        a, b = fused.tensor(tid), plain.tensor(tid)
+        d = float((a - b).abs().max().item())
+        tol = 2e-6 if tid == T_DEC_V3 else 1e-9
+        assert d <= tol + 1e-4 * float(b.abs().max().item()), (tid, d)
+        # ... and the rows beyond byte 2^31 did move (an update dropped by a range check would leave them at their start values)
+        assert float(a[-1000:].abs().sum().item()) > 0
+
+
 @pytest.mark.parametrize("N,B", [(6000, 150), (40000, 224), (100000, 512)])
 def test_row_blocked_full_steps_equal_the_three_kernel_steps(N, B):
     """Whole training steps (aae_step: ae + disc + gen) on ONE handle with 113..256-row batches - what

@@ -87,6 +87,19 @@ def test_step_matches_reference_through_the_split_output_layer(name, monkeypatch
     test_step_matches_reference(name)
 
 
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_step_matches_reference_on_the_wide_batch_chain_kernel(name, monkeypatch):
+    """The same replay with every layer-chain program on the wide-batch kernel (r5, csrc/chain16x3.h; AAE_X16_ROWS=1 lifts
+    the 256-row rule): 16 rows per workgroup, activations as three bf16 planes in LDS, the hidden layers' fp32 products
+    emulated by six bf16 products against the split weight copies the optimiser epilogues keep (device_common.h FX / DX),
+    slots renamed by live range - every option of the path (dropout, conditions incl. the two-part decoder input,
+    SELU / Tanh, priors with a softmax / sigmoid code, SGD, ragged / empty / short batches, the merged discriminator
+    program's prefix on workgroups that straddle the z_real / z_fake boundary) against the reference's recorded losses,
+    parameters and Adam moments at the SAME tolerances as the fp32 kernels."""
+    monkeypatch.setenv("AAE_X16_ROWS", "1")
+    test_step_matches_reference(name)
+
+
 def test_plain_autoencoder_matches_reference():
     """cfg.reserved[2] = 1: the reference's non-adversarial AutoEncoder (aae.py:221-458) - only the
     reconstruction step runs; fixture generated from the reference's AutoEncoder class."""

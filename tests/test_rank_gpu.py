@@ -42,6 +42,7 @@ CASES = [  # N, h, c, inc, max_batch, rows, k, exclude_known, dtype
     (700, 200, 50, 0, 100, 37, 5, True, "f32"),           # fewer tiles than CUs, a call smaller than the training batch
     (47000, 100, 50, 0, 100, 400, 10, True, "bf16"),      # C2's shape in bf16 mode (operands rounded to bf16)
     (100000, 200, 50, 0, 100, 512, 10, True, "f32"),      # C3 at the rows-per-call the benchmark's predict_topk line uses
+    (2900000, 200, 50, 0, 32, 40, 10, True, "f32"),       # PubMed's vocabulary (nmi.txt:85): dec.lin3 beyond 2^31 bytes (r5: the descriptors' window)
 ]
 
 
