@@ -218,7 +218,8 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in || cb.P.ops[i].y_glb) && !four)
             return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
     // wide batches: 16 rows per workgroup on the bf16 matrix cores (chain16x3.h)
-    if (four && m->x16_ok && cb.P.rows >= m->x16_rows && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
+    static const bool x16_dry = getenv("AAE_X16_DRY") != nullptr;      // (debug: keep the split copies, launch the 4-row kernel)
+    if (four && m->x16_ok && !x16_dry && cb.P.rows >= m->x16_rows && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
         ChainProgram X = cb.P;
         if (x16_remap_slots(X)) {
             const int grid16 = (X.rows + kX16R - 1) / kX16R;

@@ -70,7 +70,12 @@ __device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned shor
             for (int t = 0; t < NT; ++t)
                 b[ks][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)(ks * 3 + t) * plane, 0));
     __builtin_amdgcn_sched_barrier(0);          // (every load of the first k-steps is requested before the first product, chain4.h)
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Three accumulators, by the size of the terms: the leading products (a0 b0), the 2^-8 ones (a1 b0, a0 b1), the 2^-16 ones
+    // (a2 b0, a0 b2, a1 b1).  On ONE accumulator every small-term instruction rounds against the large running sum: 42 roundings
+    // per 201-deep layer where the fp32 pipe's chain has its own products' only - measured on the e2e fixture (3 epochs at the
+    // C3 shape, tests/test_host_gpu.py::test_c3_scale_ranking_matches_reference): dL/d(a1) of gen_step 5e-5 off the 4-row
+    // kernel's, enough to flip the sign of near-zero first-layer gradients and part the Adam trajectories.
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_m = acc, acc_l = acc;
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks) {
         if (ks < ksteps) {                       // (uniform)
@@ -80,11 +85,11 @@ __device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned shor
             if (BF) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[ks % kX16Depth][0], acc, 0, 0, 0);
             else {
                 const gemm_bf16x8 (&bb)[NT] = b[ks % kX16Depth];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT - 1], bb[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[NT - 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], bb[NT > 1 ? 1 : 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], bb[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[NT > 1 ? 1 : 0], acc, 0, 0, 0);
+                acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT - 1], bb[0], acc_l, 0, 0, 0);
+                acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[NT - 1], acc_l, 0, 0, 0);
+                acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], bb[NT > 1 ? 1 : 0], acc_l, 0, 0, 0);
+                acc_m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], bb[0], acc_m, 0, 0, 0);
+                acc_m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[NT > 1 ? 1 : 0], acc_m, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[0], acc, 0, 0, 0);
             }
             if (ks + kX16Depth < ksteps)
@@ -93,6 +98,7 @@ __device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned shor
                     b[ks % kX16Depth][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)((ks + kX16Depth) * 3 + t) * plane, 0));
         }
     }
+    if (!BF) acc += acc_m + acc_l;
     return acc;
 }
 
