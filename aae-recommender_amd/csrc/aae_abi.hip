@@ -115,9 +115,9 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->force_unfused = cfg->unfused_decoder == 1;   // debugging / A-B switch: unfused_decoder = 1 keeps the 3-kernel path
         if (m->fused_ok) {
             const int maxlds = 160 * 1024;
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            hipError_t e1 = aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<4>), reinterpret_cast<const void*>(dec_fused_kernel<4, kDecFused, true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            hipError_t e2 = aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<7>), reinterpret_cast<const void*>(dec_fused_kernel<7, kDecFused, true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+            hipError_t e3 = aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<13>), reinterpret_cast<const void*>(dec_fused_kernel<13, kDecFused, true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 2048);
             m->bucket_wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 16384) == hipSuccess;
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) m->fused_ok = false;
@@ -184,28 +184,28 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     if (side_ok && m->fused_ok && m->split_wgs > 0 && (!m->bf16 || getenv("AAE_NO_BF16_X3") == nullptr) &&
         (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
         bool ok = true;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+        ok = ok && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecCrit>), reinterpret_cast<const void*>(dec_fused_kernel<7, kDecCrit, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit>), reinterpret_cast<const void*>(dec_fused_kernel<13, kDecCrit, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOpt>), reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOpt, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOpt>), reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOpt, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt>), reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOpt, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOptAcc>), reinterpret_cast<const void*>(dec_fused_kernel<4, kDecOptAcc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOptAcc>), reinterpret_cast<const void*>(dec_fused_kernel<7, kDecOptAcc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc>), reinterpret_cast<const void*>(dec_fused_kernel<13, kDecOptAcc, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!m->bf16) m->split_ok = ok;
         static const bool no_x3 = getenv("AAE_NO_X3") != nullptr;
         m->x3_ok = ok && !no_x3
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<4>), reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<7>), reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13>), reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
         if (m->bf16) {
@@ -222,15 +222,15 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             // on 48-64 workgroups (tools/debug/bf16_one_sweep.sh; a claim of 120 KB leaves the 24 KB weight-gradient workgroups
             // in: 0.1865).
             m->bf16_one = m->bf16_x3 && getenv("AAE_NO_BF16_ONE") == nullptr
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_x3_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<4, true>), reinterpret_cast<const void*>(dec_opt_x3_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<7, true>), reinterpret_cast<const void*>(dec_opt_x3_kernel<7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<13, true>), reinterpret_cast<const void*>(dec_opt_x3_kernel<13, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<4>), reinterpret_cast<const void*>(dec_opt_x3_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<7>), reinterpret_cast<const void*>(dec_opt_x3_kernel<7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<13>), reinterpret_cast<const void*>(dec_opt_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             (void)hipGetLastError();
         }
         if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
@@ -249,7 +249,10 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             // step): half the chip at most - C3 0.2493 (early join, 144) -> 0.2430 ms/step on 128; 0.2515 / 0.2483 / 0.2497 /
             // 0.2492 on 112 / 120 / 136 / 144 (sharp: 124 -> 0.2459, 132 -> 0.2503); the early join on 128: 0.2608.  C2 (formula:
             // 80) is flat from 64 to 96 either way (tools/debug/late_join_sweep*.sh).
-            const int cap = m->late_enabled ? m->n_cu / 2 : m->n_cu * 9 / 16;
+            // r5: the deferred launch no longer requests the 416 float4 slots beyond a tile's span (it read 1.25x the layer): 139.7 ->
+            // 130.9 us on 128 workgroups, and the optimum moved down with it - same box, C3: 0.2469 / 0.2359 / 0.2368 / 0.2386 / 0.2378 /
+            // 0.2412 ms/step on 104 / 112 / 120 / 124 / 128 / 136 (tools/debug/sweep_split_wgs.sh): 15/32 of the chip
+            const int cap = m->late_enabled ? m->n_cu * 15 / 32 : m->n_cu * 9 / 16;
             m->split_wgs = std::max(1, std::min(w, cap));
         }
     }

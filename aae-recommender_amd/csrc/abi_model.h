@@ -349,6 +349,11 @@ size_t layout(aae_model* m, char* base, bool dry) {
 }
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// one attribute on a kernel and on its moving-window instantiation (layers beyond 2^31 bytes, dec_fused.h X3WindowT)
+inline hipError_t aae_attr2(const void* k, const void* k_win, hipFuncAttribute attr, int value) {
+    const hipError_t e = hipFuncSetAttribute(k, attr, value);
+    return e != hipSuccess ? e : hipFuncSetAttribute(k_win, attr, value);
+}
 
 // scoped hipEvent pair around one kernel launch when profiling is enabled
 struct ProfScope {

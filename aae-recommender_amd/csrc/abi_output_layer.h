@@ -25,6 +25,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // nblk launches of the split form over equal row blocks
     const int nblk = m->have_batch ? row_blocks(m) : 1;
     const int Bb = (B + nblk - 1) / nblk;                        // rows per block (the last one may be shorter)
+    const bool win = x3_big_span(m->N, m->ldh);                  // dec.lin3 beyond 2^31 bytes: the kernels' moving-window instantiations (dec_fused.h)
     const size_t fused_lds = out_bf16(m) ? dec_fused_bf16_lds_bytes(m->fused_nb ? m->fused_nb : 13) : dec_fused_lds_bytes(Bb, h);
     const float* chain_part = nullptr; size_t chain_stride = 0;
     if (fused_decoder_applies(m)) {
@@ -111,22 +112,22 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 } else if (m->x3_ok) {
                     const uint32_t lds3 = (uint32_t)dec_crit_x3_lds_bytes(m->fused_nb);
                     if (m->bf16_one) switch (m->fused_nb) {     // bf16 mode: the one-term instantiation (one matrix instruction per product)
-                    case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<4, false, true, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<4, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<7, false, true, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<7, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, false, true, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); } break;
                     } else
                     switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_crit_x3_kernel<4>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_crit_x3_kernel<7>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<4, false, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<4>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<7, false, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<7>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); } break;
                     default:
                         if (b.ts) hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b);
-                        else hipExtLaunchKernelGGL((dec_crit_x3_kernel<13>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b);
+                        else { if (win) hipExtLaunchKernelGGL((dec_crit_x3_kernel<13, false, false, true>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_crit_x3_kernel<13>), dim3(grid), dim3(kNT), lds3, s, start, stop, 0, b); }
                         break;
                     }
                 } else switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit, true>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit, true>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit, true>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecCrit>), dim3(grid), dim3(kNT), (uint32_t)fused_lds, s, start, stop, 0, b); } break;
                 }
                 LAUNCHCHK("dec_fused (critical launch)");
                 if (r == nblk - 1) HIPCHK(hipStreamWaitEvent(m->side, stop, 0));
@@ -187,9 +188,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     }
                 } else
                 switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<4>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<7>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<4, false, true>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<4>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<7, false, true>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<7>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13, false, true>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_blocks_x3_kernel<13>), dim3(g3), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
                 }
                 LAUNCHCHK("dec_opt_blocks_x3");
             } else if (one_opt) {
@@ -224,23 +225,23 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     const uint32_t lds3 = lds_kb > 0 ? std::max(lds_nat, (uint32_t)lds_kb * 1024u) : (m->bf16_one ? std::max(lds_nat, 150u * 1024u) : lds_nat);
                     if (late) { b.dh2 = m->dh2s.p; b.sc = m->sc_snap; late_launched = true; }
                     if (m->bf16_one) switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_opt_x3_kernel<13, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, true, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<13, true, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<13, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
                     } else
                     switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_opt_x3_kernel<4>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_opt_x3_kernel<7>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_opt_x3_kernel<13>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, false, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<4>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<7, false, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<7>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<13, false, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<13>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
                     }
                 } else if (r == 0) switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOpt>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
                 } else switch (m->fused_nb) {
-                    case 4: hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
-                    case 7: hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
-                    default: hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
+                    case 4: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOptAcc, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<4, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
+                    case 7: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOptAcc, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<7, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
+                    default: { if (win) hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOptAcc, true>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_fused_kernel<13, kDecOptAcc>), dim3(g2), dim3(kNT), (uint32_t)fused_lds, m->side, start, stop, 0, b); } break;
                 }
                 LAUNCHCHK("dec_fused (optimiser launch)");
             }
@@ -263,9 +264,9 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 case 7: hipLaunchKernelGGL(dec_fused_bf16_kernel<7>, dim3(grid), dim3(kBT), bf_lds, s, fa); break;
                 default: hipLaunchKernelGGL(dec_fused_bf16_kernel<13>, dim3(grid), dim3(kBT), bf_lds, s, fa); break;
             } else switch (m->fused_nb) {
-                case 4: hipLaunchKernelGGL(dec_fused_kernel<4>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
-                case 7: hipLaunchKernelGGL(dec_fused_kernel<7>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
-                default: hipLaunchKernelGGL(dec_fused_kernel<13>, dim3(grid), dim3(kNT), fused_lds, s, fa); break;
+                case 4: { if (win) hipLaunchKernelGGL((dec_fused_kernel<4, kDecFused, true>), dim3(grid), dim3(kNT), fused_lds, s, fa); else hipLaunchKernelGGL((dec_fused_kernel<4>), dim3(grid), dim3(kNT), fused_lds, s, fa); } break;
+                case 7: { if (win) hipLaunchKernelGGL((dec_fused_kernel<7, kDecFused, true>), dim3(grid), dim3(kNT), fused_lds, s, fa); else hipLaunchKernelGGL((dec_fused_kernel<7>), dim3(grid), dim3(kNT), fused_lds, s, fa); } break;
+                default: { if (win) hipLaunchKernelGGL((dec_fused_kernel<13, kDecFused, true>), dim3(grid), dim3(kNT), fused_lds, s, fa); else hipLaunchKernelGGL((dec_fused_kernel<13>), dim3(grid), dim3(kNT), fused_lds, s, fa); } break;
             }
         }
         LAUNCHCHK("dec_fused");

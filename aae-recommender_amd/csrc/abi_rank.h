@@ -65,22 +65,23 @@ int rank_rows_cap(const aae_model* m, int k) {
 
 template <int NB>
 int launch_rank_nb(const RankArgs& a, int K, int grid, hipStream_t s) {
+    const bool win = x3_big_span(a.N, a.ldv);      // (dec.lin3 beyond 2^31 bytes: the moving-window instantiations, dec_fused.h)
     static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
     if (!v1 && (K == 10 || (K == 20 && NB < 13))) {          // (the other list sizes spill registers in the v2 mapping: they keep v1)
         const uint32_t lds2 = (uint32_t)rank_x3v2_lds_bytes(NB);
         switch (K) {
-            case 10: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10>), dim3(grid), dim3(kNT), lds2, s, a); break;
-            case 20: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 20>), dim3(grid), dim3(kNT), lds2, s, a); break;
-            default: hipLaunchKernelGGL((rank_x3v2_kernel<NB, 32>), dim3(grid), dim3(kNT), lds2, s, a); break;
+            case 10: { if (win) hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10, true>), dim3(grid), dim3(kNT), lds2, s, a); else hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10>), dim3(grid), dim3(kNT), lds2, s, a); } break;
+            case 20: { if (win) hipLaunchKernelGGL((rank_x3v2_kernel<NB, 20, true>), dim3(grid), dim3(kNT), lds2, s, a); else hipLaunchKernelGGL((rank_x3v2_kernel<NB, 20>), dim3(grid), dim3(kNT), lds2, s, a); } break;
+            default: { if (win) hipLaunchKernelGGL((rank_x3v2_kernel<NB, 32, true>), dim3(grid), dim3(kNT), lds2, s, a); else hipLaunchKernelGGL((rank_x3v2_kernel<NB, 32>), dim3(grid), dim3(kNT), lds2, s, a); } break;
         }
         LAUNCHCHK("rank_x3v2");
         return AAE_OK;
     }
     const uint32_t lds = (uint32_t)rank_x3_lds_bytes(NB);
     switch (K) {
-        case 10: hipLaunchKernelGGL((rank_x3_kernel<NB, 10>), dim3(grid), dim3(kNT), lds, s, a); break;
-        case 20: hipLaunchKernelGGL((rank_x3_kernel<NB, 20>), dim3(grid), dim3(kNT), lds, s, a); break;
-        default: hipLaunchKernelGGL((rank_x3_kernel<NB, 32>), dim3(grid), dim3(kNT), lds, s, a); break;
+        case 10: { if (win) hipLaunchKernelGGL((rank_x3_kernel<NB, 10, true>), dim3(grid), dim3(kNT), lds, s, a); else hipLaunchKernelGGL((rank_x3_kernel<NB, 10>), dim3(grid), dim3(kNT), lds, s, a); } break;
+        case 20: { if (win) hipLaunchKernelGGL((rank_x3_kernel<NB, 20, true>), dim3(grid), dim3(kNT), lds, s, a); else hipLaunchKernelGGL((rank_x3_kernel<NB, 20>), dim3(grid), dim3(kNT), lds, s, a); } break;
+        default: { if (win) hipLaunchKernelGGL((rank_x3_kernel<NB, 32, true>), dim3(grid), dim3(kNT), lds, s, a); else hipLaunchKernelGGL((rank_x3_kernel<NB, 32>), dim3(grid), dim3(kNT), lds, s, a); } break;
     }
     LAUNCHCHK("rank_x3");
     return AAE_OK;
@@ -91,19 +92,19 @@ bool rank_set_attributes() {
     auto set = [&](const void* f, int NB) {
         ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_x3_lds_bytes(NB)) == hipSuccess;
     };
-    set(reinterpret_cast<const void*>(rank_x3_kernel<4, 10>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<4, 20>), 4);
-    set(reinterpret_cast<const void*>(rank_x3_kernel<4, 32>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 10>), 7);
-    set(reinterpret_cast<const void*>(rank_x3_kernel<7, 20>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 32>), 7);
-    set(reinterpret_cast<const void*>(rank_x3_kernel<13, 10>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 20>), 13);
-    set(reinterpret_cast<const void*>(rank_x3_kernel<13, 32>), 13);
+    set(reinterpret_cast<const void*>(rank_x3_kernel<4, 10>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<4, 10, true>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<4, 20>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<4, 20, true>), 4);
+    set(reinterpret_cast<const void*>(rank_x3_kernel<4, 32>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<4, 32, true>), 4); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 10>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 10, true>), 7);
+    set(reinterpret_cast<const void*>(rank_x3_kernel<7, 20>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 20, true>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 32>), 7); set(reinterpret_cast<const void*>(rank_x3_kernel<7, 32, true>), 7);
+    set(reinterpret_cast<const void*>(rank_x3_kernel<13, 10>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 10, true>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 20>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 20, true>), 13);
+    set(reinterpret_cast<const void*>(rank_x3_kernel<13, 32>), 13); set(reinterpret_cast<const void*>(rank_x3_kernel<13, 32, true>), 13);
     auto set2 = [&](const void* f, int NB) {
         ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_x3v2_lds_bytes(NB)) == hipSuccess;
     };
-    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 10>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 20>), 4);
-    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 32>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 10>), 7);
-    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 20>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 32>), 7);
-    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 10>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 20>), 13);
-    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 32>), 13);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 10>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 10, true>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 20>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 20, true>), 4);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 32>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<4, 32, true>), 4); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 10>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 10, true>), 7);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 20>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 20, true>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 32>), 7); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<7, 32, true>), 7);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 10>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 10, true>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 20>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 20, true>), 13);
+    set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 32>), 13); set2(reinterpret_cast<const void*>(rank_x3v2_kernel<13, 32, true>), 13);
     (void)hipGetLastError();
     return ok;
 }

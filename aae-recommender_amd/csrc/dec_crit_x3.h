@@ -73,7 +73,7 @@ inline size_t dec_crit_x3_lds_bytes(int NB) {
 // ONE (r4): bf16 mode's instantiation - every operand IS its first term (round-to-nearest-even bf16), so the other two images
 // are neither built nor read and a product is ONE matrix instruction instead of six (the run-time form, a.one_term on the
 // three-term instantiation, multiplies five zero terms: measured in r3 as 36.7 vs 27.9 us at C2).
-template <int NB, bool TS = false, bool ONE = false>   // NB = ceil((h + 1) / 16) column blocks
+template <int NB, bool TS = false, bool ONE = false, bool WIN = false>   // NB = ceil((h + 1) / 16) column blocks; WIN: dec.lin3 beyond 2^31 bytes (dec_fused.h X3WindowT)
 __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     const bool one = ONE || a.one_term != 0;
     constexpr int NT = ONE ? 1 : 3;            // term images in use
@@ -127,8 +127,11 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     //  is 2.4 GB at hidden 200; the window moves up, at a tile's start, once that tile lies 2^30 bytes into it: x3_window)
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    X3Window win(N, ldv, tile_bytes);
+    X3WindowT<WIN> win(N, ldv, tile_bytes);
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
+    // (a thread's second slot lies beyond the tile's span for most threads - 1632 float4 at hidden 200: slots 1632 .. 2047 are the
+    //  NEXT tile's first rows -, so this launch reads 1.25x the layer, profiles/r5_pmc_calibration.txt.  Masking those lanes, as
+    //  the deferred launch does since r5, costs this kernel a vector register it does not have: 12 bytes of scratch per lane)
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -428,7 +431,7 @@ constexpr int kXGS = 20;       // row stride (dwords) of a G image row: 32 bf16 
 
 inline size_t dec_opt_x3_lds_bytes() { return sizeof(float) * ((size_t)3 * 128 * kXGS + (size_t)kTI * kSO + 64); }
 
-template <int NB, bool ONE = false>      // ONE: bf16 mode (first terms only, one matrix instruction per product - see dec_crit_x3_kernel)
+template <int NB, bool ONE = false, bool WIN = false>      // ONE: bf16 mode (first terms only, one matrix instruction per product - see dec_crit_x3_kernel)
 __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
     const bool one = ONE || a.one_term != 0;
     constexpr int NT = ONE ? 1 : 3;
@@ -488,14 +491,15 @@ __global__ __launch_bounds__(kNT) void dec_opt_x3_kernel(DecFusedArgs a) {
     // the streams: tensor bases in buffer descriptors, tile offset scalar, slot offset in one vector register
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    X3Window win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors, as in the critical launch)
+    X3WindowT<WIN> win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors, as in the critical launch)
     const float* gbase = a.gradV3 ? a.gradV3 : a.V3a;
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V), rG = win.desc(gbase);
     const int g_f4 = B * (kTI / 4);             // float4 per stored tile (<= 1024: B <= 128)
     const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
     const __amdgpu_buffer_rsrc_t rGt = __builtin_amdgcn_make_buffer_rsrc(a.Gt, 0, gbytes, 0x00020000);
-    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 2));
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor or the tile's span: zeros, no access; aux 2 = non-temporal)
+        const unsigned vo = tid + kNT * j < tile_f4 ? lane_off + (unsigned)(kNT * 16 * j) : 0x80000000u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, win.so(tile), 2));
     };
     auto ldg = [&](int tile) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rGt, tid < g_f4 ? lane_off : 0x80000000u, (unsigned)tile * (unsigned)g_f4 * 16u, 2));
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(128) void dh2_frag_kernel(const float* __restrict__
     }
 }
 
-template <int NB, bool TS = false>   // TS: debug timeline (AAE_DEC_TS=obk) of workgroup 0, steps 8 .. 15 of its first group, waves 0 and 12
+template <int NB, bool TS = false, bool WIN = false>   // TS: debug timeline (AAE_DEC_TS=obk) of workgroup 0, steps 8 .. 15 of its first group, waves 0 and 12
 __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) {
     const bool one = a.one_term != 0;
     constexpr int KR = kXCH / 32;
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(kNT) void dec_opt_blocks_x3_kernel(DecFusedArgs a) 
 
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    X3Window win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors: it starts at a group's first tile)
+    X3WindowT<WIN> win(N, ldv, tile_bytes);            // (the descriptors' window of the tensors: it starts at a group's first tile)
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V);
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int j) {      // (beyond the tensor: zeros; aux 2 = non-temporal)
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 2));

@@ -121,9 +121,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // touches the tile in hand and the next one or two: the window starts at tile seg0 and moves up - at the START of a tile's
 // iteration, to that tile - once the tile lies 2^30 bytes into it; what was requested through the old descriptor is unaffected
 // (a descriptor is read when the instruction issues).  All scalar: a compare per tile, never taken below 2^30 bytes.
-struct X3Window {
+template <bool WIN>
+struct X3WindowT {
     int seg0; unsigned seg_tiles, tile_bytes; size_t total;
-    __device__ X3Window(int N, int ldv, unsigned tb) : seg0(0), seg_tiles((1u << 30) / tb), tile_bytes(tb), total((size_t)N * ldv * sizeof(float)) {}
+    __device__ X3WindowT(int N, int ldv, unsigned tb) : seg0(0), seg_tiles((1u << 30) / tb), tile_bytes(tb), total((size_t)N * ldv * sizeof(float)) {}
     __device__ __forceinline__ bool moves(int tile) {
         if ((unsigned)(tile - seg0) <= seg_tiles) return false;
         seg0 = tile;
@@ -136,8 +137,25 @@ struct X3Window {
                                                  (unsigned)min((size_t)0x7FFFFFF0u, total - off), 0x00020000);
     }
 };
+// WIN = false, every layer below 2^31 bytes: ONE descriptor over the whole tensor, the tile's byte offset from its start -
+// r1-r4's code, instruction for instruction (the moving window costs the critical launch five scalar registers it does not
+// have: with it the 13-block instantiation spilled four vector registers).  The dispatcher picks the instantiation
+// (x3_big_span).
+template <>
+struct X3WindowT<false> {
+    unsigned tile_bytes, tbytes;
+    __device__ X3WindowT(int N, int ldv, unsigned tb) : tile_bytes(tb), tbytes((unsigned)min((size_t)0x7FFFFFF0u, (size_t)N * ldv * sizeof(float))) {}
+    __device__ __forceinline__ bool moves(int) const { return false; }
+    __device__ __forceinline__ unsigned so(int tile) const { return (unsigned)tile * tile_bytes; }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const float* base) const {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, tbytes, 0x00020000);
+    }
+};
+// does a layer of n_items x ld floats (+ its padding tiles) need the moving window?
+inline bool x3_big_span(int n_items, int ld) { return ((size_t)n_items + 2 * 32) * (size_t)ld * sizeof(float) >= ((size_t)1 << 31) - ((size_t)1 << 24); }
 
-template <int NB, int MODE = kDecFused>   // NB = ceil((h + 1) / 16) column blocks
+
+template <int NB, int MODE = kDecFused, bool WIN = false>   // NB = ceil((h + 1) / 16) column blocks; WIN: a layer beyond 2^31 bytes (X3WindowT)
 __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     constexpr bool kFwd = MODE != kDecOpt && MODE != kDecOptAcc;     // GEMM1, entries, GEMM3, loss, slabs
     constexpr bool kOpt = MODE != kDecCrit;    // GEMM2, optimiser
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(kNT) void dec_fused_kernel(DecFusedArgs a) {
     //   m/v(t) before GEMM2(t); parameter stores of S5(t) retire behind GEMM3(t).
     float4 vreg[NV], mreg[NV], sreg[NV], areg[NV];
     typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
-    X3Window win(a.N, ldv, (unsigned)(kTI * ldv) * 4u);       // (r5: the window of the tensors the store descriptors cover - layers beyond 2^31 bytes)
+    X3WindowT<WIN> win(a.N, ldv, (unsigned)(kTI * ldv) * 4u);       // (r5: the window of the tensors the store descriptors cover - layers beyond 2^31 bytes)
     const float* gbase = a.gradV3 ? a.gradV3 : a.V3a;
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a), rM = win.desc(a.M), rV = win.desc(a.V), rG = win.desc(gbase);
     int tile = wgi;

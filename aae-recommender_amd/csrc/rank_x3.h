@@ -65,7 +65,7 @@ inline size_t rank_x3_lds_bytes(int NB) {
     return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kRRS + (size_t)lsteps * kMB * 3 * 64 * 4);
 }
 
-template <int NB, int K>
+template <int NB, int K, bool WIN = false>      // WIN: dec.lin3 beyond 2^31 bytes (dec_fused.h X3WindowT)
 __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
     const bool one = a.one_term != 0;
     constexpr int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2;
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
     // reads beyond the tensor return zero
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    X3Window win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
+    X3WindowT<WIN> win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, tid + kNT * j < tile_f4 ? lane_off + (unsigned)(kNT * 16 * j) : 0x80000000u, win.so(tile), 0));      // (a slot beyond the tile's span: no access, dec_crit_x3.h)
     };
     // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
     const int eb = tid >> 3, eq = tid & 7;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
 // fragment serves both row blocks of the pair (0.25 reads per instruction), all 16 waves multiply, the four k quarters'
 // partial sums meet in the epilogue (4 raw tiles instead of 2), and the quarter a wave takes is rotated by its pair,
 // kq = (wave + rp) & 3, so that every SIMD (wave & 3) gets 12-13 of the 49 (row block, k-step) units.
-template <int NB, int K>
+template <int NB, int K, bool WIN = false>      // WIN: dec.lin3 beyond 2^31 bytes (dec_fused.h X3WindowT)
 __global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
     const bool one = a.one_term != 0;
     constexpr int KC1 = (NB + 1) / 2, NKQ = (KC1 + 3) / 4;       // 32-wide k-steps over the h + 1 hidden columns; per k quarter
@@ -295,12 +295,12 @@ __global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
     // reads beyond the tensor return zero
     const unsigned lane_off = (unsigned)tid * 16u;
     const unsigned tile_bytes = (unsigned)(kTI * ldv) * 4u;
-    X3Window win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
+    X3WindowT<WIN> win(N, ldv, tile_bytes);            // (the descriptor's window of the tensor, dec_crit_x3.h: layers beyond 2^31 bytes)
     __amdgpu_buffer_rsrc_t rP = win.desc(a.V3a);
     auto load_span = [&](int tile, float4* r) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
+            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, tid + kNT * j < tile_f4 ? lane_off + (unsigned)(kNT * 16 * j) : 0x80000000u, win.so(tile), 0));      // (a slot beyond the tile's span: no access, dec_crit_x3.h)
     };
     // epilogue: thread -> row eb, items 4 eq .. 4 eq + 3 of the tile
     const int eb = tid >> 3, eq = tid & 7;
