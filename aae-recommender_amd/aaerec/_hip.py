@@ -1053,7 +1053,11 @@ class HipAAE:
         return self._rank_rows[key]
 
     def predict_topk(self, csr, row_start, n_rows, k, cond=None, exclude_known=True):
-        """(ids int32 [n_rows, k], scaled scores float32 [n_rows, k]) - device tensors.  n_rows <= rank_max_rows(k)."""
+        """(ids int32 [n_rows, k], scaled scores float32 [n_rows, k]) - device tensors.  n_rows <= rank_max_rows(k).
+        Ties: the reference leaves items of equal fp32 score in np.argpartition's order (evaluation.py:20-58).  Calls within
+        the fused path's row limit order such items by their LOGIT (saturated sigmoids included), the dense fallback by the
+        smaller item id: the k scores are the same either way, the items named may differ exactly where scores tie
+        (tests/test_rank_gpu.py::test_saturated_scores_tie_and_both_rank_paths_return_a_valid_top_k)."""
         b = self._batch(csr, row_start, n_rows, bounded=n_rows <= self.max_batch)     # (beyond max_batch: the fused rank path, which has no per-batch lists)
         idx = torch.empty(n_rows, k, dtype=torch.int32, device=self.device)
         val = torch.empty(n_rows, k, dtype=torch.float32, device=self.device)

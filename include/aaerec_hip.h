@@ -367,7 +367,10 @@ int aae_predict(aae_handle h, const aae_batch* batch, const float* cond_dev, flo
 /* predict followed on the device by what Evaluation does on the host with the dense matrix:
  * remove_non_missing (row-wise min-max scaling; items present in the input row excluded when
  * exclude_known != 0; evaluation.py:183-199) and argtopk (evaluation.py:20-58).  Writes the k
- * (<= 32) best item ids per row, best first, and their scaled scores: [rows][k]. */
+ * (<= 32) best item ids per row, best first, and their scaled scores: [rows][k].
+ * Items of EQUAL fp32 score (saturated sigmoids of a trained model, collisions near 1) are in np.argpartition's arbitrary
+ * order in the reference; here the fused form (aae_rank_max_rows) orders them by logit, the dense form by the smaller item
+ * id - the k scores are identical, the named items may differ exactly at ties. */
 int aae_predict_topk(aae_handle h, const aae_batch* batch, const float* cond_dev, int32_t k,
                      int32_t exclude_known, int32_t* idx_out_dev, float* val_out_dev, void* stream);
 /* Rows ONE aae_predict_topk / aae_decode_topk call may rank (>= max_batch).  Where the fused form applies (r4: the output
