@@ -364,8 +364,9 @@ class AdversarialAutoEncoder:
         elif not use_condition:
             hip.step(csr, row_start, n_rows, rows=rows, masks=masks, z_real=z_real)
         elif self._is_constant_concat():
-            blocks = [c.encode(x) for c, x in zip(self.conditions.values(), c_batch)]
-            hip.step(csr, row_start, n_rows, rows=rows, cond=torch.cat([_hip.upload(b, hip.device) for b in blocks], 1),
+            blocks = [_hip.upload(c.encode(x), hip.device) for c, x in zip(self.conditions.values(), c_batch)]
+            # (one block: as it is - torch.cat of a single tensor is a copy launch of its own, every step)
+            hip.step(csr, row_start, n_rows, rows=rows, cond=blocks[0] if len(blocks) == 1 else torch.cat(blocks, 1),
                      masks=masks, z_real=z_real)
         elif self._is_device_native():
             hip.step(csr, row_start, n_rows, rows=rows, cond=self._native_cond_block(c_batch, n_rows), masks=masks,
@@ -477,9 +478,13 @@ class AdversarialAutoEncoder:
             # content id of this epoch's row ids (aae_batch.generation): every window of perm_dev below carries it, so the
             # batch a step runs is matched with the one named ahead by content, not by the address the allocator gave it
             perm_gen = next(_hip._GENERATION)
+            perm_i64 = perm_dev.to(torch.int64) if use_condition else None      # (what index_select wants: once per epoch, not per step)
 
             def window(a, b):
-                return _hip.row_ids(perm_dev[a:b], perm_gen)
+                w = _hip.row_ids(perm_dev[a:b], perm_gen)
+                if perm_i64 is not None:
+                    w._aae_i64 = perm_i64[a:b]
+                return w
             csr = self._epoch_csr(csr0)
             for start in range(0, n_docs, self.batch_size):
                 stop = min(start + self.batch_size, n_docs)
@@ -667,7 +672,9 @@ def _take(c, idx, rows_dev=None):
     selection as a device tensor - condition data that already lives in HBM is then selected there (indexing a device
     tensor with a host array is a blocking copy on the compute stream: host and GPU in lock-step, every step)."""
     if rows_dev is not None and torch.is_tensor(c) and c.is_cuda:
-        return c.index_select(0, rows_dev.to(torch.int64))
+        # (the epoch's permutation is kept as int64 as well, fit_steps' window(): no cast launch per step)
+        i64 = getattr(rows_dev, "_aae_i64", None)
+        return c.index_select(0, i64 if i64 is not None else rows_dev.to(torch.int64))
     if isinstance(c, (list, tuple)):
         if isinstance(idx, slice):
             return list(c[idx])
