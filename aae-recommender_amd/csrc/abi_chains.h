@@ -438,7 +438,14 @@ int build_tile_buckets(aae_model* m, hipStream_t s) {
         hipLaunchKernelGGL(tile_bucket_kernel, dim3(1), dim3(1024), lds1, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
     } else if (ntiles <= kBucketMaxTiles && B <= kBucketWideDocs && m->bucket_wide_ok) {
         // (the global batch of an item slice: one launch instead of four, 25 -> 9 us)
-        const size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
+        size_t lds = sizeof(int) * ((size_t)ntiles + 1 + kBucketWideDocs + 1 + 1024);
+        // r5: this ONE workgroup runs ~90 us of LDS atomics beside the step (side stream).  With its natural ~9 KB of LDS the
+        // dispatcher dealt workgroups of the step's own launches onto its CU, and whichever tile of a weight-gradient launch
+        // landed there took 2.4x its time - the launch waits for its slowest workgroup: 31 or 75 us per launch at C4, the
+        // generator program 32 or 57, by where the workgroups fell (profiles/r5_step_timeline_c4.txt).  It claims the CU's LDS
+        // now, as the deferred launch does: nothing of the step fits beside it.
+        static const bool bk_claim = getenv("AAE_NO_BUCKET_CLAIM") == nullptr;
+        if (bk_claim) lds = std::max(lds, (size_t)(160 * 1024 - 16384));
         hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
     } else {
         const int gy = std::max(1, std::min(16, m->chunks / 16 + 1));

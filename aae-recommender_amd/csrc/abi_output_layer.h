@@ -159,7 +159,10 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 // (a slice of thousands of tiles - C5: 275 k items x 512 rows, 8 594 tiles - outlasts the step's tail by far: 7/8 of the
                 //  chip there, r4: one rank's step 1.58 | 1.52 | 1.61 | 1.59 ms on 192 | 224 | 240 | 256 workgroups)
                 const int wg_cap = ntiles >= 4096 ? m->n_cu * 7 / 8 : m->n_cu * 3 / 4;
-                const int by_tiles = std::max(m->n_cu / 2, std::min(wg_cap, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
+                // (r5: a layer of a few hundred tiles - C4: 144 - is two or three tiles per workgroup on a sixth of the chip: 0.3549 |
+                //  0.3493 | 0.3489 | 0.3486 | 0.3524 ms/step on 128 | 32 | 48 | 64 | 96 workgroups, tools/debug/c4_obk_sweep.sh)
+                const int by_tiles = ntiles < 384 ? std::max(32, std::min(m->n_cu / 2, ntiles / 3))
+                                                  : std::max(m->n_cu / 2, std::min(wg_cap, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
                 const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : by_tiles), std::min(ntiles, m->n_cu)));
                 const int rounds = (ntiles + g3 * kXBT - 1) / (g3 * kXBT);
                 b.tpp = g3 * rounds;
