@@ -768,4 +768,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
+// -----------------------------------------------------------------------------------------------
+// The same launch for WIDE batches (r5): the weight-gradient product of a hidden layer is a sum over the rows of the batch -
+// 16 slabs of 64 rows at 1 000 rows, 32 at 2 000 (the discriminator's stacked batch) - and one tile's slab loop is a chain of
+// load -> LDS -> 16 products -> barrier steps of ~1 us each: 30 us per launch at C4, three launches per step, on 70-126 tiles
+// that leave most of the chip idle.  Here a tile's workgroup has 16 waves: four GROUPS of four, each walking a quarter of the
+// rows with the 256-thread kernel's loop (its own operand images: 4 x 24 KB of LDS), the four partial tiles added in group
+// order before the optimiser epilogue - a fixed order, a function of the row count alone.  The first layer's ride-along blocks
+// run their 256-thread bodies on the first four waves (the others leave at once).
+// -----------------------------------------------------------------------------------------------
+constexpr int kDwWideGroups = 4;
+constexpr int kDwWideSmemBytes = kDwWideGroups * kDwSmemBytes;
+__global__ __launch_bounds__(1024) void grouped_dw_wide_kernel(DwGroup grp) {
+    constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024, KG = kDwWideGroups;
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];      // [KG][2 * BK * LDT]
+    const int kg = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const bool special = (grp.loss.enabled && blockIdx.x == gridDim.x - 1) || (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0);
+    if (special) {
+        if (kg) return;                                               // (whole waves: the others' barriers do not count them)
+        float* smem = smem_w;
+        if (grp.loss.enabled && blockIdx.x == gridDim.x - 1) {
+            float acc = 0.f;
+            for (int i = tid; i < grp.loss.n; i += 256) acc += grp.loss.terms[i];
+            smem[tid] = acc;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) smem[tid] += smem[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) *grp.loss.out = smem[0];
+            return;
+        }
+        const W1Job& w = grp.w1;
+        const int id = (int)blockIdx.x - w.blk0;
+        if (id < w.ncol) colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem);
+        else if (w.wave_form == 2) w1_item_hybrid_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
+        else if (w.wave_form) {
+            if (id == w.ncol && tid == 0) *w.hot_zero = 0;
+            w1_item_wave_body(w.items, w.hot, w.hot_count, reinterpret_cast<unsigned*>(smem), (id - w.ncol) * 4 + (tid >> 6), w.nitem * 4);
+        } else w1_item_update_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
+        return;
+    }
+    int j = 0;
+    for (int q = 1; q < grp.njobs; ++q) if ((int)blockIdx.x >= grp.jobs[q].tile0) j = q;
+    const DwJob& J = grp.jobs[j];
+    const int t = blockIdx.x - J.tile0;
+    const int m0 = (t / J.tiles_n) * TS, n0 = (t % J.tiles_n) * TS;
+    float* As = smem_w + kg * (2 * BK * LDT); float* Bs = As + BK * LDT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int K = J.rows;
+    const int Kq = (((K + KG - 1) / KG) + BK - 1) / BK * BK;             // rows per group, whole slabs
+    const int kb = kg * Kq, ke = min(K, kb + Kq);                        // this group's rows [kb, ke)  (possibly none)
+    const int mmax4 = ((J.M + 3) & ~3) - 4, nmax4 = ((J.N + 3) & ~3) - 4;
+    float4 ra[NV], rb[NV];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + 256 * q, kr = min(k0 + f / (TS / 4), K - 1), cq = (f % (TS / 4)) * 4;
+            ra[q] = *reinterpret_cast<const float4*>(J.G + (size_t)kr * J.ldg + min(m0 + cq, mmax4));
+            rb[q] = *reinterpret_cast<const float4*>(J.X + (size_t)kr * J.ldx + min(n0 + cq, nmax4));
+        }
+    };
+    request(kb);
+    const int erow = tid / (TS / 4), ecol = (tid % (TS / 4)) * 4;
+    const int egm = m0 + erow, egn = n0 + ecol;
+    const bool epre = kg == 0 && !J.grad && egm < J.M && egn + 3 < J.N;
+    float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0;
+    const OptScalars osc = *J.sc;
+    if (epre) {
+        const size_t off = (size_t)egm * J.ld + egn;
+        pp0 = *reinterpret_cast<const float4*>(J.p + off);
+        if (!osc.is_sgd) { mm0 = *reinterpret_cast<const float4*>(J.m + off); vv0 = *reinterpret_cast<const float4*>(J.v + off); }
+    }
+    for (int k0 = kb; k0 < kb + Kq; k0 += BK) {                          // (every group the same number of slabs: the barriers are the workgroup's)
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + 256 * q, kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
+            const bool ok = k0 + kr < ke;
+            float4 va, vb;
+            va.x = (ok && m0 + cq < J.M) ? ra[q].x : 0.f; va.y = (ok && m0 + cq + 1 < J.M) ? ra[q].y : 0.f;
+            va.z = (ok && m0 + cq + 2 < J.M) ? ra[q].z : 0.f; va.w = (ok && m0 + cq + 3 < J.M) ? ra[q].w : 0.f;
+            vb.x = (ok && n0 + cq < J.N) ? rb[q].x : 0.f; vb.y = (ok && n0 + cq + 1 < J.N) ? rb[q].y : 0.f;
+            vb.z = (ok && n0 + cq + 2 < J.N) ? rb[q].z : 0.f; vb.w = (ok && n0 + cq + 3 < J.N) ? rb[q].w : 0.f;
+            *reinterpret_cast<float4*>(&As[kr * LDT + cq]) = va;
+            *reinterpret_cast<float4*>(&Bs[kr * LDT + cq]) = vb;
+        }
+        request(k0 + BK);
+        __syncthreads();
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[(kk + fk) * LDT + wm + fr], Bs[(kk + fk) * LDT + wn + fr], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float* Cs = smem_w + kg * (2 * BK * LDT);                            // this group's partial tile [32][LDC]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cs[(wm + (lane >> 4) * 4 + r) * LDC + wn + (lane & 15)] = acc[r];
+    __syncthreads();
+    if (kg) return;
+    const int row = tid / (TS / 4), col = (tid % (TS / 4)) * 4;
+    const int gm = m0 + row, gn = n0 + col;
+    if (gm < J.M && gn < J.N) {
+        float4 g4 = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
+#pragma unroll
+        for (int q = 1; q < KG; ++q) {                                   // the groups' partial sums, in group order
+            const float4 t4 = *reinterpret_cast<const float4*>(&smem_w[q * (2 * BK * LDT) + row * LDC + col]);
+            g4.x += t4.x; g4.y += t4.y; g4.z += t4.z; g4.w += t4.w;
+        }
+        if (epre) {
+            const size_t off = (size_t)gm * J.ld + gn;
+            adam_update(pp0.x, mm0.x, vv0.x, g4.x, osc); adam_update(pp0.y, mm0.y, vv0.y, g4.y, osc);
+            adam_update(pp0.z, mm0.z, vv0.z, g4.z, osc); adam_update(pp0.w, mm0.w, vv0.w, g4.w, osc);
+            *reinterpret_cast<float4*>(J.p + off) = pp0;
+            if (!osc.is_sgd) { *reinterpret_cast<float4*>(J.m + off) = mm0; *reinterpret_cast<float4*>(J.v + off) = vv0; }
+            if (J.w4.f4) w4_put4(J.w4, gm, gn, pp0);
+        } else
+        if (J.grad) {
+            EpiStore e; e.out = J.grad; e.ld = J.ld;
+            EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
+        } else {
+            EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
+            e.w4 = J.w4;
+            EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
+        }
+    }
+}
+
 }  // namespace aae
