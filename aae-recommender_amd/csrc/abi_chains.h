@@ -222,6 +222,18 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     if (four && m->x16_ok && !x16_dry && cb.P.rows >= m->x16_rows && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
         ChainProgram X = cb.P;
         if (x16_remap_slots(X)) {
+            // the look-ahead chains of the weight prefetch: per workgroup class, every op's next linear op
+            X.x16_row_lo = 1 << 30;
+            for (int i = 0; i < X.nops; ++i) if (X.ops[i].row_lo > 0) X.x16_row_lo = X.ops[i].row_lo;
+            for (int cls = 0; cls < 2; ++cls) {
+                int nxt = -1;
+                for (int i = X.nops - 1; i >= 0; --i) {
+                    X.ops[i].x16_next_lin[cls] = nxt;
+                    const bool runs = cls == 1 || X.ops[i].row_lo == 0;
+                    if (runs && (X.ops[i].kind == COP_LINEAR || X.ops[i].kind == COP_LINEAR_DX)) nxt = i;
+                }
+                X.x16_first_lin[cls] = nxt;
+            }
             const int grid16 = (X.rows + kX16R - 1) / kX16R;
             if (want_ts && !m->bf16) hipLaunchKernelGGL((chain16x3_kernel<false, true>), dim3(grid16), dim3(kX16T), kX16Lds, s, X);
             else if (m->bf16) hipLaunchKernelGGL(chain16x3_kernel<true>, dim3(grid16), dim3(kX16T), kX16Lds, s, X);

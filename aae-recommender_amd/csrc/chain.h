@@ -58,6 +58,8 @@ struct ChainOp {
     const float* Wkn; int ldkn;         // the same layer's matrix in k-major form [K][N] (n contiguous) for chain4.h
     const float* W4; int ns4;           // ... and k4-interleaved [(K + 3) / 4][ns4][4] (device_common.h), or NULL
     const unsigned short* WX; int xpl;  // ... and split into three bf16 planes for chain16x3.h (device_common.h FX / DX; xpl = rows of a plane), or NULL
+    int x16_next_lin[2];                // chain16x3.h: the next linear op behind this one a workgroup runs ([1]: one that runs the upper rows' prefix
+                                        // ops too, [0]: one that skips them), or -1 - whose first weights it requests behind its own products
     int epi, yslot;                     // epilogue; slot holding y for ACTBWD / FINAL_BWD
     DropSpec d;
     float* out; int ldo; int out_row0;  // optional global store of dst[:, 0:N] at rows out_row0 + r
@@ -90,6 +92,7 @@ struct ChainProgram {
     int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
     unsigned long long* ts;             // debug (AAE_CHAIN_TS): per-op 100 MHz timestamps of workgroup 0, else NULL
     BucketJob bk;                       // enabled: one extra workgroup builds the fused decoder's tile buckets
+    int x16_first_lin[2], x16_row_lo;   // chain16x3.h: the program's first linear op per workgroup class, the prefix ops' row_lo (or 1 << 30)
     ChainOp ops[kCMaxOps];
 };
 

@@ -54,22 +54,36 @@ __device__ __forceinline__ float x16_get(const char* slot, int row, int col) {
 
 // One wave's 16 x 16 tile of src[16][K] * W over `ksteps` 32-deep k-steps; n0 = first column of the tile.
 //   WX: the split weight copy (FX or DX), xpl = rows of one of its planes (Mp or Np).
+//   wb: the wave's weight registers, kX16Depth k-steps deep.  x16_issue requests an op's FIRST k-steps into them - for the op
+//   in hand, or (r5) for the NEXT linear op of the program right behind the products of the current one: weights depend on
+//   nothing the launch computes, the registers are free during the epilogue and the barrier, and an op then opens with its
+//   first products instead of an L2 round trip (~1 us of the 4 us a 201 -> 200 layer's products took).
 template <bool BF>
-__device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned short* WX, int xpl, int ksteps, int n0, int lane) {
+struct X16W { gemm_bf16x8 b[kX16Depth][BF ? 1 : 3]; };
+
+template <bool BF>
+__device__ __forceinline__ void x16_issue(X16W<BF>& w, const unsigned short* WX, int xpl, int ksteps, int n0, int lane) {
     constexpr int NT = BF ? 1 : 3;
     const int r = lane & 15, kg = lane >> 4;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(WX), 0, 0x7FFFFFF0, 0x00020000);
     const unsigned vo = (unsigned)((n0 + r) * 32 + 8 * kg) * 2u;
     const unsigned plane = (unsigned)xpl * 64u;                    // bytes of one (k-step, term) plane
-    const char* a0 = src + r * kX16RowB + kg * 16;
-    gemm_bf16x8 b[kX16Depth][NT];
 #pragma unroll
     for (int ks = 0; ks < kX16Depth; ++ks)
         if (ks < ksteps)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                b[ks][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)(ks * 3 + t) * plane, 0));
-    __builtin_amdgcn_sched_barrier(0);          // (every load of the first k-steps is requested before the first product, chain4.h)
+                w.b[ks][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)(ks * 3 + t) * plane, 0));
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x4 x16_products(const char* src, X16W<BF>& w, const unsigned short* WX, int xpl, int ksteps, int n0, int lane) {
+    constexpr int NT = BF ? 1 : 3;
+    const int r = lane & 15, kg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(WX), 0, 0x7FFFFFF0, 0x00020000);
+    const unsigned vo = (unsigned)((n0 + r) * 32 + 8 * kg) * 2u;
+    const unsigned plane = (unsigned)xpl * 64u;
+    const char* a0 = src + r * kX16RowB + kg * 16;
     // Three accumulators, by the size of the terms: the leading products (a0 b0), the 2^-8 ones (a1 b0, a0 b1), the 2^-16 ones
     // (a2 b0, a0 b2, a1 b1).  On ONE accumulator every small-term instruction rounds against the large running sum: 42 roundings
     // per 201-deep layer where the fp32 pipe's chain has its own products' only - measured on the e2e fixture (3 epochs at the
@@ -82,9 +96,9 @@ __device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned shor
             gemm_bf16x8 a[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const gemm_bf16x8*>(a0 + t * kX16TermB + ks * 64);
-            if (BF) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[ks % kX16Depth][0], acc, 0, 0, 0);
+            if (BF) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], w.b[ks % kX16Depth][0], acc, 0, 0, 0);
             else {
-                const gemm_bf16x8 (&bb)[NT] = b[ks % kX16Depth];
+                const gemm_bf16x8 (&bb)[NT] = w.b[ks % kX16Depth];
                 acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT - 1], bb[0], acc_l, 0, 0, 0);
                 acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bb[NT - 1], acc_l, 0, 0, 0);
                 acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], bb[NT > 1 ? 1 : 0], acc_l, 0, 0, 0);
@@ -95,7 +109,7 @@ __device__ __forceinline__ f32x4 x16_linear(const char* src, const unsigned shor
             if (ks + kX16Depth < ksteps)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    b[ks % kX16Depth][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)((ks + kX16Depth) * 3 + t) * plane, 0));
+                    w.b[ks % kX16Depth][t] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (unsigned)((ks + kX16Depth) * 3 + t) * plane, 0));
         }
     }
     if (!BF) acc += acc_m + acc_l;
@@ -115,6 +129,21 @@ __global__ __launch_bounds__(kX16T) void chain16x3_kernel(ChainProgram P) {
     typedef const __attribute__((address_space(1))) float* gf_t;
     int nops = P.nops;
     asm volatile("" : "+s"(nops));
+    // the next linear op's first k-steps of weights (x16_issue): ops of the upper rows' program prefix count only for the
+    // workgroups that run them (pfx)
+    X16W<BF> wb;
+    const int pfx = (r0 + kX16R > P.x16_row_lo) ? 1 : 0;
+    int wb_for = -1;
+    auto look_ahead = [&](int j) {
+        wb_for = j;
+        if (j < 0) return;
+        const ChainOp& o = P.ops[j];
+        int nN = o.N, nK = o.K, nxpl = o.xpl; const unsigned short* nWX = o.WX;
+        asm volatile("" : "+s"(nN), "+s"(nK), "+s"(nxpl), "+s"(nWX));
+        if (wave * 16 < nN) x16_issue<BF>(wb, nWX, nxpl, (nK + 31) >> 5, wave * 16, lane);
+    };
+    static const bool kLookAhead = true;
+    if (kLookAhead) look_ahead(P.x16_first_lin[pfx]);
     unsigned long long* tsp = (TS && blockIdx.x == 0 && tid == 0) ? P.ts : nullptr;
     for (int oi = 0; oi < nops; ++oi) {
         const ChainOp& op = P.ops[oi];
@@ -162,7 +191,11 @@ __global__ __launch_bounds__(kX16T) void chain16x3_kernel(ChainProgram P) {
                     for (int q = 0; q < 4; ++q)
                         if (lr0 + q < nrows) yv[q] = ((gf_t)ygp)[(size_t)(r0 + lr0 + q) * yld + col];
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (n0 < N) acc = x16_linear<BF>(src, WX, xpl, ksteps, n0, lane);
+                if (n0 < N) {
+                    if (wb_for != oi) x16_issue<BF>(wb, WX, xpl, ksteps, n0, lane);
+                    acc = x16_products<BF>(src, wb, WX, xpl, ksteps, n0, lane);
+                }
+                if (kLookAhead) look_ahead(op.x16_next_lin[pfx]);
                 if (TS && tsp) { asm volatile("s_nop 0" :: "v"(acc[0])); tsp[3 * oi + 1] = wall_clock64(); }
                 const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, reinterpret_cast<const float*>(ximg));
                 const char* ys = ximg + yslot_k * kX16SlotB;
