@@ -72,6 +72,15 @@ struct ChainBuilder {
         { const char* e = getenv("AAE_CHAIN_SKIP"); P.dbg = e ? atoi(e) : 0; }
     }
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
+    int x16_rows = 0;      // > 0: this program's own row threshold for the wide-batch kernel (beside_deferred)
+    // The discriminator and generator programs of a row-blocked step over a LARGE vocabulary run beside its deferred launch,
+    // which holds 3/4 of the chip for most of the step's tail: a 4-row launch of 128 workgroups (512 rows) then takes two
+    // rounds on the CUs that are left - there the 16-row kernel pays from 512 rows on (C3 at batch 512: generator program 64 ->
+    // 46 us).  The ae programs run in front of / right behind the critical launch, on a free chip: they keep the model's rule.
+    void beside_deferred(const aae_model* m) {
+        const int ntiles = (m->N + kTI - 1) / kTI;
+        if (m->rows > 16 * kMB && ntiles >= 1024 && m->x16_rows > 512) x16_rows = 512;
+    }
 };
 
 // y of an ACTBWD epilogue that a kernel before this one left in global memory: the 4-row kernel reads it from there (the cells
@@ -219,7 +228,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
             return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
     // wide batches: 16 rows per workgroup on the bf16 matrix cores (chain16x3.h)
     static const bool x16_dry = getenv("AAE_X16_DRY") != nullptr;      // (debug: keep the split copies, launch the 4-row kernel)
-    if (four && m->x16_ok && !x16_dry && cb.P.rows >= m->x16_rows && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
+    if (four && m->x16_ok && !x16_dry && cb.P.rows >= (cb.x16_rows > 0 ? cb.x16_rows : m->x16_rows) && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
         ChainProgram X = cb.P;
         if (x16_remap_slots(X)) {
             // the look-ahead chains of the weight prefetch: per workgroup class, every op's next linear op
@@ -860,6 +869,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     }
     {   // D on [z_real; z_fake], loss, and the activation-gradient half of its backward
         ChainBuilder cb(m, 2 * B);
+        cb.beside_deferred(m);
         cb.P.loss_slot = 1; cb.P.loss_terms = m->adv_terms;
         if (merged) {
             chain_encoder_tail(m, cb, false, nullptr, 0, B, nullptr, s);
@@ -904,6 +914,7 @@ int chain_gen_step(aae_model* m, hipStream_t s) {
     const int B = m->rows, h = m->h, c = m->c;
     const aae_rng_inject& I = m->inj;
     ChainBuilder cb(m, B);
+    cb.beside_deferred(m);
     cb.P.loss_slot = 2; cb.P.loss_terms = m->adv_terms;
     cb.add(cop_load(m->a1.p, m->ldh, 0, h));
     ChainOp& e1 = cb.add(cop(COP_DROPACT, 0, 1, h));
