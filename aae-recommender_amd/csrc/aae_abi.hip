@@ -107,8 +107,6 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
-        m->dw_wide_ok = getenv("AAE_NO_DW_WIDE") == nullptr &&
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_dw_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDwWideSmemBytes) == hipSuccess;
         m->x16_rows = x16_min_rows();
         m->x16_ok = m->use_chain4 && m->FXi[P_W2] != nullptr &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess &&

@@ -302,12 +302,10 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
 int launch_w1_hot(aae_model* m, hipStream_t s);
 struct DwBuilder {
     aae_model* mh = nullptr;       // set by add_first_layer: the wave form's hot list is worked off behind the launch
-    bool wide_ok = false;          // set by add(): the model may take the 1024-thread form (its LDS attribute is set)
     DwGroup g; int tiles;
     DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
     void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
         DwJob& J = g.jobs[g.njobs++];
-        wide_ok = m->dw_wide_ok;
         const Ten& W = m->P[pid];
         const int set = (which == O_GEN) ? 1 : 0;
         J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
@@ -375,21 +373,13 @@ struct DwBuilder {
         if (g.w1.enabled) { g.w1.blk0 = tiles; blocks += g.w1.ncol + g.w1.nitem; }
         if (g.loss.enabled) blocks += 1;
         if (marked) *marked = done && !mh;
-        // wide batches: four k-groups per tile (grouped_dw_wide_kernel, chain.h)
-        int max_rows = 0;
-        for (int q = 0; q < g.njobs; ++q) max_rows = std::max(max_rows, g.jobs[q].rows);
-        // (from 1 536 rows on: the discriminator's stacked batch at C4 - 2 000 rows: C4 0.3165 -> 0.3125 ms/step - and of an item
-        //  slice's global batch at world 8 - 1 600: one rank's step 0.2895 -> 0.2835; at 1 024 rows beside the row-blocked deferred
-        //  launch the 16-wave workgroups find too few free CUs: C3 at batch 512 0.658 -> 0.666)
-        static const int wide_rows = getenv("AAE_DW_WIDE_ROWS") ? atoi(getenv("AAE_DW_WIDE_ROWS")) : 1536;
-        // (not beside the first layer's ride-along blocks: every workgroup of the launch would claim the wide form's 96 KB of LDS
-        //  and 16 wave slots - the ~500 per-item workgroups, a dependent chain each, then run one per CU: C4 0.32 -> 0.41 ms/step)
-        static const bool wide_any = getenv("AAE_DW_WIDE_ANY") != nullptr;      // (tests: every launch through the wide form)
-        const bool wide = wide_ok && max_rows >= wide_rows && (!g.w1.enabled || wide_any);
-        if (wide) {
-            if (done && !mh) hipExtLaunchKernelGGL(grouped_dw_wide_kernel, dim3(blocks), dim3(1024), kDwWideSmemBytes, s, nullptr, done, 0, g);
-            else hipLaunchKernelGGL(grouped_dw_wide_kernel, dim3(blocks), dim3(1024), kDwWideSmemBytes, s, g);
-        } else
+        // wide batches (r5): jobs of 256 rows and more take the k-split form of a tile (chain.h: every wave the whole tile over a
+        // quarter of the rows, operands straight into the matrix instructions' registers, no LDS in the loop).  Per launch of three
+        // 200 x 201 layers + the bias column sums, slab loop | k-split form (tools/debug/ubench/dw_real.hip): 256 rows 9.7 | 9.2 us,
+        // 512 12.8 | 10.4, 800 17.0 | 13.3, 1 000 19.4 | 13.6, 2 000 32.0 | 19.4 (a 16-wave kernel with four k-groups of the slab
+        // loop, this round's first answer for 1 536+ rows: 23.3 - removed).  AAE_DW_KSPLIT_ROWS=0: never
+        static const int ksplit_rows = getenv("AAE_DW_KSPLIT_ROWS") ? atoi(getenv("AAE_DW_KSPLIT_ROWS")) : 256;
+        g.ksplit = ksplit_rows;
         if (done && !mh) hipExtLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g);
         else
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);

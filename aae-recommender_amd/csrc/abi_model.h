@@ -48,7 +48,6 @@ struct aae_model {
     // the forward layers' access pattern, chain4.h's forward layers read all of it (n contiguous).  Kept in step by the fused / grouped optimiser kernels;
     // pt_ok[pid] = false after any other writer (ensure_pt() re-derives the copy before its next use)
     unsigned short* FXi[NP]; unsigned short* DXi[NP]; unsigned short* FXBi[NP];   // the split (three bf16 planes) copies for chain16x3.h, or NULL
-    bool dw_wide_ok;                             // grouped_dw_wide_kernel may take its 96 KB of LDS
     bool x16_ok; int x16_rows;                   // wide-batch chain kernel usable / from how many rows of a program on
     Ten PT[NP]; Ten D4[NP]; bool pt_ok[NP];      // PT = the F4 copy, D4 = the dX copy (device_common.h W4Copies)
     // activations

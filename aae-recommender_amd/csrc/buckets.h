@@ -129,6 +129,11 @@ __global__ __launch_bounds__(1024) void tile_bucket_wide_kernel(BatchView bv, in
                                                                 int* __restrict__ eb, int* __restrict__ en,
                                                                 float* __restrict__ ev) {
     extern __shared__ int bk_lds_dyn[];
+    // This ONE workgroup runs 50-110 us on the side stream, and whatever lands beside it on its CU crawls: at C4 the next gather of
+    // the main stream took 21-35 us instead of 9 - or, with the CU's LDS claimed (abi_chains.h), torch's index_select of the
+    // condition rows, which needs no LDS, 30 instead of 5.  128 registers per wave = the CU's whole register file for its 16
+    // waves: nothing else is dealt onto the CU while it runs.
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");
     tile_bucket_body<kBucketWideDocs>(bv, ntiles, tstart, eb, en, ev, bk_lds_dyn);
 }
 

@@ -652,13 +652,59 @@ struct W1Job {
 // the adversarial loss of the chain program in front of this launch: its per-row terms (ChainProgram::loss_terms) summed in a
 // fixed order by one extra workgroup (the launch's last) -> *out
 struct LossJob { int enabled; const float* terms; int n; float* out; };
-struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; LossJob loss; };
+struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; LossJob loss;
+                 int ksplit; };        // > 0: jobs of at least this many rows take the k-split form of a tile (grouped_dw_kernel)
 constexpr int kDwSmemBytes = 2 * 64 * (32 + 16) * 4;       // static LDS of grouped_dw_kernel (2 * BK * LDT floats)
 
+// One slab's products of a wave's 16 x 16 block: BK / 4 matrix instructions on ONE accumulator, k ascending (the order - and
+// so every bit of the result - of the plain loop).  Written out as a pipeline because hipcc, left alone, reads two operand
+// pairs into the same four registers, waits for the LDS, multiplies, reads the next two ...: 8 LDS round trips in a row, 0.6 of
+// the 0.88 us a slab took (tools/debug/ubench/dw_real.hip, in-kernel stamps).  Here the operands of four instructions are
+// in flight while the four before them multiply (16 registers).
+#ifndef DW_KSPLIT_DEPTH
+#define DW_KSPLIT_DEPTH 8          // k-steps a wave of the k-split form requests ahead (6 / 8 / 12: 8 is the fastest, dw_real.hip)
+#endif
+template <int BK, int LDT>
+__device__ __forceinline__ f32x4 dw_slab_products(const float* ap, const float* bp, f32x4 acc) {
+#ifdef DW_PLAIN_PRODUCTS
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LDT], bp[kk * LDT], acc, 0, 0, 0);
+    return acc;
+#else
+    constexpr int Q = 4, NQ = BK / 4 / Q;                   // Q instructions per stage
+    static_assert(BK % (4 * Q) == 0 && NQ >= 2, "dw_slab_products: whole stages");
+    float a[2][Q], b[2][Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { a[0][i] = ap[(4 * i) * LDT]; b[0][i] = bp[(4 * i) * LDT]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) { a[(q + 1) & 1][i] = ap[(4 * ((q + 1) * Q + i)) * LDT]; b[(q + 1) & 1][i] = bp[(4 * ((q + 1) * Q + i)) * LDT]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < Q; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][i], b[q & 1][i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+#endif
+}
+
+#ifdef DW_TS      // (tools/debug/ubench/dw_real.hip: in-kernel stamps of tile 0 and of the first column-sum block)
+__device__ unsigned long long dw_ts[96];
+#define DW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) dw_ts[i] = wall_clock64(); } while (0)
+#define DW_STAMP_W1(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == grp.w1.blk0) dw_ts[i] = wall_clock64(); } while (0)
+#else
+#define DW_STAMP(i) do { } while (0)
+#define DW_STAMP_W1(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
     constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
     static_assert(sizeof(float) * 2 * BK * LDT == kDwSmemBytes, "kDwSmemBytes");
+    static_assert(4 * TS * LDC <= 2 * BK * LDT, "the k-split form's four partial tiles");
+    DW_STAMP(0);
     if (grp.loss.enabled && blockIdx.x == gridDim.x - 1) {           // (uniform) the loss terms' sum: thread t adds terms t, t + 256, ...
         float acc = 0.f;                                              // in index order, the 256 sums meet in a fixed tree
         for (int i = threadIdx.x; i < grp.loss.n; i += 256) acc += grp.loss.terms[i];
@@ -674,7 +720,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0) {          // (uniform) first-layer workgroups
         const W1Job& w = grp.w1;
         const int id = (int)blockIdx.x - w.blk0;
-        if (id < w.ncol) colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem);
+        DW_STAMP_W1(64);
+        if (id < w.ncol) { colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem); DW_STAMP_W1(65); }
         else if (w.wave_form == 2) w1_item_hybrid_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
         else if (w.wave_form) {
             if (id == w.ncol && threadIdx.x == 0) *w.hot_zero = 0;
@@ -705,7 +752,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             rb[q] = *reinterpret_cast<const float4*>(J.X + (size_t)kr * J.ldx + min(n0 + cq, nmax4));
         }
     };
-    request(0);
+    const bool ksplit = grp.ksplit > 0 && K >= grp.ksplit;        // (uniform)
+    if (!ksplit) request(0);
     // the optimiser's operands of this thread's four cells (parameter, both moments) depend on nothing this launch
     // computes: requested here, consumed behind the product - one memory round trip less at the kernel's end
     const int erow = tid / (TS / 4), ecol = (tid % (TS / 4)) * 4;
@@ -720,38 +768,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (epre) {
         const size_t off = (size_t)egm * J.ld + egn;
         pp0 = *reinterpret_cast<const float4*>(J.p + off);
-        if (!osc.is_sgd) { mm0 = *reinterpret_cast<const float4*>(J.m + off); vv0 = *reinterpret_cast<const float4*>(J.v + off); }
+        // (both moments whatever the optimiser - they are allocated either way: asking the optimiser's scalars first is one
+        //  memory round trip in front of every tile's first products)
+        mm0 = *reinterpret_cast<const float4*>(J.m + off); vv0 = *reinterpret_cast<const float4*>(J.v + off);
     }
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    DW_STAMP(1);
+    const int row = tid / (TS / 4), col = (tid % (TS / 4)) * 4;
+    const int gm = m0 + row, gn = n0 + col;
+    float4 g4;
+    if (ksplit) {
+        // WIDE batches (r5): the slab loop above is a chain of barrier - wait for the slab's rows - LDS - barrier - products steps,
+        // 0.8-0.9 us per 64 rows however the products are scheduled (in-kernel stamps, tools/debug/ubench/dw_real.hip: 17 us per
+        // launch at 800 rows, 31 at 2 000).  Here every WAVE multiplies the whole 32 x 32 tile over a quarter of the rows, its
+        // operands straight from L2 into the matrix instructions' registers (lane (m, k) of a 16 x 16 x 4 instruction reads G[k][m]),
+        // DW_KSPLIT_DEPTH k-steps ahead, no LDS and no barrier in the loop; the four partial tiles meet in LDS and are added in
+        // wave order (a fixed order: a function of the row count alone).
+        constexpr int D = DW_KSPLIT_DEPTH;
+        const int fr = lane & 15, fk = lane >> 4;
+        const int S = (K + 3) >> 2, Sw = (S + 3) >> 2, s0 = __builtin_amdgcn_readfirstlane(wave) * Sw, s1 = min(S, s0 + Sw);
+        // lane fr of the two 16-row blocks holds tile rows 2 fr and 2 fr + 1 (columns alike): one 8-byte load per operand and
+        // k-step, a wave's load = four whole 128-byte lines.  (One 4-byte load per block row - four half lines per load - ran at
+        // 11 bytes per clock and CU: 0.15 us per k-step whatever the read-ahead depth.)
+        const unsigned ca = (unsigned)min(m0 + 2 * fr, ((J.M + 1) & ~1) - 2), cb = (unsigned)min(n0 + 2 * fr, ((J.N + 1) & ~1) - 2);
+        f32x4 c00 = (f32x4){0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+        float2 av[D], bv[D];
+        auto ld = [&](int st, int i) {          // (rows beyond the batch: the last row again, multiplied by zeros)
+            const unsigned r = (unsigned)min(4 * st + fk, K - 1);
+            av[i] = *reinterpret_cast<const float2*>(J.G + (r * (unsigned)J.ldg + ca)); bv[i] = *reinterpret_cast<const float2*>(J.X + (r * (unsigned)J.ldx + cb));
+        };
+#pragma unroll
+        for (int i = 0; i < D; ++i) { ld(s0 + i, i); __builtin_amdgcn_sched_barrier(0); }      // (in this order: they return in order)
+        int st = s0;
+        // steady passes: every step multiplied and every step requested lies inside the batch and inside this wave's share - no
+        // clamps, no selects, one offset add per load.  (A wave issues its matrix instructions ~45 cycles apart and whatever it
+        // issues between them comes on top: with the clamped addresses and the selects a k-step took 290 cycles, 180 of them
+        // the four products.)
+        const int sfull = min(s1, K >> 2);
+        unsigned oa = (unsigned)(4 * (s0 + D) + fk) * (unsigned)J.ldg + ca, ob = (unsigned)(4 * (s0 + D) + fk) * (unsigned)J.ldx + cb;
+        const unsigned da = 4u * (unsigned)J.ldg, db = 4u * (unsigned)J.ldx;
+        for (; st + 2 * D <= sfull; st += D) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].y, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].x, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, c11, 0, 0, 0);
+                av[i] = *reinterpret_cast<const float2*>(J.G + oa); bv[i] = *reinterpret_cast<const float2*>(J.X + ob);
+                oa += da; ob += db;
+                __builtin_amdgcn_sched_barrier(0);      // (left alone, hipcc gathers the loads in clumps and ends every pass with vmcnt(0))
+            }
+        }
+        for (; st < s1; st += D) {              // the last one or two passes: the general form
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const bool ok = st + i < s1 && 4 * (st + i) + fk < K;
+                const float a0 = ok ? av[i].x : 0.f, a1 = ok ? av[i].y : 0.f, b0 = bv[i].x, b1 = bv[i].y;
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c11, 0, 0, 0);
+                ld(st + i + D, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DW_STAMP(44);
+        float* Pw = smem + wave * (TS * LDC);                  // this wave's partial tile [32][LDC]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                          // (c00[r]: tile row 2 i, column 2 j with i = 4 (lane >> 4) + r, j = lane & 15)
+            const int pi = (lane >> 4) * 4 + r, pj = lane & 15;
+            *reinterpret_cast<float2*>(&Pw[(2 * pi) * LDC + 2 * pj]) = make_float2(c00[r], c01[r]);
+            *reinterpret_cast<float2*>(&Pw[(2 * pi + 1) * LDC + 2 * pj]) = make_float2(c10[r], c11[r]);
+        }
         __syncthreads();
+        g4 = *reinterpret_cast<const float4*>(&smem[row * LDC + col]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&smem[q * (TS * LDC) + row * LDC + col]);
+            g4.x += t4.x; g4.y += t4.y; g4.z += t4.z; g4.w += t4.w;
+        }
+    } else {
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        DW_STAMP(2 + min(k0 / BK, 40));
+        __syncthreads();
+        if (k0 == 4 * BK) DW_STAMP(48);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + 256 * q, kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
             const bool ok = k0 + kr < K;
+            // (selects, not branches: rows beyond the batch and columns beyond the layer become zeros)
+            const int na = ok ? J.M - (m0 + cq) : 0, nb = ok ? J.N - (n0 + cq) : 0;
             float4 va, vb;
-            va.x = (ok && m0 + cq < J.M) ? ra[q].x : 0.f; va.y = (ok && m0 + cq + 1 < J.M) ? ra[q].y : 0.f;
-            va.z = (ok && m0 + cq + 2 < J.M) ? ra[q].z : 0.f; va.w = (ok && m0 + cq + 3 < J.M) ? ra[q].w : 0.f;
-            vb.x = (ok && n0 + cq < J.N) ? rb[q].x : 0.f; vb.y = (ok && n0 + cq + 1 < J.N) ? rb[q].y : 0.f;
-            vb.z = (ok && n0 + cq + 2 < J.N) ? rb[q].z : 0.f; vb.w = (ok && n0 + cq + 3 < J.N) ? rb[q].w : 0.f;
+            va.x = na > 0 ? ra[q].x : 0.f; va.y = na > 1 ? ra[q].y : 0.f; va.z = na > 2 ? ra[q].z : 0.f; va.w = na > 3 ? ra[q].w : 0.f;
+            vb.x = nb > 0 ? rb[q].x : 0.f; vb.y = nb > 1 ? rb[q].y : 0.f; vb.z = nb > 2 ? rb[q].z : 0.f; vb.w = nb > 3 ? rb[q].w : 0.f;
             *reinterpret_cast<float4*>(&As[kr * LDT + cq]) = va;
             *reinterpret_cast<float4*>(&Bs[kr * LDT + cq]) = vb;
         }
+        if (k0 == 4 * BK) DW_STAMP(49);
         request(k0 + BK);                       // (beyond the batch: the last row again, never stored)
+        if (k0 == 4 * BK) DW_STAMP(50);
         __syncthreads();
-        const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[(kk + fk) * LDT + wm + fr], Bs[(kk + fk) * LDT + wn + fr], acc, 0, 0, 0);
+        if (k0 == 4 * BK) DW_STAMP(51);
+        acc = dw_slab_products<BK, LDT>(As + (lane >> 4) * LDT + wm + (lane & 15), Bs + (lane >> 4) * LDT + wn + (lane & 15), acc);
     }
+    DW_STAMP(44);
     __syncthreads();
     float* Cs = smem;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Cs[(wm + (lane >> 4) * 4 + r) * LDC + wn + (lane & 15)] = acc[r];
     __syncthreads();
-    const int row = tid / (TS / 4), col = (tid % (TS / 4)) * 4;
-    const int gm = m0 + row, gn = n0 + col;
+    g4 = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
+    }
     if (gm < J.M && gn < J.N) {
-        const float4 g4 = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
+        DW_STAMP(45);
         if (epre) {                             // (EpiAdam::apply's vector path on the operands requested above)
             const size_t off = (size_t)gm * J.ld + gn;
             adam_update(pp0.x, mm0.x, vv0.x, g4.x, osc); adam_update(pp0.y, mm0.y, vv0.y, g4.y, osc);
@@ -769,135 +897,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
         }
     }
+    DW_STAMP(46);
 }
 
-// -----------------------------------------------------------------------------------------------
-// The same launch for WIDE batches (r5): the weight-gradient product of a hidden layer is a sum over the rows of the batch -
-// 16 slabs of 64 rows at 1 000 rows, 32 at 2 000 (the discriminator's stacked batch) - and one tile's slab loop is a chain of
-// load -> LDS -> 16 products -> barrier steps of ~1 us each: 30 us per launch at C4, three launches per step, on 70-126 tiles
-// that leave most of the chip idle.  Here a tile's workgroup has 16 waves: four GROUPS of four, each walking a quarter of the
-// rows with the 256-thread kernel's loop (its own operand images: 4 x 24 KB of LDS), the four partial tiles added in group
-// order before the optimiser epilogue - a fixed order, a function of the row count alone.  The first layer's ride-along blocks
-// run their 256-thread bodies on the first four waves (the others leave at once).
-// -----------------------------------------------------------------------------------------------
-constexpr int kDwWideGroups = 4;
-constexpr int kDwWideSmemBytes = kDwWideGroups * kDwSmemBytes;
-__global__ __launch_bounds__(1024) void grouped_dw_wide_kernel(DwGroup grp) {
-    constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024, KG = kDwWideGroups;
-    extern __shared__ __attribute__((aligned(16))) float smem_w[];      // [KG][2 * BK * LDT]
-    const int kg = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const bool special = (grp.loss.enabled && blockIdx.x == gridDim.x - 1) || (grp.w1.enabled && (int)blockIdx.x >= grp.w1.blk0);
-    if (special) {
-        if (kg) return;                                               // (whole waves: the others' barriers do not count them)
-        float* smem = smem_w;
-        if (grp.loss.enabled && blockIdx.x == gridDim.x - 1) {
-            float acc = 0.f;
-            for (int i = tid; i < grp.loss.n; i += 256) acc += grp.loss.terms[i];
-            smem[tid] = acc;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) smem[tid] += smem[tid + o];
-                __syncthreads();
-            }
-            if (tid == 0) *grp.loss.out = smem[0];
-            return;
-        }
-        const W1Job& w = grp.w1;
-        const int id = (int)blockIdx.x - w.blk0;
-        if (id < w.ncol) colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem);
-        else if (w.wave_form == 2) w1_item_hybrid_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
-        else if (w.wave_form) {
-            if (id == w.ncol && tid == 0) *w.hot_zero = 0;
-            w1_item_wave_body(w.items, w.hot, w.hot_count, reinterpret_cast<unsigned*>(smem), (id - w.ncol) * 4 + (tid >> 6), w.nitem * 4);
-        } else w1_item_update_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
-        return;
-    }
-    int j = 0;
-    for (int q = 1; q < grp.njobs; ++q) if ((int)blockIdx.x >= grp.jobs[q].tile0) j = q;
-    const DwJob& J = grp.jobs[j];
-    const int t = blockIdx.x - J.tile0;
-    const int m0 = (t / J.tiles_n) * TS, n0 = (t % J.tiles_n) * TS;
-    float* As = smem_w + kg * (2 * BK * LDT); float* Bs = As + BK * LDT;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int K = J.rows;
-    const int Kq = (((K + KG - 1) / KG) + BK - 1) / BK * BK;             // rows per group, whole slabs
-    const int kb = kg * Kq, ke = min(K, kb + Kq);                        // this group's rows [kb, ke)  (possibly none)
-    const int mmax4 = ((J.M + 3) & ~3) - 4, nmax4 = ((J.N + 3) & ~3) - 4;
-    float4 ra[NV], rb[NV];
-    auto request = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int f = tid + 256 * q, kr = min(k0 + f / (TS / 4), K - 1), cq = (f % (TS / 4)) * 4;
-            ra[q] = *reinterpret_cast<const float4*>(J.G + (size_t)kr * J.ldg + min(m0 + cq, mmax4));
-            rb[q] = *reinterpret_cast<const float4*>(J.X + (size_t)kr * J.ldx + min(n0 + cq, nmax4));
-        }
-    };
-    request(kb);
-    const int erow = tid / (TS / 4), ecol = (tid % (TS / 4)) * 4;
-    const int egm = m0 + erow, egn = n0 + ecol;
-    const bool epre = kg == 0 && !J.grad && egm < J.M && egn + 3 < J.N;
-    float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0;
-    const OptScalars osc = *J.sc;
-    if (epre) {
-        const size_t off = (size_t)egm * J.ld + egn;
-        pp0 = *reinterpret_cast<const float4*>(J.p + off);
-        if (!osc.is_sgd) { mm0 = *reinterpret_cast<const float4*>(J.m + off); vv0 = *reinterpret_cast<const float4*>(J.v + off); }
-    }
-    for (int k0 = kb; k0 < kb + Kq; k0 += BK) {                          // (every group the same number of slabs: the barriers are the workgroup's)
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int f = tid + 256 * q, kr = f / (TS / 4), cq = (f % (TS / 4)) * 4;
-            const bool ok = k0 + kr < ke;
-            float4 va, vb;
-            va.x = (ok && m0 + cq < J.M) ? ra[q].x : 0.f; va.y = (ok && m0 + cq + 1 < J.M) ? ra[q].y : 0.f;
-            va.z = (ok && m0 + cq + 2 < J.M) ? ra[q].z : 0.f; va.w = (ok && m0 + cq + 3 < J.M) ? ra[q].w : 0.f;
-            vb.x = (ok && n0 + cq < J.N) ? rb[q].x : 0.f; vb.y = (ok && n0 + cq + 1 < J.N) ? rb[q].y : 0.f;
-            vb.z = (ok && n0 + cq + 2 < J.N) ? rb[q].z : 0.f; vb.w = (ok && n0 + cq + 3 < J.N) ? rb[q].w : 0.f;
-            *reinterpret_cast<float4*>(&As[kr * LDT + cq]) = va;
-            *reinterpret_cast<float4*>(&Bs[kr * LDT + cq]) = vb;
-        }
-        request(k0 + BK);
-        __syncthreads();
-        const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[(kk + fk) * LDT + wm + fr], Bs[(kk + fk) * LDT + wn + fr], acc, 0, 0, 0);
-    }
-    __syncthreads();
-    float* Cs = smem_w + kg * (2 * BK * LDT);                            // this group's partial tile [32][LDC]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cs[(wm + (lane >> 4) * 4 + r) * LDC + wn + (lane & 15)] = acc[r];
-    __syncthreads();
-    if (kg) return;
-    const int row = tid / (TS / 4), col = (tid % (TS / 4)) * 4;
-    const int gm = m0 + row, gn = n0 + col;
-    if (gm < J.M && gn < J.N) {
-        float4 g4 = *reinterpret_cast<const float4*>(&Cs[row * LDC + col]);
-#pragma unroll
-        for (int q = 1; q < KG; ++q) {                                   // the groups' partial sums, in group order
-            const float4 t4 = *reinterpret_cast<const float4*>(&smem_w[q * (2 * BK * LDT) + row * LDC + col]);
-            g4.x += t4.x; g4.y += t4.y; g4.z += t4.z; g4.w += t4.w;
-        }
-        if (epre) {
-            const size_t off = (size_t)gm * J.ld + gn;
-            adam_update(pp0.x, mm0.x, vv0.x, g4.x, osc); adam_update(pp0.y, mm0.y, vv0.y, g4.y, osc);
-            adam_update(pp0.z, mm0.z, vv0.z, g4.z, osc); adam_update(pp0.w, mm0.w, vv0.w, g4.w, osc);
-            *reinterpret_cast<float4*>(J.p + off) = pp0;
-            if (!osc.is_sgd) { *reinterpret_cast<float4*>(J.m + off) = mm0; *reinterpret_cast<float4*>(J.v + off) = vv0; }
-            if (J.w4.f4) w4_put4(J.w4, gm, gn, pp0);
-        } else
-        if (J.grad) {
-            EpiStore e; e.out = J.grad; e.ld = J.ld;
-            EpiStore::State st; e.apply(st, gm, gn, J.N, g4, 0);
-        } else {
-            EpiAdam e; e.p = J.p; e.m = J.m; e.v = J.v; e.ld = J.ld; e.sc = J.sc;
-            e.w4 = J.w4;
-            EpiAdam::State st; e.apply(st, gm, gn, J.N, g4, 0);
-        }
-    }
-}
 
 }  // namespace aae
