@@ -108,6 +108,12 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
         m->x16_rows = x16_min_rows();
+        if (getenv("AAE_NO_ITEM_COUNT") == nullptr) {
+            void* hp = nullptr; void* dp = nullptr;
+            if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                m->cnt_host = static_cast<int*>(hp); m->cnt_host_dev = static_cast<int*>(dp); *m->cnt_host = 0;
+            } else { if (hp) (void)hipHostFree(hp); (void)hipGetLastError(); }
+        }
         m->x16_ok = m->use_chain4 && m->FXi[P_W2] != nullptr &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(chain16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kX16Lds) == hipSuccess &&
@@ -285,6 +291,7 @@ int aae_destroy(aae_handle h) {
         (void)hipStreamDestroy(h->side);
     }
     if (h->dp_scratch) (void)hipFree(h->dp_scratch);
+    if (h->cnt_host) (void)hipHostFree(h->cnt_host);
     if (h->ev_crit) (void)hipEventDestroy(h->ev_crit);
     if (h->ev_opt) (void)hipEventDestroy(h->ev_opt);
     if (h->ev_head) (void)hipEventDestroy(h->ev_head);

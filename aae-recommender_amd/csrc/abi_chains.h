@@ -362,6 +362,23 @@ struct DwBuilder {
                 m->w1_hot_pending = true; m->w1_hot_set = set; m->w1_hot_which = which; m->w1_hot_ga1 = ga1;
                 mh = m;
             }
+            // r5: the wide batches' forms walk the item list with a stride, so the launch needs no workgroup per POSSIBLE item - an
+            // item slice of 12 500 items had 12 500 of them for the ~800 items of a batch, and the ~11 700 that find nothing to do
+            // still have to be dealt out: 32 us per launch beside the deferred launch where the busy ones need 13 (per-workgroup
+            // clocks, AAE_DW_TS).  How many a batch needs only the device knows: a workgroup of every such launch leaves the
+            // step's count in host memory, and the launch is sized by the last count seen there + a quarter (a batch with more
+            // items walks the rest with the stride; fewer workgroups than items cost C4, whose items are nearly all busy,
+            // 0.302 -> 0.313 ms/step at 1 024).  One rank's step at world 8: 0.275 -> 0.261 ms.
+            w.cnt_out = nullptr;
+            if (w.wave_form != 2 && m->cnt_host) {
+                w.cnt_out = m->cnt_host_dev;
+                const int seen = *reinterpret_cast<volatile int*>(m->cnt_host);
+                if (seen > 0) {
+                    const int per = w.wave_form == 1 ? 4 : 1;                   // items per workgroup and pass
+                    const int want = ((seen + seen / 4 + per - 1) / per + 63) & ~63;
+                    w.nitem = std::min(w.nitem, std::max(256, want));
+                }
+            }
         }
         return AAE_OK;
     }
@@ -380,10 +397,49 @@ struct DwBuilder {
         // loop, this round's first answer for 1 536+ rows: 23.3 - removed).  AAE_DW_KSPLIT_ROWS=0: never
         static const int ksplit_rows = getenv("AAE_DW_KSPLIT_ROWS") ? atoi(getenv("AAE_DW_KSPLIT_ROWS")) : 256;
         g.ksplit = ksplit_rows;
+        // AAE_DW_TS=<first launch to report>: per-workgroup clocks of six launches (three steps' worth would be nine), by block kind
+        static const int ts_from = getenv("AAE_DW_TS") ? atoi(getenv("AAE_DW_TS")) : -1;
+        static int ts_seen = 0;
+        static unsigned long long* ts_dev = nullptr;
+        constexpr int kTsCap = 1 << 16;
+        const bool ts_now = ts_from >= 0 && ts_seen >= ts_from && ts_seen < ts_from + 6;
+        if (ts_from >= 0) {
+            ++ts_seen;
+            if (!ts_dev) HIPCHK(hipMalloc(&ts_dev, sizeof(unsigned long long) * 2 * kTsCap));
+        }
+        if (ts_now) { HIPCHK(hipMemsetAsync(ts_dev, 0, sizeof(unsigned long long) * 2 * kTsCap, s)); g.ts = ts_dev; g.ts_cap = kTsCap; }
         if (done && !mh) hipExtLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g);
         else
         hipLaunchKernelGGL(grouped_dw_kernel, dim3(blocks), dim3(256), 0, s, g);
         LAUNCHCHK("grouped_dw_kernel");
+        if (ts_now) {
+            HIPCHK(hipStreamSynchronize(s));
+            const int nb = std::min(blocks, kTsCap);
+            std::vector<unsigned long long> h(2 * (size_t)nb);
+            HIPCHK(hipMemcpy(h.data(), ts_dev, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+            unsigned long long t_lo = ~0ull, t_hi = 0;
+            for (int b = 0; b < nb; ++b) if (h[2 * b]) { t_lo = std::min(t_lo, h[2 * b]); t_hi = std::max(t_hi, h[2 * b + 1]); }
+            const int ncol = g.w1.enabled ? g.w1.ncol : 0, nitem = g.w1.enabled ? g.w1.nitem : 0;
+            int max_rows = 0;
+            for (int q = 0; q < g.njobs; ++q) max_rows = std::max(max_rows, g.jobs[q].rows);
+            fprintf(stderr, "[grouped_dw launch %d: %d workgroups = %d tiles (rows %d) + %d column-sum + %d item (form %d) + %d loss; first start -> last end %.2f us]\n",
+                    ts_seen - 1, blocks, tiles, max_rows, ncol, nitem, g.w1.wave_form, g.loss.enabled, (t_hi - t_lo) * 0.01);
+            const struct { const char* name; int lo, hi; } kinds[] = {{"tiles", 0, tiles}, {"column sums", tiles, tiles + ncol}, {"items", tiles + ncol, tiles + ncol + nitem}};
+            for (const auto& k : kinds) {
+                if (k.hi <= k.lo) continue;
+                unsigned long long first = ~0ull, last = 0, worst = 0; int worst_b = -1, busy = 0; double sum = 0;
+                for (int b = k.lo; b < std::min(k.hi, nb); ++b) {
+                    if (!h[2 * b]) continue;
+                    const unsigned long long d = h[2 * b + 1] - h[2 * b];
+                    first = std::min(first, h[2 * b]); last = std::max(last, h[2 * b + 1]);
+                    if (d > worst) { worst = d; worst_b = b - k.lo; }
+                    if (d > 150) ++busy;      // (a workgroup with nothing to do leaves within 1.5 us)
+                    sum += d * 0.01;
+                }
+                fprintf(stderr, "   %-12s start %.2f us after the launch's first, end %.2f; longest workgroup %.2f us (#%d); %d of %d ran longer than 1.5 us, mean %.2f us\n",
+                        k.name, (first - t_lo) * 0.01, (last - t_lo) * 0.01, worst * 0.01, worst_b, busy, k.hi - k.lo, sum / std::max(1, k.hi - k.lo));
+            }
+        }
         if (mh) TRY(launch_w1_hot(mh, s));
         return AAE_OK;
     }

@@ -122,6 +122,9 @@ struct aae_model {
     // aae_prefetch_batch: the NEXT step's unique-item list and deferred-Adam catch-up, built on `side` while this step
     // runs, in the second list set (mark2 / ulist2 / ucount2 / stamp2; a step that consumes it swaps the sets)
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
+    // the distinct-item count of a recent step, written by a workgroup of that step's weight-gradient launch into host memory the
+    // device can reach: the NEXT launches size their first-layer item workgroups by it (abi_chains.h).  Never waited for.
+    int* cnt_host = nullptr; int* cnt_host_dev = nullptr;
     aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
     bool pf_pending; hipEvent_t ev_head, ev_pf;
     bool pf_bumped = false;  // the running step's gather bumped the next batch's stamp (launch_prefetch skips its own launch)

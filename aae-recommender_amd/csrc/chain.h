@@ -648,12 +648,14 @@ struct W1Job {
                           // (w1_item_hybrid_body); 1: wide batch - the item blocks run the one-wave-per-item form (w1_update.h), items with more rows than
     int* hot; int* hot_count; int* hot_zero;    // kW1WaveRows go to the hot list (worked off by a launch behind this one); hot_zero: the NEXT use's counter
     W1Items items;
+    int* cnt_out;         // != NULL: host-visible word that receives the step's distinct-item count (the column sums' first workgroup)
 };
 // the adversarial loss of the chain program in front of this launch: its per-row terms (ChainProgram::loss_terms) summed in a
 // fixed order by one extra workgroup (the launch's last) -> *out
 struct LossJob { int enabled; const float* terms; int n; float* out; };
 struct DwGroup { int njobs; DwJob jobs[4]; W1Job w1; LossJob loss;
-                 int ksplit; };        // > 0: jobs of at least this many rows take the k-split form of a tile (grouped_dw_kernel)
+                 int ksplit;           // > 0: jobs of at least this many rows take the k-split form of a tile (grouped_dw_kernel)
+                 unsigned long long* ts; int ts_cap; };    // debug: per-workgroup clocks
 constexpr int kDwSmemBytes = 2 * 64 * (32 + 16) * 4;       // static LDS of grouped_dw_kernel (2 * BK * LDT floats)
 
 // One slab's products of a wave's 16 x 16 block: BK / 4 matrix instructions on ONE accumulator, k ascending (the order - and
@@ -699,9 +701,8 @@ __device__ unsigned long long dw_ts[96];
 #define DW_STAMP(i) do { } while (0)
 #define DW_STAMP_W1(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
+__device__ __forceinline__ void grouped_dw_body(const DwGroup& grp, float* smem) {
     constexpr int TS = 32, BK = 64, LDT = TS + 16, LDC = TS + 4, NV = TS * BK / 1024;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDT];
     static_assert(sizeof(float) * 2 * BK * LDT == kDwSmemBytes, "kDwSmemBytes");
     static_assert(4 * TS * LDC <= 2 * BK * LDT, "the k-split form's four partial tiles");
     DW_STAMP(0);
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const W1Job& w = grp.w1;
         const int id = (int)blockIdx.x - w.blk0;
         DW_STAMP_W1(64);
+        if (id == 0 && threadIdx.x == 0 && w.cnt_out && w.nitem > 0) *w.cnt_out = *w.items.ucount;
         if (id < w.ncol) { colsum_adam_body(w.ga1, w.rows, w.h, w.ld, w.bp, w.bm, w.bv1, w.bgrad, w.sc, id, smem); DW_STAMP_W1(65); }
         else if (w.wave_form == 2) w1_item_hybrid_body(w.items, reinterpret_cast<unsigned*>(smem), id - w.ncol, w.nitem);
         else if (w.wave_form) {
@@ -898,6 +900,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
     }
     DW_STAMP(46);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
+    __shared__ __attribute__((aligned(16))) float smem[kDwSmemBytes / sizeof(float)];
+    // (AAE_DW_TS=1, abi_chains.h: every workgroup's first and last clock - which of the launch's block kinds is its long pole)
+    const unsigned long long t0 = grp.ts ? wall_clock64() : 0ull;
+    grouped_dw_body(grp, smem);
+    if (grp.ts && threadIdx.x == 0 && (int)blockIdx.x < grp.ts_cap) { grp.ts[2 * blockIdx.x] = t0; grp.ts[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
 

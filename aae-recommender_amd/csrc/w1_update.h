@@ -74,15 +74,22 @@ __device__ __forceinline__ void w1_item_update_one(const W1Items& a, unsigned* w
         for (int i = tid; i < nw; i += 256) bm[i] = 0u;
         __syncthreads();
         // pass 1: mark the rows; a thread keeps its first match in registers (tiles beyond 256 entries: re-read in pass 2)
+        // (r5: four groups of 256 entries requested together.  The tile of the 32 most popular items holds a third to a half of a
+        //  wide batch's entries - 9 000 at C4, 3 400 at C3 with 512 rows - and each of its items' workgroups walked them 256 at a
+        //  time, one memory round trip per group and pass: the long pole of the weight-gradient launches that carry these blocks)
         int my_r = -1; float my_x = 0.f;
-        for (int base = e0; base < e1; base += 256) {
-            const int e = base + tid;
-            const int ec = min(e, e1 - 1);
+        {
+            const int ec = min(e0 + tid, e1 - 1);          // the first group also keeps its value
             const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
-            if (e < e1 && en_e == it) {
-                atomicOr(&bm[r >> 5], 1u << (r & 31));
-                if (base == e0) { my_r = r; my_x = x; }
-            }
+            if (e0 + tid < e1 && en_e == it) { atomicOr(&bm[r >> 5], 1u << (r & 31)); my_r = r; my_x = x; }
+        }
+        for (int base = e0 + 256; base < e1; base += 1024) {
+            int en4[4], r4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int ec = min(base + 256 * j + tid, e1 - 1); en4[j] = a.en[ec]; r4[j] = a.eb[ec]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (base + 256 * j + tid < e1 && en4[j] == it) atomicOr(&bm[r4[j] >> 5], 1u << (r4[j] & 31));
         }
         __syncthreads();
         if (wave == 0) {                                   // exclusive prefix of the words' popcounts
@@ -103,14 +110,17 @@ __device__ __forceinline__ void w1_item_update_one(const W1Items& a, unsigned* w
             const int k = pre[my_r >> 5] + __popc(bm[my_r >> 5] & ((1u << (my_r & 31)) - 1u));
             rl[k] = my_r; xl[k] = my_x;
         }
-        for (int base = e0 + 256; base < e1; base += 256) {     // (hot tiles only)
-            const int e = base + tid;
-            const int ec = min(e, e1 - 1);
-            const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
-            if (e < e1 && en_e == it) {
-                const int k = pre[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
-                rl[k] = r; xl[k] = x;
-            }
+        for (int base = e0 + 256; base < e1; base += 1024) {    // (hot tiles only)
+            int en4[4], r4[4]; float x4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int ec = min(base + 256 * j + tid, e1 - 1); en4[j] = a.en[ec]; r4[j] = a.eb[ec]; x4[j] = a.ev[ec]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (base + 256 * j + tid < e1 && en4[j] == it) {
+                    const int r = r4[j];
+                    const int k = pre[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
+                    rl[k] = r; xl[k] = x4[j];
+                }
         }
         __syncthreads();
         const int n = *s_n;
@@ -215,14 +225,18 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
             if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o0); pv = *reinterpret_cast<const float4*>(a.V + o0); }
         }
         int n = 0;
-        for (int base = e0; base < e1; base += 64) {
-            const int e = base + lane, ec = min(e, e1 - 1);
-            const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
-            const bool hit = e < e1 && en_e == it;
-            const unsigned long long bal = __ballot(hit);
-            const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
-            if (hit && k < kW1WaveRows) { rl[k] = r; xl[k] = x; }
-            n += __popcll(bal);
+        for (int base = e0; base < e1; base += 256) {      // (r5: four groups of 64 entries requested together, taken in order)
+            int en4[4], r4[4]; float x4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int ec = min(base + 64 * j + lane, e1 - 1); en4[j] = a.en[ec]; r4[j] = a.eb[ec]; x4[j] = a.ev[ec]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = base + 64 * j + lane < e1 && en4[j] == it;
+                const unsigned long long bal = __ballot(hit);
+                const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && k < kW1WaveRows) { rl[k] = r4[j]; xl[k] = x4[j]; }
+                n += __popcll(bal);
+            }
         }
         if (n > kW1WaveRows) {                          // a head item: the workgroup form takes it
             if (lane == 0) hot[atomicAdd(hot_count, 1)] = item;
@@ -327,14 +341,18 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
             if (!s.is_sgd) { pm = *reinterpret_cast<const float4*>(a.M + o0); pv = *reinterpret_cast<const float4*>(a.V + o0); }
         }
         int n = 0;
-        for (int base = e0; base < e1; base += 64) {
-            const int e = base + lane, ec = min(e, e1 - 1);
-            const int en_e = a.en[ec], r = a.eb[ec]; const float x = a.ev[ec];
-            const bool hit = e < e1 && en_e == it;
-            const unsigned long long bal = __ballot(hit);
-            const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
-            if (hit && k < kW1HybRows) { rl[k] = r; xl[k] = x; }
-            n += __popcll(bal);
+        for (int base = e0; base < e1; base += 256) {      // (r5: four groups of 64 entries requested together, taken in order)
+            int en4[4], r4[4]; float x4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int ec = min(base + 64 * j + lane, e1 - 1); en4[j] = a.en[ec]; r4[j] = a.eb[ec]; x4[j] = a.ev[ec]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = base + 64 * j + lane < e1 && en4[j] == it;
+                const unsigned long long bal = __ballot(hit);
+                const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && k < kW1HybRows) { rl[k] = r4[j]; xl[k] = x4[j]; }
+                n += __popcll(bal);
+            }
         }
         if (n > kW1HybRows) {                           // more rows than one wave adds in the workgroup form: all four take it below
             const int b = round * 4 + wv;
