@@ -370,11 +370,13 @@ struct DwBuilder {
             // items walks the rest with the stride; fewer workgroups than items cost C4, whose items are nearly all busy,
             // 0.302 -> 0.313 ms/step at 1 024).  One rank's step at world 8: 0.275 -> 0.261 ms.
             w.cnt_out = nullptr;
-            if (w.wave_form != 2 && m->cnt_host) {
+            // (batches of one fused launch too: C3 0.2363-0.2374 -> 0.2336-0.2361 ms/step with ~560 workgroups of four busy waves instead of 800)
+            static const bool hyb_count = getenv("AAE_NO_ITEM_COUNT_HYBRID") == nullptr;
+            if ((w.wave_form != 2 || hyb_count) && m->cnt_host) {
                 w.cnt_out = m->cnt_host_dev;
                 const int seen = *reinterpret_cast<volatile int*>(m->cnt_host);
                 if (seen > 0) {
-                    const int per = w.wave_form == 1 ? 4 : 1;                   // items per workgroup and pass
+                    const int per = w.wave_form ? 4 : 1;                        // items per workgroup and pass
                     const int want = ((seen + seen / 4 + per - 1) / per + 63) & ~63;
                     w.nitem = std::min(w.nitem, std::max(256, want));
                 }
