@@ -303,9 +303,11 @@ int launch_w1_hot(aae_model* m, hipStream_t s);
 struct DwBuilder {
     aae_model* mh = nullptr;       // set by add_first_layer: the wave form's hot list is worked off behind the launch
     DwGroup g; int tiles;
+    int ksplit_rows = 0;           // set by add(): the model's threshold for the k-split form of a tile
     DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
     void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
         DwJob& J = g.jobs[g.njobs++];
+        ksplit_rows = m->dw_ksplit_rows;
         const Ten& W = m->P[pid];
         const int set = (which == O_GEN) ? 1 : 0;
         J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
@@ -396,8 +398,7 @@ struct DwBuilder {
         // quarter of the rows, operands straight into the matrix instructions' registers, no LDS in the loop).  Per launch of three
         // 200 x 201 layers + the bias column sums, slab loop | k-split form (tools/debug/ubench/dw_real.hip): 256 rows 9.7 | 9.2 us,
         // 512 12.8 | 10.4, 800 17.0 | 13.3, 1 000 19.4 | 13.6, 2 000 32.0 | 19.4 (a 16-wave kernel with four k-groups of the slab
-        // loop, this round's first answer for 1 536+ rows: 23.3 - removed).  AAE_DW_KSPLIT_ROWS=0: never
-        static const int ksplit_rows = getenv("AAE_DW_KSPLIT_ROWS") ? atoi(getenv("AAE_DW_KSPLIT_ROWS")) : 256;
+        // loop, this round's first answer for 1 536+ rows: 23.3 - removed).  AAE_DW_KSPLIT_ROWS (read by aae_create) = 0: never, 1: every batch (tests)
         g.ksplit = ksplit_rows;
         // AAE_DW_TS=<first launch to report>: per-workgroup clocks of six launches (three steps' worth would be nine), by block kind
         static const int ts_from = getenv("AAE_DW_TS") ? atoi(getenv("AAE_DW_TS")) : -1;

@@ -100,6 +100,17 @@ def test_step_matches_reference_on_the_wide_batch_chain_kernel(name, monkeypatch
     test_step_matches_reference(name)
 
 
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_step_matches_reference_on_the_k_split_weight_gradient_tiles(name, monkeypatch):
+    """The same replay with every weight-gradient tile in the wide batches' form (r5, csrc/chain.h grouped_dw_kernel;
+    AAE_DW_KSPLIT_ROWS=1 lifts the 256-row rule): each wave multiplies the whole 32 x 32 tile over a quarter of the rows,
+    operands straight from memory into the matrix instructions' registers (tile rows 2 i / 2 i + 1 on lane i of the two
+    16-row blocks), the four partial tiles added in wave order - against the reference's recorded losses, parameters and
+    Adam moments at the SAME tolerances, incl. batches of fewer rows than waves have k-steps."""
+    monkeypatch.setenv("AAE_DW_KSPLIT_ROWS", "1")
+    test_step_matches_reference(name)
+
+
 def test_plain_autoencoder_matches_reference():
     """cfg.reserved[2] = 1: the reference's non-adversarial AutoEncoder (aae.py:221-458) - only the
     reconstruction step runs; fixture generated from the reference's AutoEncoder class."""
