@@ -108,6 +108,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
         m->x16_rows = x16_min_rows();
+        m->dw_ksplit_rows = 256;                       // (the handle is zero-filled after construction: no default member values)
         if (const char* e = getenv("AAE_DW_KSPLIT_ROWS")) m->dw_ksplit_rows = atoi(e);
         if (getenv("AAE_NO_ITEM_COUNT") == nullptr) {
             void* hp = nullptr; void* dp = nullptr;

@@ -124,8 +124,8 @@ struct aae_model {
     int* mark2; int* ulist2; int* ucount2; int* stamp2;
     // the distinct-item count of a recent step, written by a workgroup of that step's weight-gradient launch into host memory the
     // device can reach: the NEXT launches size their first-layer item workgroups by it (abi_chains.h).  Never waited for.
-    int* cnt_host = nullptr; int* cnt_host_dev = nullptr;
-    int dw_ksplit_rows = 256;      // weight-gradient jobs of at least this many rows: the k-split form of a tile (0: never; AAE_DW_KSPLIT_ROWS)
+    int* cnt_host; int* cnt_host_dev;
+    int dw_ksplit_rows;            // (set by aae_create: 256) weight-gradient jobs of at least this many rows: the k-split form of a tile (0: never; AAE_DW_KSPLIT_ROWS)
     aae_batch pf_batch, pf_built_batch; bool pf_armed; bool pf_built; long long pf_step; long long hstep;
     bool pf_pending; hipEvent_t ev_head, ev_pf;
     bool pf_bumped = false;  // the running step's gather bumped the next batch's stamp (launch_prefetch skips its own launch)
