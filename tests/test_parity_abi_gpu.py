@@ -268,6 +268,43 @@ def test_a_refilled_batch_buffer_at_the_same_address_is_not_taken_for_the_batch_
     np.testing.assert_allclose(st["lin1.weight"][1], ora.opt_gen.v["enc.lin1.weight"], atol=1e-12, rtol=1e-3)
 
 
+@pytest.mark.parametrize("N,B", [(1500, 320), (9000, 100)])
+def test_item_workgroups_sized_by_the_devices_count_leave_every_bit_alone(N, B, monkeypatch):
+    """r5: the first-layer item workgroups of the weight-gradient launches are sized by the distinct-item count a workgroup of
+    an EARLIER launch stored into host-visible memory (abi_chains.h) - a number the host reads without waiting, so it
+    depends on timing.  The result must not: every item's sum is one workgroup's (or wave's) work in an order fixed by the
+    batch, whatever the grid.  Six steps with the feedback (the launches shrink after the first step) and six with one
+    workgroup per possible item (AAE_NO_ITEM_COUNT=1): every parameter and both moments of enc.lin1 bit for bit - on the wide
+    batches' workgroup form (320 rows over 1 500 items) and on the hybrid form of a 100-row batch."""
+    import torch
+    from aaerec._hip import HipAAE, DeviceCSR
+    from oracle.dense_torch_port import init_params
+    from tools.synth import throughput_corpus
+    h, c, steps = 200, 50, 6
+    X = throughput_corpus(steps * B, N, median_len=14, max_len=70, seed=9)
+    params = init_params(N, h, c, seed=3)
+    outs = []
+    for no_count in (False, True):
+        if no_count:
+            monkeypatch.setenv("AAE_NO_ITEM_COUNT", "1")
+        else:
+            monkeypatch.delenv("AAE_NO_ITEM_COUNT", raising=False)
+        m = HipAAE(N, h, c, max_batch=B, max_nnz=B * 80, rng_mode="device", seed=5, dropout=(0.2, 0.2))
+        m.load_params(params)
+        csr = DeviceCSR(X, m.device)
+        for s in range(steps):
+            m.step(csr, s * B, B)
+        torch.cuda.synchronize()
+        outs.append((m.state_dict(), m.adam_state("enc"), m.adam_state("gen")))
+        m.close()
+    (p0, e0, g0), (p1, e1, g1) = outs
+    for k in p0:
+        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)
+    for a, b in ((e0, e1), (g0, g1)):
+        np.testing.assert_array_equal(a["lin1.weight"][0], b["lin1.weight"][0])
+        np.testing.assert_array_equal(a["lin1.weight"][1], b["lin1.weight"][1])
+
+
 @pytest.mark.parametrize("N,h,c,B", [(5000, 200, 50, 100), (3001, 100, 50, 37), (4096, 200, 50, 104)])
 def test_fused_decoder_equals_unfused_path_at_headline_width(N, h, c, B):
     """The persistent fused decoder kernel (dec_fused.h, used for B <= ~104) against the
