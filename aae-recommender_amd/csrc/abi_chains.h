@@ -379,7 +379,10 @@ struct DwBuilder {
                 const int seen = *reinterpret_cast<volatile int*>(m->cnt_host);
                 if (seen > 0) {
                     const int per = w.wave_form ? 4 : 1;                        // items per workgroup and pass
-                    const int want = ((seen + seen / 4 + per - 1) / per + 63) & ~63;
+                    int want = ((seen + seen / 4 + per - 1) / per + 63) & ~63;
+                    // (hybrid form: its bitmap of deferred items holds 512 rounds of the launch's workgroups - a count left by a much
+                    //  smaller batch must not shrink the launch below what the largest possible batch walks in 512 rounds)
+                    if (w.wave_form == 2) want = std::max(want, (int)((std::min<int64_t>(m->cfg.max_nnz, m->N) + 2047) / 2048));
                     w.nitem = std::min(w.nitem, std::max(256, want));
                 }
             }

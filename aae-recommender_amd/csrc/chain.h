@@ -733,9 +733,11 @@ __device__ __forceinline__ void grouped_dw_body(const DwGroup& grp, float* smem)
     }
     int j = 0;
     for (int q = 1; q < grp.njobs; ++q) if ((int)blockIdx.x >= grp.jobs[q].tile0) j = q;
+    DW_STAMP(52);
     const DwJob& J = grp.jobs[j];
     const int t = blockIdx.x - J.tile0;
     const int m0 = (t / J.tiles_n) * TS, n0 = (t % J.tiles_n) * TS;
+    DW_STAMP(53);
     float* As = smem; float* Bs = smem + BK * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
@@ -756,6 +758,7 @@ __device__ __forceinline__ void grouped_dw_body(const DwGroup& grp, float* smem)
     };
     const bool ksplit = grp.ksplit > 0 && K >= grp.ksplit;        // (uniform)
     if (!ksplit) request(0);
+    DW_STAMP(54);
     // the optimiser's operands of this thread's four cells (parameter, both moments) depend on nothing this launch
     // computes: requested here, consumed behind the product - one memory round trip less at the kernel's end
     const int erow = tid / (TS / 4), ecol = (tid % (TS / 4)) * 4;

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
         printf("  tile 0: start -> loop %.2f us | slabs:", (h[1] - h[0]) * 0.01);
         for (int i = 0; i < std::min(nslab, 40); ++i) printf(" %.2f", ((i + 1 < nslab ? h[3 + i] : h[44]) - h[2 + i]) * 0.01);
         printf(" | partial tile -> LDS %.2f | optimiser + stores %.2f | total %.2f\n", (h[45] - h[44]) * 0.01, (h[46] - h[45]) * 0.01, (h[46] - h[0]) * 0.01);
+        printf("  start: job found %.2f | its tile %.2f | first rows requested %.2f | optimiser's operands requested %.2f\n", (h[52] - h[0]) * 0.01, (h[53] - h[52]) * 0.01, (h[54] - h[53]) * 0.01, (h[1] - h[54]) * 0.01);
         if (nslab > 5) printf("  slab 4: barrier %.2f | operands -> LDS %.2f | next slab's requests %.2f | barrier %.2f | products %.2f\n", (h[48] - h[6]) * 0.01, (h[49] - h[48]) * 0.01,
                               (h[50] - h[49]) * 0.01, (h[51] - h[50]) * 0.01, (h[7] - h[51]) * 0.01);
         if (colsum) printf("  column sums: %.2f us, starting %.2f us after tile 0\n", (h[65] - h[64]) * 0.01, ((double)h[64] - (double)h[0]) * 0.01);
