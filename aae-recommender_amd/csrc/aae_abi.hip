@@ -286,6 +286,11 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     return AAE_OK;
 }
 
+#ifdef W1_TS
+int aae_debug_w1_ts(unsigned long long* out, int n) {      // (debug builds only)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aae::w1_ts), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 int aae_destroy(aae_handle h) {
     if (!h) return AAE_OK;
     if (h->side) {

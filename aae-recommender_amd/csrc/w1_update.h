@@ -247,7 +247,7 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
             const int r = rl[lane];
             int k = 0;
             for (int j = 0; j < n; ++j) k += (rl[j] < r || (rl[j] == r && j < lane)) ? 1 : 0;   // total order: a duplicate (row, item) pair of a non-canonical CSR still gets a slot of its own
-            rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
+            rs[k] = r; xs[k] = xl[lane];        // (its row scale is requested with the row itself below: one round trip less)
         }
         // (one wave: its LDS writes are in order before its reads - no barrier)
         for (int cb = 0; cb < a.h; cb += 256) {
@@ -260,7 +260,7 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
                 for (int j = 0; j < kU; ++j) {
                     const int i = min(i0 + j, n - 1);
                     const int r = rs[i];
-                    x[j] = i0 + j < n ? xs[i] : 0.f;
+                    x[j] = (i0 + j < n ? xs[i] : 0.f) * a.rscale[r];
                     const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
                                                   : a.ga1 + (size_t)r * a.ld;
                     g[j] = *reinterpret_cast<const float4*>(grow + cc);
@@ -305,6 +305,12 @@ __device__ __forceinline__ void w1_item_wave_body(const W1Items& a, int* __restr
 // workgroup form.  No hot list, no second launch.
 // LDS: max(the workgroup form's, 4 x 4 x 16 words) + kW1HybWords.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef W1_TS       // (debug builds: hybrid-form phase clocks per workgroup and wave; read by tools/debug/w1_ts.py through aae_debug_w1_ts)
+__device__ unsigned long long w1_ts[4096 * 4 * 8];
+#define W1_STAMP(i) do { if (lane == 0 && vblock < 4096) w1_ts[(vblock * 4 + wv) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define W1_STAMP(i) do { } while (0)
+#endif
 constexpr int kW1HybRows = 16;
 constexpr int kW1HybWords = 64;        // the deferred items' bitmap: (round, wave) pairs, 512 rounds
 __host__ __device__ inline size_t w1_hybrid_lds_words(int rows) {
@@ -314,6 +320,7 @@ __host__ __device__ inline size_t w1_hybrid_lds_words(int rows) {
 __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* lds, int vblock, int vgrid) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned* defer = lds + (w1_hybrid_lds_words(a.rows) - kW1HybWords);
+    W1_STAMP(0);
     for (int i = tid; i < kW1HybWords; i += 256) defer[i] = 0u;
     __syncthreads();
     int* rl = reinterpret_cast<int*>(lds) + wv * 4 * kW1HybRows;       // rows as found
@@ -329,10 +336,12 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
     //  cost their workgroup a pass of the workgroup form each - sit together at its head.)
     const int ustep = vgrid * 4;
     int round = 0;
+    W1_STAMP(1);
     for (int u = vblock + wv * vgrid; u < cnt; u += ustep, ++round) {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
+        if (round == 0) W1_STAMP(2);
         const int c4 = 4 * lane;
         const size_t o0 = (size_t)item * a.ldw + min(c4, a.ldw - 4);
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pm = pw, pv = pw;
@@ -354,6 +363,7 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
                 n += __popcll(bal);
             }
         }
+        if (round == 0) W1_STAMP(3);
         if (n > kW1HybRows) {                           // more rows than one wave adds in the workgroup form: all four take it below
             const int b = round * 4 + wv;
             if (lane == 0) atomicOr(&defer[b >> 5], 1u << (b & 31));
@@ -363,7 +373,7 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
             const int r = rl[lane];
             int k = 0;
             for (int j = 0; j < n; ++j) k += (rl[j] < r || (rl[j] == r && j < lane)) ? 1 : 0;   // total order: a duplicate (row, item) pair of a non-canonical CSR still gets a slot of its own
-            rs[k] = r; xs[k] = xl[lane] * a.rscale[r];
+            rs[k] = r; xs[k] = xl[lane];        // (its row scale is requested with the row itself below: one round trip less)
         }
         for (int cb = 0; cb < a.h; cb += 256) {
             const int cc = min(cb + c4, a.ld - 4);
@@ -375,7 +385,7 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
                 for (int j = 0; j < kU; ++j) {
                     const int i = min(i0 + j, n - 1);
                     const int r = rs[i];
-                    x[j] = i0 + j < n ? xs[i] : 0.f;
+                    x[j] = (i0 + j < n ? xs[i] : 0.f) * a.rscale[r];
                     const float* grow = a.rpb > 0 ? a.ga1 + (size_t)(r / a.rpb) * a.bstride + (size_t)(r % a.rpb) * a.ld
                                                   : a.ga1 + (size_t)r * a.ld;
                     g[j] = *reinterpret_cast<const float4*>(grow + cc);
@@ -406,8 +416,11 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
             }
         }
         if (upd && a.mark_synced && lane == 0) a.tsync[item] = (int)*a.step_ctr;
+        if (round == 0) W1_STAMP(4);
     }
+    W1_STAMP(5);
     __syncthreads();
+    W1_STAMP(6);
     // the deferred items, in (round, wave) order, with all four waves
     const int rounds = vblock < cnt ? (cnt - vblock + ustep - 1) / ustep : 0;      // (of wave 0, the one with the most)
     const int nbits = min(rounds * 4, kW1HybWords * 32);
@@ -415,6 +428,7 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
         if (!((defer[b >> 5] >> (b & 31)) & 1u)) continue;             // (uniform: LDS word read by every thread)
         w1_item_update_one(a, lds, vblock + (b & 3) * vgrid + (b >> 2) * ustep, s, upd);
     }
+    W1_STAMP(7);
 }
 
 // (hot / hot_count: this launch's list; other_count: the list of the NEXT use, zeroed here - the two alternate)
