@@ -904,7 +904,10 @@ __device__ __forceinline__ void grouped_dw_body(const DwGroup& grp, float* smem)
     }
     DW_STAMP(46);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void grouped_dw_kernel(DwGroup grp) {
+#ifndef DW_WAVES_PER_EU
+#define DW_WAVES_PER_EU 4          // (occupancy the register allocation aims at: 4 = 128 registers, 5 = 96, 6 = 80)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_WAVES_PER_EU, 8))) void grouped_dw_kernel(DwGroup grp) {
     __shared__ __attribute__((aligned(16))) float smem[kDwSmemBytes / sizeof(float)];
     // (AAE_DW_TS=1, abi_chains.h: every workgroup's first and last clock - which of the launch's block kinds is its long pole)
     const unsigned long long t0 = grp.ts ? wall_clock64() : 0ull;
