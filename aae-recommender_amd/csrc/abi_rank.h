@@ -14,10 +14,16 @@
 namespace {
 
 constexpr int kRankBb = 16 * kMB;          // rows per row block of rank_x3_kernel (7 MFMA row blocks)
+// which of the two rank kernels a call takes (rank_x3.h) and its rows per row block
+inline bool rank_v2(const aae_model* m, int K) {
+    static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
+    return !v1 && (K == 10 || (K == 20 && m->fused_nb < 13));        // (the other list sizes spill registers in the v2 mapping: they keep v1)
+}
+inline int rank_bb(const aae_model* m, int K) { return rank_v2(m, K) ? kRankGR2 : kRankBb; }
 constexpr int kRankMaxRows = 4096;
 
 struct RankPlan {
-    int rows, K, nblk, wgs, kw;
+    int rows, K, nblk, wgs, kw, bb;
     float *a1, *eh1, *dh2, *rscale, *cand_v, *mm; int* cand_i; unsigned* known;
     size_t floats;
 };
@@ -29,7 +35,8 @@ RankPlan rank_plan(const aae_model* m, int rows, int k, float* base) {
     RankPlan p; memset(&p, 0, sizeof(p));
     p.rows = rows; p.K = rank_K(k);
     const int ntiles = (m->N + kTI - 1) / kTI;
-    p.nblk = (rows + kRankBb - 1) / kRankBb;
+    p.bb = rank_bb(m, p.K);
+    p.nblk = (rows + p.bb - 1) / p.bb;
     p.wgs = std::max(1, std::min(m->n_cu / std::max(1, p.nblk), ntiles));
     p.kw = (m->N + 31) / 32;
     size_t off = 0;
@@ -66,8 +73,7 @@ int rank_rows_cap(const aae_model* m, int k) {
 template <int NB>
 int launch_rank_nb(const RankArgs& a, int K, int grid, hipStream_t s) {
     const bool win = x3_big_span(a.N, a.ldv);      // (dec.lin3 beyond 2^31 bytes: the moving-window instantiations, dec_fused.h)
-    static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
-    if (!v1 && (K == 10 || (K == 20 && NB < 13))) {          // (the other list sizes spill registers in the v2 mapping: they keep v1)
+    if (a.Bb == kRankGR2) {                         // (rank_v2(): the plan chose this kernel's row block)
         const uint32_t lds2 = (uint32_t)rank_x3v2_lds_bytes(NB);
         switch (K) {
             case 10: { if (win) hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10, true>), dim3(grid), dim3(kNT), lds2, s, a); else hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10>), dim3(grid), dim3(kNT), lds2, s, a); } break;
@@ -117,7 +123,7 @@ int rank_from_dh2(aae_model* m, const RankPlan& p, const BatchView& bv, int k, i
     LAUNCHCHK("known_mask");
     RankArgs a; memset(&a, 0, sizeof(a));
     a.dh2 = p.dh2; a.ldh = m->ldh; a.V3a = m->P[P_V3].p; a.ldv = m->ldh; a.N = m->N; a.B = p.rows;
-    a.nblk = p.nblk; a.Bb = kRankBb; a.known = exclude_known ? p.known : nullptr; a.kw = p.kw;
+    a.nblk = p.nblk; a.Bb = p.bb; a.known = exclude_known ? p.known : nullptr; a.kw = p.kw;
     a.cand_v = p.cand_v; a.cand_i = p.cand_i; a.mm = p.mm; a.one_term = m->bf16 ? 1 : 0;
     { static const char* e = getenv("AAE_RANK_SKIP"); a.dbg = e ? atoi(e) : 0; }
     const int grid = p.wgs * p.nblk;

@@ -54,9 +54,13 @@ __global__ __launch_bounds__(256) void known_mask_kernel(BatchView bv, unsigned*
 
 constexpr int kRRS = 36;       // row stride (floats) of the raw-logit halves [b][n]: 16-byte aligned rows for the epilogue's float4 reads
 
+// rank_x3v2_kernel's row block: 8 MFMA row blocks = 128 rows (r5; its four wave pairs hold two 16-row blocks each - the training
+// kernels' 7 left the last pair half empty - and its epilogue has a thread per (row, item quad) of 128 rows): 512 rows per call
+// are 4 row blocks instead of 5, every tile's images are built 4 times instead of 5
+constexpr int kRankMB2 = 8, kRankGR2 = 16 * kRankMB2;
 inline size_t rank_x3v2_lds_bytes(int NB) {
     const int KC1 = (NB + 1) / 2, S1 = x3_stride(KC1);
-    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)4 * kGR * kRRS);
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)4 * kRankGR2 * kRRS);
 }
 
 inline size_t rank_x3_lds_bytes(int NB) {
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(kNT) void rank_x3v2_kernel(RankArgs a) {
     constexpr int S1 = x3_stride(KC1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned* v3K = reinterpret_cast<unsigned*>(lds);           // [3][32][S1] V3a tile, k = hidden column
+    constexpr int kGR = kRankGR2, kMB = kRankMB2;               // (this kernel's row block: 128 rows)
     float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [4][kGR][kRRS] the four k quarters of the logits
 
     const int nblk = a.nblk > 1 ? a.nblk : 1;
