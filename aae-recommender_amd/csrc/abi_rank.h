@@ -13,13 +13,13 @@
 
 namespace {
 
-constexpr int kRankBb = 16 * kMB;          // rows per row block of rank_x3_kernel (7 MFMA row blocks)
+constexpr int kRankBb = 16 * kMB;          // (r1-r4: rows per row block of the rank kernels - the training kernels' 7 MFMA row blocks; now kRankGR2, rank_x3.h)
 // which of the two rank kernels a call takes (rank_x3.h) and its rows per row block
-inline bool rank_v2(const aae_model* m, int K) {
+inline bool rank_v2_nb(int NB, int K) {
     static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
-    return !v1 && (K == 10 || (K == 20 && m->fused_nb < 13));        // (the other list sizes spill registers in the v2 mapping: they keep v1)
+    return !v1 && (K == 10 || (K == 20 && NB < 13));                 // (the other list sizes spill registers in the v2 mapping: they keep v1)
 }
-inline int rank_bb(const aae_model* m, int K) { return rank_v2(m, K) ? kRankGR2 : kRankBb; }
+inline int rank_bb(const aae_model*, int) { return kRankGR2; }      // (both kernels: 128-row blocks)
 constexpr int kRankMaxRows = 4096;
 
 struct RankPlan {
@@ -73,7 +73,7 @@ int rank_rows_cap(const aae_model* m, int k) {
 template <int NB>
 int launch_rank_nb(const RankArgs& a, int K, int grid, hipStream_t s) {
     const bool win = x3_big_span(a.N, a.ldv);      // (dec.lin3 beyond 2^31 bytes: the moving-window instantiations, dec_fused.h)
-    if (a.Bb == kRankGR2) {                         // (rank_v2(): the plan chose this kernel's row block)
+    if (rank_v2_nb(NB, K)) {
         const uint32_t lds2 = (uint32_t)rank_x3v2_lds_bytes(NB);
         switch (K) {
             case 10: { if (win) hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10, true>), dim3(grid), dim3(kNT), lds2, s, a); else hipLaunchKernelGGL((rank_x3v2_kernel<NB, 10>), dim3(grid), dim3(kNT), lds2, s, a); } break;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void known_mask_kernel(BatchView bv, unsigned*
 
 constexpr int kRRS = 36;       // row stride (floats) of the raw-logit halves [b][n]: 16-byte aligned rows for the epilogue's float4 reads
 
-// rank_x3v2_kernel's row block: 8 MFMA row blocks = 128 rows (r5; its four wave pairs hold two 16-row blocks each - the training
+// the rank kernels' row block: 8 MFMA row blocks = 128 rows (r5; its four wave pairs hold two 16-row blocks each - the training
 // kernels' 7 left the last pair half empty - and its epilogue has a thread per (row, item quad) of 128 rows): 512 rows per call
 // are 4 row blocks instead of 5, every tile's images are built 4 times instead of 5
 constexpr int kRankMB2 = 8, kRankGR2 = 16 * kRankMB2;
@@ -63,10 +63,10 @@ inline size_t rank_x3v2_lds_bytes(int NB) {
     return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)4 * kRankGR2 * kRRS);
 }
 
-inline size_t rank_x3_lds_bytes(int NB) {
+inline size_t rank_x3_lds_bytes(int NB) {          // (128-row blocks as well: its waves are (row block, k half) pairs - 16 of them now, not 14)
     const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1);
     const int lsteps = NKS > kXRegSteps ? NKS - kXRegSteps : 0;
-    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kGR * kRRS + (size_t)lsteps * kMB * 3 * 64 * 4);
+    return sizeof(float) * ((size_t)3 * kTI * S1 + (size_t)2 * kRankGR2 * kRRS + (size_t)lsteps * kRankMB2 * 3 * 64 * 4);
 }
 
 template <int NB, int K, bool WIN = false>      // WIN: dec.lin3 beyond 2^31 bytes (dec_fused.h X3WindowT)
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kNT) void rank_x3_kernel(RankArgs a) {
     constexpr int S1 = x3_stride(KC1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned* v3K = reinterpret_cast<unsigned*>(lds);           // [3][32][S1] V3a tile, k = hidden column
+    constexpr int kGR = kRankGR2, kMB = kRankMB2;               // (the rank kernels' row block: 128 rows)
     float* raw = reinterpret_cast<float*>(v3K + 3 * kTI * S1);  // [2][kGR][kRRS] the two k halves of the logits
     u32x4_t* dAl = reinterpret_cast<u32x4_t*>(raw + 2 * kGR * kRRS);    // [kMB][NKL][3][64] dh2 fragments beyond the register steps
 
