@@ -84,6 +84,27 @@ class Fixture:
         return out
 
 
+_RENDEZVOUS_TROUBLE = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "connect() timed out",
+                       "Socket Timeout", "timed out", "Broken pipe")
+
+
+def spawn_ranks(worker, world, args_for_port, attempts=3):
+    """mp.spawn of `world` ranks on a free rendezvous port: args_for_port(port) -> the worker's arguments.  A port read back from a
+    probe socket can be taken by someone else before the ranks bind it (seen once in this suite): a spawn that dies with a
+    RENDEZVOUS error - not an assertion of the test - is repeated on a new port."""
+    import torch.multiprocessing as mp
+    for attempt in range(attempts):
+        port = free_port()
+        try:
+            mp.spawn(worker, args=args_for_port(port), nprocs=world, join=True)
+            return
+        except Exception as e:      # noqa: BLE001 - ProcessRaisedException / ProcessExitedException carry the worker's traceback as text
+            text = str(e)
+            if attempt + 1 < attempts and "AssertionError" not in text and any(t in text for t in _RENDEZVOUS_TROUBLE):
+                continue
+            raise
+
+
 def free_port():
     """A TCP port nothing listens on right now (for the rendezvous of a spawned process group): bind to 0, read it back."""
     import socket

@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from golden_util import free_port, CAT_CASES, Fixture
+from golden_util import free_port, spawn_ranks, CAT_CASES, Fixture
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -870,10 +870,9 @@ def test_fit_on_two_ranks_equals_single_process(mode, adversarial):
     adversarial model with dropout + prior drawn by the device generator (keyed by global row, one seed)."""
     import torch.multiprocessing as mp
     import aaerec.aae                               # noqa: F401  (seeds torch at import: import before seeding below)
-    port = free_port()
     with mp.get_context("spawn").Manager() as mgr:       # (a fork()ed manager process would inherit this process's GPU objects)
         ret = mgr.dict()
-        mp.spawn(_fit_worker, args=(2, port, mode, ret, None, adversarial), nprocs=2, join=True)
+        spawn_ranks(_fit_worker, 2, lambda port: (2, port, mode, ret, None, adversarial))
         got = dict(ret)
     assert got["sliced"] == (mode != "replicated")
     X = _dp_corpus()
@@ -899,10 +898,9 @@ def test_fit_on_two_ranks_with_trainable_categorical_condition(reduce, mode):
     share to the whole batch's width, as the single process does)."""
     import torch.multiprocessing as mp
     from aaerec.aae import AutoEncoder
-    port = free_port()
     with mp.get_context("spawn").Manager() as mgr:       # (a fork()ed manager process would inherit this process's GPU objects)
         ret = mgr.dict()
-        mp.spawn(_fit_worker, args=(2, port, mode, ret, reduce), nprocs=2, join=True)
+        spawn_ranks(_fit_worker, 2, lambda port: (2, port, mode, ret, reduce))
         got = dict(ret)
     assert got["sliced"]
     X = _dp_corpus()
@@ -1240,10 +1238,9 @@ def test_native_step_driver_over_rccl_on_one_rank():
     partial_fit; parameters and predictions equal the plain single-process fit()."""
     import torch.multiprocessing as mp
     import aaerec.aae                               # noqa: F401
-    port = free_port()
     with mp.get_context("spawn").Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_rccl_world1_worker, args=(port, ret), nprocs=1, join=True)
+        spawn_ranks(_rccl_world1_worker, 1, lambda port: (port, ret))
         got = dict(ret)
     assert got["native"]
     assert got["stats"]["collectives"] == 7

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from golden_util import free_port, Fixture
+from golden_util import free_port, spawn_ranks, Fixture
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,10 +81,9 @@ def _worker(rank, world, port, name, ret):
 
 @pytest.mark.parametrize("name", ["step_masks", "step_masks_uneven", "step_ragged"])
 def test_two_ranks_equal_single_process(name):
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, name, ret), nprocs=2, join=True)
+        spawn_ranks(_worker, 2, lambda port: (2, port, name, ret))
         got = dict(ret)
     fx = Fixture(name)
     # the single-process result is the golden fixture itself (the reference's own parameters)
@@ -179,10 +178,9 @@ def _worker_sparse(rank, world, port, name, ret):
 
 
 def test_two_ranks_with_packed_first_layer_rows_equal_single_process():
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_sparse, args=(2, port, "step_masks", ret), nprocs=2, join=True)
+        spawn_ranks(_worker_sparse, 2, lambda port: (2, port, "step_masks", ret))
         got = dict(ret)
     fx = Fixture("step_masks")
     for k, w in fx.expected_params(fx.steps - 1).items():
@@ -238,10 +236,9 @@ def _worker_cond(rank, world, port, name, ret):
 
 @pytest.mark.parametrize("name", ["step_cond_categorical", "step_cat_sparse_sum"])
 def test_two_ranks_with_trainable_condition_equal_single_process(name):
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_cond, args=(2, port, name, ret), nprocs=2, join=True)
+        spawn_ranks(_worker_cond, 2, lambda port: (2, port, name, ret))
         got = dict(ret)
     fx = Fixture(name)
     last = fx.steps - 1
@@ -382,10 +379,9 @@ def _worker_vocab(rank, world, port, name, ret):
 def test_two_ranks_with_vocabulary_sharded_output_layer_equal_single_process(name):
     """VocabParallelAAE over real gloo collectives: rank r holds half the documents and half the items' output rows;
     parameters (replicas + the two slices of dec.lin3) and the reconstruction loss equal the reference's."""
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_vocab, args=(2, port, name, ret), nprocs=2, join=True)
+        spawn_ranks(_worker_vocab, 2, lambda port: (2, port, name, ret))
         got = dict(ret)
     fx = Fixture(name)
     want = fx.expected_params(fx.steps - 1)
@@ -578,10 +574,9 @@ def test_two_ranks_with_both_vocabulary_wide_layers_sharded_equal_single_process
     all-gather of dL/d(a1) with the small layers' gradients behind it, ...): rank r holds half the documents, half the
     items' rows of dec.lin3 AND half the items' columns of enc.lin1; every parameter and the reconstruction loss equal the
     reference's single-process fixtures."""
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_both, args=(2, port, name, ret), nprocs=2, join=True)
+        spawn_ranks(_worker_both, 2, lambda port: (2, port, name, ret))
         got = dict(ret)
     fx = Fixture(name)
     want = fx.expected_params(fx.steps - 1)
@@ -701,10 +696,9 @@ def test_two_ranks_item_sharded_with_replicated_hidden_stacks_equal_single_proce
     dec.lin3 and columns of enc.lin1 and runs the WHOLE batch through its own copy of the hidden layers; three all-reduces
     of [rows, n_hidden] partial sums per step and nothing else.  Every parameter and the reconstruction loss equal the
     reference's single-process fixtures; the never-exchanged hidden layers are bitwise identical on both ranks."""
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_shard, args=(2, port, name, ret), nprocs=2, join=True)
+        spawn_ranks(_worker_shard, 2, lambda port: (2, port, name, ret))
         got = dict(ret)
     fx = Fixture(name)
     want = fx.expected_params(fx.steps - 1)
@@ -750,10 +744,9 @@ def test_item_sharded_ranks_with_different_generators_apply_rank_zeros_draws():
     """dp_mode='shard' + rng_mode='reference' (ADVICE r4): the hidden stacks are replicated with no gradient exchange, so
     every rank must apply the SAME dropout masks and prior sample to the whole batch.  Two ranks seeded differently: after
     ItemShardedAAE.agree_randomness both hold rank 0's draws (rank 1's own differ), shapes and dtypes as drawn."""
-    port = free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker_shard_rng, args=(2, port, ret), nprocs=2, join=True)
+        spawn_ranks(_worker_shard_rng, 2, lambda port: (2, port, ret))
         got = dict(ret)
     assert got["agreed0"] and got["agreed1"]
     assert got["own0"] and not got["own1"]
