@@ -19,7 +19,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AAE_HIP_LIB") or os.path.join(_HERE, "libaaerec_hip.so")     # (AAE_HIP_LIB: A/B builds of the library)
 
 ABI_VERSION = 3
-ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5}
+# getattr(nn, activation)() of the reference (aae.py:110): the parameter-free element-wise classes of torch.nn at their default
+# arguments (r6: 6-19).  Classes with parameters, state or a row-wise definition (PReLU, RReLU, Threshold, GLU, Softmax,
+# Softmin, LogSoftmax, MultiheadAttention ...) and Tanhshrink have no kernel: HipAAE raises with this list.
+ACTIVATIONS = {"ReLU": 0, "SELU": 1, "Tanh": 2, "Sigmoid": 3, "ELU": 4, "LeakyReLU": 5,
+               "Softplus": 6, "Hardtanh": 7, "ReLU6": 8, "CELU": 9, "Softsign": 10, "Hardsigmoid": 11, "LogSigmoid": 12,
+               "Softshrink": 13, "Hardshrink": 14, "Identity": 15, "GELU": 16, "SiLU": 17, "Mish": 18, "Hardswish": 19}
 FINALS = {"linear": 0, "softmax": 1, "sigmoid": 2}
 OPTIMIZERS = {"adam": 0, "sgd": 1}
 PRIORS = {"gauss": 0, "categorical": 1, "bernoulli": 2}
@@ -88,6 +93,7 @@ class AaeTensor(C.Structure):
 
 _PROTOS = {
     "aae_abi_version": (C.c_int, []),
+    "aae_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "aae_last_error": (C.c_char_p, []),
     "aae_arena_bytes": (C.c_int, [C.POINTER(AaeConfig), C.POINTER(C.c_size_t)]),
     "aae_create": (C.c_int, [C.POINTER(AaeConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),

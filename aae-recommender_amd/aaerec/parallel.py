@@ -661,9 +661,14 @@ class ItemShardedAAE:
             return masks, z_real
         import numpy as np
         import torch
-        z = np.ascontiguousarray(z_real.detach().cpu().numpy(), dtype=np.float32)
+        # (a model without a prior - AutoEncoder._host_randomness - hands z_real = None: only the masks travel)
+        z = None if z_real is None else np.ascontiguousarray(z_real.detach().cpu().numpy(), dtype=np.float32)
         parts = [np.ascontiguousarray(m.cpu().numpy(), dtype=np.uint8).ravel() for m in masks if m is not None]
-        flat = np.concatenate(parts + [z.view(np.uint8).ravel()])
+        if z is not None:
+            parts.append(z.view(np.uint8).ravel())
+        if not parts:
+            return masks, z_real
+        flat = np.concatenate(parts)
         flat = broadcast_array(self.dist, self.group, flat, getattr(self.slice, "device", None))
         out, off = [], 0
         for m in masks:
@@ -673,7 +678,7 @@ class ItemShardedAAE:
             n = m.numel()
             out.append(torch.from_numpy(flat[off:off + n].reshape(tuple(m.shape)).copy()))
             off += n
-        zr = torch.from_numpy(flat[off:off + z.nbytes].view(np.float32).reshape(z.shape).copy())
+        zr = None if z is None else torch.from_numpy(flat[off:off + z.nbytes].view(np.float32).reshape(z.shape).copy())
         return out, zr
 
     def sync_conditions(self, conditions):

@@ -40,6 +40,14 @@
 
 using namespace aae;
 
+#include <map>
+static std::map<std::string, std::string> g_options;      // aae_set_option: name -> value (wins over the environment)
+const char* option_value(const char* name) {
+    auto it = g_options.find(name);
+    if (it != g_options.end()) return it->second.c_str();
+    return getenv((std::string("AAE_") + name).c_str());
+}
+
 #include "abi_model.h"
 #include "abi_layers.h"
 #include "abi_chains.h"
@@ -49,12 +57,24 @@ using namespace aae;
 extern "C" {
 
 int aae_abi_version(void) { return AAE_ABI_VERSION; }
+
+int aae_set_option(const char* name, const char* value) {
+    if (!name || !*name) return fail(AAE_EINVAL, "option name is empty");
+    static const char* known[] = {"NO_CHAIN", "CHAIN16", "SPLIT_ANY", "BLOCKED_ANY", "EARLY_ANY", "NO_LATE_JOIN", "NO_ITEM_COUNT", "W1_SERIAL",
+                                  "NO_RANK_FUSED", "X16_ROWS", "DW_KSPLIT_ROWS", "DEC_TS", "CHAIN_TS", "DW_TS", "DEC_SKIP", "CHAIN_SKIP", "RANK_SKIP"};
+    bool ok = false;
+    for (const char* k : known) ok = ok || strcmp(k, name) == 0;
+    if (!ok) return fail(AAE_EINVAL, "unknown option (aae_options, csrc/abi_model.h, lists them)");
+    if (value) g_options[name] = value; else g_options.erase(name);
+    return AAE_OK;
+}
 const char* aae_last_error(void) { return g_err.c_str(); }
 
 int aae_arena_bytes(const aae_config* cfg, size_t* bytes_out) {
     TRY(validate(cfg));
     if (!bytes_out) return fail(AAE_EINVAL, "bytes_out is NULL");
     aae_model tmp; memset((void*)&tmp, 0, sizeof(tmp)); tmp.cfg = *cfg;
+    read_options(tmp.opt);
     *bytes_out = layout(&tmp, nullptr, true);
     return AAE_OK;
 }
@@ -66,6 +86,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     aae_model* m = new aae_model();
     memset((void*)m, 0, sizeof(*m));
     m->cfg = *cfg;
+    read_options(m->opt);                // every switch of the library, once per handle (abi_model.h aae_options)
     size_t need = layout(m, static_cast<char*>(arena_dev), false);
     if (need > arena_bytes) { delete m; return fail(AAE_ENOMEM, "arena smaller than aae_arena_bytes()"); }
     m->base = static_cast<char*>(arena_dev); m->bytes = need;
@@ -73,9 +94,9 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->vae = cfg->model_kind == 3; m->vae_bwd = false; m->vae_cut = false;
     m->bf16 = cfg->dtype == 1;
     m->blocked_ok = cfg->blocked_output == 1;
-    m->blocked_any = getenv("AAE_BLOCKED_ANY") != nullptr;
-    m->split_any = getenv("AAE_SPLIT_ANY") != nullptr;
-    m->x3_gemm = !m->bf16 && getenv("AAE_NO_GEMM_X3") == nullptr;
+    m->blocked_any = m->opt.blocked_any;
+    m->split_any = m->opt.split_any;
+    m->x3_gemm = !m->bf16;
     m->noise_next = nullptr; m->noise_ld = 0; m->dense_step = false;
     m->ae_only = cfg->model_kind == 1 || m->vae;
     m->lazy = true;    // deferred Adam on W1T in both gradient modes (export mode exchanges packed rows)
@@ -90,8 +111,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
         m->fused_nb = nb <= 4 ? 4 : nb <= 7 ? 7 : nb <= 13 ? 13 : 0;
         m->fused_ok = m->fused_nb != 0 && fused_width_ok(m->h, m->ldh);       // (the arena's slab area is sized by the same test)
         // (a decoder input [z | condition | 1] of up to 2 x 208 columns: two k-parts on the 4-row kernel; the VAE's programs keep 208)
-        m->use_chain = (m->h + 1 <= 208) && (m->c + 1 <= 208) && (m->cp + 1 <= (cfg->model_kind == 3 || getenv("AAE_NO_WIDE_CHAIN") ? 208 : 2 * 208)) &&
-                       getenv("AAE_NO_CHAIN") == nullptr;      // (the code itself has to fit a slot: only the condition block may exceed it)
+        m->use_chain = (m->h + 1 <= 208) && (m->c + 1 <= 208) && (m->cp + 1 <= (cfg->model_kind == 3 ? 208 : 2 * 208)) &&
+                       !m->opt.no_chain;      // (the code itself has to fit a slot: only the condition block may exceed it)
         if (m->use_chain && (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess ||
@@ -99,7 +120,15 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess))
             m->use_chain = false;
-        m->use_chain4 = m->use_chain && getenv("AAE_CHAIN16") == nullptr &&
+        // (the r6 activation classes live in chain_kernel<.., true> alone: device_common.h act_fwd)
+        m->act_nm = cfg->activation > AAE_ACT_LEAKYRELU;
+        if (m->use_chain && m->act_nm &&
+            (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 kCSlots * kCR * kCL * (int)sizeof(float)) != hipSuccess))
+            m->use_chain = false;
+        m->use_chain4 = m->use_chain && !m->act_nm && !m->opt.chain16 &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -107,10 +136,10 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;
-        m->x16_rows = x16_min_rows();
+        m->x16_rows = m->opt.x16_rows;
         m->dw_ksplit_rows = 256;                       // (the handle is zero-filled after construction: no default member values)
-        if (const char* e = getenv("AAE_DW_KSPLIT_ROWS")) m->dw_ksplit_rows = atoi(e);
-        if (getenv("AAE_NO_ITEM_COUNT") == nullptr) {
+        if (m->opt.dw_ksplit_rows >= 0) m->dw_ksplit_rows = m->opt.dw_ksplit_rows;
+        if (!m->opt.no_item_count) {
             void* hp = nullptr; void* dp = nullptr;
             if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
                 m->cnt_host = static_cast<int*>(hp); m->cnt_host_dev = static_cast<int*>(dp); *m->cnt_host = 0;
@@ -136,10 +165,10 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 m->fused_ok = false;
         }
     }
-    m->late_enabled = getenv("AAE_NO_LATE_JOIN") == nullptr;
-    m->early_enabled = getenv("AAE_NO_EARLY_PREFETCH") == nullptr;
-    m->early_any = getenv("AAE_EARLY_ANY") != nullptr;        // (tests: the early prefetch at every batch size)
-    m->rank_ok = m->fused_ok && m->use_chain4 && !m->vae && getenv("AAE_NO_RANK_FUSED") == nullptr && rank_set_attributes();
+    m->late_enabled = !m->opt.no_late_join;
+    m->early_enabled = true;
+    m->early_any = m->opt.early_any;        // (tests: the early prefetch at every batch size)
+    m->rank_ok = m->fused_ok && m->use_chain4 && !m->vae && !m->opt.no_rank_fused && rank_set_attributes();
     m->w1_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(w1_item_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(sizeof(int) * w1_items_lds_words(16384))) == hipSuccess;
     (void)hipGetLastError();
@@ -154,7 +183,6 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     // 128 0.273 | 144 0.276 | 160 0.278 | 176 0.286.  Half the CUs again (set below once x3_ok is known; 5/8 without it):
     // beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains.
     m->split_wgs = std::max(1, (m->n_cu * 5) / 8);
-    { const char* e = getenv("AAE_SPLIT_WGS"); if (e) m->split_wgs = atoi(e); }
     m->pf_armed = m->pf_built = m->pf_pending = false; m->pf_step = -1; m->hstep = 0; m->flushed_hstep = -1; m->ev_head = m->ev_pf = nullptr;
     bool side_ok = false;
     if (cfg->grad_mode == AAE_GRAD_FUSED) {
@@ -189,7 +217,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     }
     // (bf16 mode too: its output layer runs the same kernels with every operand rounded to bf16 - DecFusedArgs::one_term - when
     //  they are available; dec_fused_bf16.h's own pair otherwise, or with AAE_NO_BF16_X3)
-    if (side_ok && m->fused_ok && m->split_wgs > 0 && (!m->bf16 || getenv("AAE_NO_BF16_X3") == nullptr) &&
+    if (side_ok && m->fused_ok && m->split_wgs > 0 && 
         (size_t)((m->N + kTI - 1) / kTI) * kTI * (size_t)std::min(m->R, 16 * kMB) * sizeof(float) < (size_t)0x7FFFFFF0u) {
         bool ok = true;
         ok = ok && aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit>), reinterpret_cast<const void*>(dec_fused_kernel<4, kDecCrit, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -205,8 +233,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!m->bf16) m->split_ok = ok;
-        static const bool no_x3 = getenv("AAE_NO_X3") != nullptr;
-        m->x3_ok = ok && !no_x3
+        m->x3_ok = ok
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<4>), reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<7>), reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<13>), reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -217,7 +244,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_opt_blocks_x3_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)hipGetLastError();
         if (m->bf16) {
-            m->bf16_x3 = m->x3_ok && ok && getenv("AAE_NO_OPT_X3") == nullptr;
+            m->bf16_x3 = m->x3_ok && ok;
             if (!m->bf16_x3) m->x3_ok = false;
             else m->split_ok = true;
             // The one-term instantiations (first terms only, ONE matrix instruction per product; AAE_NO_BF16_ONE: the three-term
@@ -229,7 +256,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             // LDS (abi_output_layer.h), which no other workgroup of the step fits beside: 0.1648 ms at the old width, 0.162-0.164
             // on 48-64 workgroups (tools/debug/bf16_one_sweep.sh; a claim of 120 KB leaves the 24 KB weight-gradient workgroups
             // in: 0.1865).
-            m->bf16_one = m->bf16_x3 && getenv("AAE_NO_BF16_ONE") == nullptr
+            m->bf16_one = m->bf16_x3
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<7, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
                 && aae_attr2(reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true>), reinterpret_cast<const void*>(dec_crit_x3_kernel<13, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
@@ -241,7 +268,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                 && aae_attr2(reinterpret_cast<const void*>(dec_opt_x3_kernel<13>), reinterpret_cast<const void*>(dec_opt_x3_kernel<13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             (void)hipGetLastError();
         }
-        if (m->x3_ok && getenv("AAE_NO_OPT_X3") == nullptr && getenv("AAE_SPLIT_WGS") == nullptr) {
+        if (m->x3_ok) {
             // Workgroups of the deferred launch (batches of one fused launch).  It has to end before the step does (the next
             // step opens behind it), and every CU it holds is one the step's own launches share with it: wide enough to take
             // ~80 us - every shape's step has that much work left behind the critical launch - and never more than 9/16 of

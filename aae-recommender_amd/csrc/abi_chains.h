@@ -69,7 +69,7 @@ struct ChainBuilder {
         memset(&P, 0, sizeof(P));
         P.rows = rows; P.act = m->cfg.activation; P.seed = m->cfg.seed; P.step_ctr = m->step_ctr;
         P.loss_out = m->losses; P.loss_slot = 3;
-        { const char* e = getenv("AAE_CHAIN_SKIP"); P.dbg = e ? atoi(e) : 0; }
+        P.dbg = m->opt.chain_skip;
     }
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
     int x16_rows = 0;      // > 0: this program's own row threshold for the wide-batch kernel (beside_deferred)
@@ -210,7 +210,7 @@ static bool x16_program_ok(const ChainProgram& P) {
 int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
     if (cb.P.nops > kCMaxOps) return fail(AAE_ESTATE, "chain program too long");
     const int grid = (cb.P.rows + kCR - 1) / kCR + (cb.P.bk.enabled ? 1 : 0);
-    static const bool want_ts = getenv("AAE_CHAIN_TS") != nullptr;      // debug: per-op timeline of workgroup 0
+    const bool want_ts = m->opt.chain_ts;      // debug: per-op timeline of workgroup 0
     static unsigned long long* ts_dev = nullptr;
     if (want_ts) {
         if (!ts_dev && hipMalloc(&ts_dev, 128 * sizeof(unsigned long long)) != hipSuccess) return fail(AAE_EHIP, "ts alloc");
@@ -227,8 +227,7 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if ((cb.P.ops[i].row_lo > 0 || cb.P.ops[i].acc_in || cb.P.ops[i].y_glb) && !four)
             return fail(AAE_ESTATE, "a program prefix for the upper rows / a layer in two k-parts needs the 4-row chain kernel");
     // wide batches: 16 rows per workgroup on the bf16 matrix cores (chain16x3.h)
-    static const bool x16_dry = getenv("AAE_X16_DRY") != nullptr;      // (debug: keep the split copies, launch the 4-row kernel)
-    if (four && m->x16_ok && !x16_dry && cb.P.rows >= (cb.x16_rows > 0 ? cb.x16_rows : m->x16_rows) && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
+    if (four && m->x16_ok && cb.P.rows >= (cb.x16_rows > 0 ? cb.x16_rows : m->x16_rows) && !cb.P.bk.enabled && x16_program_ok(cb.P)) {
         ChainProgram X = cb.P;
         if (x16_remap_slots(X)) {
             // the look-ahead chains of the weight prefetch: per workgroup class, every op's next linear op
@@ -269,6 +268,9 @@ int launch_chain(aae_model* m, ChainBuilder& cb, hipStream_t s) {
         if (want_ts && !m->bf16) hipLaunchKernelGGL((chain4_kernel<false, true>), dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
         else if (m->bf16) hipLaunchKernelGGL(chain4_kernel<true>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
         else hipLaunchKernelGGL(chain4_kernel<false>, dim3(grid4), dim3(kC4T), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+    } else if (m->act_nm) {
+        if (m->bf16) hipLaunchKernelGGL((chain_kernel<true, true>), dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
+        else hipLaunchKernelGGL((chain_kernel<false, true>), dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     } else if (m->bf16) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kCT), kCSlots * kCR * kCL * sizeof(float), s, cb.P);
     LAUNCHCHK("chain_kernel");
@@ -304,10 +306,11 @@ struct DwBuilder {
     aae_model* mh = nullptr;       // set by add_first_layer: the wave form's hot list is worked off behind the launch
     DwGroup g; int tiles;
     int ksplit_rows = 0;           // set by add(): the model's threshold for the k-split form of a tile
+    int dw_ts = -1;                // ... its DW_TS diagnostic (aae_options)
     DwBuilder() { memset(&g, 0, sizeof(g)); tiles = 0; }
     void add(aae_model* m, const float* G, int ldg, const float* X, int ldx, int rows, int pid, int which) {
         DwJob& J = g.jobs[g.njobs++];
-        ksplit_rows = m->dw_ksplit_rows;
+        ksplit_rows = m->dw_ksplit_rows; dw_ts = m->opt.dw_ts;
         const Ten& W = m->P[pid];
         const int set = (which == O_GEN) ? 1 : 0;
         J.G = G; J.ldg = ldg; J.X = X; J.ldx = ldx; J.rows = rows; J.M = (int)W.rows; J.N = (int)W.cols;
@@ -330,7 +333,7 @@ struct DwBuilder {
         // (batches up to ~2 500 rows); not for the dense noisy input (a dense product follows) or an external
         // first layer (the rows live with their item slices) - unless this handle IS the owner of its slice's rows
         // (own_first: aae_shard_step)
-        static const bool no_merge = getenv("AAE_NO_W1_MERGE") != nullptr;
+        constexpr bool no_merge = false;
         w.nitem = 0;
         m->w1_items_merged = false;
         w.wave_form = 0;
@@ -344,17 +347,15 @@ struct DwBuilder {
             // workgroup form stays ahead (tools/debug/c4_w1_ab.sh, ms/step wave | workgroup form: 1000 rows x 4.6 k items
             // 0.459 | 0.413, 10 k 0.501 | 0.465, 20 k 0.575 | 0.553, 40 k 0.723 | 0.728; 512 rows x 4.6 k 0.304 | 0.282,
             // 10 k 0.329 | 0.314, 20 k 0.362 | 0.363).
-            static const bool no_wave = getenv("AAE_NO_W1_WAVE") != nullptr;
+            constexpr bool no_wave = false;
             // batches of one fused launch: four items per workgroup (w1_item_hybrid_body: same sums, a quarter of the workgroups)
-            static const bool no_hybrid = getenv("AAE_NO_W1_HYBRID") != nullptr;
-            static const bool hyb_any = getenv("AAE_W1_HYBRID_ANY") != nullptr;      // (tests: every shape through this form)
+            constexpr bool no_hybrid = false, hyb_any = false;
             // (ms/step, four items per workgroup | one: C3 0.2528 | 0.2585, C2's shape 0.1685 | 0.1728, C1's - 1 k items, most of them
             //  in many rows - 0.1438 | 0.1419: as for the wide batches' wave form, only with >= 40 items per row of the batch)
             if (!no_hybrid && m->rows <= 16 * kMB && sizeof(int) * w1_hybrid_lds_words(m->rows) <= kDwSmemBytes &&
                 (int64_t)m->cfg.max_nnz <= 512ll * w.nitem && ((int64_t)m->N >= 40ll * m->rows || hyb_any)) {
                 w.wave_form = 2;
                 w.nitem = (w.nitem + 3) / 4;
-                { static const int wgs_env = getenv("AAE_W1_WGS") ? atoi(getenv("AAE_W1_WGS")) : 0; if (wgs_env > 0) w.nitem = wgs_env; }   // (sweep)
             } else
             if (!no_wave && m->rows > 16 * kMB && m->hot_list && (int64_t)m->N >= 40ll * m->rows) {
                 w.wave_form = 1;
@@ -373,7 +374,7 @@ struct DwBuilder {
             // 0.302 -> 0.313 ms/step at 1 024).  One rank's step at world 8: 0.275 -> 0.261 ms.
             w.cnt_out = nullptr;
             // (batches of one fused launch too: C3 0.2363-0.2374 -> 0.2336-0.2361 ms/step with ~560 workgroups of four busy waves instead of 800)
-            static const bool hyb_count = getenv("AAE_NO_ITEM_COUNT_HYBRID") == nullptr;
+            constexpr bool hyb_count = true;
             if ((w.wave_form != 2 || hyb_count) && m->cnt_host) {
                 w.cnt_out = m->cnt_host_dev;
                 const int seen = *reinterpret_cast<volatile int*>(m->cnt_host);
@@ -404,7 +405,7 @@ struct DwBuilder {
         // loop, this round's first answer for 1 536+ rows: 23.3 - removed).  AAE_DW_KSPLIT_ROWS (read by aae_create) = 0: never, 1: every batch (tests)
         g.ksplit = ksplit_rows;
         // AAE_DW_TS=<first launch to report>: per-workgroup clocks of six launches (three steps' worth would be nine), by block kind
-        static const int ts_from = getenv("AAE_DW_TS") ? atoi(getenv("AAE_DW_TS")) : -1;
+        const int ts_from = dw_ts;
         static int ts_seen = 0;
         static unsigned long long* ts_dev = nullptr;
         constexpr int kTsCap = 1 << 16;
@@ -491,10 +492,9 @@ static int row_blocks(const aae_model* m) { return m->rows <= 16 * kMB ? 1 : (m-
 // of a 2.9 M-item layer read zeros and dropped their stores), so r1-r4 kept these layers below 2^31 bytes - 2.63 M items at
 // hidden 200, while PubMed's and ACM's vocabularies (nmi.txt:68,85 of the reference) are 2.9 M and 2.6 M.  Since r5 the
 // descriptors cover a moving WINDOW of the tensors (X3Window, dec_fused.h) and the scalar offset counts from the window's first
-// tile: the limit is the Gt buffer's and the 32-bit tile arithmetic's, 4 GiB.  AAE_FUSED_SPAN_BITS=31 restores the old rule.
+// tile: the limit is the Gt buffer's and the 32-bit tile arithmetic's, 4 GiB.
 static size_t fused_span_limit(const aae_model* m) {
-    const char* e = getenv("AAE_FUSED_SPAN_BITS");
-    const int bits = e ? atoi(e) : (out_bf16(m) ? 31 : 32);     // (dec_fused_bf16.h's kernels keep fixed descriptors)
+    const int bits = out_bf16(m) ? 31 : 32;     // (dec_fused_bf16.h's kernels keep fixed descriptors)
     return ((size_t)1 << bits) - ((size_t)1 << 24);       // (head room: the padding tiles behind the tensor, the last span of a tile)
 }
 static bool fused_decoder_applies(const aae_model* m) {
@@ -506,10 +506,10 @@ static bool fused_decoder_applies(const aae_model* m) {
     // r3: with both launches on the emulated product (dec_crit_x3.h: the deferred half of all blocks in ONE launch for any
     // vocabulary, dec_opt_blocks_x3_kernel) the cap is gone: 512 x 100 k 0.77 ms/step against 0.93 on the three GEMMs.
     // (bf16 mode on the rounded-operand kernels: only with the one-launch deferred half - the per-block launches are fp32 kernels)
-    const bool bf_blocks_ok = !m->bf16 || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr && getenv("AAE_NO_OPT_BLOCKS") == nullptr);
+    const bool bf_blocks_ok = !m->bf16 || (m->x3_ok && m->dh2f.p && true);
     const bool blocked = !one && m->blocked_ok && !out_bf16(m) && bf_blocks_ok && m->split_ok && m->split_wgs > 0 && m->Gacc.p && row_blocks(m) <= kMaxRowBlocks &&
                          m->cfg.grad_mode == AAE_GRAD_FUSED &&
-                         (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p && getenv("AAE_NO_OPT_BLOCKS_X3") == nullptr));
+                         (m->blocked_any || (size_t)m->rows * m->N <= ((size_t)32 << 20) || (m->x3_ok && m->dh2f.p));
     return m->fused_ok && !m->force_unfused && (one || blocked) &&
            ((size_t)m->N + 2 * kTI) * m->ldh * sizeof(float) < fused_span_limit(m) &&
            /* (the stored dL/dlogits tiles of a row block, [tiles][rows][32] floats, stay behind ONE fixed descriptor) */
@@ -534,7 +534,7 @@ int build_tile_buckets(aae_model* m, hipStream_t s) {
         // landed there took 2.4x its time - the launch waits for its slowest workgroup: 31 or 75 us per launch at C4, the
         // generator program 32 or 57, by where the workgroups fell (profiles/r5_step_timeline_c4.txt).  It claims the CU's LDS
         // now, as the deferred launch does: nothing of the step fits beside it.
-        static const bool bk_claim = getenv("AAE_NO_BUCKET_CLAIM") == nullptr;
+        constexpr bool bk_claim = true;
         if (bk_claim) lds = std::max(lds, (size_t)(160 * 1024 - 16384));
         hipLaunchKernelGGL(tile_bucket_wide_kernel, dim3(1), dim3(1024), lds, s, m->bv, ntiles, m->tstart, m->teb, m->ten, m->tev);
     } else {
@@ -592,7 +592,7 @@ static void piggyback_buckets(aae_model* m, ChainBuilder& cb) {
     const size_t need = sizeof(int) * ((size_t)ntiles + 1 + kBucketMaxDocs + 1 + 1024);
     if (m->x16_ok && m->rows >= m->x16_rows) return;      // (the wide-batch chain kernel carries no builder; only a forced AAE_X16_ROWS meets a batch this small)
     if (m->buckets_valid || !fused_decoder_applies(m) || ntiles > kBucketMaxTiles || m->rows > kBucketMaxDocs ||
-        need > (size_t)kCSlots * kCR * kCL * sizeof(float) || getenv("AAE_NO_PIGGYBACK"))
+        need > (size_t)kCSlots * kCR * kCL * sizeof(float))
         return;
     flip_bucket_set(m);
     BucketJob& b = cb.P.bk;
@@ -737,7 +737,7 @@ int gather_first_layer(aae_model* m, bool train, const uint8_t* mk1, uint32_t si
     // wide batches: four waves per document (eight documents per CU instead of two; a document is ~20 entries: five per wave).
     // ms/step, 16 | 4 waves: C3 at batch 512 0.651 | 0.646, C4 (1 000 rows) 0.389 | 0.381; C2's shape at batch 500 0.327 | 0.331,
     // C3 at batch 100 0.239 | 0.251 (tools/debug/gather4_ab.sh)
-    static const int g4_rows = getenv("AAE_GATHER4_ROWS") ? atoi(getenv("AAE_GATHER4_ROWS")) : 512;
+    constexpr int g4_rows = 512;
     if (B >= g4_rows) {
         hipExtLaunchKernelGGL(enc_gather_kernel_t<4>, dim3(B), dim3(256), (uint32_t)(shm / 4), s, nullptr, head ? m->ev_head : nullptr, 0, m->bv,
                               (const float*)m->P[P_W1T].p, m->ldw1, (const float*)m->P[P_B1].p, h, (int)m->cfg.normalize_inputs,
@@ -909,7 +909,7 @@ int chain_disc_step(aae_model* m, hipStream_t s) {
     // Enc_eval is row-local like the discriminator program behind it: with 4-row workgroups and a batch that is a
     // multiple of 4 it runs as a PREFIX of that program in the workgroups of the z_fake rows (ChainOp::row_lo), z_fake
     // handed over in a slot - one launch (and its ~4.5 us floor) less per step
-    static const bool merge_ok = getenv("AAE_NO_DISC_MERGE") == nullptr;
+    constexpr bool merge_ok = true;
     bool merged = merge_ok && m->use_chain4 && B % kR4 == 0 && !m->vae;
     for (int pid : {P_W2, P_W3, P_D1, P_D2}) merged = merged && m->PT[pid].p != nullptr;
     if (!merged) {   // z_fake = Enc_eval(X) -> zin rows [B, 2B)

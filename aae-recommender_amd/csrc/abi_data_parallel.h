@@ -43,7 +43,7 @@ int aae_w1_import(aae_handle m, const int32_t* hdr_dev, const float* vals_dev, i
     hipLaunchKernelGGL(bump_stamp_kernel, dim3(1), dim3(1), 0, s, m->stamp, m->ucount);
     const size_t nsmall = enc_small_floats(m);
     const char* small0 = reinterpret_cast<const char*>(vals_dev + (size_t)cap * m->h);
-    if (n_peers > 1 && m->pslot && !getenv("AAE_W1_SERIAL")) {
+    if (n_peers > 1 && m->pslot && !m->opt.w1_serial) {
         // every peer in one launch each: slot map + union list, rank-ordered row sums, rank-ordered small-layer sums
         const int W = m->cfg.dp_world;
         hipLaunchKernelGGL(w1_map_kernel, dim3(std::max(1, std::min((cap + 255) / 256, 64)), n_peers), dim3(256), 0, s,

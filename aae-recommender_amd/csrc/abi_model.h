@@ -33,8 +33,48 @@ enum { O_ENC = 0, O_DEC = 1, O_GEN = 2, O_DISC = 3 };
 
 }  // namespace
 
+// Every switch of the library, in ONE place (r6; VERDICT r5: 47 getenv calls, many latched in function-local statics, A/B
+// switches of experiments long decided).  A handle reads them ONCE, in aae_create / aae_arena_bytes: a value set with
+// aae_set_option(name, value) wins over the environment variable AAE_<NAME>; nothing is read after that and nothing is latched
+// per process, so a test may create two handles with different switches.  What is left forces a PATH (the parity suites replay
+// every fixture on each of them) or is a diagnostic of a debug run; the tuning knobs and the on/off switches of r1-r5's
+// experiments are gone with their decisions taken (HISTORY.md has the numbers).
+struct aae_options {
+    // paths (tests)
+    bool no_chain;          // NO_CHAIN: one GEMM launch per hidden layer instead of the layer-chain programs
+    bool chain16;           // CHAIN16: the 16-row chain kernel on the fp32 pipe for every program (no 4-row / wide-batch kernel)
+    bool split_any;         // SPLIT_ANY: the output layer as critical + deferred launch at every size
+    bool blocked_any;       // BLOCKED_ANY: the row-blocked output layer at every size
+    bool early_any;         // EARLY_ANY: the next batch's item list started from the step before, at every batch size
+    bool no_late_join;      // NO_LATE_JOIN: a step waits for the deferred launch of the step before at its opening
+    bool no_item_count;     // NO_ITEM_COUNT: first-layer item workgroups sized by the bound, not by the device's last count
+    bool w1_serial;         // W1_SERIAL: data-parallel import of the peers' first-layer rows one launch per peer
+    bool no_rank_fused;     // NO_RANK_FUSED: predict -> rank as two kernels over the [rows, N] score matrix
+    int x16_rows;           // X16_ROWS: programs of at least this many rows run on the wide-batch chain kernel (default 1024)
+    int dw_ksplit_rows;     // DW_KSPLIT_ROWS: weight-gradient tiles take the k-split form from this many rows on (default 256; -1: unset)
+    // diagnostics (debug runs: tools/debug/*)
+    char dec_ts[8];         // DEC_TS: in-kernel timeline of the output layer ("1", "x3", "obk")
+    bool chain_ts;          // CHAIN_TS: per-op timeline of a chain program's workgroup 0
+    int dw_ts;              // DW_TS: per-workgroup clocks of the weight-gradient launches from this launch on (-1: off)
+    int dec_skip, chain_skip, rank_skip;     // *_SKIP: timing-only ablation masks (results are wrong by design)
+};
+const char* option_value(const char* name);      // (aae_abi.hip: aae_set_option's table, then the environment)
+inline void read_options(aae_options& o) {
+    auto on = [](const char* n) { return option_value(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* e = option_value(n); return e ? atoi(e) : dflt; };
+    o.no_chain = on("NO_CHAIN"); o.chain16 = on("CHAIN16"); o.split_any = on("SPLIT_ANY"); o.blocked_any = on("BLOCKED_ANY");
+    o.early_any = on("EARLY_ANY"); o.no_late_join = on("NO_LATE_JOIN"); o.no_item_count = on("NO_ITEM_COUNT");
+    o.w1_serial = on("W1_SERIAL"); o.no_rank_fused = on("NO_RANK_FUSED");
+    o.x16_rows = num("X16_ROWS", 1024); o.dw_ksplit_rows = num("DW_KSPLIT_ROWS", -1);
+    const char* ts = option_value("DEC_TS");
+    snprintf(o.dec_ts, sizeof(o.dec_ts), "%s", ts ? ts : "");
+    o.chain_ts = on("CHAIN_TS"); o.dw_ts = num("DW_TS", -1);
+    o.dec_skip = num("DEC_SKIP", 0); o.chain_skip = num("CHAIN_SKIP", 0); o.rank_skip = num("RANK_SKIP", 0);
+}
+
 struct aae_model {
     aae_config cfg;
+    aae_options opt;         // read once, in aae_create
     char* base; size_t bytes;
     int N, h, c, cp, R, R2;
     int ldh, ldw1, ldc, ldz, ldn;
@@ -66,6 +106,7 @@ struct aae_model {
     Ten mulv, gmulv, veps;   // VAE: [mu | logvar], its gradient, eps of the step
     bool use_chain;          // row-blocked layer chains (chain.h) instead of one GEMM launch per layer
     bool use_chain4;         // ... with 4 rows per workgroup (chain4.h) where a program allows it
+    bool act_nm;             // cfg.activation is one of the r6 classes (AAE_ACT_SOFTPLUS ..): its layer programs run on chain_kernel<.., true> only
     bool dec_hidden_done;    // the ae forward already ran the decoder's hidden layers (fused aae_step)
     bool fuse_enc_bwd;       // aae_step: run the encoder backward in the decoder-backward program
     bool enc_bwd_done;
@@ -182,7 +223,7 @@ int validate(const aae_config* c) {
     if (c->n_hidden > 4096) return fail(AAE_EINVAL, "n_hidden > 4096 not supported");
     if (c->max_batch < 1 || c->max_nnz < 1) return fail(AAE_EINVAL, "max_batch/max_nnz must be positive");
     if (c->max_batch > 16384) return fail(AAE_EINVAL, "max_batch > 16384 not supported");
-    if (c->activation < 0 || c->activation > AAE_ACT_LEAKYRELU) return fail(AAE_EINVAL, "unknown activation");
+    if (c->activation < 0 || c->activation >= AAE_ACT_COUNT) return fail(AAE_EINVAL, "unknown activation");
     if (c->enc_final < 0 || c->enc_final > AAE_FINAL_SIGMOID) return fail(AAE_EINVAL, "unknown enc_final");
     if (c->optimizer != AAE_OPT_ADAM && c->optimizer != AAE_OPT_SGD) return fail(AAE_EINVAL, "unknown optimizer");
     if (c->rng_mode != AAE_RNG_INJECT && c->rng_mode != AAE_RNG_DEVICE) return fail(AAE_EINVAL, "unknown rng_mode");
@@ -205,12 +246,11 @@ int validate(const aae_config* c) {
     return AAE_OK;
 }
 
-// Programs of at least this many rows run on the 16-row chain kernel (chain16x3.h); AAE_X16_ROWS overrides (tests: 1 = always).
+// Programs of at least aae_options::x16_rows rows (default 1024) run on the 16-row chain kernel (chain16x3.h).
 // A layer op is bound by getting its weights through ONE CU's vector-memory path (64 B/clk): 160 KB of fp32 per 201 x 200 layer on
 // the 4-row kernel, 280 KB of split terms on the 16-row one - its workgroup takes ~2x the time for 4x the rows, so it pays where
 // the 4-row launch needs two rounds and more of the CUs it gets (r5, same-box A/B, from 256 | 1024 rows | never: C4 0.397 | 0.351 |
 // 0.365 ms/step, C3 at batch 512 0.665 | 0.657 | 0.673, one rank's step at world 8 0.340 | 0.289 | 0.298).
-inline int x16_min_rows() { const char* e = getenv("AAE_X16_ROWS"); return e ? atoi(e) : 1024; }       // (read per model: at aae_create)
 
 // lays the model out; with dry=true only measures
 size_t layout(aae_model* m, char* base, bool dry) {
@@ -258,7 +298,7 @@ size_t layout(aae_model* m, char* base, bool dry) {
         }
     // the split weight copies of the wide-batch chain kernel (chain16x3.h): only for models that can see such a batch
     for (int i = 0; i < NP; ++i) m->FXi[i] = m->DXi[i] = m->FXBi[i] = nullptr;
-    if (chain_copies && m->R2 >= x16_min_rows() && getenv("AAE_NO_X16") == nullptr)
+    if (chain_copies && m->R2 >= m->opt.x16_rows)
         for (int pid : {P_W2, P_W3, P_V1, P_V2, P_D1, P_D2}) {
             const int64_t M = m->P[pid].rows, Nc = m->P[pid].cols, Mp = (M + 15) & ~15, Np = (Nc + 15) & ~15;
             m->FXi[pid] = reinterpret_cast<unsigned short*>(a.take((size_t)(((Nc + 31) / 32) * 3 * Mp * 32 + 1) / 2, nullptr));

@@ -46,8 +46,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         fa.partials = m->bce_partials; fa.sc = m->sc + O_DEC;
         fa.erow0 = 0; fa.acc = nullptr; fa.nblk = 1; fa.Bb = B;
         fa.one_term = m->bf16_x3 ? 1 : 0;
-        { const char* e = getenv("AAE_DEC_SKIP"); fa.dbg_skip = e ? atoi(e) : 0; }
-        static const bool want_ts = getenv("AAE_DEC_TS") != nullptr;        // debug: phase timeline of one tile
+        fa.dbg_skip = m->opt.dec_skip;
+        const bool want_ts = m->opt.dec_ts[0] != 0;        // debug: phase timeline of one tile
         static unsigned long long* ts_dev = nullptr;
         fa.ts = nullptr;
         if (want_ts) {
@@ -63,8 +63,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
         // next step waits for it (one rank's C5 share, 442 M parameters: 3.5 -> 4.8 ms/step) - both take the single launch.
         const bool split_fits = nblk > 1 || m->split_any || (ntiles >= 2 * m->n_cu && (size_t)N * m->ldh <= ((size_t)32 << 20));
         // (AAE_DEC_TS: the timeline of the single launch - or, AAE_DEC_TS=x3, of the split form's critical launch dec_crit_x3.h)
-        static const bool ts_x3 = want_ts && strcmp(getenv("AAE_DEC_TS"), "x3") == 0;
-        static const bool ts_obk = want_ts && strcmp(getenv("AAE_DEC_TS"), "obk") == 0;
+        const bool ts_x3 = want_ts && strcmp(m->opt.dec_ts, "x3") == 0;
+        const bool ts_obk = want_ts && strcmp(m->opt.dec_ts, "obk") == 0;
         if (m->split_ok && m->split_wgs > 0 && split_fits && fa.gradV3 == nullptr && (!want_ts || ((ts_x3 || ts_obk) && m->x3_ok && !out_bf16(m))) && (fa.dbg_skip & ~(256 | 0xF000 | 0x30000)) == 0) {
             // ---- split form: the critical launch(es) here, the optimiser launch(es) on the side stream behind the rest of
             // the step.  nblk > 1: one critical launch per row block (each with its block of dh2 in LDS; dA2 rows, loss
@@ -87,8 +87,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             // what the 100-row step's critical launch costs
             // late join (abi_model.h): single row block on the emulated product - dec_crit_x3_kernel sets the deferred launch's
             // dh2 and step scalars aside, dec_opt_x3_kernel reads the copies
-            static const bool no_opt_x3_l = getenv("AAE_NO_OPT_X3") != nullptr;
-            const bool late = m->late_enabled && nblk == 1 && m->x3_ok && !out_bf16(m) && !no_opt_x3_l && !want_ts &&
+            const bool late = m->late_enabled && nblk == 1 && m->x3_ok && !out_bf16(m) && !want_ts &&
                               m->dh2s.p && m->sc_snap && B <= m->dh2s.rows && grid >= B;
             const int wgs = nblk > 1 ? std::max(1, m->n_cu / nblk) : grid;
             const int crit_grid = nblk > 1 ? wgs * nblk : grid;
@@ -136,12 +135,11 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
             bool late_launched = false;
             // nblk > 1 and at most kOBT tiles per workgroup on the chip: the deferred half of every block in ONE launch
             // (dec_opt_blocks_kernel), else one launch per block with the dV3 partial going through Gacc
-            static const bool no_obk = getenv("AAE_NO_OPT_BLOCKS") != nullptr;
-            static const bool no_opt_x3 = getenv("AAE_NO_OPT_X3") != nullptr;
+            constexpr bool no_obk = false, no_opt_x3 = false;
             const bool one_opt = nblk > 1 && !out_bf16(m) && !no_obk && ntiles <= kOBT * m->n_cu &&
                                  dec_opt_blocks_lds_bytes(Bb) <= 160 * 1024;
             // (r3) the same on the emulated product, any vocabulary size: dec_opt_blocks_x3_kernel (dec_crit_x3.h)
-            static const bool no_obk_x3 = getenv("AAE_NO_OPT_BLOCKS_X3") != nullptr;
+            constexpr bool no_obk_x3 = false;
             if (nblk > 1 && !out_bf16(m) && m->x3_ok && !no_opt_x3 && !no_obk_x3 && !no_obk && m->dh2f.p) {
                 DecFusedArgs b = fa;
                 b.nblk = nblk; b.Bb = Bb;
@@ -155,7 +153,6 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 // 1.245 / 1.356 on 160 / 192 / 208; 47 k items x 500 rows 0.388 / 0.372 / 0.369 / 0.381 / 0.378 on 96 / 112 / 128 /
                 // 144 / 160; an item slice of 12.5 k items x 800 rows 0.382 / 0.379 / 0.400 / 0.387 ms of per-rank compute on
                 // 96 / 128 / 160 / 192.  (Beyond 3/4 of the chip the step's own launches lose more than this one gains.)
-                static const int obk_env = getenv("AAE_OBK_WGS") ? atoi(getenv("AAE_OBK_WGS")) : 0;
                 // (a slice of thousands of tiles - C5: 275 k items x 512 rows, 8 594 tiles - outlasts the step's tail by far: 7/8 of the
                 //  chip there, r4: one rank's step 1.58 | 1.52 | 1.61 | 1.59 ms on 192 | 224 | 240 | 256 workgroups)
                 const int wg_cap = ntiles >= 4096 ? m->n_cu * 7 / 8 : m->n_cu * 3 / 4;
@@ -163,7 +160,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                 //  0.3493 | 0.3489 | 0.3486 | 0.3524 ms/step on 128 | 32 | 48 | 64 | 96 workgroups, tools/debug/c4_obk_sweep.sh)
                 const int by_tiles = ntiles < 384 ? std::max(32, std::min(m->n_cu / 2, ntiles / 3))
                                                   : std::max(m->n_cu / 2, std::min(wg_cap, (int)(ntiles / 16.3 / 8.0 + 0.5) * 8));
-                const int g3 = std::max(1, std::min(obk_env > 0 ? obk_env : (getenv("AAE_SPLIT_WGS") ? g2 : by_tiles), std::min(ntiles, m->n_cu)));
+                const int g3 = std::max(1, std::min(by_tiles, std::min(ntiles, m->n_cu)));
                 const int rounds = (ntiles + g3 * kXBT - 1) / (g3 * kXBT);
                 b.tpp = g3 * rounds;
                 const uint32_t lds3 = (uint32_t)dec_opt_blocks_x3_lds_bytes();
@@ -223,9 +220,8 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
                     // (one-term instantiation: 78 VGPRs - six of its waves fit a SIMD, so the step's own launches would be dealt onto
                     //  its CUs and run beside its streams; its LDS claim is raised until no other workgroup of the step fits there)
-                    static const int lds_kb = getenv("AAE_OPT_LDS_KB") ? atoi(getenv("AAE_OPT_LDS_KB")) : -1;
                     const uint32_t lds_nat = (uint32_t)dec_opt_x3_lds_bytes();
-                    const uint32_t lds3 = lds_kb > 0 ? std::max(lds_nat, (uint32_t)lds_kb * 1024u) : (m->bf16_one ? std::max(lds_nat, 150u * 1024u) : lds_nat);
+                    const uint32_t lds3 = m->bf16_one ? std::max(lds_nat, 150u * 1024u) : lds_nat;
                     if (late) { b.dh2 = m->dh2s.p; b.sc = m->sc_snap; late_launched = true; }
                     if (m->bf16_one) switch (m->fused_nb) {
                     case 4: { if (win) hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); else hipExtLaunchKernelGGL((dec_opt_x3_kernel<4, true>), dim3(g2), dim3(kNT), lds3, m->side, start, stop, 0, b); } break;
@@ -372,7 +368,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
     // dV3 = G^T * dh2 -> dec_optim on V3 (the 24 B/param streaming kernel).  Like the fused path's optimiser half
     // (section 3.2c) only the NEXT step reads its result: with the fused optimiser it goes to the handle's low-priority
     // side stream, behind the rest of the step (G and dh2 stay untouched until the next step's join).
-    static const bool defer_dv3 = getenv("AAE_NO_DEFER_DV3") == nullptr;
+    constexpr bool defer_dv3 = true;
     // (not for the item slices of the vocabulary-sharded scheme: there the background GEMM slowed the replica handle's
     // kernels by more than it saved - 0.496 -> 0.560 ms of per-rank compute at world 8, tools/vocab_rank_time.py)
     if (defer_dv3 && m->side && m->cfg.grad_mode == AAE_GRAD_FUSED && !m->bf16 && !m->only_output_layer) {

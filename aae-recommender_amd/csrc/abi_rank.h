@@ -16,7 +16,7 @@ namespace {
 constexpr int kRankBb = 16 * kMB;          // (r1-r4: rows per row block of the rank kernels - the training kernels' 7 MFMA row blocks; now kRankGR2, rank_x3.h)
 // which of the two rank kernels a call takes (rank_x3.h) and its rows per row block
 inline bool rank_v2_nb(int NB, int K) {
-    static const bool v1 = getenv("AAE_RANK_V1") != nullptr;       // (A/B: the critical launch's wave mapping, rank_x3.h)
+    constexpr bool v1 = false;       // (rank_x3_kernel, the r4 wave mapping: kept for K != 10, rank_x3.h)
     return !v1 && (K == 10 || (K == 20 && NB < 13));                 // (the other list sizes spill registers in the v2 mapping: they keep v1)
 }
 inline int rank_bb(const aae_model*, int) { return kRankGR2; }      // (both kernels: 128-row blocks)
@@ -125,7 +125,7 @@ int rank_from_dh2(aae_model* m, const RankPlan& p, const BatchView& bv, int k, i
     a.dh2 = p.dh2; a.ldh = m->ldh; a.V3a = m->P[P_V3].p; a.ldv = m->ldh; a.N = m->N; a.B = p.rows;
     a.nblk = p.nblk; a.Bb = p.bb; a.known = exclude_known ? p.known : nullptr; a.kw = p.kw;
     a.cand_v = p.cand_v; a.cand_i = p.cand_i; a.mm = p.mm; a.one_term = m->bf16 ? 1 : 0;
-    { static const char* e = getenv("AAE_RANK_SKIP"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = m->opt.rank_skip;
     const int grid = p.wgs * p.nblk;
     {
         ProfScope ps(m, AAE_K_RANK, s);

@@ -29,7 +29,7 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
     // With the batch's list built ahead nothing sits between the step-opening bookkeeping and the first gather: it rides
     // in that launch (one launch floor, ~4.5 us, less per step)
-    static const bool fold_ok = getenv("AAE_NO_FOLD_ADVANCE") == nullptr;
+    constexpr bool fold_ok = true;
     const bool fold_advance = fold_ok && ahead && m->use_chain && !m->ext_first && m->noise_next == nullptr;
     if (!fold_advance)
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
@@ -88,7 +88,7 @@ static int ae_encode_impl(aae_handle m, const aae_batch* batch, const aae_rng_in
     // deferred launch, which waited for that step's output layer - the alternate bucket set's last readers are older.
     // (Not on the three-GEMM path: there the side stream holds the previous step's dV3 GEMM for most of this step.)
     {
-        static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
+        constexpr bool bk_ahead = true;
         if (bk_ahead && m->side && m->ev_bk && m->last_out_split && m->rows > 16 * kMB && !m->buckets_valid && fused_decoder_applies(m)) {
             TRY(build_tile_buckets(m, m->side));
             HIPCHK(hipEventRecord(m->ev_bk, m->side));

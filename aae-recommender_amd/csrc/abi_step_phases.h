@@ -261,7 +261,7 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         const bool ahead = m->pf_built && m->pf_step == m->hstep && same_batch(m->pf_built_batch, *batch) && m->lazy;
         m->pf_built = false;
         if (ahead) { std::swap(m->mark, m->mark2); std::swap(m->ulist, m->ulist2); std::swap(m->ucount, m->ucount2); std::swap(m->stamp, m->stamp2); }
-        static const bool fold_ok = getenv("AAE_NO_FOLD_ADVANCE") == nullptr;
+        constexpr bool fold_ok = true;
         fold_advance = fold_ok && ahead;          // (as in aae_step: nothing between the bookkeeping and the gather)
         if (!fold_advance)
         hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, m->sc, m->step_ctr, m->lazy ? m->tab : nullptr,
@@ -273,7 +273,7 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         // handle's list building and gather (and the caller's forward pass) instead of in front of the critical launch.
         // The side stream is in order behind the last deferred launch, which waited for the last critical launch - the
         // last reader of the bucket arrays; without such a launch to order it the build stays where it was.
-        static const bool bk_ahead = getenv("AAE_NO_BUCKETS_AHEAD") == nullptr;
+        constexpr bool bk_ahead = true;
         if (bk_ahead && m->side && m->ev_bk && m->last_out_split && fused_decoder_applies(m)) {
             TRY(build_tile_buckets(m, m->side));
             HIPCHK(hipEventRecord(m->ev_bk, m->side));
@@ -291,7 +291,7 @@ int aae_first_layer_forward(aae_handle m, const aae_batch* batch, const float* b
         const size_t shm = (size_t)16 * r4(m->h) * sizeof(float);
         DropSpec none; memset(&none, 0, sizeof(none));
         // (four waves per document for wide batches, as gather_first_layer: an item slice holds 1 / world of a document's entries)
-        static const int g4_rows = getenv("AAE_GATHER4_ROWS") ? atoi(getenv("AAE_GATHER4_ROWS")) : 512;
+        constexpr int g4_rows = 512;
         if (m->rows >= g4_rows)
         hipExtLaunchKernelGGL(enc_gather_kernel_t<4>, dim3(m->rows), dim3(256), (uint32_t)(shm / 4), s, nullptr, pf ? m->ev_head : nullptr, 0,
                               m->bv, (const float*)m->P[P_W1T].p, m->ldw1, bias_dev, m->h, (int)m->cfg.normalize_inputs,

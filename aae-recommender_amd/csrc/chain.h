@@ -148,13 +148,14 @@ __device__ __forceinline__ int chain_keep(const EpiCtx& c, int row, int col) {  
     return m[(size_t)r * c.width + col] != 0;
 }
 
+template <bool NM = false>      // (NM: with the non-monotone activations' derivative, device_common.h)
 __device__ __forceinline__ float chain_epi(const EpiCtx& c, int grow, int lrow, int col, float v) {
     if (c.epi == CEPI_DROPACT) {
         if (c.den) v = chain_keep(c, grow, col) ? v * c.mk + c.ak : c.ad;
-        return act_fwd(c.act, v);
+        return act_fwd<NM>(c.act, v);
     }
     if (c.epi == CEPI_ACTBWD) {
-        v *= act_grad_from_y(c.act, c.y[lrow * kCL + col]);
+        v *= act_grad_from_y<NM>(c.act, c.y[lrow * kCL + col]);
         if (c.den) v *= chain_keep(c, grow, col) ? c.mk : 0.f;
         return v;
     }
@@ -342,7 +343,7 @@ __device__ __forceinline__ void chain_linear_fwd_bf16(const ChainOp& op, const f
     }
 }
 
-template <bool BF>
+template <bool BF, bool NM = false>
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][16][kCL]
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     for (int r = 0; r < 4; ++r) {
                         const int lrow = fk * 4 + r;
                         float v = 0.f;
-                        if (col < epiN && lrow < nrows) v = chain_epi(ec, r0 + lrow, lrow, col, acc[q][r]);
+                        if (col < epiN && lrow < nrows) v = chain_epi<NM>(ec, r0 + lrow, lrow, col, acc[q][r]);
                         dst[lrow * kCL + col] = v;
                     }
                 }
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
                     const float k1 = (den && c4 * 4 + 1 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 1) ? sec.mk : 0.f) : 1.f;
                     const float k2 = (den && c4 * 4 + 2 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 2) ? sec.mk : 0.f) : 1.f;
                     const float k3 = (den && c4 * 4 + 3 < op.N) ? (chain_keep(sec, gr, c4 * 4 + 3) ? sec.mk : 0.f) : 1.f;
-                    acc4.x *= act_grad_from_y(sec.act, y4.x) * k0; acc4.y *= act_grad_from_y(sec.act, y4.y) * k1;
-                    acc4.z *= act_grad_from_y(sec.act, y4.z) * k2; acc4.w *= act_grad_from_y(sec.act, y4.w) * k3;
+                    acc4.x *= act_grad_from_y<NM>(sec.act, y4.x) * k0; acc4.y *= act_grad_from_y<NM>(sec.act, y4.y) * k1;
+                    acc4.z *= act_grad_from_y<NM>(sec.act, y4.z) * k2; acc4.w *= act_grad_from_y<NM>(sec.act, y4.w) * k3;
                 }
                 const bool ok = lrow < nrows;
                 if (!ok || c4 * 4 + 0 >= op.N) acc4.x = 0.f;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
             const int lrow = tid >> kRS;
             for (int col = tid & (kTPR - 1); col < kCL; col += kTPR)
                 dst[lrow * kCL + col] = (lrow < nrows && col < epiN)
-                    ? chain_epi(ec, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
+                    ? chain_epi<NM>(ec, r0 + lrow, lrow, col, src[lrow * kCL + col]) : 0.f;
         } else if (kind == COP_FINAL_FWD) {
             // one wave per pair of rows; softmax / sigmoid / identity over N columns, in place on dst
             for (int lrow = wave; lrow < kCR; lrow += kCW) {
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainProgram P) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = t + 64 * j;
-                if (k < kCL) dst[lrow * kCL + k] = (lrow < nrows && k < Nn) ? chain_epi(ec, grow, lrow, k, gv * wv[j]) : 0.f;
+                if (k < kCL) dst[lrow * kCL + k] = (lrow < nrows && k < Nn) ? chain_epi<NM>(ec, grow, lrow, k, gv * wv[j]) : 0.f;
             }
         } else if (kind == COP_ADV) {
             // src col 0 = D(x) of each row.  mode 0: rows < row_split real, others fake; mode 1: all fake(gen)

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kX16T) void chain16x3_kernel(ChainProgram P) {
                             v *= act_grad_from_y(ec.act, ygp ? yv[q] : x16_get(ys, lr, col));
                             if (ec.den) v *= chain_keep(ec, r0 + lr, col) ? ec.mk : 0.f;
                         } else {
-                            v = chain_epi(ec, r0 + lr, lr, col, v);
+                            v = chain_epi<false>(ec, r0 + lr, lr, col, v);
                         }
                         store(lr, col, v);
                     }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kX16T) void chain16x3_kernel(ChainProgram P) {
                 if (ecol < kX16Kp) {
                     float v = 0.f;
                     if (wave < nrows && ecol < opN) {
-                        v = chain_epi(ec, r0 + wave, wave, ecol, x16_get(src, wave, ecol));
+                        v = chain_epi<false>(ec, r0 + wave, wave, ecol, x16_get(src, wave, ecol));
                         store(wave, ecol, v);
                     }
                     x16_put(dst, wave, ecol, ecol == one_col ? (wave < nrows ? 1.f : 0.f) : v);

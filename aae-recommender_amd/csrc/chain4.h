@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                         v *= act_grad_from_y(ec.act, ygp ? yv[eh] : (slots + yslot_k * kR4 * kCL)[erow * kCL + ecol]);
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;
                     } else {
-                        v = chain_epi(ec, r0 + erow, erow, ecol, v);
+                        v = chain_epi<false>(ec, r0 + erow, erow, ecol, v);
                     }
                 }
                 // (columns >= N read as zero for the next layer; the constant-1 column of an augmented layer input rides here
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 float v = 0.f;
                 if (erow < nrows && ecol < opN) {
                     v = src[erow * kCL + ecol];
-                    if (kind == COP_DROPACT) v = chain_epi(ec, r0 + erow, erow, ecol, v);
+                    if (kind == COP_DROPACT) v = chain_epi<false>(ec, r0 + erow, erow, ecol, v);
                     else {
                         v *= act_grad_from_y(ec.act, (slots + qyslot * kR4 * kCL)[erow * kCL + ecol]);
                         if (ec.den) v *= chain_keep(ec, r0 + erow, ecol) ? ec.mk : 0.f;

@@ -59,6 +59,11 @@ __device__ __forceinline__ bf16x8 x3_frag(const unsigned* img, int row, int S, i
 constexpr int kXRS = 33;       // row stride (floats) of the raw-logit halves [b][n]
 constexpr int kXT = 32;        // row stride (floats) of the target tile [b][n]
 
+#ifndef AAE_CRIT_BAL
+#define AAE_CRIT_BAL 1
+#endif
+constexpr bool kCritBal = AAE_CRIT_BAL != 0;   // hidden 200: the products dealt to the waves by SIMD (r6, see the kernel; 0: r5's map, A/B builds)
+constexpr int kBalRows = 4;                     // ... the row blocks from here on of column blocks 12 / 10 / 11 go to waves 13 / 14 / 15
 constexpr int kXRegSteps = 3;  // k-steps of a wave's dh2 fragments kept in registers (12 VGPRs each); further ones live in LDS
 inline size_t dec_crit_x3_lds_bytes(int NB) {
     const int KC1 = (NB + 1) / 2, NKS = (KC1 + 1) / 2, S1 = x3_stride(KC1), S3 = x3_stride(1);
@@ -132,10 +137,17 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     // (a thread's second slot lies beyond the tile's span for most threads - 1632 float4 at hidden 200: slots 1632 .. 2047 are the
     //  NEXT tile's first rows -, so this launch reads 1.25x the layer, profiles/r5_pmc_calibration.txt.  Masking those lanes, as
     //  the deferred launch does since r5, costs this kernel a vector register it does not have: 12 bytes of scratch per lane)
+    // (r6) which waves take a SECOND float4 slot of the 1632-slot span (9.5 of the 16 waves): the image build follows GEMM3 in its
+    // phase, and with BAL waves 10-15 have three or four of its products where the others have seven, SIMD classes 2 and 3 the
+    // fewest - waves 10 .. 15, 2, 3, 6, 7 in place of 0 .. 9.  slot1 = 1024 + 64 x rank + lane; the wave's distance from its natural
+    // slot rides in the scalar offset of the load.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rank1 = NB == 13 && kCritBal ? (int)((0x543210FF98FF76FFull >> (4 * wave_u)) & 15ull) : wave_u;
+    const int slot1 = kNT + 64 * rank1 + (tid & 63);                                    // (>= tile_f4: no second slot)
+    const unsigned so1 = (unsigned)((kNT + 64 * rank1 - 64 * wave_u) * 16);              // slot1's bytes beyond lane_off
     auto load_span = [&](int tile, float4* r) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off + (unsigned)(kNT * 16 * j), win.so(tile), 0));
+        r[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off, win.so(tile), 0));
+        r[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, lane_off, win.so(tile) + so1, 0));
     };
     float4 vreg[NV];
     int tile = wgi;
@@ -174,8 +186,15 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 
     // ---- dh2 -> split A fragments in registers.  GEMM1: wave w < 14 = (row block w % 7, k half w / 7) takes the k-steps
     // kc = kh, kh + 2, ...; lane (fr, fk) of a fragment holds row 16 mb + fr, k = 32 kc + 8 fk + {0..7}
-    const bool g1 = wave < 2 * kMB;
-    const int mb1 = wave % kMB, kh = wave / kMB;
+    // (r6, BAL) Which wave takes which (row block, k half) unit decides what each SIMD's matrix pipe gets: waves w, w + 4, w + 8,
+    // w + 12 share a SIMD, and at hidden 200 a unit of k half 0 is 48 matrix instructions per tile, one of k half 1 is 36.
+    // wave = row block + 7 x k half (r3-r5) dealt the four SIMDs 168 / 168 / 132 / 120; the table below 144 / 144 / 156 / 144:
+    //   SIMD class 0 (waves 0 4 8 12): k half 0 of row blocks 0 1 2, -        class 1 (1 5 9 13): k half 0 of 3 4 5, -
+    //   class 2 (2 6 10 14): k half 0 of row block 6, k half 1 of 0 1 2       class 3 (3 7 11 15): k half 1 of 3 4 5 6
+    constexpr bool BAL = NB == 13 && kCritBal;
+    const int unit = BAL ? (int)((0xD9FFC852B741A630ull >> (4 * wave)) & 15ull) : wave;
+    const bool g1 = unit < 2 * kMB;
+    const int mb1 = unit % kMB, kh = g1 ? unit / kMB : 1;
     bf16x8 dA[NKR][3];
     {
         const int row = 16 * mb1 + fr;
@@ -203,18 +222,23 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
     const int nks = (KC1 - kh + 1) / 2;         // k-steps this wave really has (the rest of dA is zero and never used)
 
     // GEMM3: wave w < NB owns column block w for every row block
-    const bool own = wave < NB;
-    const int cb = min(wave, NB - 1);
+    // (BAL: 13 column blocks x 7 row blocks = 91 products per tile - one owner per column block dealt them 28 / 21 / 21 / 21 to
+    //  the SIMDs; the upper row blocks of column blocks 12, 10, 11 now go to the three waves that had none: 25 / 24 / 21 / 21.
+    //  Every accumulator still sums the tiles in order: same bits.)
+    const bool own = BAL || wave < NB;
+    const int cb = BAL && wave >= NB ? (wave == 13 ? 12 : wave == 14 ? 10 : 11) : min(wave, NB - 1);
+    const int q_lo = BAL && wave >= NB ? kBalRows : 0, q_hi = BAL && wave >= 10 && wave < NB ? kBalRows : kMB;
     f32x4 acc3[kMB];
 #pragma unroll
     for (int q = 0; q < kMB; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float loss = 0.f;
 
-    int s_rc[NV];                               // this thread's slots of a tile span: item row * 64 + float4 column
+    int s_rc = 0;                               // this thread's slots of a tile span: item row * 64 + float4 column, 16 bits each
+    static_assert(NV == 2, "two slots in one register");
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int fc = min(tid + kNT * j, tile_f4 - 1), row = fc / f4_per_row;
-        s_rc[j] = row * 64 + (fc - row * f4_per_row);
+        const int fc = min(j ? slot1 : tid, tile_f4 - 1), row = fc / f4_per_row;
+        s_rc |= (row * 64 + (fc - row * f4_per_row)) << (16 * j);
     }
     const int g_f4 = B * (kTI / 4);             // float4 per stored dL/dlogits tile
     const unsigned gbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)ntiles * g_f4 * 16);
@@ -234,10 +258,10 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         const bool ragged = x0 + kTI > N;       // (uniform) only the vocabulary's last tile has rows beyond N
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            if (tid + kNT * j < tile_f4) {
+            if ((j ? slot1 : tid) < tile_f4) {
                 float4 p = vreg[j];
                 int src;                                // (opaque copy: what is derived from it is recomputed here, not hoisted
-                asm volatile("v_mov_b32 %0, %1" : "=v"(src) : "v"(s_rc[j]));     //  out of the tile loop and spilled)
+                asm volatile("v_bfe_u32 %0, %1, %2, 16" : "=v"(src) : "v"(s_rc), "n"(16 * j));     //  out of the tile loop and spilled)
                 if (ragged && x0 + (src >> 6) >= N) p = make_float4(0.f, 0.f, 0.f, 0.f);
                 unsigned q0[3], q1[3];
                 split3_pair(p.x, p.y, q0[0], q0[1], q0[2], one);
@@ -276,12 +300,9 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
         const int frz = fr + oz, fkz = fk + oz;
         int lanez;
         asm volatile("v_mov_b32 %0, %1" : "=v"(lanez) : "v"(lane));
-        stamp(0);
-        stamp(14);
-        stamp(1);
 
         // ---- GEMM1: logits of the wave's row block x both item halves over its k-steps -> its half's raw tile
-        if (g1) {
+        auto gemm1 = [&]() {
             float* rw = raw + kh * (kGR * kXRS) + (16 * mb1 + 4 * fkz) * kXRS + frz;    // C map: row = 4 fk + r, col = fr
 #pragma unroll
             for (int nb2 = 0; nb2 < 2; ++nb2) {         // (one item half at a time: 12 fragment registers live, not 24)
@@ -307,17 +328,10 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
             }
-        }
-        // the next tile's V3a: requested HERE, behind the phase with the most live registers (its 8 would be the ones that
-        // spill), BCE and GEMM3 ahead of its use in stage() - ~2 us, an HBM round trip
-        load_span(min(tile + stride, ntiles - 1), vreg);
-        lds_barrier();
-        stamp(2);
-
+        };
         // ---- BCE: thread -> cells (b, n2), (b, n2 + 1) of pair id tid + 1024 j; the stored tile, the split G images, loss
-#pragma unroll
-        for (int j = 0; j < (kGR * (kTI / 2) + kNT - 1) / kNT; ++j) {
-            const int pid = tid + oz + kNT * j, b = pid >> 4, n2 = (pid & 15) * 2;
+        auto bce = [&](int pid0) {              // (the 64 cell pairs from pid0 on: rows pid0 / 16 .. + 3)
+            const int pid = pid0 + lanez, b = pid >> 4, n2 = (pid & 15) * 2;
             if (b < B) {
                 const float l0 = raw[b * kXRS + n2] + raw[kGR * kXRS + b * kXRS + n2];
                 const float l1 = raw[b * kXRS + n2 + 1] + raw[kGR * kXRS + b * kXRS + n2 + 1];
@@ -332,8 +346,10 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                     if (tt.y != 0.f) bce_elem(l1, tt.y, a.gscale, gB, lB);
                     *reinterpret_cast<float2*>(tgt + b * kXT + n2) = make_float2(0.f, 0.f);
                 }
-                if (i0 + n2 >= N) { gA = 0.f; lA = 0.f; }
-                if (i0 + n2 + 1 >= N) { gB = 0.f; lB = 0.f; }
+                if (i0 + kTI > N) {                     // (uniform: the vocabulary's last tile alone has cells beyond N)
+                    if (i0 + n2 >= N) { gA = 0.f; lA = 0.f; }
+                    if (i0 + n2 + 1 >= N) { gB = 0.f; lB = 0.f; }
+                }
                 loss += lA + lB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fu32x2, make_float2(gA, gB)), rGt, (unsigned)pid * 8u,
                                                       (unsigned)tile * (unsigned)g_f4 * 16u, 0);
@@ -342,13 +358,13 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) gK[t * (kGR * S3) + b * S3 + (n2 >> 1)] = q[t];
             }
-        }
+        };
         // ---- GEMM3's B operand (dA2[b][c] += sum_n G[b][n] V3a[n][c]; wave w < NB owns column block w for every row block):
         // the transpose of 2 x (4 items x 16 columns) of the v3K rows per term - ds_read_b64_tr_b16, lane 4 q + p of a 16-lane
-        // group names row q, columns 4 p .. 4 p + 3 of its block.  Read HERE, behind BCE's own work and in front of the barrier that closes
-        // it: from that barrier on the images are the next tile's.
+        // group names row q, columns 4 p .. 4 p + 3 of its block.  Read in front of the barrier behind which the images are
+        // the next tile's.
         bf16x8 vt[3];
-        if (own) {
+        auto read_vt = [&]() {
             const int lz = lane + oz, q = (lz >> 2) & 3, p = lz & 3;
             const unsigned* base = v3K + (8 * fkz + q) * S1 + 8 * cb + 2 * p;        // (16 cb + 4 p) bf16 = 8 cb + 2 p dwords
 #pragma unroll
@@ -361,21 +377,39 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 vt[t] = __builtin_bit_cast(bf16x8, v);
             }
-        }
-        lds_barrier();
-        stamp(3);
-
-        // ---- GEMM3 of this tile and the next tile's S0 (its images, its targets, the requests behind it) in one phase.
-        // k-order of a fragment (both operands): element j = item 8 fk + j - what x3_frag reads from the gK rows
-        if (own) {
+        };
+        // ---- GEMM3 over the row blocks [Q0, Q1).  k-order of a fragment (both operands): element j = item 8 fk + j - what
+        // x3_frag reads from the gK rows (rows >= B of gK are zero - no branch between the MFMAs)
+        auto gemm3 = [&](auto Q0, auto Q1) {
 #pragma unroll
-            for (int q = 0; q < kMB; ++q) {     // (every row block: rows >= B of gK are zero - no branch between the MFMAs)
+            for (int q = decltype(Q0)::value; q < decltype(Q1)::value; ++q) {
+                if (BAL && (q < q_lo || q >= q_hi)) continue;     // (uniform: the row blocks of this column block another wave owns)
                 bf16x8 ga[3];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) ga[t] = x3_frag(gK + t * (kGR * S3), 16 * q + frz, S3, 0, fkz);
                 acc3[q] = mfma_xt<ONE>(ga, vt, acc3[q]);
             }
-        }
+        };
+        typedef std::integral_constant<int, 0> Q_0;
+        typedef std::integral_constant<int, kMB> Q_E;
+        constexpr int NJ = (kGR * (kTI / 2) + kNT - 1) / kNT;
+        stamp(0);
+
+        stamp(14);
+        stamp(1);
+        if (g1) gemm1();
+        // the next tile's V3a: requested HERE, behind the phase with the most live registers (its 8 would be the ones that
+        // spill), BCE and GEMM3 ahead of its use in stage() - ~2 us, an HBM round trip
+        load_span(min(tile + stride, ntiles - 1), vreg);
+        lds_barrier();
+        stamp(2);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bce(64 * wave + kNT * j);
+        if (own) read_vt();
+        lds_barrier();
+        stamp(3);
+        // ---- GEMM3 of this tile and the next tile's S0 (its images, its targets, the requests behind it) in one phase
+        if (own) gemm3(Q_0(), Q_E());
         __builtin_amdgcn_sched_barrier(0);
         stage(tile + stride);
         stamp(4);
@@ -395,7 +429,7 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
             const int rb = q * 16 + fk * 4, cc = cb * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (rb + r < B && cc < a.ld_slab) slab[(size_t)(rb + r) * a.ld_slab + cc] = acc3[q][r];
+                if (q >= q_lo && q < q_hi && rb + r < B && cc < a.ld_slab) slab[(size_t)(rb + r) * a.ld_slab + cc] = acc3[q][r];
         }
     }
     loss = wave_sum(loss);

@@ -11,7 +11,13 @@ constexpr float kTiny = 1e-12f;                       // TINY, reference aaerec/
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
 
-enum { ACT_RELU = 0, ACT_SELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_ELU = 4, ACT_LEAKY = 5 };
+// (r6) activations 6+: the parameter-free element-wise classes of torch.nn at their default arguments - the reference takes
+// ANY class name (getattr(nn, activation)(), aae.py:110); classes with parameters, state or a row-wise definition (PReLU,
+// RReLU, Threshold, GLU, Softmax ...) are refused by the host with the list of these names.
+enum { ACT_RELU = 0, ACT_SELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_ELU = 4, ACT_LEAKY = 5,
+       ACT_SOFTPLUS = 6, ACT_HARDTANH = 7, ACT_RELU6 = 8, ACT_CELU = 9, ACT_SOFTSIGN = 10, ACT_HARDSIGMOID = 11,
+       ACT_LOGSIGMOID = 12, ACT_SOFTSHRINK = 13, ACT_HARDSHRINK = 14, ACT_IDENTITY = 15,
+       ACT_GELU = 16, ACT_SILU = 17, ACT_MISH = 18, ACT_HARDSWISH = 19, ACT_COUNT = 20 };
 
 __device__ __forceinline__ float sigmoidf_(float x) {
     // two-sided form keeps full precision for large |x|
@@ -20,28 +26,125 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return e / (1.f + e);
 }
 
+// ---- GELU / SiLU / Mish / Hardswish are not monotone: y = f(x) falls from 0 to f(x*) on x < x* and rises beyond, so the
+// derivative cannot be written in the layer's OUTPUT alone - and the output is all the backward pass of these kernels keeps
+// (an activation's input never reaches memory: dropout and activation run on the accumulators of the layer's product).
+// The one missing bit - which side of x* the input was on - rides in the LEAST SIGNIFICANT BIT of the stored output (one unit
+// in the last place of y, 6e-8 relative: far inside the tolerances of this path), and the backward pass inverts f on that
+// branch (bracketed Newton steps; Hardswish in closed form) to evaluate f'(x).  Near x* the inverse is ill-conditioned but
+// f' is ~0 there: the error of f'(x) stays below 1e-4 absolute on the ~1e-3 wide neighbourhood of x*, 1e-6 elsewhere.
+__device__ __forceinline__ float nm_xstar(int act) {        // argmin of f
+    return act == ACT_GELU ? -0.75179160f : act == ACT_SILU ? -1.27846455f : act == ACT_MISH ? -1.19245934f : -1.5f;
+}
+__device__ __forceinline__ void nm_f_df(int act, float x, float& f, float& df) {
+    if (act == ACT_GELU) {                  // x Phi(x);  Phi + x phi   (torch.nn.GELU(approximate='none'))
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f)), pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        f = x * cdf; df = cdf + x * pdf;
+    } else if (act == ACT_SILU) {           // x s(x);  s (1 + x (1 - s))
+        const float sg = sigmoidf_(x);
+        f = x * sg; df = sg * (1.f + x * (1.f - sg));
+    } else {                                // Mish: x tanh(softplus(x));  t + x s (1 - t^2)
+        const float sp = x > 20.f ? x : log1pf(__expf(x)), t = tanhf(sp), sg = sigmoidf_(x);
+        f = x * t; df = t + x * sg * (1.f - t * t);
+    }
+}
+__device__ __forceinline__ float nm_mark(int act, float x, float y) {      // the branch bit into the stored output
+    const unsigned u = (__float_as_uint(y) & ~1u) | (x < nm_xstar(act) ? 1u : 0u);
+    return __uint_as_float(u);
+}
+__device__ float nm_grad_from_y(int act, float ym) {
+    const bool left = (__float_as_uint(ym) & 1u) != 0u;
+    const float y = __uint_as_float(__float_as_uint(ym) & ~1u);
+    if (act == ACT_HARDSWISH) {             // x relu6(x + 3) / 6: 0 | x (x + 3) / 6 | x;  torch: 0 | x / 3 + 0.5 | 1
+        if (y >= 3.f) return 1.f;
+        if (left && y == 0.f) return 0.f;   // x <= -3 (the one point x = -3 itself has measure zero)
+        const float r = sqrtf(fmaxf(9.f + 24.f * y, 0.f)) * (1.f / 6.f);
+        return left ? -r : r;
+    }
+    const float xs = nm_xstar(act);
+    // bracket [lo, hi] with (f(lo) - y) and (f(hi) - y) of opposite sign on the branch's monotone piece
+    float lo = left ? -40.f : xs, hi = left ? xs : fmaxf(y, 0.f) + 2.f;
+    float x = left ? xs - 1.f : fmaxf(y, xs + 0.5f);
+    for (int it = 0; it < 24; ++it) {
+        float f, df;
+        nm_f_df(act, x, f, df);
+        const float r = f - y;
+        // left branch: f falls with x (r > 0: the root lies to the right... of a falling f: larger x); right: f rises
+        const bool root_above = left ? r > 0.f : r < 0.f;
+        if (root_above) lo = x; else hi = x;
+        float xn = x - r / df;
+        if (!(xn > lo && xn < hi)) xn = 0.5f * (lo + hi);      // (also the NaN of df == 0)
+        x = xn;
+    }
+    float f, df;
+    nm_f_df(act, x, f, df);
+    return df;
+}
+
 // getattr(nn, activation)() of the reference (aae.py:110).  Applied AFTER dropout.
+// EXT = false (the 4-row and 16-row chain kernels, at their 128-register cap): r1-r5's six classes only - the r6 classes inlined
+// there cost the 16-row kernel 74 spilled registers on EVERY activation's path.  A model with one of the r6 classes runs its
+// layer programs on chain_kernel<.., true> (16-row blocks on the fp32 pipe), the instantiation that carries them all.
+template <bool EXT = true>
 __device__ __forceinline__ float act_fwd(int act, float x) {
+    if (!EXT && act > ACT_LEAKY) return x;
     switch (act) {
         case ACT_RELU: return fmaxf(x, 0.f);
         case ACT_SELU: return x > 0.f ? kSeluScale * x : (kSeluScale * kSeluAlpha) * expm1f(x);
         case ACT_TANH: return tanhf(x);
         case ACT_SIGMOID: return sigmoidf_(x);
-        case ACT_ELU: return x > 0.f ? x : expm1f(x);
-        default: return x > 0.f ? x : 0.01f * x;
+        case ACT_ELU: case ACT_CELU: return x > 0.f ? x : expm1f(x);          // (CELU(alpha = 1) is ELU(alpha = 1))
+        case ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+        case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(__expf(x));           // beta = 1, threshold = 20
+        case ACT_HARDTANH: return fminf(fmaxf(x, -1.f), 1.f);
+        case ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+        case ACT_SOFTSIGN: return x / (1.f + fabsf(x));
+        case ACT_HARDSIGMOID: return fminf(fmaxf(x * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_LOGSIGMOID: return fminf(x, 0.f) - log1pf(__expf(-fabsf(x)));
+        case ACT_SOFTSHRINK: return x > 0.5f ? x - 0.5f : x < -0.5f ? x + 0.5f : 0.f;
+        case ACT_HARDSHRINK: return fabsf(x) > 0.5f ? x : 0.f;
+        case ACT_IDENTITY: return x;
+        case ACT_GELU: return nm_mark(act, x, x * 0.5f * (1.f + erff(x * 0.70710678118654752f)));
+        case ACT_SILU: return nm_mark(act, x, x * sigmoidf_(x));
+        case ACT_MISH: return nm_mark(act, x, x * tanhf(x > 20.f ? x : log1pf(__expf(x))));
+        case ACT_HARDSWISH: return nm_mark(act, x, x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f));
+        default: return x;
     }
 }
 
-// derivative of the activation expressed through its OUTPUT y (all six are invertible enough
-// for that), so the backward pass needs the post-activation tensor only.
+// derivative of the activation expressed through its OUTPUT y, so the backward pass needs the post-activation tensor only
+// (the monotone ones directly; GELU / SiLU / Mish / Hardswish through the branch bit, above).
+// EXT = false (the 4-row / 16-row chain kernels): r1-r5's six classes, as act_fwd<false>; the per-layer epilogues and
+// chain_kernel<.., true> carry all of them.
+template <bool EXT = false>
 __device__ __forceinline__ float act_grad_from_y(int act, float y) {
+    if (EXT && act >= ACT_GELU) return nm_grad_from_y(act, y);
+    if (!EXT) {
+        switch (act) {
+            case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+            case ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
+            case ACT_TANH: return 1.f - y * y;
+            case ACT_SIGMOID: return y * (1.f - y);
+            case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+            default: return y > 0.f ? 1.f : 0.01f;
+        }
+    }
     switch (act) {
         case ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
         case ACT_TANH: return 1.f - y * y;
         case ACT_SIGMOID: return y * (1.f - y);
-        case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
-        default: return y > 0.f ? 1.f : 0.01f;
+        case ACT_ELU: case ACT_CELU: return y > 0.f ? 1.f : y + 1.f;
+        case ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
+        case ACT_SOFTPLUS: return -expm1f(-y);                               // sigmoid(x) = 1 - exp(-softplus(x)); x > 20: 1
+        case ACT_HARDTANH: return (y > -1.f && y < 1.f) ? 1.f : 0.f;
+        case ACT_RELU6: return (y > 0.f && y < 6.f) ? 1.f : 0.f;
+        case ACT_SOFTSIGN: { const float t = 1.f - fabsf(y); return t * t; }   // 1 / (1 + |x|)^2, 1 - |y| = 1 / (1 + |x|)
+        case ACT_HARDSIGMOID: return (y > 0.f && y < 1.f) ? (1.f / 6.f) : 0.f;
+        case ACT_LOGSIGMOID: return -expm1f(y);                               // sigmoid(-x) = 1 - exp(logsigmoid(x))
+        case ACT_SOFTSHRINK: case ACT_HARDSHRINK: return y != 0.f ? 1.f : 0.f;
+        case ACT_IDENTITY: return 1.f;
+        default: return 1.f;
     }
 }
 

@@ -304,7 +304,7 @@ struct EpiActBwd {
         float* o = out + (size_t)gm * ld + gn;
         const float* yy = y + (size_t)gm * ldy + gn;
         for (int i = 0; i < 4 && gn + i < N; ++i) {
-            float gdy = (&v.x)[i] * act_grad_from_y(act, yy[i]);
+            float gdy = (&v.x)[i] * act_grad_from_y<true>(act, yy[i]);
             if (d.enabled) gdy *= drop_bwd_mul(d, drop_keep(d, st.key, gm, gn + i));
             o[i] = gdy;
         }
@@ -335,11 +335,23 @@ __device__ __forceinline__ void bce_elem(float logit, float t_raw, float gscale,
 //   loss = -log1p(-x) = softplus(l) = max(l,0) + log1p(exp(-|l|))  (the t*log(x) term is <= 1e-10).
 // fp32 saturation of the reference is kept: for l > 17.33 sigmoid rounds to exactly 1.0f, the
 // reference's log1p(-1) = -inf is clamped to -100 and its s(1-s) factor zeroes the gradient.
+// log(x) for 1 <= x <= 2 with the bits of __logf(x): OCML's log_f32 is v_log_f32 (log2) times ln 2 in two-term
+// arithmetic, wrapped in a scaling of denormal arguments and a test for infinities - neither can occur here, and the
+// wrapper is what made `e < 0.01f ? series : __logf(1 + e)` a BRANCH with 13 instructions + 2 s_nop on its far side,
+// taken by every wave (r6: the zero-target form below is 2 x this per cell pair, 1.8 k pairs per tile of the output layer).
+__device__ __forceinline__ float log_1_to_2(float x) {
+    const float y = __builtin_amdgcn_logf(x);
+    const float c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;      // ln 2 = c + cc (0x3f317217, 0x3377d1cf)
+    const float t = y * c;
+    return __builtin_fmaf(y, c, __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -t)));
+}
+
 __device__ __forceinline__ void bce_elem_t0(float l, float gscale, float& g, float& loss) {
     float e = __expf(-fabsf(l));
     float r = __builtin_amdgcn_rcpf(1.f + e);
     float s = l >= 0.f ? r : e * r;
-    float lp = e < 0.01f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+    const float lp_series = e * (1.f - e * (0.5f - e * 0.33333334f)), lp_log = log_1_to_2(1.f + e);
+    float lp = e < 0.01f ? lp_series : lp_log;
     g = s * gscale;
     loss = fmaxf(l, 0.f) + lp;
     if (l > 17.32868f) { g = 0.f; loss = 100.f; }
@@ -592,7 +604,7 @@ enum { kGemmF32 = 0, kGemmBf16 = 1, kGemmX3 = 2 };
 template <int AT, int BT, bool BIG, class Epi>
 inline hipError_t launch_gemm_mode(int mode, const GemmShape& g, const Epi& epi, int splits, hipStream_t s) {
     const bool bf16 = mode == kGemmBf16;
-    static const bool remap = getenv("AAE_NO_GEMM_REMAP") == nullptr;
+    constexpr bool remap = true;
     if (BIG && mode == kGemmX3) {
         GemmShape gg = g;
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);

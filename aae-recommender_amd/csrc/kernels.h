@@ -378,7 +378,7 @@ __global__ void slab_reduce_actbwd_kernel(const float* __restrict__ slabs, int n
         int r = i / h, c = i - r * h;
         float acc = 0.f;
         for (int z = 0; z < nslab; ++z) acc += slabs[(size_t)z * slab_stride + (size_t)r * ld + c];
-        acc *= act_grad_from_y(act, y[(size_t)r * ldy + c]);
+        acc *= act_grad_from_y<true>(act, y[(size_t)r * ldy + c]);
         if (d.enabled) acc *= drop_bwd_mul(d, drop_keep(d, key, r, c));
         out[(size_t)r * ld + c] = acc;
     }

@@ -40,7 +40,15 @@ extern "C" {
 
 /* activation ids: getattr(nn, activation) in aaerec/aae.py:110 */
 enum { AAE_ACT_RELU = 0, AAE_ACT_SELU = 1, AAE_ACT_TANH = 2, AAE_ACT_SIGMOID = 3,
-       AAE_ACT_ELU = 4, AAE_ACT_LEAKYRELU = 5 };
+       AAE_ACT_ELU = 4, AAE_ACT_LEAKYRELU = 5,
+       /* r6: the other parameter-free element-wise torch.nn classes, at their default arguments.  The layer programs of a model
+          with one of them run on the 16-row chain kernel (no 4-row / wide-batch kernel, no fused ranking launch -
+          aae_predict_topk takes its two-kernel form): supported, not tuned */
+       AAE_ACT_SOFTPLUS = 6, AAE_ACT_HARDTANH = 7, AAE_ACT_RELU6 = 8, AAE_ACT_CELU = 9, AAE_ACT_SOFTSIGN = 10,
+       AAE_ACT_HARDSIGMOID = 11, AAE_ACT_LOGSIGMOID = 12, AAE_ACT_SOFTSHRINK = 13, AAE_ACT_HARDSHRINK = 14,
+       AAE_ACT_IDENTITY = 15,
+       /* ... not monotone: the derivative is evaluated through a branch bit kept in the stored output's last place */
+       AAE_ACT_GELU = 16, AAE_ACT_SILU = 17, AAE_ACT_MISH = 18, AAE_ACT_HARDSWISH = 19, AAE_ACT_COUNT = 20 };
 /* encoder output activation: PRIOR_ACTIVATIONS, aaerec/aae.py:97-101 */
 enum { AAE_FINAL_LINEAR = 0, AAE_FINAL_SOFTMAX = 1, AAE_FINAL_SIGMOID = 2 };
 /* TORCH_OPTIMIZERS, aaerec/aae.py:216-219 */
@@ -166,6 +174,11 @@ typedef struct aae_tensor {
 
 int aae_abi_version(void);
 const char* aae_last_error(void);
+/* A switch of the library for the handles created FROM NOW ON (value NULL: back to the environment variable AAE_<name>, which
+   is what a handle reads otherwise).  Names: struct aae_options, csrc/abi_model.h - paths the parity suites force (NO_CHAIN,
+   SPLIT_ANY, BLOCKED_ANY, X16_ROWS, DW_KSPLIT_ROWS ...) and the diagnostics of debug runs (DEC_TS ...).  No counterpart in
+   the reference (it has no switches: one eager path); a handle reads its switches once, in aae_create. */
+int aae_set_option(const char* name, const char* value);
 
 /* construction: the nets + 4 optimisers of fit(), aae.py:782-804 */
 int aae_arena_bytes(const aae_config* cfg, size_t* bytes_out);

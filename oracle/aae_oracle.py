@@ -60,7 +60,41 @@ def act_fwd(name, x):
         return np.where(x > 0, x, np.expm1(np.minimum(x, f32(0)))).astype(f32)
     if name == "LeakyReLU":
         return np.where(x > 0, x, f32(0.01) * x).astype(f32)
+    # r6: the other parameter-free element-wise torch.nn classes at their default arguments (torch/nn/modules/activation.py)
+    if name == "Softplus":          # beta = 1, threshold = 20
+        return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, f32(20))))).astype(f32)
+    if name == "Hardtanh":
+        return np.clip(x, f32(-1), f32(1)).astype(f32)
+    if name == "ReLU6":
+        return np.clip(x, f32(0), f32(6)).astype(f32)
+    if name == "CELU":              # alpha = 1: max(0, x) + min(0, exp(x) - 1)
+        return np.where(x > 0, x, np.expm1(np.minimum(x, f32(0)))).astype(f32)
+    if name == "Softsign":
+        return (x / (f32(1) + np.abs(x))).astype(f32)
+    if name == "Hardsigmoid":       # relu6(x + 3) / 6
+        return np.clip(x / f32(6) + f32(0.5), f32(0), f32(1)).astype(f32)
+    if name == "LogSigmoid":
+        return (np.minimum(x, f32(0)) - np.log1p(np.exp(-np.abs(x)))).astype(f32)
+    if name == "Softshrink":        # lambda = 0.5
+        return np.where(x > 0.5, x - f32(0.5), np.where(x < -0.5, x + f32(0.5), f32(0))).astype(f32)
+    if name == "Hardshrink":        # lambda = 0.5
+        return np.where(np.abs(x) > 0.5, x, f32(0)).astype(f32)
+    if name == "Identity":
+        return x.astype(f32)
+    if name == "GELU":              # approximate = 'none': x Phi(x)
+        return (x * f32(0.5) * (f32(1) + _erf(x * f32(0.7071067811865476)))).astype(f32)
+    if name == "SiLU":
+        return (x * sigmoid(x)).astype(f32)
+    if name == "Mish":              # x tanh(softplus(x))
+        return (x * np.tanh(act_fwd("Softplus", x))).astype(f32)
+    if name == "Hardswish":         # x relu6(x + 3) / 6
+        return (x * np.clip(x + f32(3), f32(0), f32(6)) / f32(6)).astype(f32)
     raise ValueError("activation not covered by the oracle: " + name)
+
+
+def _erf(x):
+    from scipy.special import erf
+    return erf(x.astype(np.float64)).astype(f32)
 
 
 def act_bwd(name, x, y, g):
@@ -78,6 +112,37 @@ def act_bwd(name, x, y, g):
         return (g * np.where(x > 0, f32(1), y + f32(1))).astype(f32)
     if name == "LeakyReLU":
         return np.where(x > 0, g, f32(0.01) * g).astype(f32)
+    # r6 (derivatives as ATen's backward formulas state them, in the pre-activation x)
+    if name == "Softplus":
+        return (g * np.where(x > 20, f32(1), sigmoid(x))).astype(f32)
+    if name == "Hardtanh":
+        return np.where((x > -1) & (x < 1), g, f32(0)).astype(f32)
+    if name == "ReLU6":
+        return np.where((x > 0) & (x < 6), g, f32(0)).astype(f32)
+    if name == "CELU":
+        return (g * np.where(x > 0, f32(1), y + f32(1))).astype(f32)
+    if name == "Softsign":
+        return (g / np.square(f32(1) + np.abs(x))).astype(f32)
+    if name == "Hardsigmoid":
+        return np.where((x > -3) & (x < 3), g / f32(6), f32(0)).astype(f32)
+    if name == "LogSigmoid":
+        return (g * sigmoid(-x)).astype(f32)
+    if name == "Softshrink" or name == "Hardshrink":
+        return np.where(np.abs(x) > 0.5, g, f32(0)).astype(f32)
+    if name == "Identity":
+        return g.astype(f32)
+    if name == "GELU":
+        cdf = f32(0.5) * (f32(1) + _erf(x * f32(0.7071067811865476)))
+        pdf = f32(0.3989422804014327) * np.exp(f32(-0.5) * x * x)
+        return (g * (cdf + x * pdf)).astype(f32)
+    if name == "SiLU":
+        sg = sigmoid(x)
+        return (g * sg * (f32(1) + x * (f32(1) - sg))).astype(f32)
+    if name == "Mish":
+        t = np.tanh(act_fwd("Softplus", x))
+        return (g * (t + x * sigmoid(x) * (f32(1) - t * t))).astype(f32)
+    if name == "Hardswish":
+        return np.where(x < -3, f32(0), np.where(x <= 3, g * (x / f32(3) + f32(0.5)), g)).astype(f32)
     raise ValueError(name)
 
 

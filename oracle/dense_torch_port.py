@@ -21,7 +21,11 @@ import torch.nn.functional as F
 
 TINY = 1e-12
 _ACTS = {"ReLU": F.relu, "SELU": F.selu, "Tanh": torch.tanh, "Sigmoid": torch.sigmoid,
-         "ELU": F.elu, "LeakyReLU": F.leaky_relu}
+         "ELU": F.elu, "LeakyReLU": F.leaky_relu,
+         # r6: the other parameter-free element-wise classes, as getattr(nn, name)() evaluates them (aae.py:110)
+         "Softplus": F.softplus, "Hardtanh": F.hardtanh, "ReLU6": F.relu6, "CELU": F.celu, "Softsign": F.softsign,
+         "Hardsigmoid": F.hardsigmoid, "LogSigmoid": F.logsigmoid, "Softshrink": F.softshrink, "Hardshrink": F.hardshrink,
+         "Identity": lambda x: x, "GELU": F.gelu, "SiLU": F.silu, "Mish": F.mish, "Hardswish": F.hardswish}
 
 
 def init_params(n_items, n_hidden, n_code, cond_inc=0, seed=0):

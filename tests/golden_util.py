@@ -17,6 +17,12 @@ STEP_CASES = [
 # trainable CategoricalCondition variants (SparseAdam / mean / single index / behind a constant block)
 CAT_CASES = ["step_cat_sparse_sum", "step_cat_sparse_mean", "step_cat_single", "step_concat_cat"]
 
+# r6: one reference run per further class name getattr(nn, activation)() accepts (aae.py:110) that the kernels cover
+# (tools/gen_golden.py acts); the last four are not monotone: their derivative goes through the stored output's branch bit
+ACT_CASES = ["step_act_" + a for a in (
+    "softplus", "hardtanh", "relu6", "celu", "softsign", "hardsigmoid", "logsigmoid", "softshrink", "hardshrink", "identity",
+    "elu", "leakyrelu", "sigmoid", "gelu", "silu", "mish", "hardswish")]
+
 NET_KEYS = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "lin3.weight", "lin3.bias"]
 
 
@@ -84,23 +90,34 @@ class Fixture:
         return out
 
 
-_RENDEZVOUS_TROUBLE = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "connect() timed out",
-                       "Socket Timeout", "timed out", "Broken pipe")
+# Errors of the rendezvous itself - the port a probe socket read back was taken before the ranks bound it, or the store was
+# not up yet.  Nothing that a hung or crashed COLLECTIVE also prints ("timed out", "Broken pipe", "Connection reset": ADVICE r5 -
+# a real intermittent distributed bug must fail the test, not be retried into green).
+_RENDEZVOUS_TROUBLE = ("Address already in use", "EADDRINUSE", "Connection refused", "connect() timed out",
+                       "The server socket has failed to listen", "failed to bind")
 
 
 def spawn_ranks(worker, world, args_for_port, attempts=3):
     """mp.spawn of `world` ranks on a free rendezvous port: args_for_port(port) -> the worker's arguments.  A port read back from a
     probe socket can be taken by someone else before the ranks bind it (seen once in this suite): a spawn that dies with a
-    RENDEZVOUS error - not an assertion of the test - is repeated on a new port."""
+    BIND / CONNECT error of the rendezvous - not an assertion of the test, not a collective's time-out - is repeated on a new port,
+    with the shared result dicts of the failed attempt emptied, and says so."""
+    import sys
     import torch.multiprocessing as mp
     for attempt in range(attempts):
         port = free_port()
+        args = args_for_port(port)
         try:
-            mp.spawn(worker, args=args_for_port(port), nprocs=world, join=True)
+            mp.spawn(worker, args=args, nprocs=world, join=True)
             return
         except Exception as e:      # noqa: BLE001 - ProcessRaisedException / ProcessExitedException carry the worker's traceback as text
             text = str(e)
             if attempt + 1 < attempts and "AssertionError" not in text and any(t in text for t in _RENDEZVOUS_TROUBLE):
+                for a in args:      # (manager dicts the dead ranks may have written to)
+                    if hasattr(a, "keys") and hasattr(a, "clear"):
+                        a.clear()
+                print(f"spawn_ranks: rendezvous on port {port} failed ({text.strip().splitlines()[-1][:120]}); attempt {attempt + 2} of {attempts}",
+                      file=sys.stderr)
                 continue
             raise
 

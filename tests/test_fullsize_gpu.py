@@ -616,6 +616,71 @@ def test_c4_bench_shape_fit_path_matches_oracle(dtype, monkeypatch):
         assert _maxdiff(got, want) <= 2e-3, _maxdiff(got, want)
 
 
+@pytest.mark.parametrize("B", [2000, 10000])
+def test_reference_drivers_large_batches_through_fit_match_oracle(B, monkeypatch):
+    """The batch sizes of the reference's own drivers beyond one fused launch AND beyond the row-blocked form (1 664 rows):
+    eval/aminer.py:62 trains with batch_size 10 000, and 2 000 is the first size past the row-blocked limit.  There the output
+    layer is the three streaming GEMMs on the emulated product (gemm_x3_kernel: logits + BCE epilogue, dA2 as split-K slabs,
+    dV3 + dec_optim), the hidden stacks run on the 16-row chain kernel, the first layer's update takes the wave-per-item form -
+    r1-r5 pinned that path up to 260 rows only.  AdversarialAutoEncoder(batch_size=B).fit() on a 20 000-item
+    vocabulary, two steps with the host's draws (rng_mode='reference') recorded and replayed through the oracle on the same
+    permutation batches: losses at 1e-5, every parameter at 1e-5 per 1e-3 of learning rate, predictions at 1e-5."""
+    from aaerec import _hip
+    from aaerec.aae import AdversarialAutoEncoder
+    from oracle.dense_torch_port import DenseTorchAAE
+    from tools.synth import throughput_corpus
+    N, h, c, steps = 20000, 200, 50, 2
+    X = throughput_corpus(steps * B, N, median_len=20, seed=61)
+    kw = dict(dropout=(0.2, 0.2), gen_lr=1e-3, reg_lr=1e-3)
+    model = AdversarialAutoEncoder(n_hidden=h, n_code=c, batch_size=B, n_epochs=1, verbose=False, rng_mode="reference", **kw)
+    seen = {"params": None, "draws": [], "create": None}
+    load0, host0, init0 = _hip.HipAAE.load_params, AdversarialAutoEncoder._host_randomness, _hip.HipAAE.__init__
+
+    def load_params(self, params):
+        if seen["params"] is None:
+            seen["params"] = {k: np.array(v, copy=True) for k, v in params.items()}
+        return load0(self, params)
+
+    def host_randomness(self, rows):
+        masks, z_real = host0(self, rows)
+        seen["draws"].append(([m.numpy().copy() for m in masks], z_real.numpy().copy()))
+        return masks, z_real
+
+    def init(self, *a, **k):
+        seen["create"] = dict(k)
+        return init0(self, *a, **k)
+    monkeypatch.setattr(_hip.HipAAE, "load_params", load_params)
+    monkeypatch.setattr(_hip.HipAAE, "__init__", init)
+    monkeypatch.setattr(AdversarialAutoEncoder, "_host_randomness", host_randomness)
+    np.random.seed(6)
+    state = np.random.get_state()
+    torch.manual_seed(12)
+    losses = [model.hip.losses() for _ in model.fit_steps(X)]
+    np.random.set_state(state)
+    perm = np.arange(steps * B)
+    np.random.shuffle(perm)                              # fit()'s epoch permutation (aae.py:813-817 of the reference)
+    assert len(losses) == steps and len(seen["draws"]) == steps and seen["create"]["max_batch"] == B
+    # (the checker is the PyTorch-CPU port in the reference's dense formulation - oracle/dense_torch_port.py, held to the
+    #  reference's fixtures by tests/test_oracle_golden.py like the NumPy oracle, and multi-threaded: 2e8 cells per step)
+    ora = DenseTorchAAE(seen["params"], **kw)
+    for s in range(steps):
+        Xb = X[perm[s * B:(s + 1) * B]]
+        masks, z_real = seen["draws"][s]
+        want = ora.partial_fit(Xb.toarray().astype(np.float32), z_real, masks)
+        np.testing.assert_allclose(losses[s], want, rtol=1e-5, atol=1e-6, err_msg=f"B={B}: losses, step {s}")
+    sd, ref = model.hip.state_dict(), ora.state_dict()
+    worst = {k: _maxdiff(sd[k], w) for k, w in ref.items()}
+    print(f"B={B} through fit(): max |device - reference port| per tensor:", worst)
+    # (1e-5 per 1e-3 of learning rate, as everywhere; at 10 000 rows the discriminator's first layer sums 20 000 signed terms per
+    #  element and Adam's first steps move an element by ~lr whatever its gradient's size - measured 9.5e-6 on ONE element of
+    #  disc.lin1 against MKL on this box's thread count: a handful of elements may reach 3e-5, none beyond)
+    for k, w in ref.items():
+        d = np.abs(sd[k].astype(np.float64) - w)
+        assert d.max() <= 3e-5 and int((d > 1e-5).sum()) <= 4, (k, float(d.max()), int((d > 1e-5).sum()))
+    Xp = X[:512]
+    np.testing.assert_allclose(model.predict(Xp), ora.predict(Xp.toarray().astype(np.float32)), atol=1e-5)
+
+
 class _IdentityDist:
     """torch.distributed stand-in of ONE rank of `world`: all-reduce = identity (the other ranks' partial sums are zero)."""
     class ReduceOp:

@@ -3,7 +3,7 @@ real reference (tools/gen_golden.py).  Runs without a GPU."""
 import numpy as np
 import pytest
 
-from golden_util import CAT_CASES, STEP_CASES, Fixture
+from golden_util import ACT_CASES, CAT_CASES, STEP_CASES, Fixture
 from oracle import aae_oracle as O
 
 TOL_LOSS = 2e-6     # relative, fp32 summation order only
@@ -30,7 +30,7 @@ def build_oracle(fx):
     return O.OracleAAE(fx.init_params(), conditions=conds, **fx.model_kwargs())
 
 
-@pytest.mark.parametrize("name", STEP_CASES + CAT_CASES)
+@pytest.mark.parametrize("name", STEP_CASES + CAT_CASES + ACT_CASES)
 def test_oracle_reproduces_reference_steps(name):
     fx = Fixture(name)
     m = build_oracle(fx)

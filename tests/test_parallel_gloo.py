@@ -737,6 +737,18 @@ def _worker_shard_rng(rank, world, port, ret):
     ret[f"agreed{rank}"] = all(torch.equal(every[0], e) for e in every)
     ret[f"own{rank}"] = bool(torch.equal(flat, mine))
     ret[f"dtypes{rank}"] = (str(masks[0].dtype), str(z_real.dtype), tuple(z_real.shape), tuple(masks[0].shape))
+    # a model without a prior: AutoEncoder._host_randomness returns (masks, None) - only the masks travel
+    from aaerec.aae import AutoEncoder
+    ae = AutoEncoder(n_hidden=fx.cfg["h"], n_code=fx.cfg["c"], dropout=(0.2, 0.0), rng_mode="reference", verbose=False)
+    own_ae = ae._host_randomness(24)
+    assert own_ae[1] is None
+    m_ae, z_ae = sh.agree_randomness(*own_ae)
+    flat = torch.cat([m.reshape(-1).float() for m in m_ae if m is not None])
+    mine = torch.cat([m.reshape(-1).float() for m in own_ae[0] if m is not None])
+    every = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(every, flat)
+    ret[f"ae{rank}"] = (z_ae is None, all(torch.equal(every[0], e) for e in every), bool(torch.equal(flat, mine)),
+                        [m is None for m in m_ae] == [m is None for m in own_ae[0]])
     dist.destroy_process_group()
 
 
@@ -750,6 +762,7 @@ def test_item_sharded_ranks_with_different_generators_apply_rank_zeros_draws():
         got = dict(ret)
     assert got["agreed0"] and got["agreed1"]
     assert got["own0"] and not got["own1"]
+    assert got["ae0"] == (True, True, True, True) and got["ae1"] == (True, True, False, True)
     fx = Fixture("step_masks")
     assert got["dtypes0"] == got["dtypes1"] == ("torch.uint8", "torch.float32", (24, fx.cfg["c"]), (24, fx.cfg["h"]))
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import STEP_CASES, Fixture
+from golden_util import ACT_CASES, STEP_CASES, Fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ def check_state(fx, m, s, name):
         np.testing.assert_allclose(gv, ev, atol=1e-12, rtol=2e-4, err_msg=f"{name} {tag} v {k}")
 
 
-@pytest.mark.parametrize("name", FUSED_CASES)
+@pytest.mark.parametrize("name", FUSED_CASES + ACT_CASES)
 def test_step_matches_reference(name):
     fx = Fixture(name)
     m = make_model(fx)

@@ -1,0 +1,8 @@
+set -x
+L=$PWD/aae-recommender_amd/aaerec
+for v in base j4; do AAE_HIP_LIB=$L/libaaerec_hip_$v.so python tools/debug/r6_bits.py 2>&1 | tail -1; done
+for v in base j4; do AAE_HIP_LIB=$L/libaaerec_hip_$v.so B=512 python tools/debug/r6_bits.py 2>&1 | tail -1; done
+for v in base j4; do AAE_HIP_LIB=$L/libaaerec_hip_$v.so AAE_DEC_TS=x3 python tools/debug/dec_ts.py 2>&1 | grep dec_crit | tail -2; done
+AAE_HIP_LIB=$L/libaaerec_hip_j4.so timeout -k 10 600 python -m pytest tests/test_parity_abi_gpu.py -x -q -k "split_output_layer or fused_decoder_equals or late_join" 2>&1 | tail -3
+AAE_HIP_LIB=$L/libaaerec_hip_j4.so timeout -k 10 600 python -m pytest tests/test_fullsize_gpu.py -x -q -k "c3" 2>&1 | tail -3
+bash tools/debug/ab_libs2.sh base j4 2>&1

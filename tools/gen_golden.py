@@ -1034,6 +1034,10 @@ def gen_vae(only=None):
     print("e2e_vae_short written")
 
 
+ACT_NAMES = ["Softplus", "Hardtanh", "ReLU6", "CELU", "Softsign", "Hardsigmoid", "LogSigmoid", "Softshrink", "Hardshrink",
+             "Identity", "GELU", "SiLU", "Mish", "Hardswish", "ELU", "LeakyReLU", "Sigmoid"]
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_aae, ref_cond = import_reference()
@@ -1064,6 +1068,12 @@ def main():
         # one wider case so multi-tile kernel paths are pinned too
         run_case(ref_aae, ref_cond, "step_wide", seed=15, N=1100, h=72, c=24, B=40, steps=2,
                  dropout=(0.2, 0.2), batch_kw=dict(max_len=20), capture_acts=False, states='last')
+    if want("acts"):
+        # r6: one case per further activation class name the reference's getattr(nn, activation)() accepts (aae.py:110) and the
+        # kernels cover; small states (last step only) - what differs from step_masks is the activation and its derivative
+        for i, a in enumerate(ACT_NAMES):
+            run_case(ref_aae, ref_cond, "step_act_" + a.lower(), seed=60 + i, activation=a, dropout=(0.2, 0.2),
+                     capture_acts=False, states='last')
     if want("headline"):
         # the headline layer widths (h=200, c=50, batch 100: 13 column blocks in the layer chains and in the fused
         # decoder output layer, 7 row blocks) on a small vocabulary, straight from the reference
