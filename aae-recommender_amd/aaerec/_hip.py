@@ -167,6 +167,9 @@ _PROTOS = {
                                  C.POINTER(AaeRngInject), C.c_float, C.c_void_p]),
     "aae_memcpy_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aae_echo_collectives": (C.c_int, [C.c_int32, C.POINTER(AaeCollectives)]),
+    "aae_ipc_create": (C.c_int, [C.c_int64, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "aae_ipc_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(AaeCollectives)]),
+    "aae_ipc_destroy": (C.c_int, [C.POINTER(AaeCollectives), C.c_void_p]),
     "aae_set_input_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aae_prefetch_batch": (C.c_int, [C.c_void_p, C.POINTER(AaeBatch)]),
     "aae_set_split": (C.c_int, [C.c_void_p, C.c_int32]),

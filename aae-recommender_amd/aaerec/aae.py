@@ -265,7 +265,10 @@ class AdversarialAutoEncoder:
                 if shard:
                     # ONE training handle per rank: its item slice of both vocabulary-wide layers + the hidden layers, the
                     # whole global batch through it, three all-reduces of partial sums per step (parallel.ItemShardedAAE)
-                    self._dp = ItemShardedAAE(self.hip, self._slice, dist, n_items, group=dist_group, interleaved=True)
+                    # (dp_collectives = 'ipc', an attribute like _unfused_decoder: the three all-reduces as one-shot launches over
+                    #  peer-mapped mailboxes - parallel.ipc_collectives, the ranks of one node)
+                    self._dp = ItemShardedAAE(self.hip, self._slice, dist, n_items, group=dist_group, interleaved=True,
+                                              collectives=getattr(self, "dp_collectives", None), max_rows=self.batch_size)
                 else:
                     self._dp = VocabParallelAAE(self.hip, self._slice, dist, n_items, group=dist_group,
                                                 shard_first_layer=self.dp_mode == "vocab", interleaved=True)

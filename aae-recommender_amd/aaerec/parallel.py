@@ -602,7 +602,10 @@ class ItemShardedAAE:
     fills it from the slices; it takes no part in a step."""
     shard_first = True
 
-    def __init__(self, model, slice_model, dist, n_items, group=None, interleaved=True):
+    def __init__(self, model, slice_model, dist, n_items, group=None, interleaved=True, collectives=None, max_rows=None):
+        """collectives='ipc' (r6): the three all-reduces as one-shot launches over peer-mapped mailboxes (ipc_collectives: the
+        ranks of ONE node; max_rows = the largest global batch) instead of the backend's own - RCCL's ring under 'nccl', host
+        staging under 'gloo'; falls back to those when a mailbox cannot be shared."""
         self.model, self.slice, self.dist, self.group = model, slice_model, dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -621,6 +624,14 @@ class ItemShardedAAE:
             # a stand-in without the library behind it (the CPU models of tests/test_parallel_gloo.py): it gets the
             # torch.distributed-like object itself and all-reduces its three partial sums through it
             self._native = (dist, group)
+        elif collectives == "ipc" and self.world > 1:
+            ld = slice_model.a1_rows(1).stride(0)
+            rows = int(max_rows if max_rows is not None else slice_model.max_batch)
+            self._native_keep = ipc_collectives(slice_model, getattr(dist, "d", dist), rows * ld, group)     # (HostStagedCollectives: its gloo group)
+            if self._native_keep is not None:
+                self._native = self._native_keep.table
+        if self._native is not None:
+            pass
         elif backend == "nccl":
             self._native_keep = rccl_collectives(slice_model, dist, group)
             if self._native_keep is not None:
@@ -832,6 +843,76 @@ def rccl_collectives(model, dist, group=None):
             owner.close()
         return give_up("ncclCommInitRank", err)
     return owner
+
+
+class IpcTable:
+    """Owner of an aae_collectives table over peer-mapped mailboxes (aae_ipc_*): close() is COLLECTIVE - a barrier first, so
+    that no peer still reads this rank's mailbox when it is freed."""
+
+    def __init__(self, lib, table, mailbox, dist, group):
+        self.lib, self.table, self.mailbox, self.dist, self.group = lib, table, mailbox, dist, group
+
+    def close(self):
+        tab, self.table = self.table, None
+        if tab is None:
+            return
+        import ctypes as C
+        from . import _hip
+        import torch
+        torch.cuda.synchronize()
+        self.dist.barrier(group=self.group)
+        _hip._check(self.lib.aae_ipc_destroy(C.byref(tab), self.mailbox))
+
+
+def ipc_collectives(model, dist, max_floats, group=None):
+    """An aae_collectives table whose all_reduce is ONE launch over mailboxes every rank of the node maps (csrc/ipc_collectives.h):
+    for the three small all-reduces of dp_mode='shard'.  Every rank allocates a mailbox, torch.distributed carries the 64-byte
+    IPC handles to the peers (all_gather of uint8 tensors - any backend), every rank maps the others'.  Returns an IpcTable (call
+    close() on every rank when done) or None when the ranks agree that a mailbox could not be shared everywhere."""
+    import ctypes as C
+    import torch
+    from . import _hip
+    lib = model.lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nccl = str(dist.get_backend(group)).lower() == "nccl"
+    dev = model.device if nccl else torch.device("cpu")
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+    handle, mailbox, err = C.create_string_buffer(64), C.c_void_p(), None
+    try:
+        with model._on_device():
+            _hip._check(lib.aae_ipc_create(int(max_floats), handle, C.byref(mailbox)))
+    except Exception as e:              # noqa: BLE001 - agreed on below, by every rank
+        err = e
+    if not agree(err is None):
+        if err is None:
+            lib.aae_ipc_destroy(None, mailbox)
+        return None
+    mine = torch.frombuffer(bytearray(handle.raw), dtype=torch.uint8).to(dev)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(every, mine, group=group)
+    else:
+        every = [mine]
+    blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in every)
+    tab = _hip.AaeCollectives()
+    try:
+        with model._on_device():
+            _hip._check(lib.aae_ipc_init(mailbox, C.create_string_buffer(blob, 64 * world), world, rank, int(max_floats), C.byref(tab)))
+    except Exception as e:              # noqa: BLE001
+        err = e
+    if not agree(err is None):
+        if err is None:
+            dist.barrier(group=group)
+            lib.aae_ipc_destroy(C.byref(tab), mailbox)
+        else:
+            lib.aae_ipc_destroy(None, mailbox)
+        return None
+    return IpcTable(lib, tab, mailbox, dist, group)
 
 
 def python_collectives(model, dist, group=None):

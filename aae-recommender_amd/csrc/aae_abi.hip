@@ -157,6 +157,16 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
             hipError_t e3 = aae_attr2(reinterpret_cast<const void*>(dec_fused_kernel<13>), reinterpret_cast<const void*>(dec_fused_kernel<13, kDecFused, true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
             hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 2048);
             m->bucket_wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bucket_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds - 16384) == hipSuccess;
+            {   //  the wide bucket builder keeps other workgroups off its CU by its register count (buckets.h: a clobber of
+                // v127) on top of its LDS claim: say so once if a compiler stops honouring the clobber - results do not depend on it
+                hipFuncAttributes fa;
+                static bool told = false;
+                if (m->bucket_wide_ok && !told && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(tile_bucket_wide_kernel)) == hipSuccess && fa.numRegs < 121) {
+                    told = true;
+                    fprintf(stderr, "aaerec: tile_bucket_wide_kernel allocates %d vector registers, not the 128 it claims to keep its CU to itself (buckets.h)\n", fa.numRegs);
+                }
+                (void)hipGetLastError();
+            }
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) m->fused_ok = false;
             if (m->bf16 &&
                 (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fused_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess ||
@@ -493,3 +503,4 @@ int aae_sync(aae_handle h, void* stream) {
 #include "abi_data_parallel.h"
 
 #include "dp_step.h"
+#include "ipc_collectives.h"

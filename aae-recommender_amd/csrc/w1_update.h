@@ -337,7 +337,8 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
     const int ustep = vgrid * 4;
     int round = 0;
     W1_STAMP(1);
-    for (int u = vblock + wv * vgrid; u < cnt; u += ustep, ++round) {
+    constexpr int kRounds = kW1HybWords * 32 / 4;      // rounds the bitmap of deferred items holds
+    for (int u = vblock + wv * vgrid; u < cnt && round < kRounds; u += ustep, ++round) {
         const int item = a.ulist[u];
         const int tile = item / kTI, it = item - tile * kTI;
         const int e0 = a.tstart[tile], e1 = a.tstart[tile + 1];
@@ -423,11 +424,14 @@ __device__ __forceinline__ void w1_item_hybrid_body(const W1Items& a, unsigned* 
     W1_STAMP(6);
     // the deferred items, in (round, wave) order, with all four waves
     const int rounds = vblock < cnt ? (cnt - vblock + ustep - 1) / ustep : 0;      // (of wave 0, the one with the most)
-    const int nbits = min(rounds * 4, kW1HybWords * 32);
+    const int nbits = min(rounds, kRounds) * 4;
     for (int b = 0; b < nbits; ++b) {
         if (!((defer[b >> 5] >> (b & 31)) & 1u)) continue;             // (uniform: LDS word read by every thread)
         w1_item_update_one(a, lds, vblock + (b & 3) * vgrid + (b >> 2) * ustep, s, upd);
     }
+    //  a launch so narrow that its list takes more rounds than the bitmap holds - the host sizes launches so that none
+    // is (abi_chains.h), but no item may be lost to a caller that does not: the rest of the list in the workgroup form, in order
+    for (int u = vblock + kRounds * ustep; u < cnt; u += vgrid) w1_item_update_one(a, lds, u, s, upd);
     W1_STAMP(7);
 }
 

@@ -211,6 +211,41 @@ def timed_steps(it, k, barrier):
     return time.perf_counter() - t0
 
 
+def collective_breakdown(model, it, extra_steps, barrier, dist, world, dev):
+    """N > 1: what the step spends in its collectives (event pairs on the step's stream around every call of the collectives
+    table, a pass of its own behind the timed region): per rank the time from "this rank reaches the collective" to "it has
+    the result" - the transfer AND the wait for the slowest rank.  The rank that waits least is the one the others wait for:
+    min over ranks ~ the collective itself, max - min ~ the ranks' skew; step time minus a rank's collective time = its compute."""
+    handles = [hh for hh in (model.hip, model._slice) if hh is not None]
+    for hh in handles:
+        hh.profile_enable(True, kernels=(K_COLL,))
+    t0 = time.perf_counter()
+    for _ in range(extra_steps):
+        next(it)
+    barrier()
+    wall_c = time.perf_counter() - t0
+    ms_c = n_c = 0
+    for hh in handles:
+        hh.profile_enable(False)
+        ms, n = hh.profile_read(K_COLL)
+        ms_c, n_c = ms_c + ms, n_c + n
+    if not n_c:
+        return None
+    per_step = ms_c / extra_steps
+    lo = hi = per_step
+    if dist is not None and world > 1:
+        t = torch.tensor([per_step, -per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hi, lo = float(t[0].item()), -float(t[1].item())
+    step_ms = wall_c / extra_steps * 1e3
+    return dict(collectives_per_step=round(n_c / extra_steps, 2), collective_us_avg_rank0=round(ms_c / n_c * 1e3, 2),
+                collective_ms_per_step_rank0=round(per_step, 4), collective_ms_per_step_min_over_ranks=round(lo, 4),
+                collective_ms_per_step_max_over_ranks=round(hi, 4), ms_per_step_this_pass=round(step_ms, 4),
+                compute_ms_per_step_slowest_rank=round(step_ms - lo, 4),
+                note="event pairs around the collectives table's calls, a pass of its own (not the timed region); a rank's "
+                     "collective time includes its wait for the slowest rank")
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -318,39 +353,7 @@ def main():
     model.hip.profile_enable(False)
     collect((K_GATHER, K_W1, K_CHAIN), extra_steps, time.perf_counter() - t0, model.hip)
 
-    # N > 1: what the step spends in its collectives (event pairs on the step's stream around every call of the collectives
-    # table, a pass of its own behind the timed region): per rank the time from "this rank reaches the collective" to "it has
-    # the result" - the transfer AND the wait for the slowest rank.  The rank that waits least is the one the others wait for:
-    # min over ranks ~ the collective itself, max - min ~ the ranks' skew; step time minus a rank's collective time = its compute.
-    dp_breakdown = None
-    if use_dp:
-        handles = [hh for hh in (model.hip, model._slice) if hh is not None]
-        for hh in handles:
-            hh.profile_enable(True, kernels=(K_COLL,))
-        t0 = time.perf_counter()
-        for _ in range(extra_steps):
-            next(it)
-        barrier()
-        wall_c = time.perf_counter() - t0
-        ms_c = n_c = 0
-        for hh in handles:
-            hh.profile_enable(False)
-            ms, n = hh.profile_read(K_COLL)
-            ms_c, n_c = ms_c + ms, n_c + n
-        if n_c:
-            per_step = ms_c / extra_steps
-            lo = hi = per_step
-            if dist is not None and world > 1:
-                t = torch.tensor([per_step, -per_step], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                hi, lo = float(t[0].item()), -float(t[1].item())
-            step_ms = wall_c / extra_steps * 1e3
-            dp_breakdown = dict(collectives_per_step=round(n_c / extra_steps, 2), collective_us_avg_rank0=round(ms_c / n_c * 1e3, 2),
-                                collective_ms_per_step_rank0=round(per_step, 4), collective_ms_per_step_min_over_ranks=round(lo, 4),
-                                collective_ms_per_step_max_over_ranks=round(hi, 4), ms_per_step_this_pass=round(step_ms, 4),
-                                compute_ms_per_step_slowest_rank=round(step_ms - lo, 4),
-                                note="event pairs around the collectives table's calls, a pass of its own (not the timed region); a rank's "
-                                     "collective time includes its wait for the slowest rank")
+    dp_breakdown = collective_breakdown(model, it, extra_steps, barrier, dist, world, dev) if use_dp else None
 
     peak_tf = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
     roofline = roofline_critical = None
@@ -366,11 +369,14 @@ def main():
             r = dict(kernel=name, bound="mfma", achieved=ks["TFLOPs"], peak=peak_tf, unit="TFLOP/s", frac=round(mfma_frac, 4),
                      traffic=None)
         r["avg_us"] = ks["avg_us"]
-        if name == "dec_crit" and a.dtype == "f32":
-            # (r3: the launch multiplies on the bf16 matrix cores, six bf16 products per fp32 product - csrc/dec_crit_x3.h; the
-            #  ceiling of that arithmetic next to the fp32 pipe's, which `peak` stays: the line's dtype is f32)
-            r["peak_emulated"] = round(MFMA_BF16_PEAK_TF / 6.0, 1)
-            r["frac_emulated"] = round(ks["TFLOPs"] / (MFMA_BF16_PEAK_TF / 6.0), 4)
+        if name == "dec_crit" and a.dtype == "f32" and r["bound"] == "mfma":
+            # (r3: the launch multiplies on the bf16 matrix cores, six bf16 products per fp32 product - csrc/dec_crit_x3.h.  r6,
+            #  `peak` / `frac` are the ceiling of THAT arithmetic - the pipe the kernel runs on; the fp32 pipe's figure,
+            #  which it no longer uses, stays beside them)
+            r["peak_fp32_mfma"], r["frac_fp32_mfma"] = r["peak"], r["frac"]
+            r["peak"] = round(MFMA_BF16_PEAK_TF / 6.0, 1)
+            r["frac"] = round(ks["TFLOPs"] / (MFMA_BF16_PEAK_TF / 6.0), 4)
+            r["peak_note"] = "dense bf16 MFMA peak / 6: an fp32 product is six bf16 matrix instructions (three-term split)"
         return r
     if kstats:
         # the dominant kernel = the one with the largest share of launch-to-completion time.  In the split form of the
@@ -396,6 +402,7 @@ def main():
                         if r is not None and r["traffic"] is None and r["kernel"] in pmc["kernels"]:
                             r["traffic"] = pmc["kernels"][r["kernel"]]["traffic_bytes"]
                             r["traffic_source"] = "profiles/" + name
+                            r["traffic_in_run"] = False      # (a counter pass cannot share a run with the timed region)
             except (OSError, ValueError, KeyError):
                 pass
 
@@ -578,11 +585,12 @@ def main():
                 us = ms_r / n_r * 1e3
                 fl, by = 2.0 * rows_pc * N * (h + 1), 4.0 * N * (h + 1)
                 tf = fl / us * 1e-6
-                pt["roofline"] = dict(kernel="rank_x3", bound="mfma", achieved=round(tf, 2), peak=peak_tf, unit="TFLOP/s",
-                                      frac=round(tf / peak_tf, 4), avg_us=round(us, 2), traffic=None,
+                emu = MFMA_BF16_PEAK_TF / 6.0     # (f32: six bf16 matrix instructions per product, as roofline_critical)
+                pk = emu if a.dtype == "f32" else peak_tf
+                pt["roofline"] = dict(kernel="rank_x3", bound="mfma", achieved=round(tf, 2), peak=round(pk, 1), unit="TFLOP/s",
+                                      frac=round(tf / pk, 4), avg_us=round(us, 2), traffic=None,
                                       algorithmic_flops=fl, algorithmic_bytes=by, GBps=round(by / us * 1e-3, 1),
-                                      **({"peak_emulated": round(MFMA_BF16_PEAK_TF / 6.0, 1),
-                                          "frac_emulated": round(tf / (MFMA_BF16_PEAK_TF / 6.0), 4)} if a.dtype == "f32" else {}))
+                                      **({"peak_fp32_mfma": peak_tf, "frac_fp32_mfma": round(tf / peak_tf, 4)} if a.dtype == "f32" else {}))
             extra["predict_topk"] = pt
 
     cpu = None
@@ -620,6 +628,41 @@ def main():
                    sample=f"{done} partial_fit steps of batch {B} (toarray + dense fp32 PyTorch-CPU step, no conditions), "
                           f"{el:.1f} s, {cores} intra-op threads (fastest of {cands} on a {host_cores}-core host)")
 
+    # N > 1 (r6): the OTHER data-parallel scheme in the same run - the default line is `shard` (item slices, three
+    # all-reduces of partial sums), the north star's wording is `replicated` (full replicas, RCCL reduce-scatter / all-gather of
+    # the decoder gradient overlapped with backward): the first multi-GPU run measures both.  Same steps, same bracketing
+    # (barrier + synchronize, MAX over ranks), a full dp_breakdown; AAE_BENCH_EXTRAS without "dp_other" skips it.
+    dp_desc = None
+    if use_dp:          # (what the output says about the MAIN line's scheme: read before its model goes)
+        dp_desc = dict(shard_first=bool(getattr(model._dp, "shard_first", False)),
+                       comm=model._dp.comm_stats() if hasattr(model._dp, "comm_stats") else None,
+                       native=getattr(model._dp, "_native", None) is not None)
+    dp_other = None
+    if use_dp and world > 1 and not a.no_extra and "dp_other" in os.environ.get("AAE_BENCH_EXTRAS", "dp_other").split(","):
+        other = "replicated" if a.dp != "replicated" else "shard"
+        del it
+        for hh in (model.hip, model._slice):
+            if hh is not None:
+                hh.close()
+        del model
+        torch.cuda.empty_cache()
+        a2 = argparse.Namespace(**vars(a))
+        a2.dp = other
+        model2 = make_model(a2, Bg, dist, conditions=conditions)
+        with contextlib.redirect_stdout(sys.stderr):
+            it2 = model2.fit_steps(X, condition_data=cond_data)
+            next(it2)
+        for _ in range(a.warmup):
+            next(it2)
+        dts2 = [timed_steps(it2, a.steps, barrier) for _ in range(min(repeats, 3))]
+        dt2 = float(np.median(dts2))
+        t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt2 = float(t.item())
+        dp_other = dict(dp=other, value=round(a.steps * Bg / dt2, 1), unit="docs/s", ms_per_step=round(dt2 / a.steps * 1e3, 4),
+                        timed_repeats=len(dts2), dp_breakdown=collective_breakdown(model2, it2, min(a.steps, 40), barrier, dist, world, dev),
+                        **({"collectives_per_step": model2._dp.comm_stats()} if hasattr(model2._dp, "comm_stats") else {}))
+
     if rank == 0:
         cfg_name = ("C2 RCV1-scale" if a.dtype == "bf16" else "C4 EconBiz-scale + 300-d title condition" if a.cond_inc
                     else "C3 PubMed-scale")
@@ -647,7 +690,7 @@ def main():
                                        (f"dp{world}, item slices of both vocabulary-wide layers + replicated hidden stacks on the global batch, "
                                         f"3 all-reduces of partial sums per step" if a.dp == "shard" else
                                         f"dp{world}, decoder output layer and encoder first layer sharded over the vocabulary"
-                                        if getattr(model._dp, "shard_first", False) else
+                                        if dp_desc["shard_first"] else
                                         f"dp{world}, decoder output layer sharded over the vocabulary") if vocab else
                                        f"dp{world}, replicated decoder")},
             "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu, "kernels": kstats,
@@ -660,9 +703,13 @@ def main():
             out["extra"] = extra
         if dp_breakdown:
             out["dp_breakdown"] = dp_breakdown
-        if use_dp and hasattr(model._dp, "comm_stats"):
-            out["collectives_per_step"] = model._dp.comm_stats()
-            native = getattr(model._dp, "_native", None) is not None
+        if use_dp:
+            out["dp"] = a.dp
+        if dp_other:
+            out["dp_other"] = dp_other
+        if use_dp and dp_desc["comm"] is not None:
+            out["collectives_per_step"] = dp_desc["comm"]
+            native = dp_desc["native"]
             rccl = dist is not None and str(dist.get_backend()).lower() == "nccl"
             out["dp_step_driver"] = (("library call (" + ("aae_shard_step" if a.dp == "shard" else "aae_dp_step") + "), " + ("RCCL communicator of the library" if rccl else
                                                                          "collectives through host-staged callbacks (functional check)"))

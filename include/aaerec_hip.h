@@ -473,6 +473,17 @@ int aae_dp_step(aae_handle replica, aae_handle slice, const aae_collectives* col
  *   cond_dev    the condition block of ALL rows; inject as aae_step (masks / z_real of all rows) */
 int aae_shard_step(aae_handle h, const aae_collectives* coll, const aae_batch* batch, const aae_batch* next_batch,
                    const float* cond_dev, const aae_rng_inject* inject, float item_share, void* stream);
+/* r6: the same table as a ONE-SHOT all-reduce over peer-mapped mailboxes, for the ranks of one node and the small exchanges of
+ * aae_shard_step (csrc/ipc_collectives.h): every rank copies its operand into its own mailbox, publishes the call, waits for
+ * its peers' flags and adds the world mailboxes in rank order - one launch, one hop over xGMI, the same bits on every rank.
+ * all_reduce only (all_gather / reduce_scatter fail: aae_dp_step's exchanges are RCCL's).  No counterpart in the reference.
+ *   aae_ipc_create   allocates this rank's mailbox for operands of up to max_floats floats; handle_out: 64 bytes
+ *                    (hipIpcMemHandle_t) for the caller to carry to every peer (torch.distributed all_gather)
+ *   aae_ipc_init     handles = world x 64 bytes in rank order (this rank's own entry is not read); maps the peers' mailboxes
+ *   aae_ipc_destroy  after a barrier of the caller's (no peer may still read this rank's mailbox); reports a wait that timed out */
+int aae_ipc_create(int64_t max_floats, char handle_out[64], void** mailbox_out);
+int aae_ipc_init(void* mailbox, const char* handles, int32_t world, int32_t rank, int64_t max_floats, aae_collectives* out);
+int aae_ipc_destroy(aae_collectives* c, void* mailbox);
 /* a single-process stand-in table (measurement aid: one rank's compute with every exchange replaced by device copies of the
  * same shapes - all_gather = the operand repeated `world` times, reduce_scatter = its first chunk, all_reduce = identity;
  * rank 0 of `world`) */

@@ -1277,3 +1277,101 @@ def test_fit_on_two_ranks_through_the_python_step_driver(monkeypatch):
     GPU: same result as the default - the native aae_dp_step - checks against (test_fit_on_two_ranks_equals_...)."""
     monkeypatch.setenv("AAE_DP_PYTHON", "1")
     test_fit_on_two_ranks_equals_single_process("vocab", True)
+
+
+def _ipc_worker(rank, world, port, ret):
+    import ctypes as C
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "aae-recommender_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aaerec._hip import HipAAE
+    from aaerec.parallel import ipc_collectives
+    m = HipAAE(300, 20, 10, max_batch=16)                  # (the library handle, device and stream the table is built on)
+    cap = 800 * 204
+    owner = ipc_collectives(m, dist, cap)
+    assert owner is not None, "the mailboxes could not be shared between the two processes of this GPU"
+    tab = owner.table
+    gen = torch.Generator().manual_seed(100 + rank)
+    ok, worst = True, 0.0
+    for k, n in enumerate([4, 204 * 100, cap, 204 * 37, cap, 1024, 204 * 800, 8]):     # slots alternate by call; sizes up to the capacity
+        x = (torch.rand(n, generator=gen) * 2 - 1) * 10.0 ** (k % 3 - 1)
+        every = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(every, x)
+        want = every[0].clone()
+        for r in range(1, world):
+            want += every[r]                                # rank order: what the kernel adds, on every rank
+        buf = x.to(m.device)
+        rc = tab.all_reduce(tab.ctx, C.c_void_p(buf.data_ptr()), n, C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream))
+        assert rc == 0, m.lib.aae_last_error()
+        got = buf.cpu()
+        ok = ok and bool(torch.equal(got, want))
+        worst = max(worst, float((got - want).abs().max()))
+    ret[f"ok{rank}"], ret[f"worst{rank}"] = ok, worst
+    # an operand beyond the capacity / a collective the table does not carry: refused, not truncated
+    big = torch.zeros(cap + 4, device=m.device)
+    ret[f"refused{rank}"] = (tab.all_reduce(tab.ctx, C.c_void_p(big.data_ptr()), cap + 4, None) != 0,
+                             tab.all_gather(tab.ctx, C.c_void_p(big.data_ptr()), C.c_void_p(big.data_ptr()), 4, None) != 0)
+    owner.close()
+    dist.destroy_process_group()
+
+
+def test_one_shot_all_reduce_over_ipc_mailboxes_equals_the_rank_ordered_sum():
+    """r6: aae_ipc_* - the all-reduce of dp_mode='shard' as ONE launch over mailboxes every rank maps
+    (hipIpc), summed in rank order.  Two processes sharing this box's one GPU; eight calls of different sizes (the two slots
+    of a mailbox alternate) against the sum of the gloo-gathered operands in rank order: BITWISE equal on both ranks."""
+    import torch.multiprocessing as mp
+    with mp.get_context("spawn").Manager() as mgr:
+        ret = mgr.dict()
+        spawn_ranks(_ipc_worker, 2, lambda port: (2, port, ret))
+        got = dict(ret)
+    assert got["ok0"] and got["ok1"], (got["worst0"], got["worst1"])
+    assert got["refused0"] == (True, True) and got["refused1"] == (True, True)
+
+
+def _fit_ipc_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "aae-recommender_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import aaerec.aae                               # noqa: F401
+    from aaerec.parallel import HostStagedCollectives, IpcTable
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    m = _dp_model(True, data_parallel=HostStagedCollectives(dist), dp_mode="shard")
+    m.dp_collectives = "ipc"
+    m.fit(X)
+    pred = m.predict(X[:33])
+    if rank == 0:
+        ret["state"], ret["pred"], ret["loss"] = m.hip.state_dict(), pred, m.last_losses[0]
+    ret[f"ipc{rank}"] = isinstance(m._dp._native_keep, IpcTable)
+    m._dp._native_keep.close()
+    dist.destroy_process_group()
+
+
+def test_fit_on_two_ranks_through_the_ipc_all_reduce_equals_single_process():
+    """dp_mode='shard' with its three all-reduces per step as one-shot launches over the peers' mailboxes (dp_collectives='ipc')
+    instead of the host-staged gloo ones: the adversarial model, 15 steps on two ranks sharing the GPU, against one process -
+    the bounds of test_fit_on_two_ranks_equals_single_process."""
+    import torch.multiprocessing as mp
+    import aaerec.aae                               # noqa: F401
+    with mp.get_context("spawn").Manager() as mgr:
+        ret = mgr.dict()
+        spawn_ranks(_fit_ipc_worker, 2, lambda port: (2, port, ret))
+        got = dict(ret)
+    assert got["ipc0"] and got["ipc1"]
+    X = _dp_corpus()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    one = _dp_model(True)
+    one.fit(X)
+    want = one.hip.state_dict()
+    tol = 2e-4
+    for k, w in want.items():
+        d = np.abs(got["state"][k] - w)
+        assert (d > tol).sum() <= max(8, 0.01 * d.size) and d.max() < 0.02, f"{k}: {(d > tol).sum()} off, max {d.max():.2e}"
+    np.testing.assert_allclose(got["pred"], one.predict(X[:33]), atol=10 * tol)
+    assert abs(got["loss"] - one.last_losses[0]) < 1e-5
