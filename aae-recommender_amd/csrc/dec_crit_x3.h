@@ -63,6 +63,10 @@ constexpr int kXT = 32;        // row stride (floats) of the target tile [b][n]
 #define AAE_CRIT_BAL 1
 #endif
 constexpr bool kCritBal = AAE_CRIT_BAL != 0;   // hidden 200: the products dealt to the waves by SIMD (r6, see the kernel; 0: r5's map, A/B builds)
+#ifndef AAE_CRIT_G1PF
+#define AAE_CRIT_G1PF 1
+#endif
+constexpr bool kCritG1Pf = AAE_CRIT_G1PF != 0;  // GEMM1 with the next k-step's first fragments requested ahead (r6, see the kernel)
 constexpr int kBalRows = 4;                     // ... the row blocks from here on of column blocks 12 / 10 / 11 go to waves 13 / 14 / 15
 constexpr int kXRegSteps = 3;  // k-steps of a wave's dh2 fragments kept in registers (12 VGPRs each); further ones live in LDS
 inline size_t dec_crit_x3_lds_bytes(int NB) {
@@ -329,6 +333,47 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
                 for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
             }
         };
+        // (r6, kCritG1Pf) the same products with the NEXT k-step's first B fragment requested in front of the current step's six
+        // matrix instructions (NK = the wave's k-steps, a compile-time count): a wave's chain was read - wait ~100 clocks -
+        // multiply, and with the SIMD's four waves mostly in step the matrix pipe idled a quarter of the phase (in-kernel stamps:
+        // 1.68 us for 1.2 us of pipe time; 1.52 with this).  Only the FIRST term's fragment - what the step's first instruction
+        // needs - travels ahead: all three (12 registers) cost 20 spilled ones, and the third A term of the steps that keep it in
+        // LDS, or GEMM3's fragments a row block ahead, bought nothing (same-box, ms/step: 0.2310 | 0.2313 | 0.2321).
+        // Same instruction order per accumulator: same bits.
+        auto gemm1_pf = [&](auto NKc) {
+            constexpr int NK = decltype(NKc)::value;
+            float* rw = raw + kh * (kGR * kXRS) + (16 * mb1 + 4 * fkz) * kXRS + frz;
+            // (only the FIRST term's fragment travels a step ahead - the one the step's first matrix instruction needs; the other
+            //  two are requested at the step's start and arrive behind that instruction: 4 registers instead of 12)
+            bf16x8 b0n = x3_frag(v3K, frz, S1, kh, fkz);
+#pragma unroll
+            for (int nb2 = 0; nb2 < 2; ++nb2) {
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NK; ++j) {
+                    const int step = nb2 * NK + j;
+                    bf16x8 bb[3];
+                    bb[0] = b0n;
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) bb[t] = x3_frag(v3K + t * (kTI * S1), 16 * nb2 + frz, S1, kh + 2 * j, fkz);
+                    if (step + 1 < 2 * NK) b0n = x3_frag(v3K, 16 * ((step + 1) / NK) + frz, S1, kh + 2 * ((step + 1) % NK), fkz);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (XT && j == NKR - 1) {
+                        bf16x8 aa[3] = {dA[j < NKR ? j : 0][0], dA[j < NKR ? j : 0][1],
+                                        __builtin_bit_cast(bf16x8, dAx[(kh * kMB + mb1) * 64 + lanez])};
+                        c = mfma_xt<ONE>(aa, bb, c);
+                    } else if (j < NKR) c = mfma_xt<ONE>(dA[j < NKR ? j : 0], bb, c);
+                    else {
+                        bf16x8 al[3];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) al[t] = __builtin_bit_cast(bf16x8, dAl[((mb1 * NKL + (j - NKR)) * 3 + t) * 64 + lanez]);
+                        c = mfma_xt<ONE>(al, bb, c);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r * kXRS + 16 * nb2] = c[r];
+            }
+        };
         // ---- BCE: thread -> cells (b, n2), (b, n2 + 1) of pair id tid + 1024 j; the stored tile, the split G images, loss
         auto bce = [&](int pid0) {              // (the 64 cell pairs from pid0 on: rows pid0 / 16 .. + 3)
             const int pid = pid0 + lanez, b = pid >> 4, n2 = (pid & 15) * 2;
@@ -397,7 +442,9 @@ __global__ __launch_bounds__(kNT) void dec_crit_x3_kernel(DecFusedArgs a) {
 
         stamp(14);
         stamp(1);
-        if (g1) gemm1();
+        if (kCritG1Pf) {
+            if (g1) { if (nks == NKS) gemm1_pf(std::integral_constant<int, NKS>()); else gemm1_pf(std::integral_constant<int, (NKS > 1 ? NKS - 1 : 1)>()); }
+        } else if (g1) gemm1();
         // the next tile's V3a: requested HERE, behind the phase with the most live registers (its 8 would be the ones that
         // spill), BCE and GEMM3 ahead of its use in stage() - ~2 us, an HBM round trip
         load_span(min(tile + stride, ntiles - 1), vreg);
