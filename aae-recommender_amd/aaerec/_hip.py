@@ -18,7 +18,7 @@ import torch  # must be imported before the library so both share one HIP runtim
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AAE_HIP_LIB") or os.path.join(_HERE, "libaaerec_hip.so")     # (AAE_HIP_LIB: A/B builds of the library)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # getattr(nn, activation)() of the reference (aae.py:110): the parameter-free element-wise classes of torch.nn at their default
 # arguments (r6: 6-19).  Classes with parameters, state or a row-wise definition (PReLU, RReLU, Threshold, GLU, Softmax,
 # Softmin, LogSoftmax, MultiheadAttention ...) and Tanhshrink have no kernel: HipAAE raises with this list.

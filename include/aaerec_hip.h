@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define AAE_ABI_VERSION 3
+/* 4 (r6): aae_set_option, aae_ipc_create / _init / _destroy, AAE_ACT_SOFTPLUS .. AAE_ACT_HARDSWISH; no structure changed since 3 */
+#define AAE_ABI_VERSION 4
 
 /* error codes */
 #define AAE_OK 0

@@ -55,6 +55,20 @@ def test_random_configuration_matches_oracle(seed, tiny):
     _check_configuration(cfg, r, seed)
 
 
+# r6: the fourteen further activation classes (csrc/device_common.h; the general program kernel chain_kernel<.., true> and the
+# per-layer epilogues carry them): the same random configurations - widths, conditions incl. the wide ones, priors, optimisers,
+# ragged batches, permutation windows, the step cut at the output layer - with the class cycling over the seeds
+ACTS_R6 = ["Softplus", "Hardtanh", "ReLU6", "CELU", "Softsign", "Hardsigmoid", "LogSigmoid", "Softshrink", "Hardshrink", "Identity",
+           "GELU", "SiLU", "Mish", "Hardswish"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "28"))))
+def test_random_configuration_with_a_further_activation_class_matches_oracle(seed):
+    cfg, r = _config(500 + seed)
+    cfg["act"] = ACTS_R6[seed % len(ACTS_R6)]
+    _check_configuration(cfg, r, 500 + seed)
+
+
 # A decoder input [z | condition | 1] wider than a row of the layer-chain kernel's LDS slots (208 columns): dec.lin1 runs as
 # two k-parts, its dX as two column parts (csrc/abi_chains.h: add_dec_in_fwd / add_dec_in_dx).  C4's shape (code 50 +
 # 300-d condition), the narrowest wide input (209 columns: the second part is the bias column alone), the widest (416),
