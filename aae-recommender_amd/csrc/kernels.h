@@ -81,56 +81,125 @@ __global__ __launch_bounds__(64 * NW) void enc_gather_kernel_t(BatchView bv, con
     const int hp = (h + 3) & ~3;
     const int dc = bv.doc(b);
     const int64_t lo = bv.indptr[dc], hi = bv.indptr[dc + 1];
-    float s = 1.f;
-    if (normalize && doc_l1) {
-        s = 1.f / fmaxf(doc_l1[dc], 1e-12f);
-    } else if (normalize) {
-        float l1 = 0.f;
-        for (int64_t e = lo + tid; e < hi; e += 64 * NW) l1 += fabsf(bv.values[e]);
-        l1 = wave_sum(l1);
-        if (lane == 0) red[wave] = l1;
-        __syncthreads();
-        l1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) l1 += red[w];
-        s = 1.f / fmaxf(l1, 1e-12f);
-    }
-    if (tid == 0) rscale[b] = s;
-    for (int c0 = lane * 4; c0 < hp; c0 += 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NW < 16) {
-            // r5, the four-wave form (wide batches: a wave owns ~5 of a document's ~20 entries): eight entries per pass - their
-            // ids and values in one round trip, their weight rows in a second - where the loop below is two dependent round
-            // trips PER entry (17 us per launch at 1 000 rows x 20 entries).  Same products, added in the same order.
-            for (int64_t e0 = lo + wave; e0 < hi; e0 += 8 * NW) {
-                int idx[8]; float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int64_t e = e0 + (int64_t)NW * j;
-                    const int64_t ec = e < hi ? e : e0;
-                    idx[j] = bv.indices[ec];
-                    x[j] = e < hi ? bv.values[ec] : 0.f;
+    if constexpr (NW >= 16) {
+        // (r6) The FIRST pass's ids, values and weight rows are requested before the L1 norm is reduced: the scale is needed by the
+        // multiply-adds only, so the chain of dependent round trips is indptr -> {ids -> rows | values -> norm} -> sum: three deep where
+        // r1-r5 walked five (indptr -> values -> norm -> id -> row, and the 16-wave form one (id, row) pair per entry after the other:
+        // a document of 24 entries was two more).  The 16-wave form only: the 4-wave form of wide batches keeps r5's loop - eight entries per
+        // pass - where this one's extra registers (130) cost it a third of its rate (C4: 15.8 -> 20.9 us per launch).  Same products, added
+        // in the same order: same bits.
+        constexpr int EP = 4;       // (16 waves x 4 = 64 entries in the first pass)
+        const int c00 = lane * 4;
+        const bool col = c00 < hp;
+        int idx0[EP]; float x0[EP]; float4 w0[EP];
+        {
+            const int64_t e0 = lo + wave;
+    #pragma unroll
+            for (int j = 0; j < EP; ++j) {
+                const int64_t e = e0 + (int64_t)NW * j;
+                const int64_t ec = e < hi ? e : (e0 < hi ? e0 : (hi > lo ? lo : 0));
+                idx0[j] = (hi > lo) ? bv.indices[ec] : 0;
+                x0[j] = e < hi ? bv.values[ec] : 0.f;
+            }
+    #pragma unroll
+            for (int j = 0; j < EP; ++j) w0[j] = col ? *reinterpret_cast<const float4*>(W1T + (size_t)idx0[j] * ldw + c00) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float s = 1.f;
+        if (normalize && doc_l1) {
+            s = 1.f / fmaxf(doc_l1[dc], 1e-12f);
+        } else if (normalize) {
+            float l1 = 0.f;
+            for (int64_t e = lo + tid; e < hi; e += 64 * NW) l1 += fabsf(bv.values[e]);
+            l1 = wave_sum(l1);
+            if (lane == 0) red[wave] = l1;
+            __syncthreads();
+            l1 = 0.f;
+    #pragma unroll
+            for (int w = 0; w < NW; ++w) l1 += red[w];
+            s = 1.f / fmaxf(l1, 1e-12f);
+        }
+        if (tid == 0) rscale[b] = s;
+        for (int c0 = c00; c0 < hp; c0 += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t e0 = lo + wave; e0 < hi; e0 += EP * NW) {
+                const bool first = e0 == lo + wave && c0 == c00;
+                int idx[EP]; float x[EP]; float4 w[EP];
+                if (first) {
+    #pragma unroll
+                    for (int j = 0; j < EP; ++j) { x[j] = x0[j]; w[j] = w0[j]; }
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < EP; ++j) {
+                        const int64_t e = e0 + (int64_t)NW * j;
+                        const int64_t ec = e < hi ? e : e0;
+                        idx[j] = bv.indices[ec];
+                        x[j] = e < hi ? bv.values[ec] : 0.f;
+                    }
+    #pragma unroll
+                    for (int j = 0; j < EP; ++j) w[j] = *reinterpret_cast<const float4*>(W1T + (size_t)idx[j] * ldw + c0);
                 }
-                float4 w[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(W1T + (size_t)idx[j] * ldw + c0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
+    #pragma unroll
+                for (int j = 0; j < EP; ++j)
                     if (e0 + (int64_t)NW * j < hi) {
                         float xv = x[j];
                         if (normalize) xv *= s;
                         acc.x += xv * w[j].x; acc.y += xv * w[j].y; acc.z += xv * w[j].z; acc.w += xv * w[j].w;
                     }
             }
-        } else
-        for (int64_t e = lo + wave; e < hi; e += NW) {
-            const int idx = bv.indices[e];
-            float x = bv.values[e];
-            if (normalize) x *= s;
-            const float4 w = *reinterpret_cast<const float4*>(W1T + (size_t)idx * ldw + c0);
-            acc.x += x * w.x; acc.y += x * w.y; acc.z += x * w.z; acc.w += x * w.w;
+            *reinterpret_cast<float4*>(&part[wave * hp + c0]) = acc;
         }
-        *reinterpret_cast<float4*>(&part[wave * hp + c0]) = acc;
+    } else {
+        float s = 1.f;
+        if (normalize && doc_l1) {
+            s = 1.f / fmaxf(doc_l1[dc], 1e-12f);
+        } else if (normalize) {
+            float l1 = 0.f;
+            for (int64_t e = lo + tid; e < hi; e += 64 * NW) l1 += fabsf(bv.values[e]);
+            l1 = wave_sum(l1);
+            if (lane == 0) red[wave] = l1;
+            __syncthreads();
+            l1 = 0.f;
+    #pragma unroll
+            for (int w = 0; w < NW; ++w) l1 += red[w];
+            s = 1.f / fmaxf(l1, 1e-12f);
+        }
+        if (tid == 0) rscale[b] = s;
+        for (int c0 = lane * 4; c0 < hp; c0 += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NW < 16) {
+                // r5, the four-wave form (wide batches: a wave owns ~5 of a document's ~20 entries): eight entries per pass - their
+                // ids and values in one round trip, their weight rows in a second - where the loop below is two dependent round
+                // trips PER entry (17 us per launch at 1 000 rows x 20 entries).  Same products, added in the same order.
+                for (int64_t e0 = lo + wave; e0 < hi; e0 += 8 * NW) {
+                    int idx[8]; float x[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t e = e0 + (int64_t)NW * j;
+                        const int64_t ec = e < hi ? e : e0;
+                        idx[j] = bv.indices[ec];
+                        x[j] = e < hi ? bv.values[ec] : 0.f;
+                    }
+                    float4 w[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(W1T + (size_t)idx[j] * ldw + c0);
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (e0 + (int64_t)NW * j < hi) {
+                            float xv = x[j];
+                            if (normalize) xv *= s;
+                            acc.x += xv * w[j].x; acc.y += xv * w[j].y; acc.z += xv * w[j].z; acc.w += xv * w[j].w;
+                        }
+                }
+            } else
+            for (int64_t e = lo + wave; e < hi; e += NW) {
+                const int idx = bv.indices[e];
+                float x = bv.values[e];
+                if (normalize) x *= s;
+                const float4 w = *reinterpret_cast<const float4*>(W1T + (size_t)idx * ldw + c0);
+                acc.x += x * w.x; acc.y += x * w.y; acc.z += x * w.z; acc.w += x * w.w;
+            }
+            *reinterpret_cast<float4*>(&part[wave * hp + c0]) = acc;
+        }
     }
     __syncthreads();
     if (adv.enabled && blockIdx.x == gridDim.x - 1 && tid < 64) advance_step_body(adv.sc, adv.ctr, adv.tab, nullptr, nullptr, adv.losses, tid);

@@ -66,6 +66,10 @@ ACTS_R6 = ["Softplus", "Hardtanh", "ReLU6", "CELU", "Softsign", "Hardsigmoid", "
 def test_random_configuration_with_a_further_activation_class_matches_oracle(seed):
     cfg, r = _config(500 + seed)
     cfg["act"] = ACTS_R6[seed % len(ACTS_R6)]
+    # (the step cut at the output layer - aae_ae_forward / _backward - is the layer programs'; with one of these classes a decoder
+    #  input wider than a slot runs layer by layer, where the library refuses the cut form with AAE_ESTATE: the whole step there)
+    if cfg["c"] + cfg["inc"] + 1 > 208:
+        cfg["cut"] = False
     _check_configuration(cfg, r, 500 + seed)
 
 
