@@ -188,7 +188,7 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
     m->split_ok = false; m->opt_pending = false; m->side = nullptr; m->ev_crit = m->ev_opt = nullptr;
     // workgroups of the deferred optimiser launch.  r2: half the CUs (it had 50 us of slack then).  Since the critical launch
     // runs on the bf16 matrix cores (r3, 116 -> 84 us) the NEXT step waits for this launch; measured at C3, batch 100
-    // (AAE_SPLIT_WGS sweep, ms/step), with the fp32 deferred kernel: 112 0.306 | 128 0.291 | 144 0.274 | 160 0.274 | 176 0.284
+    // (r2-r3 sweep of the launch's width, ms/step), with the fp32 deferred kernel: 112 0.306 | 128 0.291 | 144 0.274 | 160 0.274 | 176 0.284
     // | 192 0.285 | 224 0.312; with the bf16-emulated one (dec_opt_x3_kernel: 160 -> 138 us on 128 workgroups): 112 0.279 |
     // 128 0.273 | 144 0.276 | 160 0.278 | 176 0.286.  Half the CUs again (set below once x3_ok is known; 5/8 without it):
     // beyond that the chain / weight-gradient kernels it runs beside lose more than the launch gains.

@@ -217,7 +217,7 @@ int aae_ae_decode_backward(aae_handle m, const float* zc_dev, int64_t zc_ld, con
                     case 7: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<7, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                     default: hipExtLaunchKernelGGL((dec_fused_bf16_kernel<13, kDecOpt>), dim3(g2), dim3(kBT), (uint32_t)fused_lds, m->side, start, stop, 0, b); break;
                 } else if (r == 0 && nblk == 1 && m->x3_ok && !no_opt_x3) {
-                    // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h; AAE_NO_OPT_X3: the fp32 matrix pipe)
+                    // (the 3-term bf16 emulation of dV3 = G^T dh2, dec_crit_x3.h)
                     // (one-term instantiation: 78 VGPRs - six of its waves fit a SIMD, so the step's own launches would be dealt onto
                     //  its CUs and run beside its streams; its LDS claim is raised until no other workgroup of the step fits there)
                     const uint32_t lds_nat = (uint32_t)dec_opt_x3_lds_bytes();
