@@ -43,6 +43,36 @@ def test_arena_size_and_validation_without_gpu():
     assert b"positive" in lib.aae_last_error()
 
 
+def test_options_are_one_table_read_per_handle_and_set_through_the_abi(monkeypatch):
+    """r6: every switch of the library is a field of aae_options (csrc/abi_model.h), read ONCE per handle in aae_create /
+    aae_arena_bytes - a value set with aae_set_option wins over the environment variable AAE_<NAME>, NULL hands the name back,
+    an unknown name is refused.  Observable without a GPU: X16_ROWS decides whether the arena carries the wide-batch chain
+    kernel's split weight copies (aae_arena_bytes)."""
+    from aaerec import _hip
+    lib = _hip.load_library()
+    cfg = _hip.AaeConfig()
+    cfg.abi_version = _hip.ABI_VERSION
+    cfg.n_items, cfg.n_hidden, cfg.n_code, cfg.max_batch, cfg.max_nnz = 5000, 200, 50, 100, 25000
+
+    def arena():
+        n = ctypes.c_size_t()
+        assert lib.aae_arena_bytes(ctypes.byref(cfg), ctypes.byref(n)) == 0
+        return n.value
+    monkeypatch.delenv("AAE_X16_ROWS", raising=False)
+    base = arena()                                         # 200 stacked rows < 1024: no split copies
+    assert lib.aae_set_option(b"X16_ROWS", b"1") == 0
+    with_copies = arena()
+    assert with_copies > base + 6 * 200 * 200 * 2          # six layers' three-plane copies, forward and dX
+    monkeypatch.setenv("AAE_X16_ROWS", "100000")           # (the table wins over the environment ...)
+    assert arena() == with_copies
+    assert lib.aae_set_option(b"X16_ROWS", None) == 0      # (... until the name is handed back)
+    assert arena() == base
+    monkeypatch.setenv("AAE_X16_ROWS", "1")
+    assert arena() == with_copies
+    assert lib.aae_set_option(b"NO_SUCH_SWITCH", b"1") == -1 and b"unknown option" in lib.aae_last_error()
+    assert lib.aae_set_option(None, b"1") == -1
+
+
 def test_no_cpu_fallback():
     from aaerec import _hip
     if torch.cuda.is_available():
