@@ -912,6 +912,25 @@ def ipc_collectives(model, dist, max_floats, group=None):
         else:
             lib.aae_ipc_destroy(None, mailbox)
         return None
+    # self-test before anybody depends on it: ONE all-reduce of a known operand through the table.  Its wait for the peers' flags
+    # spins on the device for at most 2 s - on a box where a peer's mailbox is mapped but its flag never becomes visible that is
+    # 2 s here, once, instead of 2 s per exchange of a training run; every rank must see the rank-ordered sum, in time
+    import sys
+    import time
+    probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=model.device)
+    with model._on_device():
+        torch.cuda.synchronize(model.device)
+        t0 = time.perf_counter()
+        rc = tab.all_reduce(tab.ctx, C.c_void_p(probe.data_ptr()), 1024, C.c_void_p(torch.cuda.current_stream(model.device).cuda_stream))
+        torch.cuda.synchronize(model.device)
+        dt = time.perf_counter() - t0
+    good = rc == 0 and dt < 0.5 and bool((probe == float(world * (world + 1) // 2)).all().item())
+    if not agree(good):
+        dist.barrier(group=group)
+        lib.aae_ipc_destroy(C.byref(tab), mailbox)          # (its report of the timed-out wait is the reason we are here)
+        print("aaerec: the one-shot all-reduce over mapped mailboxes failed its self-test on some rank (%.3f s, rc %d); using the "
+              "backend's collectives" % (dt, rc), file=sys.stderr, flush=True)
+        return None
     return IpcTable(lib, tab, mailbox, dist, group)
 
 

@@ -662,6 +662,39 @@ def main():
         dp_other = dict(dp=other, value=round(a.steps * Bg / dt2, 1), unit="docs/s", ms_per_step=round(dt2 / a.steps * 1e3, 4),
                         timed_repeats=len(dts2), dp_breakdown=collective_breakdown(model2, it2, min(a.steps, 40), barrier, dist, world, dev),
                         **({"collectives_per_step": model2._dp.comm_stats()} if hasattr(model2._dp, "comm_stats") else {}))
+        # ... and `shard` with its three all-reduces as one-shot launches over peer-mapped mailboxes (aae_ipc_*) in
+        # place of the backend's ring: taken only when the table passed its self-test on every rank (parallel.ipc_collectives)
+        if a.dp == "shard" or other == "shard":
+            del it2
+            for hh in (model2.hip, model2._slice):
+                if hh is not None:
+                    hh.close()
+            del model2
+            torch.cuda.empty_cache()
+            from aaerec.parallel import IpcTable
+            a3 = argparse.Namespace(**vars(a))
+            a3.dp = "shard"
+            model3 = make_model(a3, Bg, dist, conditions=conditions)
+            model3.dp_collectives = "ipc"
+            with contextlib.redirect_stdout(sys.stderr):
+                it3 = model3.fit_steps(X, condition_data=cond_data)
+                next(it3)
+            keep = getattr(model3._dp, "_native_keep", None)
+            if isinstance(keep, IpcTable):
+                for _ in range(a.warmup):
+                    next(it3)
+                dts3 = [timed_steps(it3, a.steps, barrier) for _ in range(min(repeats, 3))]
+                t = torch.tensor([float(np.median(dts3))], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt3 = float(t.item())
+                dp_other["shard_over_ipc_all_reduce"] = dict(
+                    value=round(a.steps * Bg / dt3, 1), unit="docs/s", ms_per_step=round(dt3 / a.steps * 1e3, 4), timed_repeats=len(dts3),
+                    dp_breakdown=collective_breakdown(model3, it3, min(a.steps, 40), barrier, dist, world, dev))
+                del it3
+                torch.cuda.synchronize(dev)
+                keep.close()
+            else:
+                dp_other["shard_over_ipc_all_reduce"] = None       # (a mailbox could not be shared / the self-test failed on some rank)
 
     if rank == 0:
         cfg_name = ("C2 RCV1-scale" if a.dtype == "bf16" else "C4 EconBiz-scale + 300-d title condition" if a.cond_inc
