@@ -664,7 +664,9 @@ def main():
                         **({"collectives_per_step": model2._dp.comm_stats()} if hasattr(model2._dp, "comm_stats") else {}))
         # ... and `shard` with its three all-reduces as one-shot launches over peer-mapped mailboxes (aae_ipc_*) in
         # place of the backend's ring: taken only when the table passed its self-test on every rank (parallel.ipc_collectives)
-        if a.dp == "shard" or other == "shard":
+        # (opt-in: AAE_BENCH_EXTRAS=dp_other,dp_ipc - this path has run between two processes of ONE GPU only, and a rank that
+        #  faults in it would take the whole line with it: the default N > 1 run keeps to the two schemes that RCCL carries)
+        if (a.dp == "shard" or other == "shard") and "dp_ipc" in os.environ.get("AAE_BENCH_EXTRAS", "dp_other").split(","):
             del it2
             for hh in (model2.hip, model2._slice):
                 if hh is not None:
