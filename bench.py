@@ -639,64 +639,67 @@ def main():
                        native=getattr(model._dp, "_native", None) is not None)
     dp_other = None
     if use_dp and world > 1 and not a.no_extra and "dp_other" in os.environ.get("AAE_BENCH_EXTRAS", "dp_other").split(","):
-        other = "replicated" if a.dp != "replicated" else "shard"
-        del it
-        for hh in (model.hip, model._slice):
-            if hh is not None:
-                hh.close()
-        del model
-        torch.cuda.empty_cache()
-        a2 = argparse.Namespace(**vars(a))
-        a2.dp = other
-        model2 = make_model(a2, Bg, dist, conditions=conditions)
-        with contextlib.redirect_stdout(sys.stderr):
-            it2 = model2.fit_steps(X, condition_data=cond_data)
-            next(it2)
-        for _ in range(a.warmup):
-            next(it2)
-        dts2 = [timed_steps(it2, a.steps, barrier) for _ in range(min(repeats, 3))]
-        dt2 = float(np.median(dts2))
-        t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt2 = float(t.item())
-        dp_other = dict(dp=other, value=round(a.steps * Bg / dt2, 1), unit="docs/s", ms_per_step=round(dt2 / a.steps * 1e3, 4),
-                        timed_repeats=len(dts2), dp_breakdown=collective_breakdown(model2, it2, min(a.steps, 40), barrier, dist, world, dev),
-                        **({"collectives_per_step": model2._dp.comm_stats()} if hasattr(model2._dp, "comm_stats") else {}))
-        # ... and `shard` with its three all-reduces as one-shot launches over peer-mapped mailboxes (aae_ipc_*) in
-        # place of the backend's ring: taken only when the table passed its self-test on every rank (parallel.ipc_collectives)
-        # (opt-in: AAE_BENCH_EXTRAS=dp_other,dp_ipc - this path has run between two processes of ONE GPU only, and a rank that
-        #  faults in it would take the whole line with it: the default N > 1 run keeps to the two schemes that RCCL carries)
-        if (a.dp == "shard" or other == "shard") and "dp_ipc" in os.environ.get("AAE_BENCH_EXTRAS", "dp_other").split(","):
-            del it2
-            for hh in (model2.hip, model2._slice):
+        try:
+            other = "replicated" if a.dp != "replicated" else "shard"
+            del it
+            for hh in (model.hip, model._slice):
                 if hh is not None:
                     hh.close()
-            del model2
+            del model
             torch.cuda.empty_cache()
-            from aaerec.parallel import IpcTable
-            a3 = argparse.Namespace(**vars(a))
-            a3.dp = "shard"
-            model3 = make_model(a3, Bg, dist, conditions=conditions)
-            model3.dp_collectives = "ipc"
+            a2 = argparse.Namespace(**vars(a))
+            a2.dp = other
+            model2 = make_model(a2, Bg, dist, conditions=conditions)
             with contextlib.redirect_stdout(sys.stderr):
-                it3 = model3.fit_steps(X, condition_data=cond_data)
-                next(it3)
-            keep = getattr(model3._dp, "_native_keep", None)
-            if isinstance(keep, IpcTable):
-                for _ in range(a.warmup):
+                it2 = model2.fit_steps(X, condition_data=cond_data)
+                next(it2)
+            for _ in range(a.warmup):
+                next(it2)
+            dts2 = [timed_steps(it2, a.steps, barrier) for _ in range(min(repeats, 3))]
+            dt2 = float(np.median(dts2))
+            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+            dp_other = dict(dp=other, value=round(a.steps * Bg / dt2, 1), unit="docs/s", ms_per_step=round(dt2 / a.steps * 1e3, 4),
+                            timed_repeats=len(dts2), dp_breakdown=collective_breakdown(model2, it2, min(a.steps, 40), barrier, dist, world, dev),
+                            **({"collectives_per_step": model2._dp.comm_stats()} if hasattr(model2._dp, "comm_stats") else {}))
+            # ... and `shard` with its three all-reduces as one-shot launches over peer-mapped mailboxes (aae_ipc_*) in
+            # place of the backend's ring: taken only when the table passed its self-test on every rank (parallel.ipc_collectives)
+            # (opt-in: AAE_BENCH_EXTRAS=dp_other,dp_ipc - this path has run between two processes of ONE GPU only, and a rank that
+            #  faults in it would take the whole line with it: the default N > 1 run keeps to the two schemes that RCCL carries)
+            if (a.dp == "shard" or other == "shard") and "dp_ipc" in os.environ.get("AAE_BENCH_EXTRAS", "dp_other").split(","):
+                del it2
+                for hh in (model2.hip, model2._slice):
+                    if hh is not None:
+                        hh.close()
+                del model2
+                torch.cuda.empty_cache()
+                from aaerec.parallel import IpcTable
+                a3 = argparse.Namespace(**vars(a))
+                a3.dp = "shard"
+                model3 = make_model(a3, Bg, dist, conditions=conditions)
+                model3.dp_collectives = "ipc"
+                with contextlib.redirect_stdout(sys.stderr):
+                    it3 = model3.fit_steps(X, condition_data=cond_data)
                     next(it3)
-                dts3 = [timed_steps(it3, a.steps, barrier) for _ in range(min(repeats, 3))]
-                t = torch.tensor([float(np.median(dts3))], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt3 = float(t.item())
-                dp_other["shard_over_ipc_all_reduce"] = dict(
-                    value=round(a.steps * Bg / dt3, 1), unit="docs/s", ms_per_step=round(dt3 / a.steps * 1e3, 4), timed_repeats=len(dts3),
-                    dp_breakdown=collective_breakdown(model3, it3, min(a.steps, 40), barrier, dist, world, dev))
-                del it3
-                torch.cuda.synchronize(dev)
-                keep.close()
-            else:
-                dp_other["shard_over_ipc_all_reduce"] = None       # (a mailbox could not be shared / the self-test failed on some rank)
+                keep = getattr(model3._dp, "_native_keep", None)
+                if isinstance(keep, IpcTable):
+                    for _ in range(a.warmup):
+                        next(it3)
+                    dts3 = [timed_steps(it3, a.steps, barrier) for _ in range(min(repeats, 3))]
+                    t = torch.tensor([float(np.median(dts3))], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt3 = float(t.item())
+                    dp_other["shard_over_ipc_all_reduce"] = dict(
+                        value=round(a.steps * Bg / dt3, 1), unit="docs/s", ms_per_step=round(dt3 / a.steps * 1e3, 4), timed_repeats=len(dts3),
+                        dp_breakdown=collective_breakdown(model3, it3, min(a.steps, 40), barrier, dist, world, dev))
+                    del it3
+                    torch.cuda.synchronize(dev)
+                    keep.close()
+                else:
+                    dp_other["shard_over_ipc_all_reduce"] = None       # (a mailbox could not be shared / the self-test failed on some rank)
+        except Exception as e:       # noqa: BLE001 - the main line is measured already: it is printed whatever happens to this one
+            dp_other = dict(dp_other or {}, error=f"{type(e).__name__}: {e}")
 
     if rank == 0:
         cfg_name = ("C2 RCV1-scale" if a.dtype == "bf16" else "C4 EconBiz-scale + 300-d title condition" if a.cond_inc
