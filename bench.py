@@ -55,7 +55,7 @@ def parse():
                          "with fp32 accumulation, fp32 master weights and fp32 Adam (config C2)")
     ap.add_argument("--cond-inc", type=int, default=0, help="width of a constant concatenated condition block (config C4: 300)")
     ap.add_argument("--median-len", type=int, default=20, help="median items per synthetic doc")
-    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps, the median is reported (0 = auto: 5 when "
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps, the median is reported (0 = auto: 15 for a region under 20 ms, 5 when "
                                                            "K steps take well under a second, else 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -316,7 +316,10 @@ def main():
         out_model.profile_enable(True, kernels=K_OUT)
     dts = [timed_steps(it, a.steps, barrier)]
     out_model.profile_enable(False)
-    repeats = a.repeats or (5 if dts[0] < 0.25 else 1)
+    # (a region of 20 steps - the driver's K - is 5 ms: the first three such regions behind the warm-up run 3-4 % slower than the
+    #  ones after them (the chip settles its clocks over the first ~15 ms of the loop; region_profile.py), so a median of five sat
+    #  on the settling ones.  Fifteen repeats of so short a region cost 70 ms and every one is listed in config.repeat_ms_per_step)
+    repeats = a.repeats or (15 if dts[0] < 0.02 else 5 if dts[0] < 0.25 else 1)
     for _ in range(repeats - 1):
         dts.append(timed_steps(it, a.steps, barrier))
     dt = float(np.median(dts))
