@@ -275,6 +275,16 @@ def test_random_long_run_and_execution_paths_match_oracle(seed):
 def test_random_decoder_and_vae_steps_match_oracle(seed):
     """The sibling models' entry points over random shapes: aae_decoder_step (DecodingRecommender: decoder only, input
     block from the conditions, dL/d(input) returned) and aae_vae_step / aae_vae_predict (VAE)."""
+    _decoder_vae_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AAE_FUZZ_SEEDS", "14"))))
+def test_random_decoder_and_vae_steps_with_a_further_activation_class_match_oracle(seed):
+    """... with the activation classes of r6 (the VAE's programs and the decoder-only step on chain_kernel<.., true>)."""
+    _decoder_vae_case(seed, ACTS_R6[seed % len(ACTS_R6)])
+
+
+def _decoder_vae_case(seed, act_override=None):
     import torch
     from aaerec._hip import HipAAE, DeviceCSR
     from oracle import aae_oracle as O
@@ -282,6 +292,8 @@ def test_random_decoder_and_vae_steps_match_oracle(seed):
     r = np.random.default_rng(9000 + seed)
     N, h, B = int(r.integers(17, 1500)), int(r.integers(3, 208)), int(r.integers(1, 150))
     act = str(r.choice(["ReLU", "Tanh", "SELU", "ELU"]))
+    if act_override:
+        act = act_override
     if seed % 2 == 0:
         # ---- decoder only: the input block is what the condition plugins produced (width n_code here) ----
         c = int(r.integers(2, 200))
