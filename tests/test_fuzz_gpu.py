@@ -377,6 +377,8 @@ def test_random_multi_rank_runs_match_oracle(seed, scheme):
     drop = bool(r.integers(0, 2))
     p = (0.2, 0.2) if drop else (0.0, 0.0)
     kw = dict(gen_lr=2e-3, reg_lr=1e-3, dropout=p, activation=str(r.choice(["ReLU", "Tanh", "ELU"])))
+    if os.environ.get("AAE_FUZZ_ACT"):              # (hunts: every multi-rank scheme with one activation class, e.g. GELU)
+        kw["activation"] = os.environ["AAE_FUZZ_ACT"]
     params = init_params(N, h, c, cond_inc=inc, seed=seed)
     ora = O.OracleAAE(params, conditions=[O.ConcatConst(inc)] if inc else [], **kw)
     steps = []
