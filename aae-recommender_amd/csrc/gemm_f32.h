@@ -357,6 +357,25 @@ __device__ __forceinline__ void bce_elem_t0(float l, float gscale, float& g, flo
     if (l > 17.32868f) { g = 0.f; loss = 100.f; }
 }
 
+// The zero-target form in PARTS, for an epilogue that only needs the SUM of its cells' losses (dec_crit_x3.h): loss = add +
+// log(fac) with fac = 1 + e (in [1, 2]) where bce_elem_t0 takes the logarithm and 1 where it takes the series - the caller
+// multiplies the factors of several cells and takes ONE logarithm (v_log_f32 is a quarter-rate instruction, and with it go the
+// four multiply-adds of the ln 2 product): log(prod (1 + e_i)) for sum log(1 + e_i), the rounding of the few products (< 2^-22
+// relative on a value in [1, 16]) below what the rounding of 1 + e already is.  g: the same bits as bce_elem_t0's.
+__device__ __forceinline__ void bce_elem_t0_parts(float l, float gscale, float& g, float& add, float& fac) {
+    const float e = __expf(-fabsf(l));
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float s = l >= 0.f ? r : e * r;
+    const float lp_series = e * (1.f - e * (0.5f - e * 0.33333334f));
+    const bool small = e < 0.01f;
+    g = s * gscale;
+    add = fmaxf(l, 0.f) + (small ? lp_series : 0.f);
+    fac = small ? 1.f : 1.f + e;
+    if (l > 17.32868f) { g = 0.f; add = 100.f; fac = 1.f; }
+}
+// log(x) for a positive normal x, the arithmetic of log_1_to_2 (v_log_f32 times ln 2 in two terms)
+__device__ __forceinline__ float log_pos(float x) { return log_1_to_2(x); }
+
 struct EpiBce {
     struct State { float loss; };
     float* G; int ldg; float gscale; float* partials;
