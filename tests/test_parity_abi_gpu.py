@@ -111,6 +111,37 @@ def test_step_matches_reference_on_the_k_split_weight_gradient_tiles(name, monke
     test_step_matches_reference(name)
 
 
+def test_saturated_logits_cost_the_same_on_both_forms_of_the_output_layer(monkeypatch):
+    """F.binary_cross_entropy clamps its logarithms at -100, and sigmoid rounds to exactly 1.0f from a logit of 17.33 on: such a
+    cell of a zero target costs 100 and its s (1 - s) factor zeroes its gradient (aae.py:176-177, 693-695) - the output-layer
+    kernels keep both (csrc/gemm_f32.h bce_elem_t0).  Since r6 the CRITICAL launch takes the loss of a cell in parts - one
+    logarithm per thread and tile, of the product of its cells' 1 + e (bce_elem_t0_parts) -, where a saturated cell, a target's
+    exact form and the series for small e each leave the product alone.  dec.lin3 scaled until hundreds of logits saturate (and
+    as many lie far below zero): the reconstruction loss of the first step - a function of the initial parameters alone - on
+    the single launch (the per-cell form) and on the critical + deferred launches (the form in parts), to 1e-6; the saturated
+    cells' 100s are in it.  (Against the reference such a model's loss is a matter of fp32's 1 - sigmoid(l) between logits of
+    ~10 and 17.33 - the zero-target form is exact there where the reference's log(1 - x) is quantised, DESIGN.md 3.5 -, which
+    is why this compares the two forms with each other; every fixture compares both with the reference.)"""
+    fx = Fixture("step_headline")
+    params = fx.init_params()
+    params["dec.lin3.weight"] = (params["dec.lin3.weight"] * np.float32(400.0)).astype(np.float32)
+    losses, nsat = [], 0
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("AAE_SPLIT_ANY", "1")
+        m = make_model(fx)
+        m.load_params(params)
+        csr = csr_of(fx, m, 0)
+        full = m.predict(csr, 0, csr.shape[0]).cpu().numpy()
+        nsat = int((full == 1.0).sum())
+        m.step(csr, 0, csr.shape[0], masks=fx.masks(0), z_real=fx.z["step0.z_real"])
+        losses.append(np.asarray(m.losses(), dtype=np.float64))
+    assert nsat >= 200, ("the case is meant to saturate", nsat)
+    assert losses[0][0] > 100.0 * nsat / full.size, ("the saturated cells' 100s are missing from the loss", losses[0], nsat, full.size)
+    np.testing.assert_allclose(losses[1][0], losses[0][0], rtol=1e-6)
+    print("saturated scores of the batch:", nsat, "of", full.size, "| reconstruction loss, single launch | critical launch:", losses[0][0], losses[1][0])
+
+
 def test_plain_autoencoder_matches_reference():
     """cfg.reserved[2] = 1: the reference's non-adversarial AutoEncoder (aae.py:221-458) - only the
     reconstruction step runs; fixture generated from the reference's AutoEncoder class."""
