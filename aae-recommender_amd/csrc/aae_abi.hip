@@ -61,7 +61,7 @@ int aae_abi_version(void) { return AAE_ABI_VERSION; }
 int aae_set_option(const char* name, const char* value) {
     if (!name || !*name) return fail(AAE_EINVAL, "option name is empty");
     static const char* known[] = {"NO_CHAIN", "CHAIN16", "SPLIT_ANY", "BLOCKED_ANY", "EARLY_ANY", "NO_LATE_JOIN", "NO_ITEM_COUNT", "W1_SERIAL",
-                                  "NO_RANK_FUSED", "X16_ROWS", "DW_KSPLIT_ROWS", "DEC_TS", "CHAIN_TS", "DW_TS", "DEC_SKIP", "CHAIN_SKIP", "RANK_SKIP"};
+                                  "NO_RANK_FUSED", "CHAIN_KSLICES", "X16_ROWS", "DW_KSPLIT_ROWS", "DEC_TS", "CHAIN_TS", "DW_TS", "DEC_SKIP", "CHAIN_SKIP", "RANK_SKIP"};
     bool ok = false;
     for (const char* k : known) ok = ok || strcmp(k, name) == 0;
     if (!ok) return fail(AAE_EINVAL, "unknown option (aae_options, csrc/abi_model.h, lists them)");

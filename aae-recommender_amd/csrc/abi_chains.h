@@ -69,7 +69,7 @@ struct ChainBuilder {
         memset(&P, 0, sizeof(P));
         P.rows = rows; P.act = m->cfg.activation; P.seed = m->cfg.seed; P.step_ctr = m->step_ctr;
         P.loss_out = m->losses; P.loss_slot = 3;
-        P.dbg = m->opt.chain_skip;
+        P.dbg = m->opt.chain_skip; P.kslices = (m->opt.chain_kslices || m->rows > 16 * kMB || rows > 32 * kMB) ? 1 : 0;     // (chain4.h: the column-owner form for batches of one fused launch)
     }
     ChainOp& add(const ChainOp& o) { P.ops[P.nops] = o; return P.ops[P.nops++]; }
     int x16_rows = 0;      // > 0: this program's own row threshold for the wide-batch kernel (beside_deferred)

@@ -50,6 +50,8 @@ struct aae_options {
     bool no_item_count;     // NO_ITEM_COUNT: first-layer item workgroups sized by the bound, not by the device's last count
     bool w1_serial;         // W1_SERIAL: data-parallel import of the peers' first-layer rows one launch per peer
     bool no_rank_fused;     // NO_RANK_FUSED: predict -> rank as two kernels over the [rows, N] score matrix
+    bool chain_kslices;     // CHAIN_KSLICES: the 4-row chain kernel's linear ops in the k-slice form at every batch size (bf16 mode takes the
+                            // column-owner form for batches of one fused launch: chain4.h)
     int x16_rows;           // X16_ROWS: programs of at least this many rows run on the wide-batch chain kernel (default 1024)
     int dw_ksplit_rows;     // DW_KSPLIT_ROWS: weight-gradient tiles take the k-split form from this many rows on (default 256; -1: unset)
     // diagnostics (debug runs: tools/debug/*)
@@ -64,7 +66,7 @@ inline void read_options(aae_options& o) {
     auto num = [](const char* n, int dflt) { const char* e = option_value(n); return e ? atoi(e) : dflt; };
     o.no_chain = on("NO_CHAIN"); o.chain16 = on("CHAIN16"); o.split_any = on("SPLIT_ANY"); o.blocked_any = on("BLOCKED_ANY");
     o.early_any = on("EARLY_ANY"); o.no_late_join = on("NO_LATE_JOIN"); o.no_item_count = on("NO_ITEM_COUNT");
-    o.w1_serial = on("W1_SERIAL"); o.no_rank_fused = on("NO_RANK_FUSED");
+    o.w1_serial = on("W1_SERIAL"); o.no_rank_fused = on("NO_RANK_FUSED"); o.chain_kslices = on("CHAIN_KSLICES");
     o.x16_rows = num("X16_ROWS", 1024); o.dw_ksplit_rows = num("DW_KSPLIT_ROWS", -1);
     const char* ts = option_value("DEC_TS");
     snprintf(o.dec_ts, sizeof(o.dec_ts), "%s", ts ? ts : "");

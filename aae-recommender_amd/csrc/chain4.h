@@ -179,6 +179,56 @@ __device__ __forceinline__ void chain4_linear(const Lin4& op, const float* src, 
     if (wts && lane == 0) wts[32 + wave] = wall_clock64();             // ... its partial sums are in LDS
 }
 
+// (r6) ONE BARRIER PER OP: the column-owner form of a linear op - bf16 mode, batches of one fused launch (C2).  Above, a wave =
+// (64 columns, a slice of K): the k-slices' partial sums meet in LDS behind a workgroup barrier, the epilogue reads them back, a
+// second barrier closes the op.  Here the 16 blocks of a 4x4x1 instruction are 4 k-residues x 4 column quartets instead of 16
+// column quartets: block b = (kq = b / 4, cq = b % 4), so a wave owns 16 COLUMNS for ALL of K - lane (kq, c) multiplies
+// k = 16 J + 4 kq + {0..3} of column 16 wave + c per step J (the same k4-interleaved copy: its float4 of chunk 4 J + kq; the A
+// operand x[lane % 4][16 J + 4 kq ..] one 16-byte LDS read as before), the four k-residues' sums of a column - lanes c, c + 16,
+// c + 32, c + 48 - are added across the lanes (v_permlane16_swap / v_permlane32_swap: no LDS round trip), and lane (kq, c) runs
+// the epilogue of cell (row kq, column 16 wave + c) on its own registers.  No partial sums in LDS, no barrier between products
+// and epilogue; 13 of 16 waves carry a 200-wide layer.  Chain launches at C2 21.5 -> 20.5 us, C2 bf16 0.161 -> 0.155 ms/step.
+// ANOTHER SUMMATION ORDER than the k-slice form's (fp32 accumulation of the same exact products of bf16 values), which is why
+// it is taken where it is: in fp32 mode it would move every bit of every run for nothing at C3 and 0.7 % at C4 (measured,
+// HISTORY.md), and the one statistical bound of the bf16 tests that was set with the k-slice order - the fraction of dec.lin1's
+// elements more than 1e-4 from the oracle after three 1 000-row steps with a 300-wide condition, 1.2 % there, 2 % allowed -
+// reads 2.8 % with this one (near-zero gradients change sign under any other order and Adam moves them by lr): wide batches
+// keep the k-slice order.  NJ = 16-deep k-steps (4 | 7 | 13: K <= 64 | 112 | 208); chunks beyond the copy (+ its zero rows)
+// read as zero through the descriptor's range check, the A operand beyond K is zero by construction.
+template <int NJ>
+__device__ __forceinline__ f32x4 chain4_cols(const float* W4, int ns4, int N, int K, const float* src, int wave, int lane) {
+    const int kq = lane >> 4, col = min(16 * wave + (lane & 15), N - 1);
+    const unsigned st = (unsigned)ns4 * 16u;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W4), 0, (unsigned)(((K + 3) >> 2) + kW4Pad) * st, 0x00020000);
+    const unsigned vo = (unsigned)col * 16u + (unsigned)kq * st;
+    unsigned so = 0;
+    float4 wq[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { wq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0)); so += 4u * st; }
+    __builtin_amdgcn_sched_barrier(0);          // (every weight load of the layer requested before its first product: chain4_linear)
+    const float4* a4 = reinterpret_cast<const float4*>(src + (lane & 3) * kCL + 4 * kq);
+    f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 x = a4[4 * j];             // (both operands rounded to bf16 values, multiplied as fp32: the file's header)
+        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(chain4_rb(x.x), chain4_rb(wq[j].x), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(chain4_rb(x.y), chain4_rb(wq[j].y), c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(chain4_rb(x.z), chain4_rb(wq[j].z), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(chain4_rb(x.w), chain4_rb(wq[j].w), c1, 0, 0, 0);
+    }
+    c0 += c1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // (a swap of a register with its own copy: one result holds the even 16-lane rows / the lower half twice, the other the odd
+        //  rows / the upper half - their sum is x + x[lane ^ 16] resp. x + x[lane ^ 32] in every lane, the same bits in all four)
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[r]), __float_as_uint(c0[r]), false, false);
+        const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+        c0[r] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    return c0;
+}
+
 // TS: the debug build with in-kernel stamps (AAE_CHAIN_TS).  The production build carries none: a stamp site between a layer's
 // weight loads and its products is a (flat) store the compiler orders with s_waitcnt vmcnt(0) - every product then waited for
 // ALL of the wave's loads instead of its own chunk's - and each site costs every wave scalar instructions.
@@ -199,8 +249,8 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
 
     // (debug stamps, AAE_CHAIN_TS: workgroup 0 only; one pinned pointer, NULL in production)
     unsigned long long* tsp = (TS && blockIdx.x == 0) ? P.ts : nullptr;
-    int nops = P.nops;
-    asm volatile("" : "+s"(tsp), "+s"(nops));
+    int nops = P.nops, kslices = P.kslices;
+    asm volatile("" : "+s"(tsp), "+s"(nops), "+s"(kslices));
     for (int oi = 0; oi < nops; ++oi) {
         const ChainOp& op = P.ops[oi];
         if (TS && tsp && tid == 0) tsp[oi] = wall_clock64();
@@ -242,6 +292,42 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             const int kper = (((K + KS - 1) >> (kC4WS - cgs)) + 3) & ~3;    // k-steps per wave, a multiple of 4
             unsigned long long* wts = (TS && tsp && oi == 2) ? tsp + 64 : nullptr;
             if (wts && tid == 0) { wts[48] = wall_clock64(); wts[49] = clock64(); }
+            // ---- the column-owner form (one barrier per op): the common case of every program of the step
+            // (the k-slice form below carries fp32 mode, wide batches - the host sets P.kslices -, a layer in place, a matrix without
+            //  its k4-interleaved copy and the 8-wave build; AAE_CHAIN_KSLICES forces it for the tests)
+            bool cols_ok = false;
+            if constexpr (BF && kC4W == 16) cols_ok = !kslices && lin.W4 && K <= kCWide && N <= 16 * kC4W && src_i != dst_i;
+            if (cols_ok) {                              // (uniform; bf16 mode only: the fp32 kernel carries none of this)
+                const int crow = lane >> 4, ccol = 16 * wave + (lane & 15);    // this thread's cell of the 4 x 256 block
+                float yv1 = 0.f;
+                if (ygp) {
+                    typedef const __attribute__((address_space(1))) float* gf_t;
+                    yv1 = (ccol < N && crow < nrows) ? ((gf_t)ygp)[(size_t)(r0 + crow) * yld + ccol] : 0.f;
+                }
+                f32x4 cs = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (16 * wave < N) {
+                    if (K <= 64) cs = chain4_cols<4>(lin.W4, lin.ns4, N, K, src, wave, lane);
+                    else if (K <= 112) cs = chain4_cols<7>(lin.W4, lin.ns4, N, K, src, wave, lane);
+                    else cs = chain4_cols<13>(lin.W4, lin.ns4, N, K, src, wave, lane);
+                }
+                if (wts && lane == 0) wts[32 + wave] = wall_clock64();
+                one_done = true;
+                if (16 * wave < kCL) {                  // (waves 0 .. 13: the slot row's 212 columns)
+                    const EpiCtx ec = chain_epi_ctx(epi_k, op, P, key, slots);
+                    float v = 0.f;
+                    if (ccol < N && crow < nrows) {
+                        v = crow == 0 ? cs[0] : crow == 1 ? cs[1] : crow == 2 ? cs[2] : cs[3];
+                        if (acc_in) v += dst[crow * kCL + ccol];
+                        if (ec.epi == CEPI_ACTBWD) {
+                            v *= act_grad_from_y(ec.act, ygp ? yv1 : (slots + yslot_k * kR4 * kCL)[crow * kCL + ccol]);
+                            if (ec.den) v *= chain_keep(ec, r0 + crow, ccol) ? ec.mk : 0.f;
+                        } else {
+                            v = chain_epi<false>(ec, r0 + crow, crow, ccol, v);
+                        }
+                    }
+                    if (ccol < kCL) dst[crow * kCL + ccol] = ccol == one_col ? (crow < nrows ? 1.f : 0.f) : v;
+                }
+            } else {
             // y of an ACTBWD epilogue that lives in global memory: this thread's cells, requested in front of the products
             float yv[kC4E];
             if (ygp) {
@@ -303,6 +389,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
                 // (columns >= N read as zero for the next layer; the constant-1 column of an augmented layer input rides here
                 //  instead of in a write + barrier of its own behind every op)
                 dst[erow * kCL + ecol] = ecol == one_col ? (erow < nrows ? 1.f : 0.f) : v;
+            }
             }
         } else if (kind == COP_LOAD) {
             if (ecol + qdst_col0 < kCL)

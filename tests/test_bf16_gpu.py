@@ -133,6 +133,17 @@ def test_bf16_step_matches_the_rounded_oracle(name):
         assert frac <= 1e-2 and mx <= bound, (name, k, frac, mx, bound)
 
 
+@pytest.mark.parametrize("name", BF16_STEP_CASES)
+def test_bf16_step_matches_the_rounded_oracle_with_the_chain_kernels_k_slice_form(name, monkeypatch):
+    """The same with every linear op of the 4-row chain kernel in the k-slice form (a wave = 64 columns x a slice of K, the
+    slices' partial sums through LDS, two barriers per op; AAE_CHAIN_KSLICES=1).  Since r6 bf16 mode takes the column-owner
+    form for batches of one fused launch (csrc/chain4.h: a wave owns 16 columns for all of K, the four k-residues of a 4x4x1
+    instruction's blocks added across the lanes, the epilogue on the accumulators, one barrier per op) - which the test above
+    replays; the k-slice form carries fp32 mode, wide batches, layers in place, matrices without a k4-interleaved copy."""
+    monkeypatch.setenv("AAE_CHAIN_KSLICES", "1")
+    test_bf16_step_matches_the_rounded_oracle(name)
+
+
 @pytest.mark.parametrize("name", ["step_masks", "step_headline", "step_wide", "step_c4"])
 def test_bf16_stays_within_its_bound_of_the_reference(name):
     """The same replay against what the REFERENCE (fp32) recorded: the stated bf16 bound of the mode - losses within 1 %
