@@ -133,6 +133,8 @@ int aae_create(const aae_config* cfg, void* arena_dev, size_t arena_bytes, void*
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess &&
                         hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             kCSlots * kCR * kCL * (int)sizeof(float)) == hipSuccess;
         if (m->use_chain && m->cp + 1 > 208 && !m->use_chain4) m->use_chain = false;

@@ -90,11 +90,13 @@ struct ChainProgram {
                                         // adds on ONE address (a 1 000-row batch) are ~12 ns each at the memory side, and the wave's next
                                         // weight loads return behind its atomic (one in-order vmcnt): 8 us per program, losses not bit-stable
     int dbg;                            // timing-only ablation (AAE_CHAIN_SKIP), 0 in production
-    int kslices;                        // chain4.h: 1 = every linear op in the k-slice form (AAE_CHAIN_KSLICES: tests), 0 in production
     unsigned long long* ts;             // debug (AAE_CHAIN_TS): per-op 100 MHz timestamps of workgroup 0, else NULL
     BucketJob bk;                       // enabled: one extra workgroup builds the fused decoder's tile buckets
     int x16_first_lin[2], x16_row_lo;   // chain16x3.h: the program's first linear op per workgroup class, the prefix ops' row_lo (or 1 << 30)
     ChainOp ops[kCMaxOps];
+    int kslices;                        // chain4.h: 1 = every linear op in the k-slice form (wide batches; AAE_CHAIN_KSLICES).  LAST: a field in front
+                                        // of ops[] moves every op descriptor's offset in the kernel-argument segment (and with it the width of the
+                                        // scalar loads that fetch it: +0.3 us per launch of every chain kernel, measured)
 };
 
 // Workgroup barrier that orders LDS traffic only: global stores of finished activations (consumed by

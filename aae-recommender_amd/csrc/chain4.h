@@ -232,7 +232,11 @@ __device__ __forceinline__ f32x4 chain4_cols(const float* W4, int ns4, int N, in
 // TS: the debug build with in-kernel stamps (AAE_CHAIN_TS).  The production build carries none: a stamp site between a layer's
 // weight loads and its products is a (flat) store the compiler orders with s_waitcnt vmcnt(0) - every product then waited for
 // ALL of the wave's loads instead of its own chunk's - and each site costs every wave scalar instructions.
-template <bool BF, bool TS = false>
+// COLS: the instantiation that carries the column-owner form of a linear op (bf16 mode, batches of one fused launch).  The
+// k-slice form sits at its 128-register cap: compiled beside the other form it keeps one of its thirteen weight chunks in scratch
+// memory (and waits for all of them before its first product: C4's shape in bf16 0.312 -> 0.321 ms/step) - so wide batches are
+// launched on the instantiation without it.
+template <bool BF, bool TS = false, bool COLS = false>
 __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
     extern __shared__ __attribute__((aligned(16))) float slots[];     // [kCSlots][4][kCL], then the partial-sum scratch
     if (P.bk.enabled && blockIdx.x == gridDim.x - 1) {                // (uniform) the piggy-backed bucket builder
@@ -249,8 +253,9 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
 
     // (debug stamps, AAE_CHAIN_TS: workgroup 0 only; one pinned pointer, NULL in production)
     unsigned long long* tsp = (TS && blockIdx.x == 0) ? P.ts : nullptr;
-    int nops = P.nops, kslices = P.kslices;
-    asm volatile("" : "+s"(tsp), "+s"(nops), "+s"(kslices));
+    int nops = P.nops, kslices = COLS ? P.kslices : 1;
+    asm volatile("" : "+s"(tsp), "+s"(nops));
+    if constexpr (COLS) asm volatile("" : "+s"(kslices));
     for (int oi = 0; oi < nops; ++oi) {
         const ChainOp& op = P.ops[oi];
         if (TS && tsp && tid == 0) tsp[oi] = wall_clock64();
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(kC4T) void chain4_kernel(ChainProgram P) {
             // (the k-slice form below carries fp32 mode, wide batches - the host sets P.kslices -, a layer in place, a matrix without
             //  its k4-interleaved copy and the 8-wave build; AAE_CHAIN_KSLICES forces it for the tests)
             bool cols_ok = false;
-            if constexpr (BF && kC4W == 16) cols_ok = !kslices && lin.W4 && K <= kCWide && N <= 16 * kC4W && src_i != dst_i;
+            if constexpr (BF && COLS && kC4W == 16) cols_ok = !kslices && lin.W4 && K <= kCWide && N <= 16 * kC4W && src_i != dst_i;
             if (cols_ok) {                              // (uniform; bf16 mode only: the fp32 kernel carries none of this)
                 const int crow = lane >> 4, ccol = 16 * wave + (lane & 15);    // this thread's cell of the 4 x 256 block
                 float yv1 = 0.f;
